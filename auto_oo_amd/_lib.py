@@ -1,0 +1,119 @@
+"""ctypes binding of liboovqe_hip.so (the C ABI declared in include/oovqe.h).
+
+There is NO CPU fallback: if the shared library is missing, or a compute entry point is called
+without a HIP device, this module raises.  PyTorch is used only as the owner of device memory and
+streams; every pointer handed to the library is ``tensor.data_ptr()`` of a contiguous CUDA(HIP)
+tensor.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liboovqe_hip.so")
+
+c_double_p = ctypes.c_void_p
+c_int32_p = ctypes.c_void_p
+c_stream = ctypes.c_void_p
+
+
+class OovqeError(RuntimeError):
+    pass
+
+
+class GateT(ctypes.Structure):
+    """Mirror of oovqe_gate_t (include/oovqe.h)."""
+    _fields_ = [("mask_hi", ctypes.c_uint32), ("mask_lo", ctypes.c_uint32),
+                ("mask_par", ctypes.c_uint32), ("theta_idx", ctypes.c_int32),
+                ("sign", ctypes.c_int32), ("nfix", ctypes.c_int32),
+                ("pos", ctypes.c_int32 * 4)]
+
+
+GATE_NBYTES = ctypes.sizeof(GateT)
+
+# name -> (restype, argtypes)   -- must list every symbol of include/oovqe.h
+SIGNATURES = {
+    "oovqe_version": (ctypes.c_int, []),
+    "oovqe_last_error": (ctypes.c_char_p, []),
+    "oovqe_device_count": (ctypes.c_int, []),
+    "oovqe_general_4index_transform": (ctypes.c_int, [c_double_p] * 5 + [ctypes.c_int, c_double_p,
+                                                                      c_double_p, c_stream]),
+    "oovqe_matmul_nn": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_int, c_double_p, c_stream]),
+    "oovqe_matmul_tn": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_int, c_double_p, c_stream]),
+    "oovqe_mode_contract": (ctypes.c_int, [c_double_p, c_double_p, c_double_p, ctypes.c_int64,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                           ctypes.c_int, c_stream]),
+    "oovqe_expm_skew": (ctypes.c_int, [c_double_p, c_int32_p, c_int32_p, ctypes.c_int, ctypes.c_int,
+                                       c_double_p, c_double_p, c_double_p, c_stream]),
+    "oovqe_expm": (ctypes.c_int, [c_double_p, ctypes.c_double, ctypes.c_int, c_double_p, c_double_p,
+                                  c_stream]),
+    "oovqe_circuit_state": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_uint32, ctypes.c_int, c_double_p,
+                                           c_double_p, c_stream]),
+    "oovqe_rdms": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                  c_double_p, c_double_p, c_double_p, c_stream]),
+    "oovqe_cas_half_transform": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,
+                                                c_double_p, c_stream]),
+    "oovqe_cas_finish_transform": (ctypes.c_int, [c_double_p, c_double_p, c_double_p, ctypes.c_int,
+                                                  ctypes.c_int, c_double_p, c_double_p, c_double_p,
+                                                  c_stream]),
+    "oovqe_cas_energy_gradient": (ctypes.c_int, [c_double_p] * 4 + [ctypes.c_int, ctypes.c_double,
+                                                                   ctypes.c_int, ctypes.c_int,
+                                                                   ctypes.c_int, c_int32_p,
+                                                                   c_int32_p, ctypes.c_int]
+                                  + [c_double_p] * 8 + [c_stream]),
+}
+
+_lib = None
+
+
+def load():
+    """Load liboovqe_hip.so and attach the prototypes.  Raises if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OovqeError(
+            f"{LIB_PATH} not found: build it with auto_oo_amd/csrc/build.sh "
+            "(or __graft_entry__.build()).  auto_oo_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)     # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().oovqe_last_error().decode("utf-8", "replace")
+        raise OovqeError(f"{what} failed (rc={rc}): {msg}")
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_device():
+    """Fail loudly when no HIP device is usable (product code never falls back to CPU)."""
+    if not torch.cuda.is_available():
+        raise OovqeError("auto_oo_amd needs a HIP device (MI355X); none is visible and there is "
+                         "no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def dptr(t, dtype=torch.float64):
+    """Device pointer of a contiguous CUDA tensor of the expected dtype."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise OovqeError("expected a CUDA(HIP) tensor")
+    if t.dtype != dtype:
+        raise OovqeError(f"expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise OovqeError("expected a contiguous tensor")
+    return ctypes.c_void_p(t.data_ptr())

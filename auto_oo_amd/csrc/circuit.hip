@@ -1,0 +1,265 @@
+// Statevector simulation of excitation-gate circuits (UCCD / kUpCCD / UCCSD) and RDMs.
+//
+// The reference hands a UCCD / kUpCCD operator to PennyLane's default.qubit, which decomposes
+// every FermionicDoubleExcitation into ~150 one-/two-qubit gates (src/auto_oo/ansatze/uccd.py:
+// 105-114, kUpCCD.py:118-130, pqc.py:69-76).  Here each excitation is ONE sparse Givens pass
+// over the 2^n real amplitudes (closed form: include/oovqe.h, oovqe_gate_t); the state never
+// becomes complex.  Tangent states d psi / d theta_k come from the same pass with the k-th gate
+// replaced by its derivative (forward mode).
+#include "common.h"
+
+namespace {
+
+constexpr int CIRC_THREADS = 256;
+constexpr int LDS_STATE_MAX = 8192;   // amplitudes kept in LDS (64 KiB); larger states live in HBM/L2
+
+__device__ __forceinline__ uint32_t deposit(uint32_t t, const oovqe_gate_t& g)
+{
+    // insert zero bits at the (ascending) positions g.pos[0..nfix)
+    uint32_t x = t;
+    for (int i = 0; i < g.nfix; ++i) {
+        const uint32_t p = (uint32_t)g.pos[i];
+        const uint32_t low = x & ((1u << p) - 1u);
+        x = ((x >> p) << (p + 1)) | low;
+    }
+    return x;
+}
+
+// Apply one gate (or its theta-derivative) to `st` (LDS or global), D = 2^n amplitudes.
+__device__ void apply_gate(double* st, uint32_t D, const oovqe_gate_t& g, double c, double s,
+                           bool deriv)
+{
+    const uint32_t fm = g.mask_hi | g.mask_lo;
+    const uint32_t npairs = D >> g.nfix;
+    if (!deriv) {
+        for (uint32_t t = threadIdx.x; t < npairs; t += CIRC_THREADS) {
+            const uint32_t x = deposit(t, g) | g.mask_hi;
+            const uint32_t y = x ^ fm;
+            const double pi = (__popc(x & g.mask_par) & 1) ? -1.0 : 1.0;
+            const double ax = st[x], ay = st[y];
+            st[x] = c * ax + pi * s * ay;
+            st[y] = c * ay - pi * s * ax;
+        }
+    } else {
+        // d/dtheta [c, pi s; -pi s, c] = (sign/2) [-s, pi c; -pi c, -s]; identity part -> 0
+        const double h = 0.5 * (double)g.sign;
+        for (uint32_t t = threadIdx.x; t < npairs; t += CIRC_THREADS) {
+            const uint32_t x = deposit(t, g) | g.mask_hi;
+            const uint32_t y = x ^ fm;
+            const double pi = (__popc(x & g.mask_par) & 1) ? -1.0 : 1.0;
+            const double ax = st[x], ay = st[y];
+            st[x] = h * (-s * ax + pi * c * ay);
+            st[y] = h * (-s * ay - pi * c * ax);
+        }
+        for (uint32_t x = threadIdx.x; x < D; x += CIRC_THREADS) {
+            const uint32_t f = x & fm;
+            if (f != g.mask_hi && f != g.mask_lo) st[x] = 0.0;
+        }
+    }
+}
+
+// Run the whole circuit on working buffer w (LDS or global); dgate = index of the gate to
+// differentiate, or -1.
+__device__ void run_circuit(double* w, uint32_t D, uint32_t init_index, const double* th,
+                            const oovqe_gate_t* __restrict__ gates, int n_gates, int dgate)
+{
+    for (uint32_t x = threadIdx.x; x < D; x += CIRC_THREADS) w[x] = (x == init_index) ? 1.0 : 0.0;
+    __syncthreads();
+    for (int g = 0; g < n_gates; ++g) {
+        const oovqe_gate_t gt = gates[g];
+        if (gt.theta_idx < 0) continue;   // fixed zero angle: identity (never differentiated)
+        double s, c;
+        sincos(0.5 * (double)gt.sign * th[gt.theta_idx], &s, &c);
+        apply_gate(w, D, gt, c, s, g == dgate);
+        __syncthreads();
+    }
+}
+
+// grid = batch * (1 + n_tan); block b*(1+n_tan) + 0 -> psi, + (1+k) -> d psi / d theta_k.
+// use_lds: the working state lives in LDS (D <= LDS_STATE_MAX) and is copied / accumulated to
+// the output; otherwise the output vector itself is the working state (then a parameter may
+// drive at most one gate - checked on the host).
+__global__ __launch_bounds__(CIRC_THREADS)
+void circuit_kernel(const double* __restrict__ theta, int n_theta,
+                    const oovqe_gate_t* __restrict__ gates, int n_gates, int n_qubits,
+                    uint32_t init_index, int n_tan, double* __restrict__ psi,
+                    double* __restrict__ dpsi, int use_lds)
+{
+    extern __shared__ double lds[];
+    const uint32_t D = 1u << n_qubits;
+    const int per = 1 + n_tan;
+    const int b = blockIdx.x / per;
+    const int k = blockIdx.x % per - 1;
+    const double* th = theta + (size_t)b * n_theta;
+    double* dst = (k < 0) ? psi + (size_t)b * D : dpsi + ((size_t)b * n_theta + k) * D;
+
+    if (k < 0) {
+        if (use_lds) {
+            run_circuit(lds, D, init_index, th, gates, n_gates, -1);
+            for (uint32_t x = threadIdx.x; x < D; x += CIRC_THREADS) dst[x] = lds[x];
+        } else {
+            run_circuit(dst, D, init_index, th, gates, n_gates, -1);
+        }
+        return;
+    }
+    // tangent k = sum over the gates driven by theta_k of (circuit with that gate differentiated)
+    bool first = true;
+    for (int g = 0; g < n_gates; ++g) {
+        if (gates[g].theta_idx != k) continue;
+        if (use_lds) {
+            run_circuit(lds, D, init_index, th, gates, n_gates, g);
+            for (uint32_t x = threadIdx.x; x < D; x += CIRC_THREADS)
+                dst[x] = first ? lds[x] : dst[x] + lds[x];
+            __syncthreads();
+        } else if (first) {
+            run_circuit(dst, D, init_index, th, gates, n_gates, g);
+        }
+        first = false;
+    }
+    if (first)
+        for (uint32_t x = threadIdx.x; x < D; x += CIRC_THREADS) dst[x] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// RDMs.  V[pq][x] = (E_pq psi)[x],  E_pq = a+_{2p} a_{2q} + a+_{2p+1} a_{2q+1}
+// (utils/active_space.py:46-52; Jordan-Wigner, spin orbital j = wire j = bit n-1-j, sign =
+// parity of the occupied modes strictly between).  Then
+//   gamma[p,q]     = bra . V_ket[pq]
+//   Gamma[p,q,r,s] = V_bra[qp] . V_ket[rs] - delta_qr gamma[p,s]          (pqc.py:213-217)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void epq_apply_kernel(const double* __restrict__ bra, const double* __restrict__ ket, int n_qubits,
+                      int ncas, double* __restrict__ V)
+{
+    // grid: (x-chunks, 2*ncas^2, batch); V layout [batch][2][ncas^2][D]  (0 = bra, 1 = ket)
+    const uint32_t D = 1u << n_qubits;
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    if (x >= D) return;
+    const int na2 = ncas * ncas;
+    const int which = blockIdx.y / na2;
+    const int pq = blockIdx.y - which * na2;
+    const int p = pq / ncas, q = pq - p * ncas;
+    const int b = blockIdx.z;
+    const double* src = (which == 0 ? bra : ket) + (size_t)b * D;
+    double acc = 0.0;
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+        const int P = 2 * p + sp, Q = 2 * q + sp;
+        const uint32_t bP = 1u << (n_qubits - 1 - P), bQ = 1u << (n_qubits - 1 - Q);
+        if (p == q) {
+            if (x & bP) acc += src[x];
+        } else if ((x & bP) && !(x & bQ)) {
+            // output x has P occupied, Q empty; source had Q occupied, P empty
+            const uint32_t hi = bP > bQ ? bP : bQ, lo = bP > bQ ? bQ : bP;
+            const uint32_t between = (hi - 1u) & ~((lo << 1) - 1u);
+            const double sgn = (__popc(x & between) & 1) ? -1.0 : 1.0;
+            acc += sgn * src[x ^ (bP | bQ)];
+        }
+    }
+    V[(((size_t)b * 2 + which) * na2 + pq) * D + x] = acc;
+}
+
+__global__ __launch_bounds__(256)
+void rdm_gram_kernel(const double* __restrict__ bra, const double* __restrict__ V, int n_qubits,
+                     int ncas, double* __restrict__ gamma, double* __restrict__ Gamma)
+{
+    // grid: (ncas^2 [pq], batch).  One block produces gamma[pq] and the row Gamma[pq, :].
+    __shared__ double scratch[256];
+    __shared__ double gam_row[64];   // gamma[p, s] for s < ncas (ncas <= 64)
+    const uint32_t D = 1u << n_qubits;
+    const int na2 = ncas * ncas;
+    const int pq = blockIdx.x, b = blockIdx.y;
+    const int p = pq / ncas, q = pq - p * ncas;
+    const int tid = threadIdx.x;
+    const double* br = bra + (size_t)b * D;
+    const double* Vb = V + ((size_t)b * 2 + 0) * na2 * D;
+    const double* Vk = V + ((size_t)b * 2 + 1) * na2 * D;
+
+    auto reduce = [&](double v) -> double {
+        scratch[tid] = v;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) scratch[tid] += scratch[tid + s];
+            __syncthreads();
+        }
+        const double r = scratch[0];
+        __syncthreads();
+        return r;
+    };
+
+    // gamma[p, s] for all s (needed for the delta_qr term), gamma[p,q] written by this block
+    for (int s = 0; s < ncas; ++s) {
+        const double* vk = Vk + (size_t)(p * ncas + s) * D;
+        double part = 0.0;
+        for (uint32_t x = tid; x < D; x += 256) part += br[x] * vk[x];
+        const double g = reduce(part);
+        if (tid == 0) gam_row[s] = g;
+    }
+    __syncthreads();
+    if (tid == 0) gamma[(size_t)b * na2 + pq] = gam_row[q];
+
+    const double* vb = Vb + (size_t)(q * ncas + p) * D;   // E_qp bra
+    for (int rs = 0; rs < na2; ++rs) {
+        const double* vk = Vk + (size_t)rs * D;
+        double part = 0.0;
+        for (uint32_t x = tid; x < D; x += 256) part += vb[x] * vk[x];
+        const double g = reduce(part);
+        if (tid == 0) {
+            const int r = rs / ncas, s = rs - r * ncas;
+            Gamma[((size_t)b * na2 + pq) * na2 + rs] = g - (q == r ? gam_row[s] : 0.0);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int oovqe_circuit_state(const double* theta, int n_theta, const oovqe_gate_t* gates,
+                                   int n_gates, int n_qubits, uint32_t init_index, int batch,
+                                   double* psi, double* dpsi, oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(theta && gates && psi, "circuit_state: null pointer");
+    OOVQE_REQUIRE(n_qubits >= 2 && n_qubits <= 26, "circuit_state: n_qubits=%d", n_qubits);
+    OOVQE_REQUIRE(n_theta >= 1 && n_gates >= 1 && batch >= 1, "circuit_state: bad sizes");
+    const uint32_t D = 1u << n_qubits;
+    OOVQE_REQUIRE(init_index < D, "circuit_state: init_index out of range");
+    const int use_lds = D <= (uint32_t)LDS_STATE_MAX;
+    const int n_tan = dpsi ? n_theta : 0;
+    const size_t lds_bytes = use_lds ? (size_t)D * sizeof(double) : 0;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)circuit_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           LDS_STATE_MAX * (int)sizeof(double));
+        if (e != hipSuccess) {
+            oovqe_set_error("circuit_state: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return OOVQE_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    const long nblocks = (long)batch * (1 + n_tan);
+    OOVQE_REQUIRE(nblocks <= 0x7fffffffL, "circuit_state: grid too large");
+    hipLaunchKernelGGL(circuit_kernel, dim3((unsigned)nblocks), dim3(CIRC_THREADS), lds_bytes,
+                       (hipStream_t)stream, theta, n_theta, gates, n_gates, n_qubits, init_index,
+                       n_tan, psi, dpsi, use_lds);
+    OOVQE_CHECK_LAUNCH("circuit_state");
+    return 0;
+}
+
+extern "C" int oovqe_rdms(const double* bra, const double* ket, int n_qubits, int ncas, int batch,
+                          double* gamma, double* Gamma, double* work, oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(bra && ket && gamma && Gamma && work, "rdms: null pointer");
+    OOVQE_REQUIRE(n_qubits == 2 * ncas && ncas >= 1 && ncas <= 13 && batch >= 1,
+                  "rdms: bad sizes n_qubits=%d ncas=%d", n_qubits, ncas);
+    const uint32_t D = 1u << n_qubits;
+    const int na2 = ncas * ncas;
+    hipStream_t st = (hipStream_t)stream;
+    OOVQE_REQUIRE(batch <= 65535, "rdms: batch too large");
+    hipLaunchKernelGGL(epq_apply_kernel, dim3((D + 255) / 256, 2 * na2, batch), dim3(256), 0, st,
+                       bra, ket, n_qubits, ncas, work);
+    OOVQE_CHECK_LAUNCH("rdms/epq_apply");
+    hipLaunchKernelGGL(rdm_gram_kernel, dim3(na2, batch), dim3(256), 0, st, bra, work, n_qubits,
+                       ncas, gamma, Gamma);
+    OOVQE_CHECK_LAUNCH("rdms/gram");
+    return 0;
+}

@@ -1,0 +1,40 @@
+// Shared helpers for liboovqe_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/oovqe.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+#define OOVQE_ERR_ARG   (-1)
+#define OOVQE_ERR_HIP   (-2)
+#define OOVQE_ERR_SIZE  (-3)
+
+void oovqe_set_error(const char* fmt, ...);
+
+#define OOVQE_CHECK_LAUNCH(name)                                                          \
+    do {                                                                                  \
+        hipError_t e__ = hipGetLastError();                                               \
+        if (e__ != hipSuccess) {                                                          \
+            oovqe_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));       \
+            return OOVQE_ERR_HIP;                                                         \
+        }                                                                                 \
+    } while (0)
+
+#define OOVQE_REQUIRE(cond, ...)                                                          \
+    do {                                                                                  \
+        if (!(cond)) {                                                                    \
+            oovqe_set_error(__VA_ARGS__);                                                 \
+            return OOVQE_ERR_ARG;                                                         \
+        }                                                                                 \
+    } while (0)
+
+// v_mfma_f64_16x16x4_f64: D[16x16] += A[16x4] B[4x16].
+// lane l supplies A[m = l&15][k = l>>4] and B[k = l>>4][n = l&15]; receives
+// D[m = (l>>4) + 4*i][n = l&15] in element i of the accumulator (cdna_hip_programming.md:161).
+__device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}

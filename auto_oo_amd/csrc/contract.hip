@@ -1,0 +1,277 @@
+// K1: fp64 mode-contraction GEMM on v_mfma_f64_16x16x4_f64 (gfx950).
+//
+//   INNER:  out[a, j, b] = sum_k Cm[k, j] * T[a, k, b]      T: [A, K, B]  ->  out: [A, J, B]
+//   LAST :  out[a, j]    = sum_k T[a, k]  * Cm[k, j]        T: [A, K]     ->  out: [A, J]
+//
+// This single kernel family carries every dense product of the hot path: the four quarter
+// steps of the (pq|rs)->(ij|kl) transform (reference src/auto_oo/oo_energy.py:26-29), the
+// one-electron transform C^T h C (oo_energy.py:46), mo_coeff = S^-1/2 C_oao (oo_energy.py:176),
+// C U (oo_energy.py:235) and the matrix products inside expm.
+//
+// MI355X mapping
+//   * one wave owns a 16-wide strip of the streamed tensor (16 consecutive b for INNER, 16
+//     consecutive rows a for LAST) and ALL J outputs of its j-group (NT <= 13 MFMA tiles):
+//     every element of T is fetched from HBM exactly once per j-group, straight into the
+//     MFMA operand register (one f64 per lane) - no LDS round trip for the big operand;
+//   * the small matrix Cm is shared by all 8 waves of the workgroup: it is staged through LDS
+//     in K-chunks of 40 rows, double buffered (global->VGPR prefetch during the MFMAs of the
+//     previous chunk), row pitch 16*(NT|1) doubles so that the ds_read_b64 fragment reads of
+//     the two 32-lane halves land on disjoint banks;
+//   * f64 MFMA issues one 16x16x4 every 64 cycles per SIMD, so per 13 MFMAs (832 cycles) a wave
+//     needs 1 global load + 13 LDS reads: the kernel is MFMA-bound by construction.
+#include "common.h"
+
+namespace {
+
+constexpr int KC = 40;            // K rows per LDS chunk
+constexpr int KSTEPS = KC / 4;    // MFMA k-steps per chunk
+constexpr int NWAVES = 8;
+constexpr int NTHREADS = NWAVES * 64;
+
+template <int NT, bool LAST>
+__global__ __launch_bounds__(NTHREADS, 2)
+void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm,
+                     double* __restrict__ out, long A, int K, int J, long B, int ldc, int j0,
+                     long n_items, int nbt)
+{
+    constexpr int LDJ = 16 * (NT | 1);
+    constexpr int CHUNK = KC * LDJ;
+    constexpr int CREG = (CHUNK + NTHREADS - 1) / NTHREADS;
+    extern __shared__ double lds[];   // [2][KC][LDJ]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lq = lane >> 4, lr = lane & 15;
+    const long item = (long)blockIdx.x * NWAVES + wave;
+    const bool active = item < n_items;
+
+    // ---- decode this wave's strip of T ------------------------------------------------------
+    long a = 0, tbase = 0, tstride = 0;
+    bool tvalid = false;
+    long bcol = 0;
+    if (LAST) {
+        a = item * 16;                       // first row of the strip
+        const long row = a + lr;
+        tvalid = active && row < A;
+        tbase = row * (long)K;               // + k
+        tstride = 1;
+    } else {
+        a = item / nbt;
+        const long bt = item - a * nbt;
+        bcol = bt * 16 + lr;
+        tvalid = active && bcol < B;
+        tbase = a * (long)K * B + bcol;      // + k * B
+        tstride = B;
+    }
+
+    const int nchunks = (K + KC - 1) / KC;
+
+    d4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+
+    double creg[CREG];
+    double tcur[KSTEPS], tnext[KSTEPS];
+
+    auto stage_load = [&](int kbase) {
+#pragma unroll
+        for (int i = 0; i < CREG; ++i) {
+            const int idx = tid + i * NTHREADS;
+            const int kk = idx / LDJ, jj = idx - kk * LDJ;
+            const int k = kbase + kk, j = j0 + jj;
+            double v = 0.0;
+            if (idx < CHUNK && k < K && jj < NT * 16 && j < J) v = Cm[(long)k * ldc + j];
+            creg[i] = v;
+        }
+    };
+    auto stage_store = [&](double* buf) {
+#pragma unroll
+        for (int i = 0; i < CREG; ++i) {
+            const int idx = tid + i * NTHREADS;
+            if (idx < CHUNK) buf[idx] = creg[i];
+        }
+    };
+    auto load_t = [&](int kbase, double* dst) {
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            const int k = kbase + s * 4 + lq;
+            dst[s] = (tvalid && k < K) ? T[tbase + (long)k * tstride] : 0.0;
+        }
+    };
+
+    // ---- prologue ---------------------------------------------------------------------------
+    stage_load(0);
+    load_t(0, tcur);
+    stage_store(lds);
+    __syncthreads();
+
+    for (int c = 0; c < nchunks; ++c) {
+        const int kbase = c * KC;
+        const bool more = (c + 1) < nchunks;
+        if (more) {
+            stage_load(kbase + KC);
+            load_t(kbase + KC, tnext);
+        }
+        const double* buf = lds + (c & 1) * CHUNK;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            if (kbase + s * 4 < K) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const double cv = buf[(s * 4 + lq) * LDJ + t * 16 + lr];
+                    acc[t] = LAST ? mfma_f64(tcur[s], cv, acc[t]) : mfma_f64(cv, tcur[s], acc[t]);
+                }
+            }
+        }
+        if (more) stage_store(lds + ((c + 1) & 1) * CHUNK);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) tcur[s] = tnext[s];
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------
+    if (!active) return;
+    if (LAST) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = j0 + t * 16 + lr;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long row = a + lq + 4 * i;
+                if (row < A && col < J) out[row * (long)J + col] = acc[t][i];
+            }
+        }
+    } else {
+        if (bcol >= B) return;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = j0 + t * 16 + lq + 4 * i;
+                if (j < J) out[(a * (long)J + j) * B + bcol] = acc[t][i];
+            }
+        }
+    }
+}
+
+template <int NT, bool LAST>
+int launch_nt(const double* T, const double* Cm, double* out, long A, int K, int J, long B,
+              int ldc, int j0, long n_items, int nbt, hipStream_t st)
+{
+    constexpr int LDJ = 16 * (NT | 1);
+    const size_t lds_bytes = (size_t)2 * KC * LDJ * sizeof(double);
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)contract_kernel<NT, LAST>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes);
+        if (e != hipSuccess) {
+            oovqe_set_error("mode_contract: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return OOVQE_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    const long nblocks = (n_items + NWAVES - 1) / NWAVES;
+    if (nblocks > 0x7fffffffL) {
+        oovqe_set_error("mode_contract: grid too large");
+        return OOVQE_ERR_SIZE;
+    }
+    hipLaunchKernelGGL((contract_kernel<NT, LAST>), dim3((unsigned)nblocks), dim3(NTHREADS),
+                       lds_bytes, st, T, Cm, out, A, K, J, B, ldc, j0, n_items, nbt);
+    OOVQE_CHECK_LAUNCH("mode_contract");
+    return 0;
+}
+
+template <bool LAST>
+int launch_group(int nt, const double* T, const double* Cm, double* out, long A, int K, int J,
+                 long B, int ldc, int j0, long n_items, int nbt, hipStream_t st)
+{
+    switch (nt) {
+#define OOVQE_CASE(n) \
+    case n: return launch_nt<n, LAST>(T, Cm, out, A, K, J, B, ldc, j0, n_items, nbt, st);
+        OOVQE_CASE(1) OOVQE_CASE(2) OOVQE_CASE(3) OOVQE_CASE(4) OOVQE_CASE(5) OOVQE_CASE(6)
+        OOVQE_CASE(7) OOVQE_CASE(8) OOVQE_CASE(9) OOVQE_CASE(10) OOVQE_CASE(11) OOVQE_CASE(12)
+        OOVQE_CASE(13)
+#undef OOVQE_CASE
+    }
+    oovqe_set_error("mode_contract: bad tile count %d", nt);
+    return OOVQE_ERR_ARG;
+}
+
+}  // namespace
+
+int oovqe_mode_contract_impl(const double* T, const double* Cm, double* out, long A, int K, int J,
+                             long B, int ldc, int last, hipStream_t st)
+{
+    OOVQE_REQUIRE(T && Cm && out, "mode_contract: null pointer");
+    OOVQE_REQUIRE(A >= 1 && K >= 1 && J >= 1 && B >= 1 && ldc >= J,
+                  "mode_contract: bad dims A=%ld K=%d J=%d B=%ld ldc=%d", A, K, J, B, ldc);
+    OOVQE_REQUIRE(!last || B == 1, "mode_contract: last-mode needs B == 1");
+    const int JT = (J + 15) / 16;
+    long n_items;
+    int nbt = 1;
+    if (last) {
+        n_items = (A + 15) / 16;
+    } else {
+        const long nb = (B + 15) / 16;
+        OOVQE_REQUIRE(nb <= 0x7fffffffL, "mode_contract: B too large");
+        nbt = (int)nb;
+        n_items = A * nb;
+    }
+    // tiles per wave: as many as fit (T is then streamed once), fewer when the problem is too
+    // small to fill 256 CUs with 8-wave workgroups.
+    int nt = JT < 13 ? JT : 13;
+    const long wgs = (n_items + NWAVES - 1) / NWAVES;
+    while (nt > 1 && wgs * ((JT + nt - 1) / nt) < 512) nt = (nt + 1) / 2;
+    for (int jt0 = 0; jt0 < JT; jt0 += nt) {
+        const int ntg = (JT - jt0) < nt ? (JT - jt0) : nt;
+        int rc = last ? launch_group<true>(ntg, T, Cm, out, A, K, J, B, ldc, jt0 * 16, n_items,
+                                           nbt, st)
+                      : launch_group<false>(ntg, T, Cm, out, A, K, J, B, ldc, jt0 * 16, n_items,
+                                            nbt, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int oovqe_mode_contract(const double* T, const double* Cm, double* out, int64_t A, int K,
+                                   int J, int64_t B, int ldc, int last, oovqe_stream_t stream)
+{
+    return oovqe_mode_contract_impl(T, Cm, out, (long)A, K, J, (long)B, ldc, last,
+                                    (hipStream_t)stream);
+}
+
+extern "C" int oovqe_matmul_nn(const double* A, const double* B, int M, int K, int N, double* out,
+                               oovqe_stream_t stream)
+{
+    // out[m,n] = sum_k A[m,k] B[k,n]  == LAST with T = A ([M,K]), Cm = B ([K,N])
+    return oovqe_mode_contract_impl(A, B, out, M, K, N, 1, N, 1, (hipStream_t)stream);
+}
+
+extern "C" int oovqe_matmul_tn(const double* A, const double* B, int M, int K, int N, double* out,
+                               oovqe_stream_t stream)
+{
+    // out[m,n] = sum_k A[k,m] B[k,n]  == INNER with a single slab: Cm = A ([K,M]), T = B ([1,K,N])
+    return oovqe_mode_contract_impl(B, A, out, 1, K, M, N, M, 0, (hipStream_t)stream);
+}
+
+extern "C" int oovqe_general_4index_transform(const double* M, const double* C0, const double* C1,
+                                              const double* C2, const double* C3, int N, double* out,
+                                              double* work, oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(M && C0 && C1 && C2 && C3 && out && work, "4index_transform: null pointer");
+    OOVQE_REQUIRE(N >= 1, "4index_transform: N=%d", N);
+    OOVQE_REQUIRE(out != M && out != work && work != M, "4index_transform: aliased buffers");
+    hipStream_t st = (hipStream_t)stream;
+    const long n = N, n2 = n * n, n3 = n2 * n;
+    int rc;
+    // 'pi,pqrs->iqrs'
+    if ((rc = oovqe_mode_contract_impl(M, C0, work, 1, N, N, n3, N, 0, st))) return rc;
+    // 'qj,iqrs->ijrs'
+    if ((rc = oovqe_mode_contract_impl(work, C1, out, n, N, N, n2, N, 0, st))) return rc;
+    // 'rk,ijrs->ijks'
+    if ((rc = oovqe_mode_contract_impl(out, C2, work, n2, N, N, n, N, 0, st))) return rc;
+    // 'sl,ijks->ijkl'
+    if ((rc = oovqe_mode_contract_impl(work, C3, out, n3, N, N, 1, N, 1, st))) return rc;
+    return 0;
+}

@@ -1,0 +1,318 @@
+// K2: matrix exponential U = expm(sign * X) by scaling-and-squaring with a degree-16 Taylor
+// polynomial evaluated in Paterson-Stockmeyer form (6 matrix products + s squarings, all on
+// the fp64 MFMA).  Replaces math.expm(-K) = torch.linalg.matrix_exp (reference
+// src/auto_oo/oo_energy.py:226-230) together with the kappa -> skew-matrix scatter
+// (oo_energy.py:63-87,213-219).
+//
+// With ||A||_1 <= 1/2 after scaling the truncation error is 0.5^17/17! = 2e-20, i.e. the result
+// is accurate to fp64 rounding (times the 2^s growth of the squarings), independent of the
+// reference's own (Pade / Taylor) degree choice.
+//
+//   N <= 48 : ONE workgroup, all six N x N matrices resident in LDS (<= 115 KiB), the number
+//             of squarings decided on the device - a single launch, no host round trip.
+//   N  > 48 : matrices in HBM/L2, products through the K1 contraction kernel; the 1-norm is read
+//             back once (8 bytes) to choose s on the host.
+#include "common.h"
+
+int oovqe_mode_contract_impl(const double* T, const double* Cm, double* out, long A, int K, int J,
+                             long B, int ldc, int last, hipStream_t st);
+
+namespace {
+
+constexpr double THETA = 0.5;
+constexpr int SMALL_MAX = 48;
+constexpr int EX_THREADS = 512;
+
+// 1/k!
+__constant__ double INV_FACT[17] = {
+    1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+    1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0, 1.0 / 87178291200.0,
+    1.0 / 1307674368000.0, 1.0 / 20922789888000.0};
+static const double H_INV_FACT[17] = {
+    1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+    1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0, 1.0 / 87178291200.0,
+    1.0 / 1307674368000.0, 1.0 / 20922789888000.0};
+
+// C = A * B for zero-padded [NP][LD] LDS matrices (NP = 16 * nt).  8 waves share the nt^2 tiles.
+__device__ void lds_matmul(const double* A, const double* B, double* C, int nt, int ksteps, int LD)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lq = lane >> 4, lr = lane & 15;
+    for (int tile = wave; tile < nt * nt; tile += EX_THREADS / 64) {
+        const int m0 = (tile / nt) * 16, n0 = (tile % nt) * 16;
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        const double* ap = A + (m0 + lr) * LD + lq;
+        const double* bp = B + lq * LD + n0 + lr;
+        for (int ks = 0; ks < ksteps; ++ks) acc = mfma_f64(ap[ks * 4], bp[ks * 4 * LD], acc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) C[(m0 + lq + 4 * i) * LD + n0 + lr] = acc[i];
+    }
+    __syncthreads();
+}
+
+// P = alpha*T + c0 I + c1 A + c2 A2 + c3 A3  on the N x N block
+__device__ void lds_combine(double* P, const double* T, double alpha, const double* A,
+                            const double* A2, const double* A3, double c0, double c1, double c2,
+                            double c3, int N, int LD)
+{
+    for (int idx = threadIdx.x; idx < N * N; idx += EX_THREADS) {
+        const int r = idx / N, c = idx - r * N;
+        const int o = r * LD + c;
+        double v = c1 * A[o] + c2 * A2[o] + c3 * A3[o] + (r == c ? c0 : 0.0);
+        if (T) v += alpha * T[o];
+        P[o] = v;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(EX_THREADS)
+void expm_small_kernel(const double* __restrict__ X, const double* __restrict__ kappa,
+                       const int32_t* __restrict__ kap_row, const int32_t* __restrict__ kap_col,
+                       int n_kappa, double sign, int N, double* __restrict__ Kout,
+                       double* __restrict__ U)
+{
+    extern __shared__ double lds[];
+    __shared__ double colsum[SMALL_MAX];
+    __shared__ int s_shared;
+    const int nt = (N + 15) / 16, NP = nt * 16;
+    const int LD = NP + 2;
+    const int msz = NP * LD;
+    double* A = lds;
+    double* A2 = A + msz;
+    double* A3 = A2 + msz;
+    double* A4 = A3 + msz;
+    double* P = A4 + msz;
+    double* T = P + msz;
+    const int tid = threadIdx.x;
+    const int ksteps = (N + 3) / 4;
+
+    for (int idx = tid; idx < 6 * msz; idx += EX_THREADS) lds[idx] = 0.0;
+    __syncthreads();
+    if (X) {
+        for (int idx = tid; idx < N * N; idx += EX_THREADS) {
+            const int r = idx / N, c = idx - r * N;
+            A[r * LD + c] = sign * X[idx];
+        }
+    } else {
+        // kappa vector -> skew matrix K (lower = +kappa, upper = -kappa); A = sign * K
+        for (int t = tid; t < n_kappa; t += EX_THREADS) {
+            const int r = kap_row[t], c = kap_col[t];
+            const double v = kappa[t];
+            A[r * LD + c] = sign * v;
+            A[c * LD + r] = -sign * v;
+        }
+    }
+    __syncthreads();
+    if (Kout) {
+        for (int idx = tid; idx < N * N; idx += EX_THREADS) {
+            const int r = idx / N, c = idx - r * N;
+            Kout[idx] = sign * A[r * LD + c];   // sign = +-1: undo
+        }
+    }
+    // 1-norm and scaling
+    if (tid < N) {
+        double cs = 0.0;
+        for (int r = 0; r < N; ++r) cs += fabs(A[r * LD + tid]);
+        colsum[tid] = cs;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double nrm = 0.0;
+        for (int c = 0; c < N; ++c) nrm = fmax(nrm, colsum[c]);
+        int s = 0;
+        while (nrm > THETA && s < 60) { nrm *= 0.5; ++s; }
+        s_shared = s;
+    }
+    __syncthreads();
+    const int s = s_shared;
+    const double scale = ldexp(1.0, -s);
+    for (int idx = tid; idx < N * N; idx += EX_THREADS) {
+        const int r = idx / N, c = idx - r * N;
+        A[r * LD + c] *= scale;
+    }
+    __syncthreads();
+    lds_matmul(A, A, A2, nt, ksteps, LD);
+    lds_matmul(A2, A, A3, nt, ksteps, LD);
+    lds_matmul(A2, A2, A4, nt, ksteps, LD);
+    const double* f = INV_FACT;
+    // P = c16 A4 + (c12 I + c13 A + c14 A2 + c15 A3)
+    lds_combine(P, A4, f[16], A, A2, A3, f[12], f[13], f[14], f[15], N, LD);
+    lds_matmul(P, A4, T, nt, ksteps, LD);
+    lds_combine(P, T, 1.0, A, A2, A3, f[8], f[9], f[10], f[11], N, LD);
+    lds_matmul(P, A4, T, nt, ksteps, LD);
+    lds_combine(P, T, 1.0, A, A2, A3, f[4], f[5], f[6], f[7], N, LD);
+    lds_matmul(P, A4, T, nt, ksteps, LD);
+    lds_combine(P, T, 1.0, A, A2, A3, f[0], f[1], f[2], f[3], N, LD);
+    double* cur = P;
+    double* oth = T;
+    for (int i = 0; i < s; ++i) {
+        lds_matmul(cur, cur, oth, nt, ksteps, LD);
+        double* tmp = cur; cur = oth; oth = tmp;
+    }
+    for (int idx = tid; idx < N * N; idx += EX_THREADS) {
+        const int r = idx / N, c = idx - r * N;
+        U[idx] = cur[r * LD + c];
+    }
+}
+
+// ---- large-N helpers (matrices in global memory, [N][N] dense) ------------------------------
+__global__ void scatter_skew_kernel(const double* kappa, const int32_t* kap_row,
+                                    const int32_t* kap_col, int n_kappa, int N, double* K)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_kappa) {
+        const int r = kap_row[t], c = kap_col[t];
+        K[(size_t)r * N + c] = kappa[t];
+        K[(size_t)c * N + r] = -kappa[t];
+    }
+}
+
+__global__ __launch_bounds__(256)
+void norm1_kernel(const double* X, int N, double* out)
+{
+    __shared__ double red[256];
+    double best = 0.0;
+    for (int c = threadIdx.x; c < N; c += 256) {
+        double cs = 0.0;
+        for (int r = 0; r < N; ++r) cs += fabs(X[(size_t)r * N + c]);
+        best = fmax(best, cs);
+    }
+    red[threadIdx.x] = best;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+__global__ void scale_kernel(const double* X, double f, long n, double* A)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) A[i] = f * X[i];
+}
+
+__global__ void combine_kernel(double* P, const double* T, double alpha, const double* A,
+                               const double* A2, const double* A3, double c0, double c1, double c2,
+                               double c3, int N)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * N) return;
+    const int r = (int)(i / N), c = (int)(i - (long)r * N);
+    double v = c1 * A[i] + c2 * A2[i] + c3 * A3[i] + (r == c ? c0 : 0.0);
+    if (T) v += alpha * T[i];
+    P[i] = v;
+}
+
+int expm_large(const double* X, double sign, int N, double* U, double* work, hipStream_t st)
+{
+    const long n2 = (long)N * N;
+    double* A = work;
+    double* A2 = A + n2;
+    double* A3 = A2 + n2;
+    double* A4 = A3 + n2;
+    double* P = A4 + n2;
+    double* T = P + n2;
+    // 1-norm -> host (8 bytes) -> number of squarings
+    norm1_kernel<<<1, 256, 0, st>>>(X, N, T);
+    double nrm = 0.0;
+    hipError_t e = hipMemcpyAsync(&nrm, T, sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        oovqe_set_error("expm: norm readback: %s", hipGetErrorString(e));
+        return OOVQE_ERR_HIP;
+    }
+    if (!(nrm == nrm) || nrm > 1e300) {
+        oovqe_set_error("expm: non-finite input");
+        return OOVQE_ERR_ARG;
+    }
+    int s = 0;
+    while (nrm > THETA && s < 60) { nrm *= 0.5; ++s; }
+    const unsigned nb = (unsigned)((n2 + 255) / 256);
+    scale_kernel<<<nb, 256, 0, st>>>(X, sign * ldexp(1.0, -s), n2, A);
+    int rc;
+#define MM(a, b, c) if ((rc = oovqe_mode_contract_impl(a, b, c, N, N, N, 1, N, 1, st))) return rc
+    MM(A, A, A2);
+    MM(A2, A, A3);
+    MM(A2, A2, A4);
+    const double* f = H_INV_FACT;
+    combine_kernel<<<nb, 256, 0, st>>>(P, A4, f[16], A, A2, A3, f[12], f[13], f[14], f[15], N);
+    MM(P, A4, T);
+    combine_kernel<<<nb, 256, 0, st>>>(P, T, 1.0, A, A2, A3, f[8], f[9], f[10], f[11], N);
+    MM(P, A4, T);
+    combine_kernel<<<nb, 256, 0, st>>>(P, T, 1.0, A, A2, A3, f[4], f[5], f[6], f[7], N);
+    MM(P, A4, T);
+    combine_kernel<<<nb, 256, 0, st>>>(P, T, 1.0, A, A2, A3, f[0], f[1], f[2], f[3], N);
+    double* cur = P;
+    double* oth = T;
+    for (int i = 0; i < s; ++i) {
+        MM(cur, cur, oth);
+        double* tmp = cur; cur = oth; oth = tmp;
+    }
+#undef MM
+    e = hipMemcpyAsync(U, cur, n2 * sizeof(double), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) {
+        oovqe_set_error("expm: copy: %s", hipGetErrorString(e));
+        return OOVQE_ERR_HIP;
+    }
+    OOVQE_CHECK_LAUNCH("expm");
+    return 0;
+}
+
+int expm_small(const double* X, const double* kappa, const int32_t* kap_row, const int32_t* kap_col,
+               int n_kappa, double sign, int N, double* Kout, double* U, hipStream_t st)
+{
+    const int nt = (N + 15) / 16, NP = nt * 16, LD = NP + 2;
+    const size_t lds_bytes = (size_t)6 * NP * LD * sizeof(double);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)expm_small_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) {
+            oovqe_set_error("expm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return OOVQE_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(expm_small_kernel, dim3(1), dim3(EX_THREADS), lds_bytes, st, X, kappa,
+                       kap_row, kap_col, n_kappa, sign, N, Kout, U);
+    OOVQE_CHECK_LAUNCH("expm_small");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int oovqe_expm(const double* X, double sign, int N, double* U, double* work,
+                          oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(X && U, "expm: null pointer");
+    OOVQE_REQUIRE(N >= 1 && N <= 4096, "expm: N=%d", N);
+    OOVQE_REQUIRE(sign == 1.0 || sign == -1.0, "expm: sign must be +-1");
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= SMALL_MAX) return expm_small(X, nullptr, nullptr, nullptr, 0, sign, N, nullptr, U, st);
+    OOVQE_REQUIRE(work, "expm: work buffer required for N > %d", SMALL_MAX);
+    return expm_large(X, sign, N, U, work, st);
+}
+
+extern "C" int oovqe_expm_skew(const double* kappa, const int32_t* kap_row, const int32_t* kap_col,
+                               int n_kappa, int N, double* K, double* U, double* work,
+                               oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(kappa && kap_row && kap_col && U, "expm_skew: null pointer");
+    OOVQE_REQUIRE(N >= 1 && N <= 4096 && n_kappa >= 0, "expm_skew: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= SMALL_MAX)
+        return expm_small(nullptr, kappa, kap_row, kap_col, n_kappa, -1.0, N, K, U, st);
+    OOVQE_REQUIRE(work, "expm_skew: work buffer (7*N*N doubles) required for N > %d", SMALL_MAX);
+    // K lives in the 7th N*N block of work unless the caller wants it back
+    double* Kbuf = K ? K : work + (size_t)6 * N * N;
+    hipError_t e = hipMemsetAsync(Kbuf, 0, (size_t)N * N * sizeof(double), st);
+    if (e != hipSuccess) {
+        oovqe_set_error("expm_skew: memset: %s", hipGetErrorString(e));
+        return OOVQE_ERR_HIP;
+    }
+    if (n_kappa > 0)
+        scatter_skew_kernel<<<(n_kappa + 255) / 256, 256, 0, st>>>(kappa, kap_row, kap_col, n_kappa,
+                                                                  N, Kbuf);
+    return expm_large(Kbuf, -1.0, N, U, work, st);
+}

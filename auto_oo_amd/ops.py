@@ -1,0 +1,179 @@
+"""Thin torch-tensor wrappers over the C ABI (include/oovqe.h).
+
+Each function allocates its outputs with torch (device memory + stream plumbing only), passes raw
+device pointers to liboovqe_hip.so and returns torch tensors.  No arithmetic happens here and
+there is no CPU path: every call needs a HIP device.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, dptr, stream_ptr
+
+F64 = torch.float64
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise _lib.OovqeError("auto_oo_amd ops need CUDA(HIP) tensors; no CPU fallback exists")
+    return t.device
+
+
+def as_device(x, device=None):
+    """numpy / torch (any device) -> contiguous fp64 tensor on the HIP device."""
+    dev = device if device is not None else _lib.require_device()
+    if isinstance(x, torch.Tensor):
+        return x.detach().to(device=dev, dtype=F64).contiguous()
+    return torch.as_tensor(np.asarray(x, dtype=np.float64), dtype=F64, device=dev).contiguous()
+
+
+def mode_contract(T, Cm, A, K, J, B, last, out=None):
+    lib = _lib.load()
+    dev = _dev(T)
+    if out is None:
+        out = torch.empty(A * J * B, dtype=F64, device=dev)
+    ldc = Cm.shape[-1]
+    check(lib.oovqe_mode_contract(dptr(T), dptr(Cm), dptr(out), A, K, J, B, ldc, int(bool(last)),
+                                  stream_ptr()), "oovqe_mode_contract")
+    return out
+
+
+def matmul_nn(A, B):
+    """A @ B"""
+    lib = _lib.load()
+    M, K = A.shape
+    K2, N = B.shape
+    assert K == K2
+    out = torch.empty((M, N), dtype=F64, device=_dev(A))
+    check(lib.oovqe_matmul_nn(dptr(A), dptr(B), M, K, N, dptr(out), stream_ptr()),
+          "oovqe_matmul_nn")
+    return out
+
+
+def matmul_tn(A, B):
+    """A.T @ B"""
+    lib = _lib.load()
+    K, M = A.shape
+    K2, N = B.shape
+    assert K == K2
+    out = torch.empty((M, N), dtype=F64, device=_dev(A))
+    check(lib.oovqe_matmul_tn(dptr(A), dptr(B), M, K, N, dptr(out), stream_ptr()),
+          "oovqe_matmul_tn")
+    return out
+
+
+def general_4index_transform(M, C0, C1, C2, C3, out=None, work=None):
+    lib = _lib.load()
+    N = M.shape[0]
+    dev = _dev(M)
+    if out is None:
+        out = torch.empty((N, N, N, N), dtype=F64, device=dev)
+    if work is None:
+        work = torch.empty((N, N, N, N), dtype=F64, device=dev)
+    check(lib.oovqe_general_4index_transform(dptr(M), dptr(C0), dptr(C1), dptr(C2), dptr(C3), N,
+                                             dptr(out), dptr(work), stream_ptr()),
+          "oovqe_general_4index_transform")
+    return out
+
+
+def expm_skew(kappa, kap_row, kap_col, N, want_K=False):
+    lib = _lib.load()
+    dev = _dev(kappa)
+    U = torch.empty((N, N), dtype=F64, device=dev)
+    K = torch.empty((N, N), dtype=F64, device=dev) if want_K else None
+    work = torch.empty(7 * N * N, dtype=F64, device=dev) if N > 48 else None
+    check(lib.oovqe_expm_skew(dptr(kappa), dptr(kap_row, torch.int32), dptr(kap_col, torch.int32),
+                              kappa.numel(), N, dptr(K), dptr(U), dptr(work), stream_ptr()),
+          "oovqe_expm_skew")
+    return (U, K) if want_K else U
+
+
+def expm(X, sign=1.0):
+    lib = _lib.load()
+    N = X.shape[0]
+    dev = _dev(X)
+    U = torch.empty((N, N), dtype=F64, device=dev)
+    work = torch.empty(6 * N * N, dtype=F64, device=dev) if N > 48 else None
+    check(lib.oovqe_expm(dptr(X), float(sign), N, dptr(U), dptr(work), stream_ptr()), "oovqe_expm")
+    return U
+
+
+def circuit_state(theta, gates_dev, n_gates, n_qubits, init_index, tangents=False):
+    """theta [batch, n_theta] -> psi [batch, D] (and dpsi [batch, n_theta, D])."""
+    lib = _lib.load()
+    dev = _dev(theta)
+    batch, n_theta = theta.shape
+    D = 1 << n_qubits
+    psi = torch.empty((batch, D), dtype=F64, device=dev)
+    dpsi = torch.empty((batch, n_theta, D), dtype=F64, device=dev) if tangents else None
+    check(lib.oovqe_circuit_state(dptr(theta), n_theta, dptr(gates_dev, torch.uint8), n_gates,
+                                  n_qubits, ctypes.c_uint32(init_index), batch, dptr(psi),
+                                  dptr(dpsi), stream_ptr()), "oovqe_circuit_state")
+    return (psi, dpsi) if tangents else psi
+
+
+def rdms(bra, ket, ncas):
+    """bra, ket [batch, D] -> gamma [batch, a, a], Gamma [batch, a, a, a, a] (transition RDMs)."""
+    lib = _lib.load()
+    dev = _dev(bra)
+    batch, D = bra.shape
+    n_qubits = 2 * ncas
+    assert D == 1 << n_qubits and ket.shape == bra.shape
+    gamma = torch.empty((batch, ncas, ncas), dtype=F64, device=dev)
+    Gamma = torch.empty((batch, ncas, ncas, ncas, ncas), dtype=F64, device=dev)
+    work = torch.empty(batch * 2 * ncas * ncas * D, dtype=F64, device=dev)
+    check(lib.oovqe_rdms(dptr(bra), dptr(ket), n_qubits, ncas, batch, dptr(gamma), dptr(Gamma),
+                         dptr(work), stream_ptr()), "oovqe_rdms")
+    return gamma, Gamma
+
+
+def cas_half_transform(g_ao, C, M, out=None):
+    lib = _lib.load()
+    N = C.shape[0]
+    if out is None:
+        out = torch.empty((N, N, M, M), dtype=F64, device=_dev(g_ao))
+    check(lib.oovqe_cas_half_transform(dptr(g_ao), dptr(C), N, M, dptr(out), stream_ptr()),
+          "oovqe_cas_half_transform")
+    return out
+
+
+def cas_finish_transform(T2, h_ao, C, M, Gm=None, hmo=None, work=None):
+    lib = _lib.load()
+    N = C.shape[0]
+    dev = _dev(T2)
+    if Gm is None:
+        Gm = torch.empty((N, M, M, M), dtype=F64, device=dev)
+    if hmo is None:
+        hmo = torch.empty((N, M), dtype=F64, device=dev)
+    if work is None:
+        work = torch.empty(N * M * M * M + N * M, dtype=F64, device=dev)
+    check(lib.oovqe_cas_finish_transform(dptr(T2), dptr(h_ao), dptr(C), N, M, dptr(Gm), dptr(hmo),
+                                         dptr(work), stream_ptr()), "oovqe_cas_finish_transform")
+    return Gm, hmo
+
+
+def cas_energy_gradient(Gm, hmo, gamma, Gamma, nuc, n_occ, ncas, kap_row, kap_col,
+                        want_matrices=True):
+    """gamma [nrdm, a, a], Gamma [nrdm, a, a, a, a]; set 0 = the RDMs, sets >= 1 = derivative RDMs.
+    Returns dict(c0, c1, c2, E, fock, gmat, gvec [nrdm, n_kappa], dE [nrdm-1])."""
+    lib = _lib.load()
+    dev = _dev(Gm)
+    N = Gm.shape[0]
+    nrdm = gamma.shape[0]
+    n_kappa = kap_row.numel()
+    c0 = torch.empty(1, dtype=F64, device=dev)
+    E = torch.empty(1, dtype=F64, device=dev)
+    c1 = torch.empty((ncas, ncas), dtype=F64, device=dev)
+    c2 = torch.empty((ncas,) * 4, dtype=F64, device=dev)
+    fock = torch.empty((N, N), dtype=F64, device=dev) if want_matrices else None
+    gmat = torch.empty((N, N), dtype=F64, device=dev) if want_matrices else None
+    gvec = torch.empty((nrdm, n_kappa), dtype=F64, device=dev)
+    dE = torch.empty(max(nrdm - 1, 1), dtype=F64, device=dev)
+    check(lib.oovqe_cas_energy_gradient(dptr(Gm), dptr(hmo), dptr(gamma), dptr(Gamma), nrdm,
+                                        float(nuc), N, n_occ, ncas, dptr(kap_row, torch.int32),
+                                        dptr(kap_col, torch.int32), n_kappa, dptr(c0), dptr(c1),
+                                        dptr(c2), dptr(E), dptr(fock), dptr(gmat), dptr(gvec),
+                                        dptr(dE), stream_ptr()), "oovqe_cas_energy_gradient")
+    return dict(c0=c0, c1=c1, c2=c2, E=E, fock=fock, gmat=gmat, gvec=gvec, dE=dE[:nrdm - 1])

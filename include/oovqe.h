@@ -1,0 +1,138 @@
+/* oovqe.h -- C ABI of liboovqe_hip.so, the MI355X (gfx950) engine behind auto_oo's
+ * OO_energy / OO_pqc / Parameterized_circuit cost-function API.
+ *
+ * The reference (Emieeel/auto_oo) has no FFI layer: its hot path is a sequence of
+ * pennylane.math / torch / PennyLane-simulator calls.  Each entry point below replaces one such
+ * call sequence; the reference file:line it stands in for is cited per function.  Paths are
+ * relative to the reference repository root.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc'd / torch.Tensor.data_ptr()), caller-owned;
+ *   - all floating point data is fp64, C-contiguous (row-major), exactly the reference's layout;
+ *   - index tables are int32;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work;
+ *   - return value: 0 on success, negative on error (oovqe_last_error() gives the text);
+ *     no exceptions cross the ABI, no global state besides the last-error string.
+ */
+#ifndef OOVQE_H
+#define OOVQE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* oovqe_stream_t;
+
+/* ---- library ------------------------------------------------------------------------------ */
+int         oovqe_version(void);
+const char* oovqe_last_error(void);
+/* number of visible HIP devices (<=0: none / runtime error) */
+int         oovqe_device_count(void);
+
+/* ---- gate table for the statevector kernels ----------------------------------------------- *
+ * One entry per excitation gate (qml.FermionicDoubleExcitation / FermionicSingleExcitation /
+ * DoubleExcitation closed forms; src/auto_oo/ansatze/uccd.py:105-114, kUpCCD.py:118-130).
+ * Qubit (wire) w of an n-qubit register is bit (n-1-w) of the basis index (wire 0 = MSB).
+ * For every basis index x with (x & (mask_hi|mask_lo)) == mask_hi and partner y = x ^ (mask_hi|mask_lo):
+ *     pi = (-1)^popcount(x & mask_par);  c = cos(sign*theta/2);  s = sin(sign*theta/2)
+ *     psi'[x] =  c psi[x] + pi s psi[y]
+ *     psi'[y] = -pi s psi[x] + c psi[y]
+ */
+typedef struct {
+    uint32_t mask_hi;    /* bits set in x (the "occupied" pair s,r of an FDE)                 */
+    uint32_t mask_lo;    /* bits set in y (q,p)                                                */
+    uint32_t mask_par;   /* bits whose parity gives the fermionic sign                         */
+    int32_t  theta_idx;  /* which parameter drives this gate (<0: fixed angle 0)               */
+    int32_t  sign;       /* +1 / -1 multiplies theta                                           */
+    int32_t  nfix;       /* popcount(mask_hi|mask_lo): 4 (double) or 2 (single)                */
+    int32_t  pos[4];     /* bit positions of mask_hi|mask_lo, ascending                        */
+} oovqe_gate_t;
+
+/* ---- a1: four-index transform --------------------------------------------------------------
+ * replaces general_4index_transform / uniform_4index_transform / int2e_transform
+ * (src/auto_oo/oo_energy.py:21-30,33-41,49-51):
+ *     out[i,j,k,l] = sum_pqrs C0[p,i] C1[q,j] C2[r,k] C3[s,l] M[p,q,r,s]
+ * M, out: [N,N,N,N]; C*: [N,N]; work: [N^4] scratch.  out may not alias M or work. */
+int oovqe_general_4index_transform(const double* M, const double* C0, const double* C1,
+                                   const double* C2, const double* C3, int N,
+                                   double* out, double* work, oovqe_stream_t stream);
+
+/* ---- a2/a6: small dense products -----------------------------------------------------------
+ * out[m,n] = sum_k A[m,k] B[k,n]         (A: [M,K], B: [K,N])    `@` in oo_energy.py:46,176,201,235
+ * out[m,n] = sum_k A[k,m] B[k,n]         (A: [K,M], B: [K,N])    `.T @` in oo_energy.py:46      */
+int oovqe_matmul_nn(const double* A, const double* B, int M, int K, int N, double* out,
+                    oovqe_stream_t stream);
+int oovqe_matmul_tn(const double* A, const double* B, int M, int K, int N, double* out,
+                    oovqe_stream_t stream);
+
+/* generic mode contraction used by all of the above (and exported for tests):
+ *   last == 0: out[a,j,b] = sum_k Cm[k*ldc + j] * T[a,k,b]     T: [A,K,B], out: [A,J,B]
+ *   last != 0: out[a,j]   = sum_k T[a,k] * Cm[k*ldc + j]       T: [A,K],   out: [A,J]        */
+int oovqe_mode_contract(const double* T, const double* Cm, double* out, int64_t A, int K, int J,
+                        int64_t B, int ldc, int last, oovqe_stream_t stream);
+
+/* ---- a3/a5: kappa -> U = expm(-K) ----------------------------------------------------------
+ * replaces OO_energy.kappa_vector_to_matrix + vector_to_skew_symmetric + math.expm(-K)
+ * (src/auto_oo/oo_energy.py:63-87,213-219,226-230).  kap_row/kap_col [n_kappa]: (row,col) with
+ * row>col of each non-redundant parameter (np.tril_indices order filtered by params_idx).
+ * K: [N,N] out (skew matrix, optional: may be NULL); U: [N,N] out; work: [7*N*N] scratch (only
+ * touched when N > 48; below that the whole computation lives in one workgroup's LDS). */
+int oovqe_expm_skew(const double* kappa, const int32_t* kap_row, const int32_t* kap_col,
+                    int n_kappa, int N, double* K, double* U, double* work,
+                    oovqe_stream_t stream);
+/* U = expm(sign * X) for a general [N,N] matrix X (sign = -1 reproduces math.expm(-X));
+ * work: [6*N*N] scratch (only touched when N > 48). */
+int oovqe_expm(const double* X, double sign, int N, double* U, double* work,
+               oovqe_stream_t stream);
+
+/* ---- a9/a10/a11: statevector + RDMs --------------------------------------------------------
+ * replaces Parameterized_circuit.qnode / uccd_state (src/auto_oo/pqc.py:69-76,121-134,165-172;
+ * ansatze/uccd.py:105-114; ansatze/kUpCCD.py:118-130) and get_rdms_from_state (pqc.py:192-221)
+ * with E_pq / e_pqrs of utils/active_space.py:29-83 (spin orbital 2p = alpha, 2p+1 = beta).
+ *
+ * theta [batch, n_theta]; psi out [batch, D] (real amplitudes; D = 2^n_qubits);
+ * dpsi out [batch, n_theta, D] tangents d psi / d theta_k, or NULL.                          */
+int oovqe_circuit_state(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
+                        int n_qubits, uint32_t init_index, int batch, double* psi, double* dpsi,
+                        oovqe_stream_t stream);
+/* gamma[b,p,q] = bra_b^T E_pq ket_b ; Gamma[b,p,q,r,s] = bra_b^T (E_pq E_rs - d_qr E_ps) ket_b.
+ * bra == ket gives the reference's RDMs; bra != ket gives transition RDMs (used for
+ * d gamma / d theta = T(dpsi,psi) + T(psi,dpsi)).  work: [batch * 2 * ncas^2 * D] scratch.    */
+int oovqe_rdms(const double* bra, const double* ket, int n_qubits, int ncas, int batch,
+               double* gamma, double* Gamma, double* work, oovqe_stream_t stream);
+
+/* ---- a7/a8/a12/a13/a14: fused CAS energy + gradients ---------------------------------------
+ * replaces int1e_transform + int2e_transform + molecular_hamiltonian_coefficients
+ * (oo_energy.py:204-211; utils/active_space.py:111-212), the energy contraction
+ * (oo_energy.py:195-197), fock_core / fock_active / fock_generalized /
+ * analytic_gradient_from_integrals (oo_energy.py:238-309) and kappa_matrix_to_vector
+ * (oo_energy.py:221-224) WITHOUT materialising the N^4 MO tensor: only
+ * Gm[n,x,y,z] = g_mo[n,x,y,z], x,y,z < n_occ+ncas, is formed.
+ *
+ * Stage 1 (the N^4 pass):  T2[p,q,y,z] = sum_rs C[r,y] g_ao[p,q,r,s] C[s,z],  y,z < M.       */
+int oovqe_cas_half_transform(const double* g_ao, const double* C, int N, int M, double* T2,
+                             oovqe_stream_t stream);
+/* Stage 2: Gm[n,x,y,z] = sum_pq C[p,n] C[q,x] T2[p,q,y,z]; hmo[n,x] = (C^T h_ao C)[n,x].
+ * work: [N*M*M*M + N*M] scratch. */
+int oovqe_cas_finish_transform(const double* T2, const double* h_ao, const double* C, int N,
+                               int M, double* Gm, double* hmo, double* work,
+                               oovqe_stream_t stream);
+/* Stage 3: everything that is O(N M^3).  nrdm >= 1 RDM sets: set 0 is (gamma, Gamma) itself and
+ * yields c0,c1,c2,E, the generalized Fock matrix and the orbital gradient; sets k>=1 are
+ * derivative RDMs (d gamma/d theta_k, d Gamma/d theta_k) and yield dE/dtheta_k and the
+ * orbital-circuit Hessian column d G_kappa / d theta_k (oo_pqc.py:86-95,113-119).
+ * outputs: c0[1], c1[a,a], c2[a^4], E[1], fock[N,N], gmat[N,N] (=2(F-F^T)),
+ *          gvec[nrdm, n_kappa] (row 0 = orbital gradient), dE[nrdm-1] (may be NULL if nrdm==1). */
+int oovqe_cas_energy_gradient(const double* Gm, const double* hmo, const double* gamma,
+                              const double* Gamma, int nrdm, double nuc, int N, int n_occ,
+                              int ncas, const int32_t* kap_row, const int32_t* kap_col,
+                              int n_kappa, double* c0, double* c1, double* c2, double* E,
+                              double* fock, double* gmat, double* gvec, double* dE,
+                              oovqe_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OOVQE_H */

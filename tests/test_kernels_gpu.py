@@ -1,0 +1,219 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against the CPU oracle and
+the reference's golden vectors.  Tolerances: fp64 rounding level (<= 1e-11 absolute on O(1..50)
+data); golden literals at the reference's own allclose(rtol=1e-5, atol=1e-8)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from auto_oo_amd import ops, excitations as X   # noqa: E402
+from oracle import cpu_ref as R                  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEV = "cuda"
+
+
+def _load(name):
+    with open(os.path.join(HERE, "golden", name)) as fh:
+        return json.load(fh)
+
+
+def _rand(rng, *shape):
+    return torch.tensor(rng.standard_normal(shape))
+
+
+@pytest.mark.parametrize("A,K,J,B", [(1, 13, 13, 13 ** 3), (13, 13, 13, 169), (169, 13, 13, 13),
+                                     (3, 43, 9, 81), (1, 43, 43, 729), (5, 17, 33, 7),
+                                     (2, 100, 250, 40), (1, 4, 1, 1), (7, 41, 16, 16)])
+def test_mode_contract_inner(A, K, J, B):
+    rng = np.random.default_rng(A * 1000 + K)
+    T = _rand(rng, A, K, B)
+    C = _rand(rng, K, J)
+    ref = torch.einsum("kj,akb->ajb", C, T)
+    out = ops.mode_contract(T.to(DEV), C.to(DEV), A, K, J, B, last=False).cpu().reshape(A, J, B)
+    assert (out - ref).abs().max() < 1e-11 * max(1.0, ref.abs().max())
+
+
+@pytest.mark.parametrize("A,K,J", [(13 ** 3, 13, 13), (43, 43, 9), (100, 43, 43), (1, 5, 3),
+                                   (37, 70, 210), (16, 16, 16)])
+def test_mode_contract_last(A, K, J):
+    rng = np.random.default_rng(A + K)
+    T = _rand(rng, A, K)
+    C = _rand(rng, K, J)
+    ref = T @ C
+    out = ops.mode_contract(T.to(DEV), C.to(DEV), A, K, J, 1, last=True).cpu().reshape(A, J)
+    assert (out - ref).abs().max() < 1e-11 * max(1.0, ref.abs().max())
+
+
+def test_mode_contract_asymmetric_identity():
+    """A = I with an asymmetric second operand catches a swapped C/D row/col map."""
+    K = 32
+    T = torch.arange(K * 48, dtype=torch.float64).reshape(1, K, 48)
+    out = ops.mode_contract(T.to(DEV), torch.eye(K, dtype=torch.float64).to(DEV), 1, K, K, 48,
+                            last=False).cpu().reshape(K, 48)
+    assert torch.equal(out, T[0])
+    T2 = torch.arange(40 * K, dtype=torch.float64).reshape(40, K)
+    out2 = ops.mode_contract(T2.to(DEV), torch.eye(K, dtype=torch.float64).to(DEV), 40, K, K, 1,
+                             last=True).cpu().reshape(40, K)
+    assert torch.equal(out2, T2)
+
+
+def test_matmuls():
+    rng = np.random.default_rng(3)
+    A, B = _rand(rng, 43, 43), _rand(rng, 43, 43)
+    assert (ops.matmul_nn(A.to(DEV), B.to(DEV)).cpu() - A @ B).abs().max() < 1e-12
+    assert (ops.matmul_tn(A.to(DEV), B.to(DEV)).cpu() - A.T @ B).abs().max() < 1e-12
+    A, B = _rand(rng, 30, 17), _rand(rng, 17, 55)
+    assert (ops.matmul_nn(A.to(DEV), B.to(DEV)).cpu() - A @ B).abs().max() < 1e-12
+    A, B = _rand(rng, 17, 30), _rand(rng, 17, 55)
+    assert (ops.matmul_tn(A.to(DEV), B.to(DEV)).cpu() - A.T @ B).abs().max() < 1e-12
+
+
+@pytest.mark.parametrize("N", [13, 43, 20])
+def test_general_4index_transform(N):
+    rng = np.random.default_rng(N)
+    M = _rand(rng, N, N, N, N)
+    Cs = [_rand(rng, N, N) for _ in range(4)]
+    ref = R.general_4index_transform(M, *Cs)
+    out = ops.general_4index_transform(M.to(DEV), *[c.to(DEV) for c in Cs]).cpu()
+    assert (out - ref).abs().max() < 1e-11 * ref.abs().max()
+
+
+@pytest.mark.parametrize("N", [4, 13, 43, 48, 49, 64, 100])
+def test_expm(N):
+    rng = np.random.default_rng(N)
+    for scale in (0.01, 0.3, 3.0):
+        Xm = _rand(rng, N, N) * scale / np.sqrt(N)
+        Xm = Xm - Xm.T
+        ref = torch.linalg.matrix_exp(-Xm)
+        out = ops.expm(Xm.to(DEV), sign=-1.0).cpu()
+        assert (out - ref).abs().max() < 1e-12
+        assert (out.T @ out - torch.eye(N, dtype=torch.float64)).abs().max() < 1e-12
+
+
+@pytest.mark.parametrize("N,no,na", [(13, 6, 3), (43, 6, 3), (60, 5, 4)])
+def test_expm_skew(N, no, na):
+    occ = list(range(no)); act = list(range(no, no + na)); virt = list(range(no + na, N))
+    pidx = X.non_redundant_indices(occ, act, virt, False)
+    rows, cols = X.tril_tables(N, pidx)
+    rng = np.random.default_rng(N)
+    kappa = torch.tensor(rng.normal(0, 0.05, len(pidx)))
+    total = torch.zeros(N * (N - 1) // 2, dtype=torch.float64)
+    total[pidx] = kappa
+    Kref = R.vector_to_skew_symmetric(total)
+    Uref = torch.linalg.matrix_exp(-Kref)
+    U, K = ops.expm_skew(kappa.to(DEV), torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV), N,
+                         want_K=True)
+    assert torch.equal(K.cpu(), Kref)
+    assert (U.cpu() - Uref).abs().max() < 1e-13
+
+
+def _gates_dev(gates):
+    return torch.tensor(X.gates_to_numpy(gates)).to(DEV)
+
+
+@pytest.mark.parametrize("case", [c for c in _load("pqc_states.json") if c["ansatz"] == "ucc"],
+                         ids=lambda c: c["source"])
+def test_circuit_state_golden(case):
+    n = 2 * case["ncas"]
+    gates, n_theta = X.uccd_gates(case["ncas"], case["nelecas"], bool(case["add_singles"]))
+    theta = torch.tensor([case["theta"]], dtype=torch.float64).to(DEV)
+    psi = ops.circuit_state(theta, _gates_dev(gates), len(gates), n,
+                            X.basis_index(X.hf_state(case["nelecas"], n))).cpu().numpy()[0]
+    ref = np.array(case["state_real"])
+    assert np.allclose(psi, ref, rtol=1e-5, atol=1e-8)
+    if not case["source"].endswith(":36"):
+        assert np.abs(psi - ref).max() < 1e-8
+
+
+@pytest.mark.parametrize("case", [c for c in _load("pqc_rdms.json") if c["ansatz"] == "ucc"],
+                         ids=lambda c: c["source"])
+def test_rdms_golden(case):
+    ncas = case["ncas"]
+    n = 2 * ncas
+    gates, _ = X.uccd_gates(ncas, case["nelecas"], bool(case["add_singles"]))
+    theta = torch.tensor([case["theta"]], dtype=torch.float64).to(DEV)
+    psi = ops.circuit_state(theta, _gates_dev(gates), len(gates), n,
+                            X.basis_index(X.hf_state(case["nelecas"], n)))
+    g1, g2 = ops.rdms(psi, psi, ncas)
+    assert np.allclose(g1.cpu().numpy()[0], np.array(case["one_rdm"]), rtol=1e-5, atol=1e-8)
+    assert np.allclose(g2.cpu().numpy()[0], np.array(case["two_rdm"]), rtol=1e-5, atol=1e-8)
+    assert np.abs(g1.cpu().numpy()[0] - np.array(case["one_rdm"])).max() < 1e-8
+    assert np.abs(g2.cpu().numpy()[0] - np.array(case["two_rdm"])).max() < 1e-8
+
+
+@pytest.mark.parametrize("ncas,nelecas,kind", [(3, 4, "uccd"), (3, 4, "uccsd"), (4, 4, "kupccd"),
+                                               (2, 2, "uccd")])
+def test_state_tangents_and_rdms_vs_oracle(ncas, nelecas, kind):
+    n = 2 * ncas
+    if kind == "kupccd":
+        gates, n_theta = X.kupccd_gates(ncas, 1)
+        pqc = R.OraclePQC(ncas, nelecas, "kupccd", k=1)
+    else:
+        gates, n_theta = X.uccd_gates(ncas, nelecas, kind == "uccsd")
+        pqc = R.OraclePQC(ncas, nelecas, "ucc", add_singles=(kind == "uccsd"))
+    rng = np.random.default_rng(11)
+    th = torch.tensor(rng.uniform(0, 2 * np.pi, (2, n_theta)))
+    psi, dpsi = ops.circuit_state(th.to(DEV), _gates_dev(gates), len(gates), n,
+                                  X.basis_index(X.hf_state(nelecas, n)), tangents=True)
+    for b in range(2):
+        ref = pqc.qnode(th[b]).real
+        assert (psi[b].cpu() - ref).abs().max() < 1e-13
+        jac = torch.autograd.functional.jacobian(lambda t: pqc.qnode(t).real, th[b])  # [D, n_theta]
+        assert (dpsi[b].cpu() - jac.T).abs().max() < 1e-12
+    g1, g2 = ops.rdms(psi, psi, ncas)
+    for b in range(2):
+        r1, r2 = pqc.get_rdms(th[b])
+        assert (g1[b].cpu() - r1).abs().max() < 1e-12
+        assert (g2[b].cpu() - r2).abs().max() < 1e-12
+
+
+def _problem(N, seed, nelec, ncas, nelecas):
+    P = R.synthetic_problem(N, seed)
+    mol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec)
+    pqc = R.OraclePQC(ncas, nelecas, "ucc")
+    oo = R.OracleOOPQC(pqc, mol, ncas, nelecas, P["oao_mo_coeff"])
+    return P, oo, pqc
+
+
+@pytest.mark.parametrize("N,seed", [(13, 20261), (43, 20262)])
+def test_cas_pipeline_vs_oracle(N, seed):
+    ncas, nelecas = 3, 4
+    P, oo, pqc = _problem(N, seed, 16, ncas, nelecas)
+    no = len(oo.occ_idx)
+    M = no + ncas
+    C = oo.mo_coeff
+    theta = torch.tensor(np.random.default_rng(5).uniform(0, 2 * np.pi, pqc.theta_shape))
+    g1, g2 = pqc.get_rdms(theta)
+    # oracle
+    E_ref = oo.energy_from_parameters(theta)
+    c0r, c1r, c2r = oo.get_active_integrals(C)
+    G_ref = oo.analytic_gradient(g1, g2)
+    gv_ref = oo.kappa_matrix_to_vector(G_ref)
+    g_mo = R.int2e_transform(oo.int2e_ao, C)
+    h_mo = R.int1e_transform(oo.int1e_ao, C)
+    F_ref = oo.fock_generalized(h_mo, g_mo, g1, g2)
+    # HIP
+    Cd = C.to(DEV).contiguous()
+    gd = oo.int2e_ao.to(DEV).contiguous()
+    T2 = ops.cas_half_transform(gd, Cd, M)
+    T2_ref = torch.einsum("ry,pqrs,sz->pqyz", C[:, :M], oo.int2e_ao, C[:, :M])
+    assert (T2.cpu() - T2_ref).abs().max() < 1e-11
+    Gm, hmo = ops.cas_finish_transform(T2, oo.int1e_ao.to(DEV).contiguous(), Cd, M)
+    assert (Gm.cpu() - g_mo[:, :M, :M, :M]).abs().max() < 1e-11
+    assert (hmo.cpu() - h_mo[:, :M]).abs().max() < 1e-11
+    rows, cols = X.tril_tables(N, oo.params_idx)
+    res = ops.cas_energy_gradient(Gm, hmo, g1.to(DEV)[None].contiguous(),
+                                  g2.to(DEV)[None].contiguous(), oo.nuc, no, ncas,
+                                  torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV))
+    assert abs(res["E"].item() - E_ref.item()) < 1e-9
+    assert abs(res["c0"].item() - float(c0r)) < 1e-9
+    assert (res["c1"].cpu() - c1r).abs().max() < 1e-11
+    assert (res["c2"].cpu() - c2r).abs().max() < 1e-11
+    assert (res["fock"].cpu() - F_ref).abs().max() < 1e-10
+    assert (res["gmat"].cpu() - G_ref).abs().max() < 1e-10
+    assert (res["gvec"].cpu()[0] - gv_ref).abs().max() < 1e-10
