@@ -55,6 +55,9 @@ SIGNATURES = {
                                            c_double_p, c_stream]),
     "oovqe_rdms": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                   c_double_p, c_double_p, c_double_p, c_stream]),
+    "oovqe_rdms_tangent": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
+                                          c_double_p, c_stream]),
     "oovqe_cas_half_transform": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,
                                                 c_double_p, c_stream]),
     "oovqe_cas_finish_transform": (ctypes.c_int, [c_double_p, c_double_p, c_double_p, ctypes.c_int,

@@ -211,6 +211,107 @@ void rdm_gram_kernel(const double* __restrict__ bra, const double* __restrict__ 
     }
 }
 
+// Apply E_pq to nvec vectors per batch element: vec layout [batch][nvec][D] given as psi (vector 0)
+// and dpsi (vectors 1..nvec-1);  V layout [batch][nvec][ncas^2][D].
+__global__ __launch_bounds__(256)
+void epq_apply_multi_kernel(const double* __restrict__ psi, const double* __restrict__ dpsi,
+                            int n_qubits, int ncas, int nvec, double* __restrict__ V)
+{
+    const uint32_t D = 1u << n_qubits;
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    if (x >= D) return;
+    const int na2 = ncas * ncas;
+    const int v = blockIdx.y / na2;
+    const int pq = blockIdx.y - v * na2;
+    const int p = pq / ncas, q = pq - p * ncas;
+    const int b = blockIdx.z;
+    const double* src = (v == 0) ? psi + (size_t)b * D
+                                 : dpsi + ((size_t)b * (nvec - 1) + (v - 1)) * D;
+    double acc = 0.0;
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+        const int P = 2 * p + sp, Q = 2 * q + sp;
+        const uint32_t bP = 1u << (n_qubits - 1 - P), bQ = 1u << (n_qubits - 1 - Q);
+        if (p == q) {
+            if (x & bP) acc += src[x];
+        } else if ((x & bP) && !(x & bQ)) {
+            const uint32_t hi = bP > bQ ? bP : bQ, lo = bP > bQ ? bQ : bP;
+            const uint32_t between = (hi - 1u) & ~((lo << 1) - 1u);
+            const double sgn = (__popc(x & between) & 1) ? -1.0 : 1.0;
+            acc += sgn * src[x ^ (bP | bQ)];
+        }
+    }
+    V[(((size_t)b * nvec + v) * na2 + pq) * D + x] = acc;
+}
+
+// RDMs of psi (set 0) and their theta-derivatives (set k >= 1):
+//   d gamma_k[pq]   = dpsi_k . V0[pq] + psi . Vk[pq]
+//   d Gamma_k[pqrs] = Vk[qp] . V0[rs] + V0[qp] . Vk[rs] - delta_qr d gamma_k[ps]
+// grid: (ncas^2 [pq], nvec [k], batch)
+__global__ __launch_bounds__(256)
+void rdm_tangent_gram_kernel(const double* __restrict__ psi, const double* __restrict__ dpsi,
+                             const double* __restrict__ V, int n_qubits, int ncas, int nvec,
+                             double* __restrict__ gamma, double* __restrict__ Gamma)
+{
+    __shared__ double scratch[256];
+    __shared__ double gam_row[64];
+    const uint32_t D = 1u << n_qubits;
+    const int na2 = ncas * ncas;
+    const int pq = blockIdx.x, k = blockIdx.y, b = blockIdx.z;
+    const int p = pq / ncas, q = pq - p * ncas;
+    const int tid = threadIdx.x;
+    const double* ps = psi + (size_t)b * D;
+    const double* dk = (k == 0) ? ps : dpsi + ((size_t)b * (nvec - 1) + (k - 1)) * D;
+    const double* V0 = V + ((size_t)b * nvec + 0) * na2 * D;
+    const double* Vk = V + ((size_t)b * nvec + k) * na2 * D;
+
+    auto reduce = [&](double v) -> double {
+        scratch[tid] = v;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) scratch[tid] += scratch[tid + s];
+            __syncthreads();
+        }
+        const double r = scratch[0];
+        __syncthreads();
+        return r;
+    };
+
+    for (int s = 0; s < ncas; ++s) {
+        const double* v0 = V0 + (size_t)(p * ncas + s) * D;
+        const double* vk = Vk + (size_t)(p * ncas + s) * D;
+        double part = 0.0;
+        if (k == 0) {
+            for (uint32_t x = tid; x < D; x += 256) part += ps[x] * v0[x];
+        } else {
+            for (uint32_t x = tid; x < D; x += 256) part += dk[x] * v0[x] + ps[x] * vk[x];
+        }
+        const double g = reduce(part);
+        if (tid == 0) gam_row[s] = g;
+    }
+    __syncthreads();
+    const size_t set = (size_t)b * nvec + k;
+    if (tid == 0) gamma[set * na2 + pq] = gam_row[q];
+
+    const double* b0 = V0 + (size_t)(q * ncas + p) * D;   // E_qp psi
+    const double* bk = Vk + (size_t)(q * ncas + p) * D;   // E_qp dpsi_k
+    for (int rs = 0; rs < na2; ++rs) {
+        const double* k0 = V0 + (size_t)rs * D;
+        const double* kk = Vk + (size_t)rs * D;
+        double part = 0.0;
+        if (k == 0) {
+            for (uint32_t x = tid; x < D; x += 256) part += b0[x] * k0[x];
+        } else {
+            for (uint32_t x = tid; x < D; x += 256) part += bk[x] * k0[x] + b0[x] * kk[x];
+        }
+        const double g = reduce(part);
+        if (tid == 0) {
+            const int r = rs / ncas, s = rs - r * ncas;
+            Gamma[(set * na2 + pq) * na2 + rs] = g - (q == r ? gam_row[s] : 0.0);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int oovqe_circuit_state(const double* theta, int n_theta, const oovqe_gate_t* gates,
@@ -261,5 +362,27 @@ extern "C" int oovqe_rdms(const double* bra, const double* ket, int n_qubits, in
     hipLaunchKernelGGL(rdm_gram_kernel, dim3(na2, batch), dim3(256), 0, st, bra, work, n_qubits,
                        ncas, gamma, Gamma);
     OOVQE_CHECK_LAUNCH("rdms/gram");
+    return 0;
+}
+
+extern "C" int oovqe_rdms_tangent(const double* psi, const double* dpsi, int n_qubits, int ncas,
+                                  int n_tan, int batch, double* gamma, double* Gamma, double* work,
+                                  oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(psi && gamma && Gamma && work, "rdms_tangent: null pointer");
+    OOVQE_REQUIRE(n_tan == 0 || dpsi, "rdms_tangent: dpsi required when n_tan > 0");
+    OOVQE_REQUIRE(n_qubits == 2 * ncas && ncas >= 1 && ncas <= 13 && batch >= 1 && n_tan >= 0,
+                  "rdms_tangent: bad sizes n_qubits=%d ncas=%d", n_qubits, ncas);
+    const uint32_t D = 1u << n_qubits;
+    const int na2 = ncas * ncas;
+    const int nvec = 1 + n_tan;
+    OOVQE_REQUIRE(batch <= 65535 && (long)nvec * na2 <= 65535, "rdms_tangent: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(epq_apply_multi_kernel, dim3((D + 255) / 256, nvec * na2, batch), dim3(256),
+                       0, st, psi, dpsi, n_qubits, ncas, nvec, work);
+    OOVQE_CHECK_LAUNCH("rdms_tangent/epq_apply");
+    hipLaunchKernelGGL(rdm_tangent_gram_kernel, dim3(na2, nvec, batch), dim3(256), 0, st, psi, dpsi,
+                       work, n_qubits, ncas, nvec, gamma, Gamma);
+    OOVQE_CHECK_LAUNCH("rdms_tangent/gram");
     return 0;
 }

@@ -31,9 +31,10 @@ constexpr int NTHREADS = NWAVES * 64;
 template <int NT, bool LAST>
 __global__ __launch_bounds__(NTHREADS, 2)
 void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm,
-                     double* __restrict__ out, long A, int K, int J, long B, int ldc, int j0,
+                     double* __restrict__ out, long A, int K, int J, long B, int ldc,
                      long n_items, int nbt)
 {
+    const int j0 = blockIdx.y * (NT * 16);   // this workgroup's j-group
     constexpr int LDJ = 16 * (NT | 1);
     constexpr int CHUNK = KC * LDJ;
     constexpr int CREG = (CHUNK + NTHREADS - 1) / NTHREADS;
@@ -156,7 +157,7 @@ void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm
 
 template <int NT, bool LAST>
 int launch_nt(const double* T, const double* Cm, double* out, long A, int K, int J, long B,
-              int ldc, int j0, long n_items, int nbt, hipStream_t st)
+              int ldc, int ngroups, long n_items, int nbt, hipStream_t st)
 {
     constexpr int LDJ = 16 * (NT | 1);
     const size_t lds_bytes = (size_t)2 * KC * LDJ * sizeof(double);
@@ -176,19 +177,19 @@ int launch_nt(const double* T, const double* Cm, double* out, long A, int K, int
         oovqe_set_error("mode_contract: grid too large");
         return OOVQE_ERR_SIZE;
     }
-    hipLaunchKernelGGL((contract_kernel<NT, LAST>), dim3((unsigned)nblocks), dim3(NTHREADS),
-                       lds_bytes, st, T, Cm, out, A, K, J, B, ldc, j0, n_items, nbt);
+    hipLaunchKernelGGL((contract_kernel<NT, LAST>), dim3((unsigned)nblocks, (unsigned)ngroups),
+                       dim3(NTHREADS), lds_bytes, st, T, Cm, out, A, K, J, B, ldc, n_items, nbt);
     OOVQE_CHECK_LAUNCH("mode_contract");
     return 0;
 }
 
 template <bool LAST>
 int launch_group(int nt, const double* T, const double* Cm, double* out, long A, int K, int J,
-                 long B, int ldc, int j0, long n_items, int nbt, hipStream_t st)
+                 long B, int ldc, int ngroups, long n_items, int nbt, hipStream_t st)
 {
     switch (nt) {
 #define OOVQE_CASE(n) \
-    case n: return launch_nt<n, LAST>(T, Cm, out, A, K, J, B, ldc, j0, n_items, nbt, st);
+    case n: return launch_nt<n, LAST>(T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, st);
         OOVQE_CASE(1) OOVQE_CASE(2) OOVQE_CASE(3) OOVQE_CASE(4) OOVQE_CASE(5) OOVQE_CASE(6)
         OOVQE_CASE(7) OOVQE_CASE(8) OOVQE_CASE(9) OOVQE_CASE(10) OOVQE_CASE(11) OOVQE_CASE(12)
         OOVQE_CASE(13)
@@ -219,18 +220,16 @@ int oovqe_mode_contract_impl(const double* T, const double* Cm, double* out, lon
         n_items = A * nb;
     }
     // tiles per wave: as many as fit (T is then streamed once), fewer when the problem is too
-    // small to fill 256 CUs with 8-wave workgroups.
+    // small to fill 256 CUs with 8-wave workgroups.  The j-groups are grid.y of ONE launch.
     int nt = JT < 13 ? JT : 13;
     const long wgs = (n_items + NWAVES - 1) / NWAVES;
     while (nt > 1 && wgs * ((JT + nt - 1) / nt) < 512) nt = (nt + 1) / 2;
-    for (int jt0 = 0; jt0 < JT; jt0 += nt) {
-        const int ntg = (JT - jt0) < nt ? (JT - jt0) : nt;
-        int rc = last ? launch_group<true>(ntg, T, Cm, out, A, K, J, B, ldc, jt0 * 16, n_items,
-                                           nbt, st)
-                      : launch_group<false>(ntg, T, Cm, out, A, K, J, B, ldc, jt0 * 16, n_items,
-                                            nbt, st);
-        if (rc) return rc;
-    }
+    const int ngroups = (JT + nt - 1) / nt;
+    nt = (JT + ngroups - 1) / ngroups;   // even split
+    OOVQE_REQUIRE(ngroups <= 65535, "mode_contract: J too large");
+    int rc = last ? launch_group<true>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, st)
+                  : launch_group<false>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, st);
+    if (rc) return rc;
     return 0;
 }
 

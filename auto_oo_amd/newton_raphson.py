@@ -1,0 +1,103 @@
+"""Damped Newton step with augmented Hessian and backtracking line search.
+
+Mirror of the reference's ``NewtonStep`` (src/auto_oo/utils/newton_raphson.py:12-224): same
+hyper-parameters, same control flow, same printed messages.  It is a host-side driver over the
+cost function; the (n_theta + n_kappa)-sized ``eigh`` runs through torch on the device (SURVEY.md
+section 2 row 8: out of scope as a kernel).
+"""
+import torch
+
+
+def wolfe(t, grad, dp, alpha=1e-4):
+    """newton_raphson.py:12-13"""
+    return alpha * t * torch.dot(grad, dp)
+
+
+def split_list_shapes(parameters, paramshapes):
+    """newton_raphson.py:214-224"""
+    chunks = []
+    num = 0
+    for shape in paramshapes:
+        shapesize = 1
+        for s in shape:
+            shapesize *= int(s)
+        chunks.append(parameters[num:num + shapesize].reshape(shape))
+        num += shapesize
+    return chunks
+
+
+class NewtonStep():
+    def __init__(self, alpha=0.0001, beta=.5, mu=1e-6, rho=1.1, lmax=20, lambda_min=1e-6,
+                 aug=True, verbose=1):
+        """newton_raphson.py:47-77"""
+        self.alpha = alpha
+        self.beta = beta
+        self.mu = mu
+        self.rho = rho
+        self.lmax = lmax
+        self.lambda_min = lambda_min
+        self.aug = aug
+        self.verbose = verbose
+
+    def newton_step(self, gradient, hessian):
+        """newton_raphson.py:78-129"""
+        vhessian, whessian = torch.linalg.eigh(hessian)
+        lowest_eigenvalue = vhessian[0].item()
+        if self.verbose:
+            print("lowest eigval hessian =", lowest_eigenvalue)
+        if lowest_eigenvalue < self.lambda_min and self.aug:
+            if self.verbose:
+                print("augmenting hessian...")
+            hessian = hessian + (self.mu + self.rho * abs(lowest_eigenvalue)) * torch.eye(
+                hessian.shape[0], dtype=hessian.dtype, device=hessian.device)
+            vhessian, whessian = torch.linalg.eigh(hessian)
+            if self.verbose:
+                print("Lowest eigenvalue of augmented hessian:", vhessian[0].item())
+        hessian_inv = whessian @ torch.diag(1 / vhessian) @ whessian.T
+        dp = - (hessian_inv @ gradient)
+        return dp, lowest_eigenvalue
+
+    def backtracking(self, objective_fn, parameters, dp, gradient):
+        """newton_raphson.py:131-192"""
+        nargs = len(parameters)
+        t = 1.
+        energy = objective_fn(*parameters).item()
+        parameters_tot = torch.cat([parameter.flatten() for parameter in parameters])
+        paramshapes = [tuple(parameter.shape) for parameter in parameters]
+        newp = parameters_tot + (t * dp)
+        test_energy = objective_fn(*split_list_shapes(newp, paramshapes))
+        if test_energy > energy + wolfe(t, gradient, dp, alpha=self.alpha):
+            assert (wolfe(t, gradient, dp, alpha=self.alpha) < 0)
+            num = 0
+            if self.verbose:
+                print("test_energy:", test_energy.item(), "... old energy:", energy)
+                print("do backtracking line search...")
+            while test_energy > energy + wolfe(t, gradient, dp, alpha=self.alpha):
+                t = self.beta * t
+                if self.verbose:
+                    print("t =", t)
+                newp = parameters_tot + (t * dp)
+                test_energy = objective_fn(*split_list_shapes(newp, paramshapes))
+                num += 1
+                if num > self.lmax:
+                    t = 0.
+                    test_energy = objective_fn(*parameters)
+                    if self.verbose:
+                        print("Warning: line search failed. Output previous parameters.")
+                    break
+        new_energy = test_energy.item()
+        newp = parameters_tot + (t * dp)
+        if self.verbose:
+            print("new energy:", new_energy)
+            print("old energy:", energy)
+        if nargs > 1:
+            new_parameters = tuple(split_list_shapes(newp, paramshapes))
+        else:
+            new_parameters = newp
+        return new_parameters, new_energy
+
+    def damped_newton_step(self, objective_fn, parameters, gradient, hessian):
+        """newton_raphson.py:194-211"""
+        dp, lowest_eigenvalue = self.newton_step(gradient, hessian)
+        new_parameters, new_energy = self.backtracking(objective_fn, parameters, dp, gradient)
+        return new_parameters, lowest_eigenvalue

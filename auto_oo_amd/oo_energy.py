@@ -1,0 +1,246 @@
+"""OO_energy: orbital-optimized energy, analytic orbital gradient (and Hessian) on the MI355X.
+
+Drop-in for the reference's ``auto_oo.OO_energy`` and the free functions of
+src/auto_oo/oo_energy.py (same names, argument meaning and error behaviour).  All arithmetic runs
+in hand-written HIP kernels behind the C ABI of include/oovqe.h; torch tensors only carry device
+memory.  There is no CPU path.
+"""
+from functools import partial
+
+import numpy as np
+import torch
+
+from . import _lib, excitations as X, ops
+from .newton_raphson import NewtonStep
+
+F64 = torch.float64
+
+
+# ------------------------------------------------------------------------------------------------
+# free functions (oo_energy.py:21-118)
+# ------------------------------------------------------------------------------------------------
+def general_4index_transform(M, C0, C1, C2, C3):
+    """oo_energy.py:21-30: M'_{ijkl} = sum_pqrs C0_pi C1_qj C2_rk C3_sl M_pqrs (four fp64-MFMA
+    mode contractions, ``oovqe_general_4index_transform``)."""
+    dev = _lib.require_device()
+    return ops.general_4index_transform(ops.as_device(M, dev), ops.as_device(C0, dev),
+                                        ops.as_device(C1, dev), ops.as_device(C2, dev),
+                                        ops.as_device(C3, dev))
+
+
+def uniform_4index_transform(M, C):
+    """oo_energy.py:33-41"""
+    return general_4index_transform(M, C, C, C, C)
+
+
+def int1e_transform(int1e_ao, mo_coeff):
+    """oo_energy.py:44-46: C^T h C"""
+    dev = _lib.require_device()
+    h, C = ops.as_device(int1e_ao, dev), ops.as_device(mo_coeff, dev)
+    return ops.matmul_nn(ops.matmul_tn(C, h), C)
+
+
+def int2e_transform(int2e_ao, mo_coeff):
+    """oo_energy.py:49-51"""
+    return uniform_4index_transform(int2e_ao, mo_coeff)
+
+
+def mo_ao_to_mo_oao(mo_coeff, overlap):
+    """oo_energy.py:54-60 (numpy on the host, once per molecule, as in the reference)"""
+    S_eigval, S_eigvec = np.linalg.eigh(np.asarray(overlap, dtype=np.float64))
+    S_half = S_eigvec @ np.diag(S_eigval ** 0.5) @ S_eigvec.T
+    return S_half @ np.asarray(mo_coeff, dtype=np.float64)
+
+
+def vector_to_skew_symmetric(vector):
+    """oo_energy.py:63-87: strict lower triangle (np.tril_indices order) = vector, upper = -vector.
+    Pure data movement (index scatter)."""
+    vector = torch.as_tensor(vector)
+    size = int(np.sqrt(8 * vector.shape[0] + 1) + 1) // 2
+    matrix = torch.zeros((size, size), dtype=vector.dtype, device=vector.device)
+    tril = np.tril_indices(size, k=-1)
+    r = torch.as_tensor(tril[0], device=vector.device)
+    c = torch.as_tensor(tril[1], device=vector.device)
+    matrix[r, c] = vector
+    matrix[c, r] = -vector
+    return matrix
+
+
+def skew_symmetric_to_vector(kappa_matrix):
+    """oo_energy.py:90-94"""
+    size = kappa_matrix.shape[0]
+    tril = np.tril_indices(size, k=-1)
+    return kappa_matrix[tril[0], tril[1]]
+
+
+def non_redundant_indices(occ_idx, act_idx, virt_idx, freeze_active):
+    """oo_energy.py:97-118"""
+    return X.non_redundant_indices(occ_idx, act_idx, virt_idx, freeze_active)
+
+
+# ------------------------------------------------------------------------------------------------
+class OO_energy:
+    """Orbital Optimized energy class for extracting energies for any given set of RDMs.  Can
+    compute analytical orbital gradients and hessians (oo_energy.py:121-474)."""
+
+    def __init__(self, mol, ncas, nelecas, oao_mo_coeff=None, freeze_active=False,
+                 interface='torch'):
+        if interface != 'torch':
+            raise ValueError("auto_oo_amd supports interface='torch' only (PyTorch-ROCm tensors)")
+        self.device = _lib.require_device()
+        if oao_mo_coeff is None:
+            mol.run_rhf()
+            self.oao_mo_coeff = ops.as_device(mo_ao_to_mo_oao(mol.hf.mo_coeff, mol.overlap),
+                                              self.device)
+        else:
+            self.oao_mo_coeff = ops.as_device(oao_mo_coeff, self.device)
+        self.interface = interface
+
+        # molecular data, resident in HBM
+        self.int1e_ao = ops.as_device(mol.int1e_ao, self.device)
+        self.int2e_ao = ops.as_device(mol.int2e_ao, self.device)
+        self.overlap = mol.overlap
+        self.oao_coeff = ops.as_device(mol.oao_coeff, self.device)
+        self.nuc = mol.nuc
+        self.nao = mol.nao
+
+        self.ncas = ncas
+        self.nelecas = nelecas
+        self.occ_idx, self.act_idx, self.virt_idx = mol.get_active_space_idx(ncas, nelecas)
+        if len(self.occ_idx) and not np.array_equal(self.occ_idx, np.arange(len(self.occ_idx))):
+            raise ValueError("occupied orbitals must be the leading contiguous range")
+        self._n_occ = len(self.occ_idx)
+        self._M = self._n_occ + ncas
+
+        self.params_idx = non_redundant_indices(self.occ_idx, self.act_idx, self.virt_idx,
+                                                freeze_active)
+        self.n_kappa = len(self.params_idx)
+        rows, cols = X.tril_tables(self.nao, self.params_idx)
+        self._kap_row = torch.as_tensor(rows).to(self.device)
+        self._kap_col = torch.as_tensor(cols).to(self.device)
+
+    # ---- helpers ----------------------------------------------------------------------------------
+    def _t(self, x):
+        return ops.as_device(x, self.device)
+
+    def _cas_intermediates(self, mo_coeff):
+        """Stage 1 + 2 of the CAS path: Gm[n,x,y,z] and hmo[n,x] (x,y,z < n_occ+ncas)."""
+        C = self._t(mo_coeff)
+        T2 = ops.cas_half_transform(self.int2e_ao, C, self._M)
+        return ops.cas_finish_transform(T2, self.int1e_ao, C, self._M)
+
+    def _cas_eval(self, mo_coeff, gamma_sets, Gamma_sets, want_matrices=False):
+        """Fused energy / Fock / orbital gradient for a stack of RDM sets (set 0 = RDMs, sets k>=1
+        = derivative RDMs)."""
+        Gm, hmo = self._cas_intermediates(mo_coeff)
+        return ops.cas_energy_gradient(Gm, hmo, gamma_sets, Gamma_sets, self.nuc, self._n_occ,
+                                       self.ncas, self._kap_row, self._kap_col,
+                                       want_matrices=want_matrices)
+
+    def _rdm_stack(self, one_rdm, two_rdm):
+        g1 = self._t(one_rdm).reshape(1, self.ncas, self.ncas)
+        g2 = self._t(two_rdm).reshape((1,) + (self.ncas,) * 4)
+        return g1, g2
+
+    # ---- reference API ------------------------------------------------------------------------------
+    @property
+    def mo_coeff(self):
+        """oo_energy.py:173-176: oao_coeff @ oao_mo_coeff, recomputed on every access."""
+        return ops.matmul_nn(self.oao_coeff, self._t(self.oao_mo_coeff))
+
+    def energy_from_mo_coeff(self, mo_coeff, one_rdm, two_rdm):
+        """oo_energy.py:178-197: E = c0 + sum c1*gamma + sum c2*Gamma (0-dim tensor)."""
+        g1, g2 = self._rdm_stack(one_rdm, two_rdm)
+        return self._cas_eval(mo_coeff, g1, g2)["E"].reshape(())
+
+    def energy_from_kappa(self, kappa, one_rdm, two_rdm):
+        """oo_energy.py:199-202"""
+        mo_coeff = ops.matmul_nn(self.mo_coeff, self.kappa_to_mo_coeff(kappa))
+        return self.energy_from_mo_coeff(mo_coeff, one_rdm, two_rdm)
+
+    def get_active_integrals(self, mo_coeff):
+        """oo_energy.py:204-211: CAS Hamiltonian coefficients (c0, c1, c2) in chemist notation."""
+        dummy1 = torch.zeros((1, self.ncas, self.ncas), dtype=F64, device=self.device)
+        dummy2 = torch.zeros((1,) + (self.ncas,) * 4, dtype=F64, device=self.device)
+        res = self._cas_eval(mo_coeff, dummy1, dummy2)
+        return res["c0"].reshape(()), res["c1"], res["c2"]
+
+    def kappa_vector_to_matrix(self, kappa):
+        """oo_energy.py:213-219"""
+        kappa = self._t(kappa)
+        total = torch.zeros(self.nao * (self.nao - 1) // 2, dtype=F64, device=self.device)
+        total[torch.as_tensor(self.params_idx, device=self.device)] = kappa
+        return vector_to_skew_symmetric(total)
+
+    def kappa_matrix_to_vector(self, kappa_matrix):
+        """oo_energy.py:221-224 (index gather)"""
+        return kappa_matrix[self._kap_row.long(), self._kap_col.long()]
+
+    def kappa_to_mo_coeff(self, kappa):
+        """oo_energy.py:226-230: expm(-K) (``oovqe_expm_skew``: scatter + expm in one launch)."""
+        return ops.expm_skew(self._t(kappa).reshape(-1), self._kap_row, self._kap_col, self.nao)
+
+    def get_transformed_mo(self, mo_coeff, kappa):
+        """oo_energy.py:232-236"""
+        return ops.matmul_nn(self._t(mo_coeff), self.kappa_to_mo_coeff(kappa))
+
+    # ---- Fock matrices / gradient -------------------------------------------------------------------
+    def _fock_from_integrals(self, int1e_mo, int2e_mo, one_rdm, two_rdm):
+        M = self._M
+        g = self._t(int2e_mo)
+        Gm = g[:, :M, :M, :M].contiguous()
+        hmo = self._t(int1e_mo)[:, :M].contiguous()
+        g1, g2 = self._rdm_stack(one_rdm, two_rdm)
+        return ops.cas_energy_gradient(Gm, hmo, g1, g2, self.nuc, self._n_occ, self.ncas,
+                                       self._kap_row, self._kap_col, want_matrices=True)
+
+    def fock_generalized(self, int1e_mo, int2e_mo, one_rdm, two_rdm):
+        """oo_energy.py:238-270: generalized Fock matrix from MO integrals (only the slices
+        g_mo[:, :M, :M, :M] and h_mo[:, :M] are ever read)."""
+        return self._fock_from_integrals(int1e_mo, int2e_mo, one_rdm, two_rdm)["fock"]
+
+    def analytic_gradient_from_integrals(self, int1e_mo, int2e_mo, one_rdm, two_rdm):
+        """oo_energy.py:300-309: G = 2 (F - F^T)"""
+        return self._fock_from_integrals(int1e_mo, int2e_mo, one_rdm, two_rdm)["gmat"]
+
+    def analytic_gradient(self, one_rdm, two_rdm, mo_coeff=None):
+        """oo_energy.py:404-413 (the transform is redone on every call, as in the reference, but
+        only the N M^3 block the gradient reads is formed)."""
+        if mo_coeff is None:
+            mo_coeff = self.mo_coeff
+        g1, g2 = self._rdm_stack(one_rdm, two_rdm)
+        return self._cas_eval(mo_coeff, g1, g2, want_matrices=True)["gmat"]
+
+    def full_hessian_to_matrix(self, full_hess):
+        """oo_energy.py:395-402 (index gathers)"""
+        r, c = self._kap_row.long(), self._kap_col.long()
+        return full_hess[r, c, :, :][:, r, c]
+
+    def orbital_optimization(self, one_rdm, two_rdm, conv_tol=1e-8, max_iterations=100, verbose=0,
+                             **kwargs):
+        """oo_energy.py:426-474: damped-Newton orbital optimisation for fixed RDMs."""
+        objective_fn = partial(self.energy_from_kappa, one_rdm=one_rdm, two_rdm=two_rdm)
+        opt = NewtonStep(verbose=verbose, **kwargs)
+        energy_l = []
+        if verbose:
+            energy = self.energy_from_mo_coeff(self.mo_coeff, one_rdm, two_rdm).item()
+            print(f"Starting energy: {energy:.12f}")
+        for n in range(max_iterations):
+            kappa = torch.zeros(self.n_kappa, dtype=F64, device=self.device)
+            gradient = self.kappa_matrix_to_vector(self.analytic_gradient(one_rdm, two_rdm))
+            hessian = self.full_hessian_to_matrix(self.analytic_hessian(one_rdm, two_rdm))
+            kappa, lowest_eigenvalue = opt.damped_newton_step(objective_fn, (kappa,), gradient,
+                                                              hessian)
+            self.oao_mo_coeff = ops.matmul_nn(self._t(self.oao_mo_coeff),
+                                              self.kappa_to_mo_coeff(kappa))
+            energy = self.energy_from_mo_coeff(self.mo_coeff, one_rdm, two_rdm).item()
+            energy_l.append(energy)
+            if verbose is not None:
+                print(f"iter = {n:03}, energy = {energy:.12f}")
+            if n > 1:
+                if abs(energy_l[-1] - energy_l[-2]) < conv_tol:
+                    if verbose:
+                        print("Orbital optimization finished.")
+                        print("E_fin =", energy_l[-1])
+                    break
+        return energy_l

@@ -1,0 +1,114 @@
+"""OO_pqc: hybrid orbital-optimized VQE cost function (energy, composite gradients, Hessians).
+
+Drop-in for the reference's ``auto_oo.OO_pqc`` (src/auto_oo/oo_pqc.py:30-207).  Where the
+reference obtains theta-derivatives by back-propagating torch autograd through ~500 simulator ops
+(oo_pqc.py:86-95,103-125), this engine propagates tangent states through the Givens passes and
+feeds the derivative RDMs into the same Fock kernel -- the numbers are the same derivatives.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .newton_raphson import NewtonStep
+from .oo_energy import OO_energy
+
+F64 = torch.float64
+
+
+class OO_pqc(OO_energy):
+    def __init__(self, pqc, mol, ncas, nelecas, oao_mo_coeff=None, freeze_active=False,
+                 interface='torch'):
+        """oo_pqc.py:36-62"""
+        super().__init__(mol, ncas, nelecas, oao_mo_coeff=oao_mo_coeff,
+                         freeze_active=freeze_active, interface=interface)
+        self.pqc = pqc
+
+    def _n_theta(self):
+        return int(np.prod(self.pqc.theta_shape))
+
+    # ---- fused evaluation (one pass: state + tangents, RDMs + derivative RDMs, one N^4 sweep) -----
+    def _evaluate(self, theta, mo_coeff=None, derivatives=True, want_matrices=False):
+        if mo_coeff is None:
+            mo_coeff = self.mo_coeff
+        if derivatives:
+            gamma, Gamma = self.pqc.rdms_with_derivatives(theta)
+        else:
+            g1, g2 = self.pqc.get_rdms(theta)
+            gamma, Gamma = g1[None], g2[None]
+        return self._cas_eval(mo_coeff, gamma, Gamma, want_matrices=want_matrices)
+
+    def energy_and_gradient(self, theta):
+        """Extension: E and the full gradient (circuit part, then orbital part) from ONE fused pass
+        (the reference needs three simulations and three N^5 transforms for the same numbers,
+        oo_pqc.py:64-101,132-134)."""
+        res = self._evaluate(theta)
+        return res["E"].reshape(()), torch.cat((res["dE"], res["gvec"][0]))
+
+    # ---- reference API ------------------------------------------------------------------------------
+    def energy_from_parameters(self, theta, kappa=None):
+        """oo_pqc.py:64-84"""
+        if kappa is None:
+            mo_coeff = self.mo_coeff
+        else:
+            mo_coeff = self.get_transformed_mo(self.mo_coeff, kappa)
+        return self._evaluate(theta, mo_coeff, derivatives=False)["E"].reshape(())
+
+    def circuit_gradient(self, theta):
+        """oo_pqc.py:86-95: dE/dtheta"""
+        return self._evaluate(theta)["dE"].reshape(self._n_theta())
+
+    def orbital_gradient(self, theta):
+        """oo_pqc.py:97-101: analytic orbital gradient, flattened to the non-redundant kappa."""
+        return self._evaluate(theta, derivatives=False)["gvec"][0]
+
+    def orbital_circuit_hessian(self, theta):
+        """oo_pqc.py:113-125: d(orbital gradient)/d theta, shape [n_kappa, n_theta]."""
+        res = self._evaluate(theta)
+        return res["gvec"][1:].T.contiguous()
+
+    def full_gradient(self, theta):
+        """oo_pqc.py:132-134"""
+        return self.energy_and_gradient(theta)[1]
+
+    def full_circuit_hessian_to_matrix(self, full_circuit_hessian):
+        """oo_pqc.py:150-153"""
+        size = self._n_theta()
+        return full_circuit_hessian.reshape(size, size)
+
+    def full_optimization(self, theta_init, max_iterations=50, conv_tol=1e-10, verbose=0,
+                          flush=True, **kwargs):
+        """oo_pqc.py:155-207: Newton-Raphson on circuit and orbital parameters together.  The
+        reference's quirks are kept: ``kappa_l`` collects theta (oo_pqc.py:189) and convergence is
+        only tested for n > 1 (oo_pqc.py:200)."""
+        opt = NewtonStep(verbose=verbose, **kwargs)
+        theta_init = self._t(theta_init)
+        energy_init = self.energy_from_parameters(theta_init).item()
+        if verbose is not None:
+            print(f"iter = 000, energy = {energy_init:.12f}", flush=flush)
+        theta_l, kappa_l, oao_mo_coeff_l, energy_l, hess_eig_l = [], [], [], [], []
+        theta = theta_init
+        for n in range(max_iterations):
+            kappa = torch.zeros(self.n_kappa, dtype=F64, device=self.device)
+            grad = self.full_gradient(theta)
+            hess = self.full_hessian(theta)
+            new_theta_kappa, hess_eig = opt.damped_newton_step(
+                self.energy_from_parameters, (theta, kappa), grad, hess)
+            hess_eig_l.append(hess_eig)
+            theta = new_theta_kappa[0].reshape(self.pqc.theta_shape)
+            kappa = new_theta_kappa[1]
+            theta_l.append(theta)
+            kappa_l.append(theta)
+            self.oao_mo_coeff = ops.matmul_nn(self._t(self.oao_mo_coeff),
+                                              self.kappa_to_mo_coeff(kappa))
+            oao_mo_coeff_l.append(self.oao_mo_coeff)
+            energy = self.energy_from_parameters(theta).item()
+            energy_l.append(energy)
+            if verbose is not None:
+                print(f"iter = {n+1:03}, energy = {energy:.12f}")
+            if n > 1:
+                if abs(energy_l[-1] - energy_l[-2]) < conv_tol:
+                    if verbose is not None:
+                        print("optimization finished.")
+                        print("E_fin =", energy_l[-1])
+                    break
+        return energy_l, theta_l, kappa_l, oao_mo_coeff_l, hess_eig_l

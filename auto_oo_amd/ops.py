@@ -14,6 +14,10 @@ from ._lib import check, dptr, stream_ptr
 
 F64 = torch.float64
 
+# Optional (before, after) callables around the dominant kernel launch; bench.py uses it to put
+# HIP events on the launch stream inside its timed region.  None in normal operation.
+KERNEL_HOOK = None
+
 
 def _dev(t):
     if not t.is_cuda:
@@ -129,13 +133,33 @@ def rdms(bra, ket, ncas):
     return gamma, Gamma
 
 
+def rdms_tangent(psi, dpsi, ncas):
+    """psi [batch, D], dpsi [batch, n_tan, D] (or None) -> gamma [batch, 1+n_tan, a, a],
+    Gamma [batch, 1+n_tan, a, a, a, a]: set 0 = RDMs, set k = d/dtheta_k."""
+    lib = _lib.load()
+    dev = _dev(psi)
+    batch, D = psi.shape
+    n_tan = 0 if dpsi is None else dpsi.shape[1]
+    nvec = 1 + n_tan
+    gamma = torch.empty((batch, nvec, ncas, ncas), dtype=F64, device=dev)
+    Gamma = torch.empty((batch, nvec, ncas, ncas, ncas, ncas), dtype=F64, device=dev)
+    work = torch.empty(batch * nvec * ncas * ncas * D, dtype=F64, device=dev)
+    check(lib.oovqe_rdms_tangent(dptr(psi), dptr(dpsi), 2 * ncas, ncas, n_tan, batch, dptr(gamma),
+                                 dptr(Gamma), dptr(work), stream_ptr()), "oovqe_rdms_tangent")
+    return gamma, Gamma
+
+
 def cas_half_transform(g_ao, C, M, out=None):
     lib = _lib.load()
     N = C.shape[0]
     if out is None:
         out = torch.empty((N, N, M, M), dtype=F64, device=_dev(g_ao))
+    hook = KERNEL_HOOK
+    tok = hook[0]() if hook else None
     check(lib.oovqe_cas_half_transform(dptr(g_ao), dptr(C), N, M, dptr(out), stream_ptr()),
           "oovqe_cas_half_transform")
+    if hook:
+        hook[1](tok)
     return out
 
 

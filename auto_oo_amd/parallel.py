@@ -1,0 +1,41 @@
+"""Geometry sharding over the GPUs of one node (one process per GPU, torch.distributed; backend
+"nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for tests).
+
+The reference has no distributed code at all.  The only naturally parallel
+axis of the hot path is the batch of molecular geometries of a Berry-phase loop
+(examples/Tutorial_Berry_phase.ipynb): every geometry owns its AO integrals (27 MB at cc-pVDZ
+shape), nothing is split, and the per-geometry results (energy, gradient, Newton step ...: a few
+KB) are exchanged ONCE per batch with a single all_gather -- latency-bound, so the collective is
+kept out of the per-evaluation path.
+"""
+import torch
+
+
+def shard_geometries(n_geom, rank, world):
+    """Cyclic partition: geometry g lives on rank g % world."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of size {world}")
+    return list(range(rank, n_geom, world))
+
+
+def gather_results(local, my_geoms, n_geom, dist=None):
+    """local [len(my_geoms), n_out] -> [n_geom, n_out] on every rank (row g = geometry g).
+
+    One all_gather of equally sized, zero-padded blocks (ranks may own one geometry more or less)."""
+    n_out = local.shape[1]
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        full = torch.zeros((n_geom, n_out), dtype=local.dtype, device=local.device)
+        full[torch.as_tensor(my_geoms, device=local.device)] = local
+        return full
+    world = dist.get_world_size()
+    per = (n_geom + world - 1) // world
+    block = torch.zeros((per, n_out), dtype=local.dtype, device=local.device)
+    block[:local.shape[0]] = local
+    blocks = [torch.empty_like(block) for _ in range(world)]
+    dist.all_gather(blocks, block)
+    full = torch.zeros((n_geom, n_out), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        geoms = shard_geometries(n_geom, r, world)
+        if geoms:
+            full[torch.as_tensor(geoms, device=local.device)] = blocks[r][:len(geoms)]
+    return full

@@ -1,0 +1,151 @@
+"""Parameterized_circuit: statevector ansatz + RDMs on the MI355X.
+
+Drop-in for the reference's ``auto_oo.Parameterized_circuit`` (src/auto_oo/pqc.py:86-235) for
+``ansatz='ucc'`` (UCCD, and UCCSD with ``add_singles=True``) plus ``ansatz='kupccd'`` (the
+reference defines the kUpCCD operator, ansatze/kUpCCD.py:36-154, but never wires it into
+``Parameterized_circuit``).  The PennyLane device argument ``dev`` is accepted and ignored: the
+state is produced by ``oovqe_circuit_state`` and the RDMs by ``oovqe_rdms*`` (include/oovqe.h).
+"""
+import warnings
+
+import numpy as np
+import torch
+
+from . import _lib, excitations as X, ops
+
+
+class Parameterized_circuit():
+    """Parameterized quantum circuit class.  Defined by an active space of nelecas electrons in
+    ncas orbitals.  ``qnode(theta)`` outputs the quantum state, ``get_rdms`` the one- and two-RDMs."""
+
+    def __init__(self, ncas, nelecas, dev=None, ansatz='ucc', n_layers=3,
+                 add_singles=False, interface='torch', diff_method='backprop', k=1):
+        """
+        Args (pqc.py:91-111):
+            ncas: Number of active orbitals
+            nelecas: Number of active electrons
+            dev: ignored (kept for signature compatibility with the PennyLane-based reference)
+            ansatz: 'ucc' (UCCD / UCCSD) or 'kupccd'
+            n_layers: layers of an 'np_fabric' ansatz (not built yet)
+            add_singles: add UCC single excitations to a 'ucc' ansatz
+            k: number of kUpCCD layers (``ansatz='kupccd'`` only)
+        """
+        if interface != 'torch':
+            raise ValueError("auto_oo_amd supports interface='torch' only (PyTorch-ROCm tensors)")
+        self.ncas = ncas
+        self.nelecas = nelecas
+        self.n_qubits = 2 * ncas
+        self.dev = dev
+        self.add_singles = add_singles
+        self.interface = interface
+        self.device = _lib.require_device()
+
+        self.e_pq = None      # kept for attribute compatibility (pqc.py:118-119); unused:
+        self.e_pqrs = None    # the RDM kernels apply E_pq by bit operations
+        self.up_then_down = False
+
+        if ansatz == 'ucc':
+            self.singles, self.doubles = X.excitations(nelecas, self.n_qubits)
+            self.s_wires, self.d_wires = X.excitations_to_wires(self.singles, self.doubles)
+            self._gates, self.theta_shape = X.uccd_gates(ncas, nelecas, add_singles)
+        elif ansatz == 'kupccd':
+            self.k = k
+            self.d_wires = X.generalized_pair_doubles(range(self.n_qubits))
+            self._gates, n_theta = X.kupccd_gates(ncas, k)
+            self.theta_shape = n_theta
+        elif ansatz == 'np_fabric':
+            raise NotImplementedError(
+                "ansatz='np_fabric' (GateFabric) is not built yet in auto_oo_amd "
+                "(SURVEY.md section 8(f) rank 2)")
+        else:
+            raise ValueError(f"unknown ansatz {ansatz!r}: expected 'ucc' or 'kupccd'")
+        self.ansatz = ansatz
+        self.hfstate = X.hf_state(nelecas, self.n_qubits)
+        self.wires = range(self.n_qubits)
+        self._init_index = X.basis_index(self.hfstate)
+        self._n_gates = len(self._gates)
+        self._gates_dev = torch.as_tensor(X.gates_to_numpy(self._gates)).to(self.device)
+        self.qnode = self._qnode
+
+    # ---- internal real-amplitude entry points ---------------------------------------------------
+    def _theta2d(self, theta):
+        theta = torch.as_tensor(theta)
+        if theta.dtype != torch.float64:
+            warnings.warn("Input a single precision theta. Only double precision is supported.")
+        theta = ops.as_device(theta, self.device).reshape(1, -1)
+        if theta.shape[1] != int(np.prod(self.theta_shape)):
+            raise ValueError(f"Weights tensor must be of shape {(int(np.prod(self.theta_shape)),)}; "
+                             f"got {tuple(theta.shape[1:])}.")
+        return theta
+
+    def state_real(self, theta, tangents=False):
+        """Real amplitudes psi [D] (and tangents d psi/d theta [n_theta, D]) on the device."""
+        th = self._theta2d(theta)
+        res = ops.circuit_state(th, self._gates_dev, self._n_gates, self.n_qubits,
+                                self._init_index, tangents=tangents)
+        if tangents:
+            return res[0][0], res[1][0]
+        return res[0]
+
+    def rdms_with_derivatives(self, theta):
+        """gamma [1+n_theta, a, a], Gamma [1+n_theta, a,a,a,a]: set 0 = RDMs of psi(theta), set k =
+        d/dtheta_k (what autograd yields in the reference, oo_pqc.py:86-95,113-119)."""
+        th = self._theta2d(theta)
+        psi, dpsi = ops.circuit_state(th, self._gates_dev, self._n_gates, self.n_qubits,
+                                      self._init_index, tangents=True)
+        gamma, Gamma = ops.rdms_tangent(psi, dpsi, self.ncas)
+        return gamma[0], Gamma[0]
+
+    # ---- reference API ----------------------------------------------------------------------------
+    def _qnode(self, theta):
+        """State as a complex128 vector of length 2^n (pqc.py:133,165-172).  The UCC(S)D / kUpCCD
+        state is real; the imaginary part is exactly zero here (1e-17 dust in the reference)."""
+        return self.state_real(theta).to(torch.complex128)
+
+    def uccd_state(self, theta):
+        return self._qnode(theta)
+
+    def init_zeros(self):
+        """pqc.py:188-190"""
+        return torch.zeros(self.theta_shape, dtype=torch.float64, device=self.device)
+
+    def get_rdms_from_state(self, state, restricted=True):
+        """pqc.py:192-218: gamma_pq = (state @ (E_pq @ state)).real, Gamma_pqrs likewise with
+        e_pqrs = E_pq E_rs - delta_qr E_ps -- the bilinear form (no conjugation) of the
+        reference: Re[psi^T E psi] = Re(psi)^T E Re(psi) - Im(psi)^T E Im(psi)."""
+        if not restricted:
+            raise NotImplementedError("unrestricted RDMs are not built (never used on the hot path)")
+        state = torch.as_tensor(state)
+        if state.is_complex():
+            re = ops.as_device(state.real, self.device).reshape(1, -1)
+            im = ops.as_device(state.imag, self.device).reshape(1, -1)
+            g1, g2 = ops.rdms(re, re, self.ncas)
+            if bool((im != 0).any()):
+                i1, i2 = ops.rdms(im, im, self.ncas)
+                g1, g2 = g1 - i1, g2 - i2
+            return g1[0], g2[0]
+        re = ops.as_device(state, self.device).reshape(1, -1)
+        g1, g2 = ops.rdms(re, re, self.ncas)
+        return g1[0], g2[0]
+
+    def get_rdms(self, theta, restricted=True):
+        """pqc.py:220-221"""
+        if not restricted:
+            raise NotImplementedError("unrestricted RDMs are not built (never used on the hot path)")
+        psi = self.state_real(theta).reshape(1, -1)
+        g1, g2 = ops.rdms_tangent(psi, None, self.ncas)
+        return g1[0, 0], g2[0, 0]
+
+    def draw_circuit(self, theta):
+        """pqc.py:223-225 (text listing of the excitation gates instead of qml.draw)."""
+        lines = []
+        for g in self._gates:
+            lines.append(f"Givens(theta[{g.theta_idx}]*{g.sign}/2) hi={g.mask_hi:0{self.n_qubits}b} "
+                         f"lo={g.mask_lo:0{self.n_qubits}b} parity={g.mask_par:0{self.n_qubits}b}")
+        return "\n".join(lines)
+
+    def init_e_pq(self, restricted=True):
+        """pqc.py:227-230: nothing to build, E_pq is applied by bit operations on the device."""
+
+    def init_e_pqrs(self, restricted=True):
+        """pqc.py:232-235: see init_e_pq."""

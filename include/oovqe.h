@@ -103,6 +103,15 @@ int oovqe_circuit_state(const double* theta, int n_theta, const oovqe_gate_t* ga
 int oovqe_rdms(const double* bra, const double* ket, int n_qubits, int ncas, int batch,
                double* gamma, double* Gamma, double* work, oovqe_stream_t stream);
 
+/* RDMs of psi and their theta-derivatives in one call (what torch autograd produces for the
+ * reference when it differentiates get_rdms through the simulator, oo_pqc.py:86-95,113-119):
+ *   set 0: gamma, Gamma of psi;  set k>=1: d gamma / d theta_k, d Gamma / d theta_k from the
+ *   tangent dpsi[:,k-1,:].  gamma [batch, 1+n_tan, a, a]; Gamma [batch, 1+n_tan, a,a,a,a];
+ *   work: [batch * (1+n_tan) * ncas^2 * D] scratch.                                             */
+int oovqe_rdms_tangent(const double* psi, const double* dpsi, int n_qubits, int ncas, int n_tan,
+                       int batch, double* gamma, double* Gamma, double* work,
+                       oovqe_stream_t stream);
+
 /* ---- a7/a8/a12/a13/a14: fused CAS energy + gradients ---------------------------------------
  * replaces int1e_transform + int2e_transform + molecular_hamiltonian_coefficients
  * (oo_energy.py:204-211; utils/active_space.py:111-212), the energy contraction

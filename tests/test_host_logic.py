@@ -94,3 +94,10 @@ def test_excitation_lists():
     assert X.excitations(4, 6) == R.excitations(4, 6)
     assert X.excitations(6, 12) == R.excitations(6, 12)
     assert len(X.generalized_pair_doubles(range(16))) == 56
+
+
+def test_synthetic_generator_matches_oracle_copy():
+    from auto_oo_amd.synthetic import synthetic_problem
+    a, b = synthetic_problem(9, 123), R.synthetic_problem(9, 123)
+    for key in a:
+        assert np.array_equal(np.asarray(a[key]), np.asarray(b[key]))
