@@ -71,7 +71,9 @@ def cpu_baseline(seconds_budget=20.0):
     """Reference algorithm (3 simulations + 3 full N^5 transforms + autograd jacobian per
     evaluation, oo_pqc.py:64-101,132-134) restated in plain torch, on the host cores."""
     from oracle import cpu_ref as R
-    cores = os.cpu_count() or 1
+    # a 1-GPU box is given a 16-core share of the host (more threads only oversubscribe the
+    # many tiny torch ops of the reference algorithm)
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     P = R.synthetic_problem(NAO, 20260 + 2)
     mol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], NELEC)
