@@ -37,6 +37,9 @@ SIGNATURES = {
     "oovqe_version": (ctypes.c_int, []),
     "oovqe_last_error": (ctypes.c_char_p, []),
     "oovqe_device_count": (ctypes.c_int, []),
+    "oovqe_profile_begin": (ctypes.c_int, []),
+    "oovqe_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double),
+                                         ctypes.POINTER(ctypes.c_int)]),
     "oovqe_general_4index_transform": (ctypes.c_int, [c_double_p] * 5 + [ctypes.c_int, c_double_p,
                                                                       c_double_p, c_stream]),
     "oovqe_matmul_nn": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,
@@ -58,6 +61,10 @@ SIGNATURES = {
     "oovqe_rdms_tangent": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
                                           c_double_p, c_stream]),
+    "oovqe_circuit_rdms": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int,
+                                          ctypes.c_int, c_double_p, c_double_p, c_double_p,
+                                          c_double_p, c_double_p, c_stream]),
     "oovqe_cas_half_transform": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,
                                                 c_double_p, c_stream]),
     "oovqe_cas_finish_transform": (ctypes.c_int, [c_double_p, c_double_p, c_double_p, ctypes.c_int,
@@ -68,6 +75,11 @@ SIGNATURES = {
                                                                    ctypes.c_int, c_int32_p,
                                                                    c_int32_p, ctypes.c_int]
                                   + [c_double_p] * 8 + [c_stream]),
+    "oovqe_cas_eval": (ctypes.c_int, [c_double_p] * 5 + [ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                                        ctypes.c_int, ctypes.c_int, c_int32_p,
+                                                        c_int32_p, ctypes.c_int]
+                       + [c_double_p] * 11 + [c_stream]),
+    "oovqe_cas_eval_work_size": (ctypes.c_int64, [ctypes.c_int] * 4),
 }
 
 _lib = None

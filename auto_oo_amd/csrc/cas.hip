@@ -18,132 +18,109 @@ int oovqe_mode_contract_impl(const double* T, const double* Cm, double* out, lon
 namespace {
 
 // ------------------------------------------------------------------------------------------
-// Stage 1: one workgroup (4 waves) per (p,q) slab G = g_ao[p,q,:,:]  (N x N, contiguous).
-// Each wave takes 16-row blocks of the slab: coalesced 16-byte global loads -> its private LDS
-// tile (row pitch = 2 mod 4 doubles: conflict-free ds_read_b64 A-fragments), then
-//   X[r,z]  = sum_s G[r,s] C[s,z]        MFMA, A = G tile (LDS), B = C[:, :M] (LDS, shared)
-//   J[y,z] += sum_r C[r,y] X[r,z]        MFMA, A = C (LDS), B = X accumulator registers as-is
-// (the f64 C/D layout row=(lane>>4)+4i, col=lane&15 is exactly a B operand of k-step i).
+// Stage 1: one WAVE per (p,q) slab G = g_ao[p,q,:,:] (N x N, contiguous, 8 N^2 bytes), 8 waves
+// per workgroup sharing only the LDS copy of C[:, :M].  Per 16-column tile (s0..s0+15) of the slab:
+//   Xt[s,y]  = sum_r G[r,s] C[r,y]   MFMA: A = G^T fragment (m = s, k = r), loaded from HBM
+//                                     straight into the operand register: lane (l&15, l>>4) reads
+//                                     G[4ks + (l>>4)][s0 + (l&15)], i.e. four fully used 128-byte
+//                                     segments per wave instruction;  B = C[:, :M] from LDS.
+//   Jt[z,y] += sum_s C[s,z] Xt[s,y]  MFMA: A = C from LDS; B = the Xt accumulator registers as
+//                                     they stand (the f64 C/D layout row=(lane>>4)+4i, col=lane&15
+//                                     IS the B operand of k-step i) - no LDS round trip.
+// Jt stays in the wave's registers for the whole slab: no cross-wave reduction, no barrier after
+// the prologue, every byte of g_ao requested exactly once.  The loads of chunk c+1 are issued
+// before the MFMAs of chunk c (register double buffer).
 // Algorithmic HBM bytes: 8 N^4 read + 8 N^2 M^2 written.
 // ------------------------------------------------------------------------------------------
-template <int ZT>
-__global__ __launch_bounds__(256)
+constexpr int HALF_WAVES = 8;
+
+template <int ZT, int KCH>
+__global__ __launch_bounds__(HALF_WAVES * 64)
 void half_transform_kernel(const double* __restrict__ g, const double* __restrict__ C,
-                           double* __restrict__ T2, int N, int M, int ldG, int nrb,
-                           unsigned magicN, size_t total)
+                           double* __restrict__ T2, int N, int M, int nst, int nkc, long nslabs)
 {
     constexpr int LDM = 16 * (ZT | 1);
-    constexpr int JD = ZT * 16;
     extern __shared__ double lds[];
-    const int RT16 = nrb * 16;
-    double* Cl = lds;                           // [RT16][LDM]
-    double* Gall = Cl + (size_t)RT16 * LDM;     // [4][16][ldG]
-    double* red = Gall + (size_t)4 * 16 * ldG;  // [JD][JD]
+    const int RT16 = nst * 16;
+    double* Cl = lds;   // [RT16][LDM], zero padded
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
-    const size_t slab = blockIdx.x;
-    const size_t slab_off = slab * (size_t)N * N;
-    double* Gw = Gall + (size_t)wave * 16 * ldG;
 
-    for (int idx = tid; idx < RT16 * LDM; idx += 256) {
+    for (int idx = tid; idx < RT16 * LDM; idx += HALF_WAVES * 64) {
         const int r = idx / LDM, z = idx - r * LDM;
         Cl[idx] = (r < N && z < M) ? C[(size_t)r * N + z] : 0.0;
     }
-    for (int idx = tid; idx < JD * JD; idx += 256) red[idx] = 0.0;
+    __syncthreads();
 
-    d4 jacc[ZT][ZT];
-#pragma unroll
-    for (int y = 0; y < ZT; ++y)
-#pragma unroll
-        for (int z = 0; z < ZT; ++z) jacc[y][z] = d4{0.0, 0.0, 0.0, 0.0};
+    const long slab = (long)blockIdx.x * HALF_WAVES + wave;
+    if (slab >= nslabs) return;
+    const double* gs = g + (size_t)slab * N * N;
 
-    const int ksteps = (N + 3) >> 2;
-    const int iters = (nrb + 3) >> 2;
-    for (int it = 0; it < iters; ++it) {
-        const int rb = it * 4 + wave;
-        const bool active = rb < nrb;
-        const int r0 = rb * 16;
-        __syncthreads();   // previous tile fully consumed (and Cl / red initialised)
-        if (active) {
-            const int rows = (N - r0) < 16 ? (N - r0) : 16;
-            const int nel = rows * N;
-            const size_t gs = slab_off + (size_t)r0 * N;
-            const int shift = (int)(gs & 1);
-            const int span = 16 * N;
-            for (int e0 = lane * 2 - shift; e0 < span; e0 += 128) {
-                double v0 = 0.0, v1 = 0.0;
-                if (e0 + 1 >= 0 && e0 < nel) {
-                    const size_t gi = gs + (size_t)(long)e0;   // even -> 16-byte aligned
-                    if (e0 >= 0 && e0 + 1 < nel && gi + 1 < total) {
-                        const d2 v = *reinterpret_cast<const d2*>(g + gi);
-                        v0 = v.x;
-                        v1 = v.y;
-                    } else {
-                        if (e0 >= 0) v0 = g[gi];
-                        if (e0 + 1 < nel) v1 = g[gi + 1];
-                    }
-                }
-                if (e0 >= 0) {
-                    const int row = (int)__umulhi((unsigned)e0, magicN);
-                    Gw[row * ldG + (e0 - row * N)] = v0;
-                }
-                if (e0 + 1 < span) {
-                    const int e1 = e0 + 1;
-                    const int row = (int)__umulhi((unsigned)e1, magicN);
-                    Gw[row * ldG + (e1 - row * N)] = v1;
-                }
-            }
-            // zero the pad columns [N, ldG)
-            const int npad = ldG - N;
-            for (int idx = lane; idx < 16 * npad; idx += 64) {
-                const int row = idx / npad;
-                Gw[row * ldG + N + (idx - row * npad)] = 0.0;
+    d4 jt[ZT][ZT];   // [z tile][y tile]
+#pragma unroll
+    for (int z = 0; z < ZT; ++z)
+#pragma unroll
+        for (int y = 0; y < ZT; ++y) jt[z][y] = d4{0.0, 0.0, 0.0, 0.0};
+
+    // chunk c = st * nkc + kc: column tile st (s = st*16 + lr), k-steps kc*KCH .. +KCH-1 over r
+    const int nchunks = nst * nkc;
+    double acur[KCH], anext[KCH];
+    auto load_chunk = [&](int c, double* dst) {
+        const int st = c / nkc, kc = c - st * nkc;
+        const int col = st * 16 + lr;
+        const int r0 = kc * KCH * 4 + lq;
+        const double* src = gs + (size_t)r0 * N + col;
+#pragma unroll
+        for (int i = 0; i < KCH; ++i)
+            dst[i] = (col < N && r0 + 4 * i < N) ? src[(size_t)4 * i * N] : 0.0;
+    };
+    load_chunk(0, acur);
+    d4 xt[ZT];       // [y tile]
+#pragma unroll
+    for (int y = 0; y < ZT; ++y) xt[y] = d4{0.0, 0.0, 0.0, 0.0};
+
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) load_chunk(c + 1, anext);
+        const int st = c / nkc, kc = c - st * nkc;
+        const double* cb = Cl + (size_t)(kc * KCH * 4 + lq) * LDM + lr;
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            if ((kc * KCH + i) * 4 < N) {
+#pragma unroll
+                for (int y = 0; y < ZT; ++y)
+                    xt[y] = mfma_f64(acur[i], cb[i * 4 * LDM + y * 16], xt[y]);
             }
         }
-        __syncthreads();
-        if (active) {
-            d4 x[ZT];
-#pragma unroll
-            for (int z = 0; z < ZT; ++z) x[z] = d4{0.0, 0.0, 0.0, 0.0};
-            const double* ga = Gw + lr * ldG + lq;
-            const double* cb = Cl + lq * LDM + lr;
-            for (int ks = 0; ks < ksteps; ++ks) {
-                const double av = ga[ks * 4];
-#pragma unroll
-                for (int z = 0; z < ZT; ++z) x[z] = mfma_f64(av, cb[ks * 4 * LDM + z * 16], x[z]);
-            }
-            const double* ca = Cl + (size_t)(r0 + lq) * LDM + lr;
+        if (kc == nkc - 1) {
+            const double* ca = Cl + (size_t)(st * 16 + lq) * LDM + lr;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                for (int y = 0; y < ZT; ++y) {
-                    const double av = ca[i * 4 * LDM + y * 16];
+                for (int z = 0; z < ZT; ++z) {
+                    const double av = ca[i * 4 * LDM + z * 16];
 #pragma unroll
-                    for (int z = 0; z < ZT; ++z) jacc[y][z] = mfma_f64(av, x[z][i], jacc[y][z]);
+                    for (int y = 0; y < ZT; ++y) jt[z][y] = mfma_f64(av, xt[y][i], jt[z][y]);
                 }
             }
+#pragma unroll
+            for (int y = 0; y < ZT; ++y) xt[y] = d4{0.0, 0.0, 0.0, 0.0};
         }
-    }
-    // deterministic cross-wave reduction (fixed order 0,1,2,3)
-    for (int w = 0; w < 4; ++w) {
-        __syncthreads();
-        if (wave == w) {
 #pragma unroll
-            for (int y = 0; y < ZT; ++y)
-#pragma unroll
-                for (int z = 0; z < ZT; ++z)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        red[(y * 16 + lq + 4 * i) * JD + z * 16 + lr] += jacc[y][z][i];
-        }
+        for (int i = 0; i < KCH; ++i) acur[i] = anext[i];
     }
-    __syncthreads();
-    double* dst = T2 + slab * (size_t)M * M;
-    for (int idx = tid; idx < M * M; idx += 256) {
-        const int y = idx / M, z = idx - y * M;
-        dst[idx] = red[y * JD + z];
-    }
+
+    // jt[z tile][y tile][i] = Jt[z = zt*16 + lq + 4i][y = yt*16 + lr]  ->  T2[slab][y][z]
+    double* dst = T2 + (size_t)slab * M * M;
+#pragma unroll
+    for (int z = 0; z < ZT; ++z)
+#pragma unroll
+        for (int y = 0; y < ZT; ++y)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int zz = z * 16 + lq + 4 * i, yy = y * 16 + lr;
+                if (yy < M && zz < M) dst[yy * M + zz] = jt[z][y][i];
+            }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -294,6 +271,179 @@ void fock_kernel(const double* __restrict__ Gm, const double* __restrict__ hmo,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Fused stage 2b + 3 ("column" kernel): one workgroup per general index n.
+//   in : U[n,q,y,z] = sum_p C[p,n] T2[p,q,y,z]   (from the K1 contraction kernel)
+//   Gn[x,y,z] = sum_q C[q,x] U[n,q,y,z]          (= g_mo[n,x,y,z], kept in LDS, 8 M^3 bytes)
+//   hn[x]     = sum_q (sum_p C[p,n] h[p,q]) C[q,x]
+//   FI[n,x], and for every RDM set k the n-th COLUMN of the generalized Fock matrix
+//   (rows m < M only; virtual rows are zero), the per-n pieces of c0 / c1 / c2 and of the energy.
+// Everything the orbital gradient needs from index n is local to this workgroup, so the MO
+// integrals never travel back to HBM unless the caller asks for them (Gm_out != NULL).
+// ------------------------------------------------------------------------------------------
+constexpr int COL_THREADS = 256;
+
+__global__ __launch_bounds__(COL_THREADS)
+void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ h_ao,
+                       const double* __restrict__ C, const double* __restrict__ gamma,
+                       const double* __restrict__ Gamma, int nrdm, int N, int no, int na,
+                       double* __restrict__ Fcol, double* __restrict__ Epart,
+                       double* __restrict__ Cpart, double* __restrict__ c1, double* __restrict__ c2,
+                       double* __restrict__ Gm_out, double* __restrict__ hmo_out)
+{
+    extern __shared__ double lds[];
+    const int M = no + na, M2 = M * M, M3 = M2 * M;
+    const int na2 = na * na, na3 = na2 * na, na4 = na2 * na2;
+    double* Un = lds;                    // [N][M2]
+    double* Cl = Un + (size_t)N * M2;    // [N][M]   C[:, :M]
+    double* Gn = Cl + (size_t)N * M;     // [M3]
+    double* Wn = Gn + M3;                // [N]      (C^T h)[n, :]
+    double* hn = Wn + N;                 // [M]
+    double* FIn = hn + M;                // [M]
+    double* cn = FIn + M;                // [N]      C[:, n]
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x;
+
+    const double* Usrc = U + (size_t)n * N * M2;
+    for (int idx = tid; idx < N * M2; idx += COL_THREADS) Un[idx] = Usrc[idx];
+    for (int idx = tid; idx < N * M; idx += COL_THREADS) {
+        const int q = idx / M, x = idx - q * M;
+        Cl[idx] = C[(size_t)q * N + x];
+    }
+    for (int p = tid; p < N; p += COL_THREADS) cn[p] = C[(size_t)p * N + n];
+    __syncthreads();
+    for (int q = tid; q < N; q += COL_THREADS) {
+        double acc = 0.0;
+        for (int p = 0; p < N; ++p) acc += cn[p] * h_ao[(size_t)p * N + q];
+        Wn[q] = acc;
+    }
+    for (int idx = tid; idx < M3; idx += COL_THREADS) {
+        const int x = idx / M2, yz = idx - x * M2;
+        double acc = 0.0;
+        for (int q = 0; q < N; ++q) acc += Cl[q * M + x] * Un[q * M2 + yz];
+        Gn[idx] = acc;
+    }
+    __syncthreads();
+    if (tid < M) {
+        double acc = 0.0;
+        for (int q = 0; q < N; ++q) acc += Wn[q] * Cl[q * M + tid];
+        hn[tid] = acc;
+        double fi = acc;
+        for (int i = 0; i < no; ++i) fi += 2.0 * Gn[tid * M2 + i * M + i] - Gn[i * M2 + i * M + tid];
+        FIn[tid] = fi;
+    }
+    if (Gm_out)
+        for (int idx = tid; idx < M3; idx += COL_THREADS) Gm_out[(size_t)n * M3 + idx] = Gn[idx];
+    __syncthreads();
+    if (hmo_out && tid < M) hmo_out[(size_t)n * M + tid] = hn[tid];
+
+    // Fock columns: one thread per (set k, row m)
+    for (int idx = tid; idx < nrdm * M; idx += COL_THREADS) {
+        const int k = idx / M, m = idx - k * M;
+        const double* gam = gamma + (size_t)k * na2;
+        double val;
+        if (m < no) {
+            double fa = 0.0;
+            for (int v = 0; v < na; ++v)
+                for (int w = 0; w < na; ++w) {
+                    const int V = no + v, W = no + w;
+                    fa += gam[v * na + w] * (Gn[m * M2 + V * M + W] - 0.5 * Gn[W * M2 + V * M + m]);
+                }
+            val = 2.0 * ((k == 0 ? FIn[m] : 0.0) + fa);
+        } else {
+            const int v = m - no;
+            const double* Gv = Gamma + (size_t)k * na4 + (size_t)v * na3;
+            double acc = 0.0;
+            for (int w = 0; w < na; ++w) acc += FIn[no + w] * gam[v * na + w];
+            for (int w = 0; w < na; ++w)
+                for (int x = 0; x < na; ++x)
+                    for (int y = 0; y < na; ++y)
+                        acc += Gv[(w * na + x) * na + y] * Gn[(no + w) * M2 + (no + x) * M + no + y];
+            val = acc;
+        }
+        Fcol[((size_t)k * M + m) * N + n] = val;
+    }
+
+    // per-n pieces of the CAS coefficients and of the energy
+    if (n < no) {
+        if (tid == 0) Cpart[n] = hn[n] + FIn[n];
+        for (int k = tid; k < nrdm; k += COL_THREADS) Epart[(size_t)k * N + n] = 0.0;
+    } else if (n < M) {
+        const int p = n - no;
+        if (tid == 0) Cpart[n] = 0.0;
+        for (int q = tid; q < na; q += COL_THREADS) c1[p * na + q] = FIn[no + q];
+        for (int idx = tid; idx < na3; idx += COL_THREADS) {
+            int t = idx;
+            const int s = t % na; t /= na;
+            const int r = t % na; t /= na;
+            const int q = t;
+            c2[(size_t)p * na3 + idx] = 0.5 * Gn[(no + q) * M2 + (no + r) * M + no + s];
+        }
+        // E_k contribution of row p: sum_q FI[P,Q] gam_k[p,q] + sum_qrs 1/2 g[P,Q,R,S] Gam_k[p,q,r,s]
+        // (serial per set in a fixed order: deterministic)
+        for (int k = tid; k < nrdm; k += COL_THREADS) {
+            const double* gam = gamma + (size_t)k * na2 + (size_t)p * na;
+            const double* Gp = Gamma + (size_t)k * na4 + (size_t)p * na3;
+            double acc = 0.0;
+            for (int q = 0; q < na; ++q) acc += FIn[no + q] * gam[q];
+            for (int q = 0; q < na; ++q)
+                for (int r = 0; r < na; ++r)
+                    for (int s2 = 0; s2 < na; ++s2)
+                        acc += 0.5 * Gn[(no + q) * M2 + (no + r) * M + no + s2]
+                               * Gp[(q * na + r) * na + s2];
+            Epart[(size_t)k * N + n] = acc;
+        }
+    } else {
+        if (tid == 0) Cpart[n] = 0.0;
+        for (int k = tid; k < nrdm; k += COL_THREADS) Epart[(size_t)k * N + n] = 0.0;
+    }
+}
+
+// Final assembly: orbital-gradient vectors, energy, c0, dE/dtheta.  One workgroup.
+__global__ __launch_bounds__(512)
+void cas_final_kernel(const double* __restrict__ Fcol, const double* __restrict__ Epart,
+                      const double* __restrict__ Cpart, double nuc, int nrdm, int N, int M,
+                      const int32_t* __restrict__ kap_row, const int32_t* __restrict__ kap_col,
+                      int n_kappa, double* __restrict__ c0, double* __restrict__ E,
+                      double* __restrict__ gvec, double* __restrict__ dE, double* __restrict__ fock,
+                      double* __restrict__ gmat)
+{
+    const int tid = threadIdx.x;
+    for (long idx = tid; idx < (long)nrdm * n_kappa; idx += 512) {
+        const int k = (int)(idx / n_kappa), t = (int)(idx - (long)k * n_kappa);
+        const int r = kap_row[t], c = kap_col[t];
+        const double* F = Fcol + (size_t)k * M * N;
+        const double frc = r < M ? F[(size_t)r * N + c] : 0.0;
+        const double fcr = c < M ? F[(size_t)c * N + r] : 0.0;
+        gvec[idx] = 2.0 * (frc - fcr);
+    }
+    if (fock)
+        for (int idx = tid; idx < N * N; idx += 512) {
+            const int m = idx / N;
+            fock[idx] = m < M ? Fcol[idx] : 0.0;
+        }
+    if (gmat)
+        for (int idx = tid; idx < N * N; idx += 512) {
+            const int m = idx / N, n = idx - m * N;
+            const double fmn = m < M ? Fcol[(size_t)m * N + n] : 0.0;
+            const double fnm = n < M ? Fcol[(size_t)n * N + m] : 0.0;
+            gmat[idx] = 2.0 * (fmn - fnm);
+        }
+    if (tid < nrdm) {
+        const int k = tid;
+        double acc = 0.0;
+        for (int n = 0; n < M; ++n) acc += Epart[(size_t)k * N + n];
+        if (k == 0) {
+            double core = nuc;
+            for (int n = 0; n < M; ++n) core += Cpart[n];
+            c0[0] = core;
+            E[0] = core + acc;
+        } else if (dE) {
+            dE[k - 1] = acc;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int oovqe_cas_half_transform(const double* g_ao, const double* C, int N, int M, double* T2,
@@ -301,29 +451,25 @@ extern "C" int oovqe_cas_half_transform(const double* g_ao, const double* C, int
 {
     OOVQE_REQUIRE(g_ao && C && T2, "cas_half_transform: null pointer");
     OOVQE_REQUIRE(N >= 1 && M >= 1 && M <= N, "cas_half_transform: bad N=%d M=%d", N, M);
-    OOVQE_REQUIRE(((uintptr_t)g_ao & 15) == 0, "cas_half_transform: g_ao must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const int ZT = (M + 15) / 16;
     const int nrb = (N + 15) / 16;
-    const int ldG = ((N + 3) & ~3) + 2;
+    const int ksteps = (N + 3) / 4;
     const int LDM = 16 * (ZT | 1);
-    const size_t lds_bytes =
-        ((size_t)nrb * 16 * LDM + (size_t)4 * 16 * ldG + (size_t)ZT * 16 * ZT * 16) * sizeof(double);
-    const size_t total = (size_t)N * N * N * N;
-    if (ZT > 3 || lds_bytes > 160 * 1024) {
-        // large N or M: two generic contraction passes (needs an N^3 M scratch we do not have
-        // here) -> report; callers route big problems through oovqe_mode_contract themselves.
-        oovqe_set_error("cas_half_transform: N=%d M=%d needs %zu B of LDS (max 163840)", N, M,
-                        lds_bytes);
-        return OOVQE_ERR_SIZE;
-    }
-    const unsigned magicN = (unsigned)((0x100000000ULL + (unsigned)N - 1) / (unsigned)N);
-    const unsigned grid = (unsigned)N * (unsigned)N;
-#define OOVQE_LAUNCH_HALF(Z)                                                                      \
+    const size_t lds_bytes = (size_t)nrb * 16 * LDM * sizeof(double);
+    OOVQE_REQUIRE(ZT <= 3, "cas_half_transform: n_occ+ncas = %d > 48 not supported", M);
+    OOVQE_REQUIRE(lds_bytes <= 160 * 1024, "cas_half_transform: N=%d M=%d needs %zu B of LDS", N, M,
+                  lds_bytes);
+    const long nslabs = (long)N * N;
+    const unsigned grid = (unsigned)((nslabs + HALF_WAVES - 1) / HALF_WAVES);
+    // k-steps per register chunk: the whole row when it fits (<= 16 k-steps), else chunks of 16
+    int kch = ksteps <= 4 ? 4 : ksteps <= 8 ? 8 : ksteps <= 11 ? 11 : 16;
+    const int nkc = (ksteps + kch - 1) / kch;
+#define OOVQE_LAUNCH_HALF(Z, KC_)                                                                 \
     do {                                                                                          \
         static bool attr_done = false;                                                            \
         if (!attr_done) {                                                                         \
-            hipError_t e = hipFuncSetAttribute((const void*)half_transform_kernel<Z>,             \
+            hipError_t e = hipFuncSetAttribute((const void*)half_transform_kernel<Z, KC_>,        \
                                                hipFuncAttributeMaxDynamicSharedMemorySize,        \
                                                160 * 1024);                                       \
             if (e != hipSuccess) {                                                                \
@@ -333,12 +479,22 @@ extern "C" int oovqe_cas_half_transform(const double* g_ao, const double* C, int
             }                                                                                     \
             attr_done = true;                                                                     \
         }                                                                                         \
-        hipLaunchKernelGGL((half_transform_kernel<Z>), dim3(grid), dim3(256), lds_bytes, st, g_ao, \
-                           C, T2, N, M, ldG, nrb, magicN, total);                                 \
+        hipLaunchKernelGGL((half_transform_kernel<Z, KC_>), dim3(grid), dim3(HALF_WAVES * 64),    \
+                           lds_bytes, st, g_ao, C, T2, N, M, nrb, nkc, nslabs);                   \
     } while (0)
-    if (ZT == 1) OOVQE_LAUNCH_HALF(1);
-    else if (ZT == 2) OOVQE_LAUNCH_HALF(2);
-    else OOVQE_LAUNCH_HALF(3);
+#define OOVQE_DISPATCH_KCH(Z)                                                                     \
+    do {                                                                                          \
+        if (kch == 4) OOVQE_LAUNCH_HALF(Z, 4);                                                    \
+        else if (kch == 8) OOVQE_LAUNCH_HALF(Z, 8);                                               \
+        else if (kch == 11) OOVQE_LAUNCH_HALF(Z, 11);                                             \
+        else OOVQE_LAUNCH_HALF(Z, 16);                                                            \
+    } while (0)
+    oovqe_profile_mark_start(st);
+    if (ZT == 1) OOVQE_DISPATCH_KCH(1);
+    else if (ZT == 2) OOVQE_DISPATCH_KCH(2);
+    else OOVQE_DISPATCH_KCH(3);
+    oovqe_profile_mark_stop(st);
+#undef OOVQE_DISPATCH_KCH
 #undef OOVQE_LAUNCH_HALF
     OOVQE_CHECK_LAUNCH("cas_half_transform");
     return 0;
@@ -396,4 +552,58 @@ extern "C" int oovqe_cas_energy_gradient(const double* Gm, const double* hmo, co
                        c2, E, fock, gmat, gvec, dE);
     OOVQE_CHECK_LAUNCH("cas_energy_gradient");
     return 0;
+}
+
+extern "C" int oovqe_cas_eval(const double* g_ao, const double* h_ao, const double* C,
+                              const double* gamma, const double* Gamma, int nrdm, double nuc, int N,
+                              int n_occ, int ncas, const int32_t* kap_row, const int32_t* kap_col,
+                              int n_kappa, double* work, double* c0, double* c1, double* c2,
+                              double* E, double* gvec, double* dE, double* fock, double* gmat,
+                              double* Gm, double* hmo, oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(g_ao && h_ao && C && gamma && Gamma && work && c0 && c1 && c2 && E && gvec,
+                  "cas_eval: null pointer");
+    OOVQE_REQUIRE(nrdm >= 1 && N >= 1 && n_occ >= 0 && ncas >= 1 && n_occ + ncas <= N,
+                  "cas_eval: bad sizes");
+    OOVQE_REQUIRE(n_kappa == 0 || (kap_row && kap_col), "cas_eval: null index table");
+    OOVQE_REQUIRE(nrdm == 1 || dE, "cas_eval: dE required when nrdm > 1");
+    hipStream_t st = (hipStream_t)stream;
+    const int M = n_occ + ncas;
+    const long m2 = (long)M * M, m3 = m2 * M;
+    // workspace layout
+    double* T2 = work;                              // [N][N][M][M]
+    double* U = T2 + (size_t)N * N * m2;            // [N][N][M][M]
+    double* Fcol = U + (size_t)N * N * m2;          // [nrdm][M][N]
+    double* Epart = Fcol + (size_t)nrdm * M * N;    // [nrdm][N]
+    double* Cpart = Epart + (size_t)nrdm * N;       // [N]
+    int rc;
+    if ((rc = oovqe_cas_half_transform(g_ao, C, N, M, T2, stream))) return rc;
+    // U[n,(q y z)] = sum_p C[p,n] T2[p,(q y z)]
+    if ((rc = oovqe_mode_contract_impl(T2, C, U, 1, N, N, (long)N * m2, N, 0, st))) return rc;
+    const size_t lds_bytes =
+        ((size_t)N * m2 + (size_t)N * M + m3 + N + M + M + N) * sizeof(double);
+    OOVQE_REQUIRE(lds_bytes <= 160 * 1024, "cas_eval: N=%d M=%d needs %zu B of LDS", N, M, lds_bytes);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)cas_column_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            oovqe_set_error("cas_eval: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return OOVQE_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(cas_column_kernel, dim3(N), dim3(COL_THREADS), lds_bytes, st, U, h_ao, C,
+                       gamma, Gamma, nrdm, N, n_occ, ncas, Fcol, Epart, Cpart, c1, c2, Gm, hmo);
+    OOVQE_CHECK_LAUNCH("cas_eval/column");
+    hipLaunchKernelGGL(cas_final_kernel, dim3(1), dim3(512), 0, st, Fcol, Epart, Cpart, nuc, nrdm, N,
+                       M, kap_row, kap_col, n_kappa, c0, E, gvec, dE, fock, gmat);
+    OOVQE_CHECK_LAUNCH("cas_eval/final");
+    return 0;
+}
+
+extern "C" int64_t oovqe_cas_eval_work_size(int N, int n_occ, int ncas, int nrdm)
+{
+    const int64_t M = n_occ + ncas;
+    return 2 * (int64_t)N * N * M * M + (int64_t)nrdm * M * N + (int64_t)nrdm * N + N;
 }

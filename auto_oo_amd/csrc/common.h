@@ -14,6 +14,8 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define OOVQE_ERR_SIZE  (-3)
 
 void oovqe_set_error(const char* fmt, ...);
+void oovqe_profile_mark_start(hipStream_t st);
+void oovqe_profile_mark_stop(hipStream_t st);
 
 #define OOVQE_CHECK_LAUNCH(name)                                                          \
     do {                                                                                  \

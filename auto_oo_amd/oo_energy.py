@@ -121,6 +121,9 @@ class OO_energy:
 
     # ---- helpers ----------------------------------------------------------------------------------
     def _t(self, x):
+        if (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == F64 and x.is_contiguous()
+                and not x.requires_grad):
+            return x
         return ops.as_device(x, self.device)
 
     def _cas_intermediates(self, mo_coeff):
@@ -132,10 +135,9 @@ class OO_energy:
     def _cas_eval(self, mo_coeff, gamma_sets, Gamma_sets, want_matrices=False):
         """Fused energy / Fock / orbital gradient for a stack of RDM sets (set 0 = RDMs, sets k>=1
         = derivative RDMs)."""
-        Gm, hmo = self._cas_intermediates(mo_coeff)
-        return ops.cas_energy_gradient(Gm, hmo, gamma_sets, Gamma_sets, self.nuc, self._n_occ,
-                                       self.ncas, self._kap_row, self._kap_col,
-                                       want_matrices=want_matrices)
+        return ops.cas_eval(self.int2e_ao, self.int1e_ao, self._t(mo_coeff), gamma_sets, Gamma_sets,
+                            self.nuc, self._n_occ, self.ncas, self._kap_row, self._kap_col,
+                            want_matrices=want_matrices)
 
     def _rdm_stack(self, one_rdm, two_rdm):
         g1 = self._t(one_rdm).reshape(1, self.ncas, self.ncas)
@@ -145,8 +147,16 @@ class OO_energy:
     # ---- reference API ------------------------------------------------------------------------------
     @property
     def mo_coeff(self):
-        """oo_energy.py:173-176: oao_coeff @ oao_mo_coeff, recomputed on every access."""
-        return ops.matmul_nn(self.oao_coeff, self._t(self.oao_mo_coeff))
+        """oo_energy.py:173-176: oao_coeff @ oao_mo_coeff.  The reference recomputes the product on
+        every access; here it is recomputed whenever ``oao_mo_coeff`` was reassigned or modified in
+        place (tensor identity + version counter), which yields the same values."""
+        src = self.oao_mo_coeff
+        key = (id(src), src._version if isinstance(src, torch.Tensor) else None,
+               id(self.oao_coeff))
+        cache = getattr(self, "_mo_cache", None)
+        if cache is None or cache[0] != key or cache[1] is not src:
+            self._mo_cache = (key, src, ops.matmul_nn(self.oao_coeff, self._t(src)))
+        return self._mo_cache[2]
 
     def energy_from_mo_coeff(self, mo_coeff, one_rdm, two_rdm):
         """oo_energy.py:178-197: E = c0 + sum c1*gamma + sum c2*Gamma (0-dim tensor)."""

@@ -42,7 +42,8 @@ class OO_pqc(OO_energy):
         (the reference needs three simulations and three N^5 transforms for the same numbers,
         oo_pqc.py:64-101,132-134)."""
         res = self._evaluate(theta)
-        return res["E"].reshape(()), torch.cat((res["dE"], res["gvec"][0]))
+        packed = res["packed"]            # [E | dE/dtheta | dE/dkappa], written by one kernel
+        return packed[0], packed[1:]
 
     # ---- reference API ------------------------------------------------------------------------------
     def energy_from_parameters(self, theta, kappa=None):

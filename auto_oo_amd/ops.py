@@ -14,9 +14,17 @@ from ._lib import check, dptr, stream_ptr
 
 F64 = torch.float64
 
-# Optional (before, after) callables around the dominant kernel launch; bench.py uses it to put
-# HIP events on the launch stream inside its timed region.  None in normal operation.
-KERNEL_HOOK = None
+
+def profile_begin():
+    """Start bracketing every half-transform launch with HIP events (bench.py roofline)."""
+    _lib.load().oovqe_profile_begin()
+
+
+def profile_end():
+    """-> (total kernel milliseconds, number of launches)"""
+    tot, cnt = ctypes.c_double(0.0), ctypes.c_int(0)
+    _lib.load().oovqe_profile_end(ctypes.byref(tot), ctypes.byref(cnt))
+    return tot.value, cnt.value
 
 
 def _dev(t):
@@ -149,17 +157,42 @@ def rdms_tangent(psi, dpsi, ncas):
     return gamma, Gamma
 
 
+def circuit_rdms(theta, gates_dev, n_gates, n_qubits, ncas, init_index, tangents=True,
+                 want_states=False):
+    """theta [batch, n_theta] -> gamma [batch, 1+n_tan, a, a], Gamma [batch, 1+n_tan, a,a,a,a]
+    (and psi, dpsi when want_states) through oovqe_circuit_rdms."""
+    lib = _lib.load()
+    dev = _dev(theta)
+    batch, n_theta = theta.shape
+    D = 1 << n_qubits
+    n_tan = n_theta if tangents else 0
+    nvec = 1 + n_tan
+    small = n_qubits <= 10 and (nvec * (D + 2) * (1 + ncas * ncas)
+                                + 2 * nvec * 256 * ((ncas * ncas + 16) // 16)
+                                * ((ncas * ncas + 15) // 16)) * 8 <= 150 * 1024
+    gamma = torch.empty((batch, nvec, ncas, ncas), dtype=F64, device=dev)
+    Gamma = torch.empty((batch, nvec, ncas, ncas, ncas, ncas), dtype=F64, device=dev)
+    need_states = want_states or not small
+    psi = torch.empty((batch, D), dtype=F64, device=dev) if need_states else None
+    dpsi = (torch.empty((batch, n_theta, D), dtype=F64, device=dev)
+            if (need_states and tangents) else None)
+    work = None if small else torch.empty(batch * nvec * ncas * ncas * D, dtype=F64, device=dev)
+    check(lib.oovqe_circuit_rdms(dptr(theta), n_theta, dptr(gates_dev, torch.uint8), n_gates,
+                                 n_qubits, ncas, ctypes.c_uint32(init_index), int(bool(tangents)),
+                                 batch, dptr(psi), dptr(dpsi), dptr(gamma), dptr(Gamma), dptr(work),
+                                 stream_ptr()), "oovqe_circuit_rdms")
+    if want_states:
+        return gamma, Gamma, psi, dpsi
+    return gamma, Gamma
+
+
 def cas_half_transform(g_ao, C, M, out=None):
     lib = _lib.load()
     N = C.shape[0]
     if out is None:
         out = torch.empty((N, N, M, M), dtype=F64, device=_dev(g_ao))
-    hook = KERNEL_HOOK
-    tok = hook[0]() if hook else None
     check(lib.oovqe_cas_half_transform(dptr(g_ao), dptr(C), N, M, dptr(out), stream_ptr()),
           "oovqe_cas_half_transform")
-    if hook:
-        hook[1](tok)
     return out
 
 
@@ -201,3 +234,38 @@ def cas_energy_gradient(Gm, hmo, gamma, Gamma, nuc, n_occ, ncas, kap_row, kap_co
                                         dptr(c2), dptr(E), dptr(fock), dptr(gmat), dptr(gvec),
                                         dptr(dE), stream_ptr()), "oovqe_cas_energy_gradient")
     return dict(c0=c0, c1=c1, c2=c2, E=E, fock=fock, gmat=gmat, gvec=gvec, dE=dE[:nrdm - 1])
+
+
+def cas_eval(g_ao, h_ao, C, gamma, Gamma, nuc, n_occ, ncas, kap_row, kap_col, want_matrices=False,
+             want_integrals=False, work=None):
+    """The whole CAS path (oovqe_cas_eval).  gamma [nrdm,a,a], Gamma [nrdm,a,a,a,a]."""
+    lib = _lib.load()
+    dev = _dev(g_ao)
+    N = C.shape[0]
+    M = n_occ + ncas
+    nrdm = gamma.shape[0]
+    n_kappa = kap_row.numel()
+    if work is None:
+        work = torch.empty(lib.oovqe_cas_eval_work_size(N, n_occ, ncas, nrdm), dtype=F64, device=dev)
+    # one packed output buffer: [c0 | E | dE (n_theta) | gvec (nrdm x n_kappa) | c1 | c2]; the slice
+    # [E | dE | gvec[0]] is the energy followed by the full gradient, contiguous.
+    n_t = max(nrdm - 1, 1)
+    small = torch.empty(2 + n_t + nrdm * n_kappa + ncas * ncas + ncas ** 4, dtype=F64, device=dev)
+    c0, E = small[0:1], small[1:2]
+    o = 2
+    dE = small[o:o + n_t]; o += nrdm - 1 if nrdm > 1 else 1
+    gvec = small[o:o + nrdm * n_kappa].view(nrdm, n_kappa); o += nrdm * n_kappa
+    c1 = small[o:o + ncas * ncas].view(ncas, ncas); o += ncas * ncas
+    c2 = small[o:o + ncas ** 4].view((ncas,) * 4)
+    fock = torch.empty((N, N), dtype=F64, device=dev) if want_matrices else None
+    gmat = torch.empty((N, N), dtype=F64, device=dev) if want_matrices else None
+    Gm = torch.empty((N, M, M, M), dtype=F64, device=dev) if want_integrals else None
+    hmo = torch.empty((N, M), dtype=F64, device=dev) if want_integrals else None
+    check(lib.oovqe_cas_eval(dptr(g_ao), dptr(h_ao), dptr(C), dptr(gamma), dptr(Gamma), nrdm,
+                             float(nuc), N, n_occ, ncas, dptr(kap_row, torch.int32),
+                             dptr(kap_col, torch.int32), n_kappa, dptr(work), dptr(c0), dptr(c1),
+                             dptr(c2), dptr(E), dptr(gvec), dptr(dE), dptr(fock), dptr(gmat),
+                             dptr(Gm), dptr(hmo), stream_ptr()), "oovqe_cas_eval")
+    packed = small[1:2 + (nrdm - 1) + n_kappa] if nrdm > 1 else None   # [E, dE..., gvec[0]...]
+    return dict(c0=c0, c1=c1, c2=c2, E=E, fock=fock, gmat=gmat, gvec=gvec, dE=dE[:nrdm - 1],
+                Gm=Gm, hmo=hmo, packed=packed)

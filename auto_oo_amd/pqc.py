@@ -69,10 +69,13 @@ class Parameterized_circuit():
 
     # ---- internal real-amplitude entry points ---------------------------------------------------
     def _theta2d(self, theta):
-        theta = torch.as_tensor(theta)
-        if theta.dtype != torch.float64:
-            warnings.warn("Input a single precision theta. Only double precision is supported.")
-        theta = ops.as_device(theta, self.device).reshape(1, -1)
+        if not (isinstance(theta, torch.Tensor) and theta.is_cuda and theta.dtype == torch.float64
+                and theta.is_contiguous()):
+            theta = torch.as_tensor(theta)
+            if theta.dtype != torch.float64:
+                warnings.warn("Input a single precision theta. Only double precision is supported.")
+            theta = ops.as_device(theta, self.device)
+        theta = theta.detach().reshape(1, -1)
         if theta.shape[1] != int(np.prod(self.theta_shape)):
             raise ValueError(f"Weights tensor must be of shape {(int(np.prod(self.theta_shape)),)}; "
                              f"got {tuple(theta.shape[1:])}.")
@@ -91,9 +94,8 @@ class Parameterized_circuit():
         """gamma [1+n_theta, a, a], Gamma [1+n_theta, a,a,a,a]: set 0 = RDMs of psi(theta), set k =
         d/dtheta_k (what autograd yields in the reference, oo_pqc.py:86-95,113-119)."""
         th = self._theta2d(theta)
-        psi, dpsi = ops.circuit_state(th, self._gates_dev, self._n_gates, self.n_qubits,
-                                      self._init_index, tangents=True)
-        gamma, Gamma = ops.rdms_tangent(psi, dpsi, self.ncas)
+        gamma, Gamma = ops.circuit_rdms(th, self._gates_dev, self._n_gates, self.n_qubits,
+                                        self.ncas, self._init_index, tangents=True)
         return gamma[0], Gamma[0]
 
     # ---- reference API ----------------------------------------------------------------------------
@@ -132,8 +134,9 @@ class Parameterized_circuit():
         """pqc.py:220-221"""
         if not restricted:
             raise NotImplementedError("unrestricted RDMs are not built (never used on the hot path)")
-        psi = self.state_real(theta).reshape(1, -1)
-        g1, g2 = ops.rdms_tangent(psi, None, self.ncas)
+        th = self._theta2d(theta)
+        g1, g2 = ops.circuit_rdms(th, self._gates_dev, self._n_gates, self.n_qubits, self.ncas,
+                                  self._init_index, tangents=False)
         return g1[0, 0], g2[0, 0]
 
     def draw_circuit(self, theta):

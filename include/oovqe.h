@@ -31,6 +31,12 @@ const char* oovqe_last_error(void);
 /* number of visible HIP devices (<=0: none / runtime error) */
 int         oovqe_device_count(void);
 
+/* HIP-event timing of the dominant kernel (the N^4 half-transform sweep) on its launch stream:
+ * between begin and end every oovqe_cas_half_transform launch is bracketed by two events;
+ * end() returns the summed kernel time and the number of launches.  Used by bench.py only. */
+int         oovqe_profile_begin(void);
+int         oovqe_profile_end(double* total_ms, int* count);
+
 /* ---- gate table for the statevector kernels ----------------------------------------------- *
  * One entry per excitation gate (qml.FermionicDoubleExcitation / FermionicSingleExcitation /
  * DoubleExcitation closed forms; src/auto_oo/ansatze/uccd.py:105-114, kUpCCD.py:118-130).
@@ -112,6 +118,17 @@ int oovqe_rdms_tangent(const double* psi, const double* dpsi, int n_qubits, int 
                        int batch, double* gamma, double* Gamma, double* work,
                        oovqe_stream_t stream);
 
+/* State, tangents and all RDM sets in one call (= Parameterized_circuit.get_rdms and its
+ * theta-jacobian, pqc.py:220-221 under oo_pqc.py:86-95).  For small active spaces (n_qubits <= 10
+ * and everything fits 150 KiB of LDS, e.g. CAS(4e,3o)) this is ONE launch of one workgroup per
+ * batch element; otherwise it chains oovqe_circuit_state + oovqe_rdms_tangent.
+ * psi [batch,D] / dpsi [batch,n_theta,D] may be NULL on the small path (not written back then);
+ * work as for oovqe_rdms_tangent (may be NULL on the small path). */
+int oovqe_circuit_rdms(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
+                       int n_qubits, int ncas, uint32_t init_index, int want_tangents, int batch,
+                       double* psi, double* dpsi, double* gamma, double* Gamma, double* work,
+                       oovqe_stream_t stream);
+
 /* ---- a7/a8/a12/a13/a14: fused CAS energy + gradients ---------------------------------------
  * replaces int1e_transform + int2e_transform + molecular_hamiltonian_coefficients
  * (oo_energy.py:204-211; utils/active_space.py:111-212), the energy contraction
@@ -140,6 +157,19 @@ int oovqe_cas_energy_gradient(const double* Gm, const double* hmo, const double*
                               int n_kappa, double* c0, double* c1, double* c2, double* E,
                               double* fock, double* gmat, double* gvec, double* dE,
                               oovqe_stream_t stream);
+
+/* The whole CAS path in one call (stage 1, contraction p->n, fused per-n column kernel, final
+ * assembly: 4 launches, no N M^3 MO tensor round trip unless Gm/hmo are requested).
+ * Same inputs/outputs as the three stages above; work: oovqe_cas_eval_work_size() doubles;
+ * fock, gmat, Gm [N,M,M,M], hmo [N,M], dE may be NULL (dE only when nrdm == 1).
+ * This is what OO_pqc.energy_from_parameters / full_gradient / orbital_circuit_hessian run on
+ * (src/auto_oo/oo_pqc.py:64-134). */
+int oovqe_cas_eval(const double* g_ao, const double* h_ao, const double* C, const double* gamma,
+                   const double* Gamma, int nrdm, double nuc, int N, int n_occ, int ncas,
+                   const int32_t* kap_row, const int32_t* kap_col, int n_kappa, double* work,
+                   double* c0, double* c1, double* c2, double* E, double* gvec, double* dE,
+                   double* fock, double* gmat, double* Gm, double* hmo, oovqe_stream_t stream);
+int64_t oovqe_cas_eval_work_size(int N, int n_occ, int ncas, int nrdm);
 
 #ifdef __cplusplus
 }

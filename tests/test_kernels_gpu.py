@@ -224,3 +224,67 @@ def test_cas_pipeline_vs_oracle(N, seed):
     assert (res["fock"].cpu() - F_ref).abs().max() < 1e-10
     assert (res["gmat"].cpu() - G_ref).abs().max() < 1e-10
     assert (res["gvec"].cpu()[0] - gv_ref).abs().max() < 1e-10
+
+
+@pytest.mark.parametrize("N,seed,nelec,ncas,nelecas", [(13, 20261, 16, 3, 4), (43, 20262, 16, 3, 4),
+                                                     (20, 7, 8, 2, 2), (16, 9, 4, 4, 4)])
+def test_cas_eval_fused_matches_staged_and_oracle(N, seed, nelec, ncas, nelecas):
+    """oovqe_cas_eval (4 launches, column kernel) against the staged kernels and the oracle, with
+    a stack of RDM sets (set 0 = RDMs, sets >= 1 = arbitrary 'derivative' RDMs)."""
+    P = R.synthetic_problem(N, seed)
+    mol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec)
+    pqc = R.OraclePQC(ncas, nelecas, "ucc")
+    oo = R.OracleOOPQC(pqc, mol, ncas, nelecas, P["oao_mo_coeff"])
+    no = len(oo.occ_idx)
+    M = no + ncas
+    C = oo.mo_coeff
+    rng = np.random.default_rng(seed)
+    theta = torch.tensor(rng.uniform(0, 2 * np.pi, pqc.theta_shape))
+    g1, g2 = pqc.get_rdms(theta)
+    nrdm = 3
+    gam = torch.stack([g1] + [_rand(rng, ncas, ncas) for _ in range(nrdm - 1)])
+    Gam = torch.stack([g2] + [_rand(rng, ncas, ncas, ncas, ncas) for _ in range(nrdm - 1)])
+    rows, cols = X.tril_tables(N, oo.params_idx)
+    rows_d, cols_d = torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV)
+    Cd = C.to(DEV).contiguous()
+    gd = oo.int2e_ao.to(DEV).contiguous()
+    hd = oo.int1e_ao.to(DEV).contiguous()
+    res = ops.cas_eval(gd, hd, Cd, gam.to(DEV).contiguous(), Gam.to(DEV).contiguous(), oo.nuc, no,
+                       ncas, rows_d, cols_d, want_matrices=True, want_integrals=True)
+    T2 = ops.cas_half_transform(gd, Cd, M)
+    Gm, hmo = ops.cas_finish_transform(T2, hd, Cd, M)
+    st = ops.cas_energy_gradient(Gm, hmo, gam.to(DEV).contiguous(), Gam.to(DEV).contiguous(),
+                                 oo.nuc, no, ncas, rows_d, cols_d)
+    g_mo = R.int2e_transform(oo.int2e_ao, C)
+    h_mo = R.int1e_transform(oo.int1e_ao, C)
+    assert (res["Gm"].cpu() - g_mo[:, :M, :M, :M]).abs().max() < 1e-11
+    assert (res["hmo"].cpu() - h_mo[:, :M]).abs().max() < 1e-11
+    for key in ("c0", "c1", "c2", "E", "fock", "gmat", "gvec", "dE"):
+        assert (res[key] - st[key]).abs().max() < 1e-10, key
+    assert abs(res["E"].item() - oo.energy_from_mo_coeff(C, g1, g2).item()) < 1e-9
+    gv_ref = oo.kappa_matrix_to_vector(oo.analytic_gradient(g1, g2))
+    assert (res["gvec"].cpu()[0] - gv_ref).abs().max() < 1e-10
+
+
+@pytest.mark.parametrize("ncas,nelecas,kind", [(3, 4, "uccd"), (3, 4, "uccsd"), (2, 2, "uccd"),
+                                               (2, 2, "uccsd"), (4, 4, "kupccd"), (3, 2, "kupccd")])
+def test_circuit_rdms_fused_matches_staged(ncas, nelecas, kind):
+    """oovqe_circuit_rdms (one-workgroup LDS kernel with the MFMA Gram for small active spaces,
+    chained kernels otherwise) against oovqe_circuit_state + oovqe_rdms_tangent."""
+    n = 2 * ncas
+    if kind == "kupccd":
+        gates, n_theta = X.kupccd_gates(ncas, 1)
+    else:
+        gates, n_theta = X.uccd_gates(ncas, nelecas, kind == "uccsd")
+    rng = np.random.default_rng(23)
+    th = torch.tensor(rng.uniform(0, 2 * np.pi, (3, n_theta))).to(DEV)
+    gd = _gates_dev(gates)
+    init = X.basis_index(X.hf_state(nelecas, n))
+    psi, dpsi = ops.circuit_state(th, gd, len(gates), n, init, tangents=True)
+    g1, g2 = ops.rdms_tangent(psi, dpsi, ncas)
+    f1, f2, fpsi, fdpsi = ops.circuit_rdms(th, gd, len(gates), n, ncas, init, tangents=True,
+                                           want_states=True)
+    assert (fpsi - psi).abs().max() < 1e-14 and (fdpsi - dpsi).abs().max() < 1e-14
+    assert (f1 - g1).abs().max() < 1e-12 and (f2 - g2).abs().max() < 1e-12
+    n1, n2 = ops.circuit_rdms(th, gd, len(gates), n, ncas, init, tangents=False)
+    assert (n1[:, 0] - g1[:, 0]).abs().max() < 1e-12 and (n2[:, 0] - g2[:, 0]).abs().max() < 1e-12
