@@ -34,7 +34,10 @@ namespace {
 // ------------------------------------------------------------------------------------------
 constexpr int HALF_WAVES = 8;
 
-template <int ZT, int KCH>
+// NST > 0: the slab has exactly NST column tiles and nkc == 1; ALL its loads (NST*KCH per lane) are
+// issued at kernel entry, before the prologue barrier, so the HBM latency is paid once per wave.
+// NST == 0: streaming variant for large N (register double buffer, one chunk ahead).
+template <int ZT, int KCH, int NST>
 __global__ __launch_bounds__(HALF_WAVES * 64)
 void half_transform_kernel(const double* __restrict__ g, const double* __restrict__ C,
                            double* __restrict__ T2, int N, int M, int nst, int nkc, long nslabs)
@@ -47,67 +50,143 @@ void half_transform_kernel(const double* __restrict__ g, const double* __restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
 
-    for (int idx = tid; idx < RT16 * LDM; idx += HALF_WAVES * 64) {
-        const int r = idx / LDM, z = idx - r * LDM;
-        Cl[idx] = (r < N && z < M) ? C[(size_t)r * N + z] : 0.0;
-    }
-    __syncthreads();
-
     const long slab = (long)blockIdx.x * HALF_WAVES + wave;
-    if (slab >= nslabs) return;
-    const double* gs = g + (size_t)slab * N * N;
+    const bool have = slab < nslabs;
+    const double* gs = g + (size_t)(have ? slab : 0) * N * N;
 
     d4 jt[ZT][ZT];   // [z tile][y tile]
 #pragma unroll
     for (int z = 0; z < ZT; ++z)
 #pragma unroll
         for (int y = 0; y < ZT; ++y) jt[z][y] = d4{0.0, 0.0, 0.0, 0.0};
-
-    // chunk c = st * nkc + kc: column tile st (s = st*16 + lr), k-steps kc*KCH .. +KCH-1 over r
-    const int nchunks = nst * nkc;
-    double acur[KCH], anext[KCH];
-    auto load_chunk = [&](int c, double* dst) {
-        const int st = c / nkc, kc = c - st * nkc;
-        const int col = st * 16 + lr;
-        const int r0 = kc * KCH * 4 + lq;
-        const double* src = gs + (size_t)r0 * N + col;
-#pragma unroll
-        for (int i = 0; i < KCH; ++i)
-            dst[i] = (col < N && r0 + 4 * i < N) ? src[(size_t)4 * i * N] : 0.0;
-    };
-    load_chunk(0, acur);
     d4 xt[ZT];       // [y tile]
 #pragma unroll
     for (int y = 0; y < ZT; ++y) xt[y] = d4{0.0, 0.0, 0.0, 0.0};
 
-    for (int c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks) load_chunk(c + 1, anext);
-        const int st = c / nkc, kc = c - st * nkc;
-        const double* cb = Cl + (size_t)(kc * KCH * 4 + lq) * LDM + lr;
+    // one column tile st (s = st*16 + lr), k-steps kc*KCH .. +KCH-1 over r.  Loads are
+    // unconditional on clamped addresses, masked by a select: no branches between them.
+    auto load_chunk = [&](int st, int kc, double* dst) {
+        const int col = st * 16 + lr;
+        const int colc = col < N ? col : N - 1;
+        const int r0 = kc * KCH * 4 + lq;
 #pragma unroll
         for (int i = 0; i < KCH; ++i) {
-            if ((kc * KCH + i) * 4 < N) {
-#pragma unroll
-                for (int y = 0; y < ZT; ++y)
-                    xt[y] = mfma_f64(acur[i], cb[i * 4 * LDM + y * 16], xt[y]);
-            }
+            const int r = r0 + 4 * i;
+            const int rc = r < N ? r : N - 1;
+            const double v = gs[(size_t)rc * N + colc];
+            // multiplicative mask (the clamped load is always finite): a select here is turned
+            // back into a branch around the load by the compiler, serialising the loads
+            dst[i] = v * ((have && col < N && r < N) ? 1.0 : 0.0);
         }
+    };
+    // Rows of Cl beyond N are zero and masked A values are zero, so every k-step can be executed
+    // unconditionally (straight-line MFMA stream, C fragments read ahead).
+    auto compute_chunk = [&](int st, int kc, const double* a) {
+        const double* cb = Cl + (size_t)(kc * KCH * 4 + lq) * LDM + lr;
+        double cf[KCH][ZT];
+#pragma unroll
+        for (int i = 0; i < KCH; ++i)
+#pragma unroll
+            for (int y = 0; y < ZT; ++y) cf[i][y] = cb[i * 4 * LDM + y * 16];
+#pragma unroll
+        for (int i = 0; i < KCH; ++i)
+#pragma unroll
+            for (int y = 0; y < ZT; ++y) xt[y] = mfma_f64(a[i], cf[i][y], xt[y]);
         if (kc == nkc - 1) {
             const double* ca = Cl + (size_t)(st * 16 + lq) * LDM + lr;
+            double af[4][ZT];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int z = 0; z < ZT; ++z) {
-                    const double av = ca[i * 4 * LDM + z * 16];
+                for (int z = 0; z < ZT; ++z) af[i][z] = ca[i * 4 * LDM + z * 16];
 #pragma unroll
-                    for (int y = 0; y < ZT; ++y) jt[z][y] = mfma_f64(av, xt[y][i], jt[z][y]);
-                }
-            }
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int z = 0; z < ZT; ++z)
+#pragma unroll
+                    for (int y = 0; y < ZT; ++y) jt[z][y] = mfma_f64(af[i][z], xt[y][i], jt[z][y]);
 #pragma unroll
             for (int y = 0; y < ZT; ++y) xt[y] = d4{0.0, 0.0, 0.0, 0.0};
         }
+    };
+    auto stage_C = [&]() {
+        for (int idx = tid; idx < RT16 * LDM; idx += HALF_WAVES * 64) {
+            const int r = idx / LDM, z = idx - r * LDM;
+            Cl[idx] = (r < N && z < M) ? C[(size_t)r * N + z] : 0.0;
+        }
+        __syncthreads();
+    };
+
+    if constexpr (NST > 0) {
+        // Small N: no LDS, no barrier.  Each lane fetches its own C fragments straight from L2
+        // (cfr[j][y] = C[4j + lq][16y + lr]: the B operand of k-step j of stage 1 AND the A operand
+        // of k-step j%4 of column tile j/4 in stage 2), then the whole slab; 12 + NST*KCH loads
+        // per lane are in flight together and every wave runs independently of the others.
+        if (!have) return;
+        constexpr int NCF = NST * 4;
+        static_assert(KCH <= NCF, "C fragments must cover every k-step");
+        double cfr[NCF][ZT];
+        double aall[NST][KCH];
+        // raw loads on clamped addresses first (all in flight together) ...
 #pragma unroll
-        for (int i = 0; i < KCH; ++i) acur[i] = anext[i];
+        for (int j = 0; j < NCF; ++j)
+#pragma unroll
+            for (int y = 0; y < ZT; ++y) {
+                const int r = 4 * j + lq, z = 16 * y + lr;
+                cfr[j][y] = C[(size_t)(r < N ? r : N - 1) * N + (z < M ? z : M - 1)];
+            }
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const int col = st * 16 + lr;
+            const int colc = col < N ? col : N - 1;
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) {
+                const int r = 4 * i + lq;
+                aall[st][i] = gs[(size_t)(r < N ? r : N - 1) * N + colc];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ... then the masks (multiplicative: a select would be turned back into a branch around
+        // the load, serialising the loads)
+#pragma unroll
+        for (int j = 0; j < NCF; ++j)
+#pragma unroll
+            for (int y = 0; y < ZT; ++y)
+                cfr[j][y] *= ((4 * j + lq) < N && (16 * y + lr) < M) ? 1.0 : 0.0;
+#pragma unroll
+        for (int st = 0; st < NST; ++st)
+#pragma unroll
+            for (int i = 0; i < KCH; ++i)
+                aall[st][i] *= ((st * 16 + lr) < N && (4 * i + lq) < N) ? 1.0 : 0.0;
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+#pragma unroll
+            for (int i = 0; i < KCH; ++i)
+#pragma unroll
+                for (int y = 0; y < ZT; ++y) xt[y] = mfma_f64(aall[st][i], cfr[i][y], xt[y]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int z = 0; z < ZT; ++z)
+#pragma unroll
+                    for (int y = 0; y < ZT; ++y)
+                        jt[z][y] = mfma_f64(cfr[4 * st + i][z], xt[y][i], jt[z][y]);
+#pragma unroll
+            for (int y = 0; y < ZT; ++y) xt[y] = d4{0.0, 0.0, 0.0, 0.0};
+        }
+    } else {
+        // chunk c = st * nkc + kc
+        const int nchunks = nst * nkc;
+        double acur[KCH], anext[KCH];
+        load_chunk(0, 0, acur);
+        stage_C();
+        if (!have) return;
+        for (int c = 0; c < nchunks; ++c) {
+            if (c + 1 < nchunks) load_chunk((c + 1) / nkc, (c + 1) % nkc, anext);
+            compute_chunk(c / nkc, c % nkc, acur);
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) acur[i] = anext[i];
+        }
     }
 
     // jt[z tile][y tile][i] = Jt[z = zt*16 + lq + 4i][y = yt*16 + lr]  ->  T2[slab][y][z]
@@ -301,8 +380,14 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
     double* hn = Wn + N;                 // [M]
     double* FIn = hn + M;                // [M]
     double* cn = FIn + M;                // [N]      C[:, n]
+    double* hl = cn + N;                 // [N][N]   h_ao
+    double* gml = hl + (size_t)N * N;    // [nrdm][na2]
+    double* Gml = gml + (size_t)nrdm * na2;   // [nrdm][na4]
     const int tid = threadIdx.x;
     const int n = blockIdx.x;
+    for (int idx = tid; idx < N * N; idx += COL_THREADS) hl[idx] = h_ao[idx];
+    for (int idx = tid; idx < nrdm * na2; idx += COL_THREADS) gml[idx] = gamma[idx];
+    for (int idx = tid; idx < nrdm * na4; idx += COL_THREADS) Gml[idx] = Gamma[idx];
 
     const double* Usrc = U + (size_t)n * N * M2;
     for (int idx = tid; idx < N * M2; idx += COL_THREADS) Un[idx] = Usrc[idx];
@@ -314,7 +399,7 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
     __syncthreads();
     for (int q = tid; q < N; q += COL_THREADS) {
         double acc = 0.0;
-        for (int p = 0; p < N; ++p) acc += cn[p] * h_ao[(size_t)p * N + q];
+        for (int p = 0; p < N; ++p) acc += cn[p] * hl[p * N + q];
         Wn[q] = acc;
     }
     for (int idx = tid; idx < M3; idx += COL_THREADS) {
@@ -340,7 +425,7 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
     // Fock columns: one thread per (set k, row m)
     for (int idx = tid; idx < nrdm * M; idx += COL_THREADS) {
         const int k = idx / M, m = idx - k * M;
-        const double* gam = gamma + (size_t)k * na2;
+        const double* gam = gml + (size_t)k * na2;
         double val;
         if (m < no) {
             double fa = 0.0;
@@ -352,7 +437,7 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
             val = 2.0 * ((k == 0 ? FIn[m] : 0.0) + fa);
         } else {
             const int v = m - no;
-            const double* Gv = Gamma + (size_t)k * na4 + (size_t)v * na3;
+            const double* Gv = Gml + (size_t)k * na4 + (size_t)v * na3;
             double acc = 0.0;
             for (int w = 0; w < na; ++w) acc += FIn[no + w] * gam[v * na + w];
             for (int w = 0; w < na; ++w)
@@ -382,8 +467,8 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
         // E_k contribution of row p: sum_q FI[P,Q] gam_k[p,q] + sum_qrs 1/2 g[P,Q,R,S] Gam_k[p,q,r,s]
         // (serial per set in a fixed order: deterministic)
         for (int k = tid; k < nrdm; k += COL_THREADS) {
-            const double* gam = gamma + (size_t)k * na2 + (size_t)p * na;
-            const double* Gp = Gamma + (size_t)k * na4 + (size_t)p * na3;
+            const double* gam = gml + (size_t)k * na2 + (size_t)p * na;
+            const double* Gp = Gml + (size_t)k * na4 + (size_t)p * na3;
             double acc = 0.0;
             for (int q = 0; q < na; ++q) acc += FIn[no + q] * gam[q];
             for (int q = 0; q < na; ++q)
@@ -456,20 +541,21 @@ extern "C" int oovqe_cas_half_transform(const double* g_ao, const double* C, int
     const int nrb = (N + 15) / 16;
     const int ksteps = (N + 3) / 4;
     const int LDM = 16 * (ZT | 1);
-    const size_t lds_bytes = (size_t)nrb * 16 * LDM * sizeof(double);
+    const size_t lds_elems = (((size_t)nrb * 16 * LDM + 511) / 512) * 512;   // padded, see kernel
+    const size_t lds_bytes = lds_elems * sizeof(double);
     OOVQE_REQUIRE(ZT <= 3, "cas_half_transform: n_occ+ncas = %d > 48 not supported", M);
     OOVQE_REQUIRE(lds_bytes <= 160 * 1024, "cas_half_transform: N=%d M=%d needs %zu B of LDS", N, M,
                   lds_bytes);
     const long nslabs = (long)N * N;
     const unsigned grid = (unsigned)((nslabs + HALF_WAVES - 1) / HALF_WAVES);
     // k-steps per register chunk: the whole row when it fits (<= 16 k-steps), else chunks of 16
-    int kch = ksteps <= 4 ? 4 : ksteps <= 8 ? 8 : ksteps <= 11 ? 11 : 16;
+    int kch = ksteps <= 4 ? 4 : ksteps <= 8 ? 8 : ksteps <= 11 ? 11 : ksteps <= 12 ? 12 : 16;
     const int nkc = (ksteps + kch - 1) / kch;
-#define OOVQE_LAUNCH_HALF(Z, KC_)                                                                 \
+#define OOVQE_LAUNCH_HALF(Z, KC_, NS_)                                                            \
     do {                                                                                          \
         static bool attr_done = false;                                                            \
         if (!attr_done) {                                                                         \
-            hipError_t e = hipFuncSetAttribute((const void*)half_transform_kernel<Z, KC_>,        \
+            hipError_t e = hipFuncSetAttribute((const void*)half_transform_kernel<Z, KC_, NS_>,   \
                                                hipFuncAttributeMaxDynamicSharedMemorySize,        \
                                                160 * 1024);                                       \
             if (e != hipSuccess) {                                                                \
@@ -479,15 +565,22 @@ extern "C" int oovqe_cas_half_transform(const double* g_ao, const double* C, int
             }                                                                                     \
             attr_done = true;                                                                     \
         }                                                                                         \
-        hipLaunchKernelGGL((half_transform_kernel<Z, KC_>), dim3(grid), dim3(HALF_WAVES * 64),    \
+        hipLaunchKernelGGL((half_transform_kernel<Z, KC_, NS_>), dim3(grid),                      \
+                           dim3(HALF_WAVES * 64),                                                 \
                            lds_bytes, st, g_ao, C, T2, N, M, nrb, nkc, nslabs);                   \
     } while (0)
 #define OOVQE_DISPATCH_KCH(Z)                                                                     \
     do {                                                                                          \
-        if (kch == 4) OOVQE_LAUNCH_HALF(Z, 4);                                                    \
-        else if (kch == 8) OOVQE_LAUNCH_HALF(Z, 8);                                               \
-        else if (kch == 11) OOVQE_LAUNCH_HALF(Z, 11);                                             \
-        else OOVQE_LAUNCH_HALF(Z, 16);                                                            \
+        /* whole-slab preload when the slab is one k-chunk deep and <= 48 loads per lane */      \
+        if (kch == 4 && nrb == 1) OOVQE_LAUNCH_HALF(Z, 4, 1);                                     \
+        else if (kch == 8 && nrb == 2) OOVQE_LAUNCH_HALF(Z, 8, 2);                                \
+        else if (kch == 11 && nrb == 3) OOVQE_LAUNCH_HALF(Z, 11, 3);                              \
+        else if (kch == 12 && nrb == 3) OOVQE_LAUNCH_HALF(Z, 12, 3);                              \
+        else if (kch == 4) OOVQE_LAUNCH_HALF(Z, 4, 0);                                            \
+        else if (kch == 8) OOVQE_LAUNCH_HALF(Z, 8, 0);                                            \
+        else if (kch == 11) OOVQE_LAUNCH_HALF(Z, 11, 0);                                          \
+        else if (kch == 12) OOVQE_LAUNCH_HALF(Z, 12, 0);                                          \
+        else OOVQE_LAUNCH_HALF(Z, 16, 0);                                                         \
     } while (0)
     oovqe_profile_mark_start(st);
     if (ZT == 1) OOVQE_DISPATCH_KCH(1);
@@ -580,9 +673,11 @@ extern "C" int oovqe_cas_eval(const double* g_ao, const double* h_ao, const doub
     if ((rc = oovqe_cas_half_transform(g_ao, C, N, M, T2, stream))) return rc;
     // U[n,(q y z)] = sum_p C[p,n] T2[p,(q y z)]
     if ((rc = oovqe_mode_contract_impl(T2, C, U, 1, N, N, (long)N * m2, N, 0, st))) return rc;
-    const size_t lds_bytes =
-        ((size_t)N * m2 + (size_t)N * M + m3 + N + M + M + N) * sizeof(double);
-    OOVQE_REQUIRE(lds_bytes <= 160 * 1024, "cas_eval: N=%d M=%d needs %zu B of LDS", N, M, lds_bytes);
+    const size_t na2 = (size_t)ncas * ncas;
+    const size_t lds_bytes = ((size_t)N * m2 + (size_t)N * M + m3 + N + M + M + N + (size_t)N * N +
+                              (size_t)nrdm * (na2 + na2 * na2)) * sizeof(double);
+    OOVQE_REQUIRE(lds_bytes <= 160 * 1024, "cas_eval: N=%d M=%d nrdm=%d needs %zu B of LDS", N, M,
+                  nrdm, lds_bytes);
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)cas_column_kernel,
@@ -606,4 +701,58 @@ extern "C" int64_t oovqe_cas_eval_work_size(int N, int n_occ, int ncas, int nrdm
 {
     const int64_t M = n_occ + ncas;
     return 2 * (int64_t)N * N * M * M + (int64_t)nrdm * M * N + (int64_t)nrdm * N + N;
+}
+
+// ------------------------------------------------------------------------------------------
+// One call = one OO-VQE evaluation: circuit (+tangents) -> RDM sets -> CAS path.
+// ------------------------------------------------------------------------------------------
+extern "C" int64_t oovqe_oo_eval_work_size(int n_theta, int n_gates, int n_qubits, int N, int n_occ,
+                                           int ncas, int derivatives)
+{
+    const int64_t D = (int64_t)1 << n_qubits;
+    const int64_t nvec = derivatives ? 1 + n_theta : 1;
+    const int64_t na2 = (int64_t)ncas * ncas;
+    int64_t w = nvec * na2 + nvec * na2 * na2;                 // gamma, Gamma
+    w += oovqe_cas_eval_work_size(N, n_occ, ncas, (int)nvec);
+    if (!oovqe_circuit_rdms_is_small(n_qubits, ncas, (int)nvec, n_gates))
+        w += nvec * D + nvec * na2 * D;                        // psi | dpsi, V
+    return w;
+}
+
+extern "C" int oovqe_oo_eval(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
+                             int n_qubits, uint32_t init_index, const double* g_ao,
+                             const double* h_ao, const double* C, double nuc, int N, int n_occ,
+                             int ncas, const int32_t* kap_row, const int32_t* kap_col, int n_kappa,
+                             int derivatives, double* work, double* out, oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(theta && gates && g_ao && h_ao && C && work && out, "oo_eval: null pointer");
+    OOVQE_REQUIRE(n_qubits == 2 * ncas, "oo_eval: n_qubits != 2*ncas");
+    const int nvec = derivatives ? 1 + n_theta : 1;
+    const size_t D = (size_t)1 << n_qubits;
+    const size_t na2 = (size_t)ncas * ncas, na4 = na2 * na2;
+    double* gamma = work;
+    double* Gamma = gamma + (size_t)nvec * na2;
+    double* cas_work = Gamma + (size_t)nvec * na4;
+    double* rest = cas_work + oovqe_cas_eval_work_size(N, n_occ, ncas, nvec);
+    double *psi = nullptr, *dpsi = nullptr, *rwork = nullptr;
+    if (!oovqe_circuit_rdms_is_small(n_qubits, ncas, nvec, n_gates)) {
+        psi = rest;
+        dpsi = psi + D;
+        rwork = psi + (size_t)nvec * D;
+    }
+    int rc = oovqe_circuit_rdms(theta, n_theta, gates, n_gates, n_qubits, ncas, init_index,
+                                derivatives, 1, psi, derivatives ? dpsi : nullptr, gamma, Gamma,
+                                rwork, stream);
+    if (rc) return rc;
+    // packed output: [c0 | E | dE (max(nvec-1,1)) | gvec (nvec x n_kappa) | c1 (a^2) | c2 (a^4)]
+    const int n_t = nvec > 1 ? nvec - 1 : 1;
+    double* c0 = out;
+    double* E = out + 1;
+    double* dE = out + 2;
+    double* gvec = dE + n_t;
+    double* c1 = gvec + (size_t)nvec * n_kappa;
+    double* c2 = c1 + na2;
+    return oovqe_cas_eval(g_ao, h_ao, C, gamma, Gamma, nvec, nuc, N, n_occ, ncas, kap_row, kap_col,
+                          n_kappa, cas_work, c0, c1, c2, E, gvec, dE, nullptr, nullptr, nullptr,
+                          nullptr, stream);
 }

@@ -368,10 +368,28 @@ void circuit_rdm_small_kernel(const double* __restrict__ theta, int n_theta,
     double* vec = lds;                                   // [nvec][LDV]
     double* V = vec + (size_t)nvec * LDV;                // [nvec][na2][LDV]
     double* R = V + (size_t)nvec * na2 * LDV;            // [2*nvec][MT*16][NT*16]
+    const int RSZ = MT * 16 * NT * 16;
+    double* cs_l = R + (size_t)2 * nvec * RSZ;           // [n_gates][2] cos, sin
+    oovqe_gate_t* gl = reinterpret_cast<oovqe_gate_t*>(cs_l + 2 * n_gates);   // [n_gates]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
     const int b = blockIdx.x;
     const double* th = theta + (size_t)b * n_theta;
+    // gate table, cos/sin of every gate angle: once per workgroup, then LDS only
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(gates);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(gl);
+        for (int idx = tid; idx < n_gates * (int)(sizeof(oovqe_gate_t) / 4); idx += SMALL_THREADS)
+            dst[idx] = src[idx];
+        for (int g = tid; g < n_gates; g += SMALL_THREADS) {
+            const int ti = gates[g].theta_idx;
+            double sn = 0.0, cs = 1.0;
+            if (ti >= 0) sincos(0.5 * (double)gates[g].sign * th[ti], &sn, &cs);
+            cs_l[2 * g] = cs;
+            cs_l[2 * g + 1] = sn;
+        }
+    }
+    __syncthreads();
 
     // ---- phase 1: circuits (one vector per wave at a time; a tangent whose parameter drives
     // several gates is the sum over those gates, accumulated in place) -------------------------
@@ -384,7 +402,7 @@ void circuit_rdm_small_kernel(const double* __restrict__ theta, int n_theta,
             int dgate = -1;
             if (k >= 0) {
                 for (int g = g_start; g < n_gates; ++g)
-                    if (gates[g].theta_idx == k) { dgate = g; break; }
+                    if (gl[g].theta_idx == k) { dgate = g; break; }
                 if (dgate < 0) break;
                 g_start = dgate + 1;
             }
@@ -394,11 +412,9 @@ void circuit_rdm_small_kernel(const double* __restrict__ theta, int n_theta,
             for (uint32_t x = lane; x < D; x += 64) w[x] = (x == init_index) ? 1.0 : 0.0;
             __builtin_amdgcn_wave_barrier();
             for (int g = 0; g < n_gates; ++g) {
-                const oovqe_gate_t gt = gates[g];
+                const oovqe_gate_t gt = gl[g];
                 if (gt.theta_idx < 0) continue;
-                double sn, cs;
-                sincos(0.5 * (double)gt.sign * th[gt.theta_idx], &sn, &cs);
-                apply_gate_wave(w, D, gt, cs, sn, g == dgate, lane);
+                apply_gate_wave(w, D, gt, cs_l[2 * g], cs_l[2 * g + 1], g == dgate, lane);
                 __builtin_amdgcn_wave_barrier();
             }
             if (!first)
@@ -444,7 +460,7 @@ void circuit_rdm_small_kernel(const double* __restrict__ theta, int n_theta,
     __syncthreads();
 
     // ---- phase 3: Gram products.  unit u = 2k + h: h = 0 -> A_k . B_0, h = 1 -> A_0 . B_k ------
-    const int RS = MT * 16 * NT * 16;
+    const int RS = RSZ;
     const int ntile = MT * NT;
     const int nunits = 2 * nvec * ntile;
     for (int uu = wave; uu < nunits; uu += SMALL_THREADS / 64) {
@@ -574,14 +590,19 @@ extern "C" int oovqe_rdms_tangent(const double* psi, const double* dpsi, int n_q
     return 0;
 }
 
-static size_t small_lds_bytes(int n_qubits, int ncas, int nvec)
+static size_t small_lds_bytes(int n_qubits, int ncas, int nvec, int n_gates)
 {
     const size_t D = (size_t)1 << n_qubits;
     const size_t LDV = D + 2;
     const int na2 = ncas * ncas;
     const int MT = (na2 + 1 + 15) / 16, NT = (na2 + 15) / 16;
-    return ((size_t)nvec * LDV + (size_t)nvec * na2 * LDV + (size_t)2 * nvec * MT * 16 * NT * 16) *
-           sizeof(double);
+    return ((size_t)nvec * LDV + (size_t)nvec * na2 * LDV + (size_t)2 * nvec * MT * 16 * NT * 16 +
+            (size_t)2 * n_gates) * sizeof(double) + (size_t)n_gates * sizeof(oovqe_gate_t);
+}
+
+extern "C" int oovqe_circuit_rdms_is_small(int n_qubits, int ncas, int nvec, int n_gates)
+{
+    return n_qubits <= 10 && small_lds_bytes(n_qubits, ncas, nvec, n_gates) <= 150 * 1024;
 }
 
 extern "C" int oovqe_circuit_rdms(const double* theta, int n_theta, const oovqe_gate_t* gates,
@@ -594,8 +615,8 @@ extern "C" int oovqe_circuit_rdms(const double* theta, int n_theta, const oovqe_
     OOVQE_REQUIRE(n_theta >= 1 && n_gates >= 1 && batch >= 1, "circuit_rdms: bad sizes");
     const int n_tan = want_tangents ? n_theta : 0;
     const int nvec = 1 + n_tan;
-    const size_t lds_bytes = small_lds_bytes(n_qubits, ncas, nvec);
-    if (n_qubits <= 10 && lds_bytes <= 150 * 1024) {
+    const size_t lds_bytes = small_lds_bytes(n_qubits, ncas, nvec, n_gates);
+    if (oovqe_circuit_rdms_is_small(n_qubits, ncas, nvec, n_gates)) {
         static bool attr_done = false;
         if (!attr_done) {
             hipError_t e = hipFuncSetAttribute((const void*)circuit_rdm_small_kernel,

@@ -40,3 +40,4 @@ void oovqe_profile_mark_stop(hipStream_t st);
 __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
+

@@ -14,7 +14,7 @@
 //     every element of T is fetched from HBM exactly once per j-group, straight into the
 //     MFMA operand register (one f64 per lane) - no LDS round trip for the big operand;
 //   * the small matrix Cm is shared by all 8 waves of the workgroup: it is staged through LDS
-//     in K-chunks of 40 rows, double buffered (global->VGPR prefetch during the MFMAs of the
+//     in K-chunks of 20 rows, double buffered (global->VGPR prefetch during the MFMAs of the
 //     previous chunk), row pitch 16*(NT|1) doubles so that the ds_read_b64 fragment reads of
 //     the two 32-lane halves land on disjoint banks;
 //   * f64 MFMA issues one 16x16x4 every 64 cycles per SIMD, so per 13 MFMAs (832 cycles) a wave
@@ -23,22 +23,25 @@
 
 namespace {
 
-constexpr int KC = 40;            // K rows per LDS chunk
-constexpr int KSTEPS = KC / 4;    // MFMA k-steps per chunk
+// K rows per LDS chunk = 4 * KS (KS MFMA k-steps): KS = 5 for long contractions, 3 for short ones
+// (K is padded with zero rows of Cm to a multiple of the chunk, so a smaller chunk wastes fewer
+// MFMAs when K is small, e.g. K = 43 -> 48 instead of 60).
 constexpr int NWAVES = 8;
 constexpr int NTHREADS = NWAVES * 64;
 
-template <int NT, bool LAST>
+template <int NT, bool LAST, int KSTEPS>
 __global__ __launch_bounds__(NTHREADS, 2)
 void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm,
                      double* __restrict__ out, long A, int K, int J, long B, int ldc,
                      long n_items, int nbt)
 {
     const int j0 = blockIdx.y * (NT * 16);   // this workgroup's j-group
+    constexpr int KC = 4 * KSTEPS;
     constexpr int LDJ = 16 * (NT | 1);
     constexpr int CHUNK = KC * LDJ;
     constexpr int CREG = (CHUNK + NTHREADS - 1) / NTHREADS;
-    extern __shared__ double lds[];   // [2][KC][LDJ]
+    constexpr int BUF = CREG * NTHREADS;      // chunk buffer, padded so staging stores need no guard
+    extern __shared__ double lds[];           // [2][BUF]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -74,57 +77,74 @@ void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm
     double creg[CREG];
     double tcur[KSTEPS], tnext[KSTEPS];
 
+    // Every global load is unconditional on a clamped (always in-bounds) address and lives in the
+    // same basic block as its use: nothing for the compiler to sink behind a branch, so the loads
+    // of a chunk stay in flight together and vmcnt is counted, not drained.  Masks are
+    // multiplicative (a select on a loaded value is turned back into a branch around the load).
+    // T needs no mask: a lane outside the tensor (bcol >= B / row >= A) only feeds output columns
+    // / rows that are never stored, and rows k >= K meet zero rows of Cm.
+    const double* tp = T + (tvalid ? tbase : 0);
     auto stage_load = [&](int kbase) {
 #pragma unroll
         for (int i = 0; i < CREG; ++i) {
             const int idx = tid + i * NTHREADS;
             const int kk = idx / LDJ, jj = idx - kk * LDJ;
             const int k = kbase + kk, j = j0 + jj;
-            double v = 0.0;
-            if (idx < CHUNK && k < K && jj < NT * 16 && j < J) v = Cm[(long)k * ldc + j];
-            creg[i] = v;
+            creg[i] = Cm[(long)(k < K ? k : K - 1) * ldc + (j < J ? j : J - 1)];
         }
     };
-    auto stage_store = [&](double* buf) {
+    auto stage_store = [&](int kbase, double* buf) {
 #pragma unroll
         for (int i = 0; i < CREG; ++i) {
             const int idx = tid + i * NTHREADS;
-            if (idx < CHUNK) buf[idx] = creg[i];
+            const int kk = idx / LDJ, jj = idx - kk * LDJ;
+            const bool ok = kk < KC && (kbase + kk) < K && jj < NT * 16 && (j0 + jj) < J;
+            buf[idx] = creg[i] * (ok ? 1.0 : 0.0);
         }
     };
     auto load_t = [&](int kbase, double* dst) {
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             const int k = kbase + s * 4 + lq;
-            dst[s] = (tvalid && k < K) ? T[tbase + (long)k * tstride] : 0.0;
+            dst[s] = tp[(long)(k < K ? k : K - 1) * tstride];
         }
     };
 
     // ---- prologue ---------------------------------------------------------------------------
     stage_load(0);
     load_t(0, tcur);
-    stage_store(lds);
+    stage_store(0, lds);
     __syncthreads();
 
     for (int c = 0; c < nchunks; ++c) {
         const int kbase = c * KC;
-        const bool more = (c + 1) < nchunks;
-        if (more) {
-            stage_load(kbase + KC);
-            load_t(kbase + KC, tnext);
-        }
-        const double* buf = lds + (c & 1) * CHUNK;
+        // prefetch the next chunk (on the last iteration: a harmless re-read of row K-1)
+        const int knext = (c + 1 < nchunks) ? kbase + KC : K - 1;
+        stage_load(knext);
+        load_t(knext, tnext);
+        // One straight-line code path for every chunk (rows k >= K of the staged Cm are zero, so
+        // the padded k-steps of the last chunk add nothing).  The Cm fragments of k-step s+1 are
+        // read from LDS while the MFMAs of k-step s issue: an explicit two-stage pipeline,
+        // because letting the scheduler hoist all fragment reads of the chunk costs 2*KS*NT
+        // registers, and a second (tail) code path makes the compiler keep two copies of acc.
+        const double* buf = lds + (c & 1) * BUF + lq * LDJ + lr;
+        double cv[2][NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) cv[0][t] = buf[t * 16];
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
-            if (kbase + s * 4 < K) {
+            if (s + 1 < KSTEPS) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const double cv = buf[(s * 4 + lq) * LDJ + t * 16 + lr];
-                    acc[t] = LAST ? mfma_f64(tcur[s], cv, acc[t]) : mfma_f64(cv, tcur[s], acc[t]);
-                }
+                for (int t = 0; t < NT; ++t) cv[(s + 1) & 1][t] = buf[(s + 1) * 4 * LDJ + t * 16];
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = LAST ? mfma_f64(tcur[s], cv[s & 1][t], acc[t])
+                              : mfma_f64(cv[s & 1][t], tcur[s], acc[t]);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) stage_store(lds + ((c + 1) & 1) * CHUNK);
+        stage_store(knext, lds + ((c + 1) & 1) * BUF);
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) tcur[s] = tnext[s];
@@ -155,15 +175,17 @@ void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm
     }
 }
 
-template <int NT, bool LAST>
+template <int NT, bool LAST, int KS>
 int launch_nt(const double* T, const double* Cm, double* out, long A, int K, int J, long B,
               int ldc, int ngroups, long n_items, int nbt, hipStream_t st)
 {
     constexpr int LDJ = 16 * (NT | 1);
-    const size_t lds_bytes = (size_t)2 * KC * LDJ * sizeof(double);
+    constexpr int KC = 4 * KS;
+    constexpr int CREG = (KC * LDJ + NTHREADS - 1) / NTHREADS;
+    const size_t lds_bytes = (size_t)2 * CREG * NTHREADS * sizeof(double);
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)contract_kernel<NT, LAST>,
+        hipError_t e = hipFuncSetAttribute((const void*)contract_kernel<NT, LAST, KS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes);
         if (e != hipSuccess) {
@@ -177,19 +199,19 @@ int launch_nt(const double* T, const double* Cm, double* out, long A, int K, int
         oovqe_set_error("mode_contract: grid too large");
         return OOVQE_ERR_SIZE;
     }
-    hipLaunchKernelGGL((contract_kernel<NT, LAST>), dim3((unsigned)nblocks, (unsigned)ngroups),
+    hipLaunchKernelGGL((contract_kernel<NT, LAST, KS>), dim3((unsigned)nblocks, (unsigned)ngroups),
                        dim3(NTHREADS), lds_bytes, st, T, Cm, out, A, K, J, B, ldc, n_items, nbt);
     OOVQE_CHECK_LAUNCH("mode_contract");
     return 0;
 }
 
-template <bool LAST>
+template <bool LAST, int KS>
 int launch_group(int nt, const double* T, const double* Cm, double* out, long A, int K, int J,
                  long B, int ldc, int ngroups, long n_items, int nbt, hipStream_t st)
 {
     switch (nt) {
 #define OOVQE_CASE(n) \
-    case n: return launch_nt<n, LAST>(T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, st);
+    case n: return launch_nt<n, LAST, KS>(T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, st);
         OOVQE_CASE(1) OOVQE_CASE(2) OOVQE_CASE(3) OOVQE_CASE(4) OOVQE_CASE(5) OOVQE_CASE(6)
         OOVQE_CASE(7) OOVQE_CASE(8) OOVQE_CASE(9) OOVQE_CASE(10) OOVQE_CASE(11) OOVQE_CASE(12)
         OOVQE_CASE(13)
@@ -227,8 +249,16 @@ int oovqe_mode_contract_impl(const double* T, const double* Cm, double* out, lon
     const int ngroups = (JT + nt - 1) / nt;
     nt = (JT + ngroups - 1) / ngroups;   // even split
     OOVQE_REQUIRE(ngroups <= 65535, "mode_contract: J too large");
-    int rc = last ? launch_group<true>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, st)
-                  : launch_group<false>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, st);
+    // chunk depth: 20 rows when that wastes <= 5 % of the MFMAs on zero padding, else 12 rows
+    const int pad20 = ((K + 19) / 20) * 20, pad12 = ((K + 11) / 12) * 12;
+    const bool deep = pad20 <= pad12 || pad20 * 100 <= K * 105;
+    int rc;
+    if (deep)
+        rc = last ? launch_group<true, 5>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, st)
+                  : launch_group<false, 5>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, st);
+    else
+        rc = last ? launch_group<true, 3>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, st)
+                  : launch_group<false, 3>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, st);
     if (rc) return rc;
     return 0;
 }

@@ -30,6 +30,20 @@ class OO_pqc(OO_energy):
     def _evaluate(self, theta, mo_coeff=None, derivatives=True, want_matrices=False):
         if mo_coeff is None:
             mo_coeff = self.mo_coeff
+        if not want_matrices:
+            # one C call: circuit (+tangents) -> RDM sets -> CAS path, persistent workspace
+            plans = self.__dict__.setdefault("_plans2", {})
+            key = (bool(derivatives), id(self.pqc), id(self.int2e_ao), id(self.int1e_ao))
+            plan = plans.get(key)
+            if plan is None:
+                pqc = self.pqc
+                plan = ops.OoEvalPlan(pqc._gates_dev, pqc._n_gates, self._n_theta(), pqc.n_qubits,
+                                      pqc._init_index, self.int2e_ao, self.int1e_ao, self.nuc,
+                                      self._n_occ, self.ncas, self._kap_row, self._kap_col,
+                                      derivatives=derivatives)
+                plans[key] = plan
+            th = self.pqc._theta2d(theta).reshape(-1)
+            return plan.unpack(plan(th, self._t(mo_coeff)))
         if derivatives:
             gamma, Gamma = self.pqc.rdms_with_derivatives(theta)
         else:

@@ -167,9 +167,7 @@ def circuit_rdms(theta, gates_dev, n_gates, n_qubits, ncas, init_index, tangents
     D = 1 << n_qubits
     n_tan = n_theta if tangents else 0
     nvec = 1 + n_tan
-    small = n_qubits <= 10 and (nvec * (D + 2) * (1 + ncas * ncas)
-                                + 2 * nvec * 256 * ((ncas * ncas + 16) // 16)
-                                * ((ncas * ncas + 15) // 16)) * 8 <= 150 * 1024
+    small = bool(lib.oovqe_circuit_rdms_is_small(n_qubits, ncas, nvec, n_gates))
     gamma = torch.empty((batch, nvec, ncas, ncas), dtype=F64, device=dev)
     Gamma = torch.empty((batch, nvec, ncas, ncas, ncas, ncas), dtype=F64, device=dev)
     need_states = want_states or not small
@@ -269,3 +267,49 @@ def cas_eval(g_ao, h_ao, C, gamma, Gamma, nuc, n_occ, ncas, kap_row, kap_col, wa
     packed = small[1:2 + (nrdm - 1) + n_kappa] if nrdm > 1 else None   # [E, dE..., gvec[0]...]
     return dict(c0=c0, c1=c1, c2=c2, E=E, fock=fock, gmat=gmat, gvec=gvec, dE=dE[:nrdm - 1],
                 Gm=Gm, hmo=hmo, packed=packed)
+
+
+class OoEvalPlan:
+    """Pre-resolved arguments + persistent workspace for oovqe_oo_eval (one geometry, one circuit).
+    Calling it costs one small allocation (the packed result) and one ctypes call."""
+
+    def __init__(self, gates_dev, n_gates, n_theta, n_qubits, init_index, g_ao, h_ao, nuc, n_occ,
+                 ncas, kap_row, kap_col, derivatives=True):
+        self.lib = _lib.load()
+        self.dev = _dev(g_ao)
+        self.N = h_ao.shape[0]
+        self.n_theta, self.ncas, self.derivatives = n_theta, ncas, bool(derivatives)
+        self.n_kappa = kap_row.numel()
+        self.nvec = 1 + n_theta if derivatives else 1
+        self.n_t = max(self.nvec - 1, 1)
+        wsz = self.lib.oovqe_oo_eval_work_size(n_theta, n_gates, n_qubits, self.N, n_occ, ncas,
+                                               int(self.derivatives))
+        self.work = torch.empty(wsz, dtype=F64, device=self.dev)
+        self.out_size = 2 + self.n_t + self.nvec * self.n_kappa + ncas ** 2 + ncas ** 4
+        self._keep = (gates_dev, g_ao, h_ao, kap_row, kap_col)
+        self._pre = (n_theta, ctypes.c_void_p(gates_dev.data_ptr()), n_gates, n_qubits,
+                     ctypes.c_uint32(init_index), dptr(g_ao), dptr(h_ao))
+        self._post = (float(nuc), self.N, n_occ, ncas, dptr(kap_row, torch.int32),
+                      dptr(kap_col, torch.int32), self.n_kappa, int(self.derivatives),
+                      dptr(self.work))
+
+    def __call__(self, theta, C):
+        """theta: contiguous fp64 device tensor [n_theta]; C: mo_coeff [N,N].  -> packed output."""
+        out = torch.empty(self.out_size, dtype=F64, device=self.dev)
+        rc = self.lib.oovqe_oo_eval(ctypes.c_void_p(theta.data_ptr()), *self._pre,
+                                    ctypes.c_void_p(C.data_ptr()), *self._post,
+                                    ctypes.c_void_p(out.data_ptr()), stream_ptr())
+        if rc != 0:
+            check(rc, "oovqe_oo_eval")
+        return out
+
+    def unpack(self, out):
+        nk, a = self.n_kappa, self.ncas
+        o = 2 + self.n_t
+        gvec = out[o:o + self.nvec * nk].view(self.nvec, nk)
+        o += self.nvec * nk
+        c1 = out[o:o + a * a].view(a, a)
+        c2 = out[o + a * a:o + a * a + a ** 4].view((a,) * 4)
+        packed = out[1:2 + (self.nvec - 1) + nk] if self.nvec > 1 else None
+        return dict(c0=out[0:1], E=out[1:2], dE=out[2:2 + self.nvec - 1], gvec=gvec, c1=c1, c2=c2,
+                    packed=packed, fock=None, gmat=None, Gm=None, hmo=None)

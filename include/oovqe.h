@@ -171,6 +171,24 @@ int oovqe_cas_eval(const double* g_ao, const double* h_ao, const double* C, cons
                    double* fock, double* gmat, double* Gm, double* hmo, oovqe_stream_t stream);
 int64_t oovqe_cas_eval_work_size(int N, int n_occ, int ncas, int nrdm);
 
+/* ---- a12/a13/a14/a16: one evaluation of the hybrid cost function in ONE call ---------------------
+ * OO_pqc.energy_from_parameters / circuit_gradient / orbital_gradient / orbital_circuit_hessian
+ * (src/auto_oo/oo_pqc.py:64-125) for a single geometry: circuit (+ tangents when derivatives != 0)
+ * -> RDM sets -> CAS path.  5 launches on `stream`, no host synchronisation.
+ * out (packed): [c0 | E | dE/dtheta (n_theta, or 1 slot when derivatives == 0) |
+ *                gvec (nvec x n_kappa; row 0 = dE/dkappa, rows k>=1 = d^2E/dkappa dtheta_k) |
+ *                c1 (a^2) | c2 (a^4)],  nvec = derivatives ? 1 + n_theta : 1.
+ * work: oovqe_oo_eval_work_size() doubles. */
+int oovqe_oo_eval(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
+                  int n_qubits, uint32_t init_index, const double* g_ao, const double* h_ao,
+                  const double* C, double nuc, int N, int n_occ, int ncas, const int32_t* kap_row,
+                  const int32_t* kap_col, int n_kappa, int derivatives, double* work, double* out,
+                  oovqe_stream_t stream);
+int64_t oovqe_oo_eval_work_size(int n_theta, int n_gates, int n_qubits, int N, int n_occ, int ncas,
+                                int derivatives);
+/* 1 when oovqe_circuit_rdms takes its one-workgroup LDS path for these sizes */
+int oovqe_circuit_rdms_is_small(int n_qubits, int ncas, int nvec, int n_gates);
+
 #ifdef __cplusplus
 }
 #endif

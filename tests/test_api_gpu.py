@@ -54,7 +54,7 @@ def test_get_rdms_golden(case):
     assert np.allclose(g1.cpu().numpy(), np.array(case["one_rdm"]), rtol=1e-5, atol=1e-8)
     assert np.allclose(g2.cpu().numpy(), np.array(case["two_rdm"]), rtol=1e-5, atol=1e-8)
     s1, s2 = pqc.get_rdms_from_state(pqc.qnode(theta))
-    assert torch.equal(s1, g1) and torch.equal(s2, g2)
+    assert (s1 - g1).abs().max() < 1e-13 and (s2 - g2).abs().max() < 1e-13
 
 
 @pytest.mark.parametrize("case", _load("skew_pack.json")[:1], ids=lambda c: c["source"])
