@@ -12,6 +12,7 @@ _lib.load()   # fail loudly at import time when the HIP extension is missing
 from .pqc import Parameterized_circuit                      # noqa: E402
 from .moldata import Moldata, ao_to_oao                     # noqa: E402
 from .oo_pqc import OO_pqc                                  # noqa: E402
+from .batch import OO_pqc_batch                             # noqa: E402
 from .oo_energy import (                                    # noqa: E402
     OO_energy,
     mo_ao_to_mo_oao,
@@ -27,7 +28,7 @@ from .newton_raphson import NewtonStep                      # noqa: E402
 from .excitations import generalized_pair_doubles           # noqa: E402
 
 __all__ = [
-    "Parameterized_circuit", "Moldata", "ao_to_oao", "OO_pqc", "OO_energy", "mo_ao_to_mo_oao",
+    "Parameterized_circuit", "Moldata", "ao_to_oao", "OO_pqc", "OO_pqc_batch", "OO_energy", "mo_ao_to_mo_oao",
     "int1e_transform", "int2e_transform", "general_4index_transform", "uniform_4index_transform",
     "vector_to_skew_symmetric", "skew_symmetric_to_vector", "non_redundant_indices", "NewtonStep",
     "generalized_pair_doubles",

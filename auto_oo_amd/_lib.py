@@ -86,6 +86,13 @@ SIGNATURES = {
                                      c_int32_p, c_int32_p, ctypes.c_int, ctypes.c_int, c_double_p,
                                      c_double_p, c_stream]),
     "oovqe_oo_eval_work_size": (ctypes.c_int64, [ctypes.c_int] * 7),
+    "oovqe_oo_eval_out_size": (ctypes.c_int64, [ctypes.c_int] * 4),
+    "oovqe_oo_eval_batch": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_uint32, c_double_p, c_double_p,
+                                           c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int, c_int32_p, c_int32_p, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
+                                           c_stream]),
     "oovqe_circuit_rdms_is_small": (ctypes.c_int, [ctypes.c_int] * 4),
 }
 

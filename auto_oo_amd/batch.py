@@ -1,0 +1,120 @@
+"""Batched evaluation over molecular geometries (the Berry-phase-loop batch of the north star).
+
+The reference evaluates one geometry at a time (examples/Tutorial_Berry_phase.ipynb builds a new
+``OO_pqc`` per point).  At cc-pVDZ size one evaluation is only ~27 MB of HBM traffic, far too
+little to fill an MI355X, so ``OO_pqc_batch`` stacks the per-geometry tensors of G ``OO_pqc``-like
+problems (same basis size, same active space, same circuit) and evaluates all of them with ONE
+call of ``oovqe_oo_eval_batch`` -- 5 kernel launches in which the geometry index is a grid
+dimension.  Per geometry the arithmetic is exactly that of ``OO_pqc.energy_and_gradient``.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, excitations as X, ops
+from ._lib import check, dptr, stream_ptr
+from .oo_energy import mo_ao_to_mo_oao, non_redundant_indices
+
+F64 = torch.float64
+
+
+class OO_pqc_batch:
+    def __init__(self, pqc, mols, ncas, nelecas, oao_mo_coeffs=None, freeze_active=False):
+        """
+        Args:
+            pqc: Parameterized_circuit shared by all geometries
+            mols: sequence of Moldata (same nao, same electron count)
+            ncas, nelecas: active space
+            oao_mo_coeffs: sequence of [N,N] OAO->MO coefficients (default: from mol.hf.mo_coeff)
+            freeze_active: freeze active-active rotations (oo_energy.py:139-140)
+        """
+        self.lib = _lib.load()
+        self.device = _lib.require_device()
+        self.pqc = pqc
+        self.G = len(mols)
+        if self.G < 1:
+            raise ValueError("need at least one geometry")
+        self.nao = mols[0].nao
+        self.ncas, self.nelecas = ncas, nelecas
+        for m in mols:
+            if m.nao != self.nao or m.nelectron != mols[0].nelectron:
+                raise ValueError("all geometries of a batch must share nao and the electron count")
+        self.occ_idx, self.act_idx, self.virt_idx = mols[0].get_active_space_idx(ncas, nelecas)
+        self._n_occ = len(self.occ_idx)
+        self.params_idx = non_redundant_indices(self.occ_idx, self.act_idx, self.virt_idx,
+                                                freeze_active)
+        self.n_kappa = len(self.params_idx)
+        rows, cols = X.tril_tables(self.nao, self.params_idx)
+        self._kap_row = torch.as_tensor(rows).to(self.device)
+        self._kap_col = torch.as_tensor(cols).to(self.device)
+        self.n_theta = int(np.prod(pqc.theta_shape))
+
+        N = self.nao
+        self.int2e_ao = torch.empty((self.G, N, N, N, N), dtype=F64, device=self.device)
+        self.int1e_ao = torch.empty((self.G, N, N), dtype=F64, device=self.device)
+        self.oao_coeff = torch.empty((self.G, N, N), dtype=F64, device=self.device)
+        self.oao_mo_coeff = torch.empty((self.G, N, N), dtype=F64, device=self.device)
+        self.mo_coeff = torch.empty((self.G, N, N), dtype=F64, device=self.device)
+        self.nuc = torch.empty(self.G, dtype=F64, device=self.device)
+        nuc_host = np.empty(self.G)
+        for g, m in enumerate(mols):
+            self.int2e_ao[g].copy_(ops.as_device(m.int2e_ao, self.device))
+            self.int1e_ao[g].copy_(ops.as_device(m.int1e_ao, self.device))
+            self.oao_coeff[g].copy_(ops.as_device(m.oao_coeff, self.device))
+            if oao_mo_coeffs is None:
+                m.run_rhf()
+                c = mo_ao_to_mo_oao(m.hf.mo_coeff, m.overlap)
+            else:
+                c = oao_mo_coeffs[g]
+            self.set_oao_mo_coeff(g, c)
+            nuc_host[g] = m.nuc
+        self.nuc.copy_(torch.as_tensor(nuc_host))
+        self._plans = {}
+
+    def set_oao_mo_coeff(self, g, oao_mo_coeff):
+        """Replace the orbitals of geometry g and refresh mo_coeff[g] = S^-1/2 C_oao
+        (oo_energy.py:173-176)."""
+        c = ops.as_device(oao_mo_coeff, self.device)
+        self.oao_mo_coeff[g].copy_(c)
+        self.mo_coeff[g].copy_(ops.matmul_nn(self.oao_coeff[g].contiguous(), c))
+
+    def _plan(self, derivatives):
+        key = bool(derivatives)
+        if key not in self._plans:
+            pqc = self.pqc
+            wsz = self.lib.oovqe_oo_eval_work_size(self.n_theta, pqc._n_gates, pqc.n_qubits, self.nao,
+                                                   self._n_occ, self.ncas, int(key))
+            osz = self.lib.oovqe_oo_eval_out_size(self.n_theta, self.n_kappa, self.ncas, int(key))
+            work = torch.empty(self.G * wsz, dtype=F64, device=self.device)
+            self._plans[key] = (work, int(osz))
+        return self._plans[key]
+
+    def evaluate(self, thetas, derivatives=True, count=None):
+        """thetas [G, n_theta] (device, fp64) -> packed outputs [G, out_size]
+        ([c0 | E | dE/dtheta | gvec rows | c1 | c2] per geometry, include/oovqe.h).
+        ``count``: evaluate only the first ``count`` geometries of the batch."""
+        G = self.G if count is None else int(count)
+        if not 1 <= G <= self.G:
+            raise ValueError(f"count must be in 1..{self.G}")
+        thetas = ops.as_device(thetas, self.device).reshape(-1, self.n_theta)[:G]
+        work, osz = self._plan(derivatives)
+        out = torch.empty((G, osz), dtype=F64, device=self.device)
+        pqc = self.pqc
+        check(self.lib.oovqe_oo_eval_batch(
+            dptr(thetas), self.n_theta, dptr(pqc._gates_dev, torch.uint8), pqc._n_gates,
+            pqc.n_qubits, ctypes.c_uint32(pqc._init_index), dptr(self.int2e_ao),
+            dptr(self.int1e_ao), dptr(self.mo_coeff), dptr(self.nuc), self.nao, self._n_occ,
+            self.ncas, dptr(self._kap_row, torch.int32), dptr(self._kap_col, torch.int32),
+            self.n_kappa, int(bool(derivatives)), G, dptr(work), dptr(out), stream_ptr()),
+            "oovqe_oo_eval_batch")
+        return out
+
+    def energy_and_gradient(self, thetas, count=None):
+        """-> [G, 1 + n_theta + n_kappa]: column 0 = E, then dE/dtheta, then dE/dkappa."""
+        out = self.evaluate(thetas, derivatives=True, count=count)
+        return out[:, 1:2 + self.n_theta + self.n_kappa]
+
+    def energy(self, thetas):
+        """-> [G] energies (OO_pqc.energy_from_parameters per geometry)."""
+        return self.evaluate(thetas, derivatives=False)[:, 1]

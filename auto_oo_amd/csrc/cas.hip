@@ -14,6 +14,10 @@
 
 int oovqe_mode_contract_impl(const double* T, const double* Cm, double* out, long A, int K, int J,
                              long B, int ldc, int last, hipStream_t st);
+int oovqe_mode_contract_batched(const double* T, const double* Cm, double* out, long A, int K, int J,
+                                long B, int ldc, int last, int batch, long t_bs, long c_bs, long o_bs,
+                                hipStream_t st);
+extern "C" int oovqe_circuit_rdms_is_small(int n_qubits, int ncas, int nvec, int n_gates);
 
 namespace {
 
@@ -49,6 +53,10 @@ void half_transform_kernel(const double* __restrict__ g, const double* __restric
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
+    // blockIdx.y = geometry of a batch (stacked g_ao [G][N^4], C [G][N^2], T2 [G][N^2 M^2])
+    g += (size_t)blockIdx.y * nslabs * N * N;
+    C += (size_t)blockIdx.y * N * N;
+    T2 += (size_t)blockIdx.y * nslabs * M * M;
 
     const long slab = (long)blockIdx.x * HALF_WAVES + wave;
     const bool have = slab < nslabs;
@@ -119,15 +127,20 @@ void half_transform_kernel(const double* __restrict__ g, const double* __restric
 
     if constexpr (NST > 0) {
         // Small N: no LDS, no barrier.  Each lane fetches its own C fragments straight from L2
-        // (cfr[j][y] = C[4j + lq][16y + lr]: the B operand of k-step j of stage 1 AND the A operand
-        // of k-step j%4 of column tile j/4 in stage 2), then the whole slab; 12 + NST*KCH loads
-        // per lane are in flight together and every wave runs independently of the others.
+        // (cfr[j][y] = C[4j + lq][16y + lr]), then the whole slab; all loads of the wave are in
+        // flight together and every wave runs independently of the others.
+        //
+        // Column tiles come in PAIRS: a pair covers 32 consecutive columns, lane lr loads the two
+        // adjacent columns (2lr, 2lr+1) of row 4i+lq with ONE 16-byte load (8-byte loads reach
+        // only ~0.55x of the per-CU HBM rate); .x feeds the "even" tile, .y the "odd" tile, whose
+        // MFMA row index m = lr therefore stands for column c0 + 2lr (+1).  An odd last tile is a
+        // single 16-column tile on 8-byte loads.
         if (!have) return;
-        constexpr int NCF = NST * 4;
+        constexpr int NP = NST / 2, NS1 = NST % 2;
+        constexpr int NROW = NST * 16;                 // rows of C touched by stage 2
+        constexpr int NCF = NROW / 4;
         static_assert(KCH <= NCF, "C fragments must cover every k-step");
         double cfr[NCF][ZT];
-        double aall[NST][KCH];
-        // raw loads on clamped addresses first (all in flight together) ...
 #pragma unroll
         for (int j = 0; j < NCF; ++j)
 #pragma unroll
@@ -135,44 +148,103 @@ void half_transform_kernel(const double* __restrict__ g, const double* __restric
                 const int r = 4 * j + lq, z = 16 * y + lr;
                 cfr[j][y] = C[(size_t)(r < N ? r : N - 1) * N + (z < M ? z : M - 1)];
             }
+        d2u apair[NP > 0 ? NP : 1][KCH];
+        double asing[KCH];
 #pragma unroll
-        for (int st = 0; st < NST; ++st) {
-            const int col = st * 16 + lr;
+        for (int pp = 0; pp < NP; ++pp) {
+            const int col = pp * 32 + 2 * lr;
+            const int colc = col + 1 < N ? col : (N >= 2 ? N - 2 : 0);
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) {
+                const int r = 4 * i + lq;
+                apair[pp][i] = *reinterpret_cast<const d2u*>(gs + (size_t)(r < N ? r : N - 1) * N + colc);
+            }
+        }
+        if constexpr (NS1) {
+            const int col = NP * 32 + lr;
             const int colc = col < N ? col : N - 1;
 #pragma unroll
             for (int i = 0; i < KCH; ++i) {
                 const int r = 4 * i + lq;
-                aall[st][i] = gs[(size_t)(r < N ? r : N - 1) * N + colc];
+                asing[i] = gs[(size_t)(r < N ? r : N - 1) * N + colc];
             }
         }
+        // stage 2 needs C rows in the order of the MFMA row index of each tile:
+        //   even tile of pair pp: row m = lq + 4i  <->  column pp*32 + 2(lq+4i)
+        //   odd  tile of pair pp:                       column pp*32 + 2(lq+4i) + 1
+        //   single tile         :                       column NP*32 + lq + 4i  (= cfr[NP*8 + i])
+        double cpr[NP > 0 ? NP : 1][2][4][ZT];
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int z = 0; z < ZT; ++z) {
+                        const int col = pp * 32 + 2 * (lq + 4 * i) + half, zz = 16 * z + lr;
+                        cpr[pp][half][i][z] =
+                            C[(size_t)(col < N ? col : N - 1) * N + (zz < M ? zz : M - 1)];
+                    }
         __builtin_amdgcn_sched_barrier(0);
-        // ... then the masks (multiplicative: a select would be turned back into a branch around
-        // the load, serialising the loads)
+        // masks (multiplicative: a select would be turned back into a branch around the load)
 #pragma unroll
         for (int j = 0; j < NCF; ++j)
 #pragma unroll
             for (int y = 0; y < ZT; ++y)
                 cfr[j][y] *= ((4 * j + lq) < N && (16 * y + lr) < M) ? 1.0 : 0.0;
 #pragma unroll
-        for (int st = 0; st < NST; ++st)
+        for (int pp = 0; pp < NP; ++pp)
 #pragma unroll
-            for (int i = 0; i < KCH; ++i)
-                aall[st][i] *= ((st * 16 + lr) < N && (4 * i + lq) < N) ? 1.0 : 0.0;
+            for (int half = 0; half < 2; ++half)
 #pragma unroll
-        for (int st = 0; st < NST; ++st) {
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < KCH; ++i)
+                    for (int z = 0; z < ZT; ++z)
+                        cpr[pp][half][i][z] *= ((pp * 32 + 2 * (lq + 4 * i) + half) < N &&
+                                                (16 * z + lr) < M) ? 1.0 : 0.0;
 #pragma unroll
-                for (int y = 0; y < ZT; ++y) xt[y] = mfma_f64(aall[st][i], cfr[i][y], xt[y]);
+        for (int pp = 0; pp < NP; ++pp) {
+            const int c0 = pp * 32 + 2 * lr;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const double colok = (c0 + half < N) ? 1.0 : 0.0;
+#pragma unroll
+                for (int i = 0; i < KCH; ++i) {
+                    const double rowok = (4 * i + lq) < N ? colok : 0.0;
+                    const double av = (half == 0 ? apair[pp][i].x : apair[pp][i].y) * rowok;
+#pragma unroll
+                    for (int y = 0; y < ZT; ++y) xt[y] = mfma_f64(av, cfr[i][y], xt[y]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int z = 0; z < ZT; ++z) {
+                        const double cz = cpr[pp][half][i][z];
+#pragma unroll
+                        for (int y = 0; y < ZT; ++y) jt[z][y] = mfma_f64(cz, xt[y][i], jt[z][y]);
+                    }
+#pragma unroll
+                for (int y = 0; y < ZT; ++y) xt[y] = d4{0.0, 0.0, 0.0, 0.0};
+            }
+        }
+        if constexpr (NS1) {
+            const double colok = (NP * 32 + lr) < N ? 1.0 : 0.0;
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) {
+                const double av = asing[i] * ((4 * i + lq) < N ? colok : 0.0);
+#pragma unroll
+                for (int y = 0; y < ZT; ++y) xt[y] = mfma_f64(av, cfr[i][y], xt[y]);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int z = 0; z < ZT; ++z)
+                for (int z = 0; z < ZT; ++z) {
+                    // column NP*32 + lq + 4i = row (NP*8 + i)*4 + lq of C: an existing fragment
+                    const double cz = cfr[NP * 8 + i][z];
 #pragma unroll
-                    for (int y = 0; y < ZT; ++y)
-                        jt[z][y] = mfma_f64(cfr[4 * st + i][z], xt[y][i], jt[z][y]);
-#pragma unroll
-            for (int y = 0; y < ZT; ++y) xt[y] = d4{0.0, 0.0, 0.0, 0.0};
+                    for (int y = 0; y < ZT; ++y) jt[z][y] = mfma_f64(cz, xt[y][i], jt[z][y]);
+                }
         }
     } else {
         // chunk c = st * nkc + kc
@@ -368,7 +440,7 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
                        const double* __restrict__ Gamma, int nrdm, int N, int no, int na,
                        double* __restrict__ Fcol, double* __restrict__ Epart,
                        double* __restrict__ Cpart, double* __restrict__ c1, double* __restrict__ c2,
-                       double* __restrict__ Gm_out, double* __restrict__ hmo_out)
+                       double* __restrict__ Gm_out, double* __restrict__ hmo_out, size_t out_stride)
 {
     extern __shared__ double lds[];
     const int M = no + na, M2 = M * M, M3 = M2 * M;
@@ -385,6 +457,21 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
     double* Gml = gml + (size_t)nrdm * na2;   // [nrdm][na4]
     const int tid = threadIdx.x;
     const int n = blockIdx.x;
+    {   // blockIdx.y = geometry of a batch: every per-geometry array is stacked
+        const size_t gi = blockIdx.y;
+        U += gi * (size_t)N * N * M2;
+        h_ao += gi * (size_t)N * N;
+        C += gi * (size_t)N * N;
+        gamma += gi * (size_t)nrdm * na2;
+        Gamma += gi * (size_t)nrdm * na4;
+        Fcol += gi * (size_t)nrdm * M * N;
+        Epart += gi * (size_t)nrdm * N;
+        Cpart += gi * (size_t)N;
+        c1 += gi * out_stride;
+        c2 += gi * out_stride;
+        if (Gm_out) Gm_out += gi * (size_t)N * M3;
+        if (hmo_out) hmo_out += gi * (size_t)N * M;
+    }
     for (int idx = tid; idx < N * N; idx += COL_THREADS) hl[idx] = h_ao[idx];
     for (int idx = tid; idx < nrdm * na2; idx += COL_THREADS) gml[idx] = gamma[idx];
     for (int idx = tid; idx < nrdm * na4; idx += COL_THREADS) Gml[idx] = Gamma[idx];
@@ -491,9 +578,23 @@ void cas_final_kernel(const double* __restrict__ Fcol, const double* __restrict_
                       const int32_t* __restrict__ kap_row, const int32_t* __restrict__ kap_col,
                       int n_kappa, double* __restrict__ c0, double* __restrict__ E,
                       double* __restrict__ gvec, double* __restrict__ dE, double* __restrict__ fock,
-                      double* __restrict__ gmat)
+                      double* __restrict__ gmat, const double* __restrict__ nuc_arr,
+                      size_t out_stride)
 {
     const int tid = threadIdx.x;
+    {   // blockIdx.x = geometry of a batch
+        const size_t gi = blockIdx.x;
+        Fcol += gi * (size_t)nrdm * M * N;
+        Epart += gi * (size_t)nrdm * N;
+        Cpart += gi * (size_t)N;
+        c0 += gi * out_stride;
+        E += gi * out_stride;
+        gvec += gi * out_stride;
+        if (dE) dE += gi * out_stride;
+        if (fock) fock += gi * (size_t)N * N;
+        if (gmat) gmat += gi * (size_t)N * N;
+        if (nuc_arr) nuc = nuc_arr[gi];
+    }
     for (long idx = tid; idx < (long)nrdm * n_kappa; idx += 512) {
         const int k = (int)(idx / n_kappa), t = (int)(idx - (long)k * n_kappa);
         const int r = kap_row[t], c = kap_col[t];
@@ -531,10 +632,20 @@ void cas_final_kernel(const double* __restrict__ Fcol, const double* __restrict_
 
 }  // namespace
 
+static int half_transform_batched(const double* g_ao, const double* C, int N, int M, double* T2,
+                                  int batch, oovqe_stream_t stream);
+
 extern "C" int oovqe_cas_half_transform(const double* g_ao, const double* C, int N, int M, double* T2,
                                         oovqe_stream_t stream)
 {
+    return half_transform_batched(g_ao, C, N, M, T2, 1, stream);
+}
+
+static int half_transform_batched(const double* g_ao, const double* C, int N, int M, double* T2,
+                                  int batch, oovqe_stream_t stream)
+{
     OOVQE_REQUIRE(g_ao && C && T2, "cas_half_transform: null pointer");
+    OOVQE_REQUIRE(batch >= 1 && batch <= 65535, "cas_half_transform: batch=%d", batch);
     OOVQE_REQUIRE(N >= 1 && M >= 1 && M <= N, "cas_half_transform: bad N=%d M=%d", N, M);
     hipStream_t st = (hipStream_t)stream;
     const int ZT = (M + 15) / 16;
@@ -565,7 +676,7 @@ extern "C" int oovqe_cas_half_transform(const double* g_ao, const double* C, int
             }                                                                                     \
             attr_done = true;                                                                     \
         }                                                                                         \
-        hipLaunchKernelGGL((half_transform_kernel<Z, KC_, NS_>), dim3(grid),                      \
+        hipLaunchKernelGGL((half_transform_kernel<Z, KC_, NS_>), dim3(grid, batch),               \
                            dim3(HALF_WAVES * 64),                                                 \
                            lds_bytes, st, g_ao, C, T2, N, M, nrb, nkc, nslabs);                   \
     } while (0)
@@ -647,12 +758,15 @@ extern "C" int oovqe_cas_energy_gradient(const double* Gm, const double* hmo, co
     return 0;
 }
 
-extern "C" int oovqe_cas_eval(const double* g_ao, const double* h_ao, const double* C,
-                              const double* gamma, const double* Gamma, int nrdm, double nuc, int N,
-                              int n_occ, int ncas, const int32_t* kap_row, const int32_t* kap_col,
-                              int n_kappa, double* work, double* c0, double* c1, double* c2,
-                              double* E, double* gvec, double* dE, double* fock, double* gmat,
-                              double* Gm, double* hmo, oovqe_stream_t stream)
+// Batched CAS path: `batch` geometries of identical shape, every per-geometry array stacked.
+// Outputs c0/c1/c2/E/gvec/dE of geometry g live at pointer + g * out_stride (doubles).
+static int cas_eval_batched(const double* g_ao, const double* h_ao, const double* C,
+                            const double* gamma, const double* Gamma, int nrdm, double nuc,
+                            const double* nuc_arr, int N, int n_occ, int ncas, const int32_t* kap_row,
+                            const int32_t* kap_col, int n_kappa, double* work, double* c0, double* c1,
+                            double* c2, double* E, double* gvec, double* dE, double* fock,
+                            double* gmat, double* Gm, double* hmo, int batch, size_t out_stride,
+                            oovqe_stream_t stream)
 {
     OOVQE_REQUIRE(g_ao && h_ao && C && gamma && Gamma && work && c0 && c1 && c2 && E && gvec,
                   "cas_eval: null pointer");
@@ -660,19 +774,23 @@ extern "C" int oovqe_cas_eval(const double* g_ao, const double* h_ao, const doub
                   "cas_eval: bad sizes");
     OOVQE_REQUIRE(n_kappa == 0 || (kap_row && kap_col), "cas_eval: null index table");
     OOVQE_REQUIRE(nrdm == 1 || dE, "cas_eval: dE required when nrdm > 1");
+    OOVQE_REQUIRE(batch >= 1 && batch <= 65535, "cas_eval: batch=%d", batch);
     hipStream_t st = (hipStream_t)stream;
     const int M = n_occ + ncas;
     const long m2 = (long)M * M, m3 = m2 * M;
-    // workspace layout
-    double* T2 = work;                              // [N][N][M][M]
-    double* U = T2 + (size_t)N * N * m2;            // [N][N][M][M]
-    double* Fcol = U + (size_t)N * N * m2;          // [nrdm][M][N]
-    double* Epart = Fcol + (size_t)nrdm * M * N;    // [nrdm][N]
-    double* Cpart = Epart + (size_t)nrdm * N;       // [N]
+    // workspace layout (each block stacked over the batch)
+    const size_t nb = (size_t)batch;
+    double* T2 = work;                                   // [G][N][N][M][M]
+    double* U = T2 + nb * N * N * m2;                    // [G][N][N][M][M]
+    double* Fcol = U + nb * N * N * m2;                  // [G][nrdm][M][N]
+    double* Epart = Fcol + nb * nrdm * M * N;            // [G][nrdm][N]
+    double* Cpart = Epart + nb * nrdm * N;               // [G][N]
     int rc;
-    if ((rc = oovqe_cas_half_transform(g_ao, C, N, M, T2, stream))) return rc;
+    if ((rc = half_transform_batched(g_ao, C, N, M, T2, batch, stream))) return rc;
     // U[n,(q y z)] = sum_p C[p,n] T2[p,(q y z)]
-    if ((rc = oovqe_mode_contract_impl(T2, C, U, 1, N, N, (long)N * m2, N, 0, st))) return rc;
+    if ((rc = oovqe_mode_contract_batched(T2, C, U, 1, N, N, (long)N * m2, N, 0, batch,
+                                          (long)N * N * m2, (long)N * N, (long)N * N * m2, st)))
+        return rc;
     const size_t na2 = (size_t)ncas * ncas;
     const size_t lds_bytes = ((size_t)N * m2 + (size_t)N * M + m3 + N + M + M + N + (size_t)N * N +
                               (size_t)nrdm * (na2 + na2 * na2)) * sizeof(double);
@@ -688,13 +806,27 @@ extern "C" int oovqe_cas_eval(const double* g_ao, const double* h_ao, const doub
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL(cas_column_kernel, dim3(N), dim3(COL_THREADS), lds_bytes, st, U, h_ao, C,
-                       gamma, Gamma, nrdm, N, n_occ, ncas, Fcol, Epart, Cpart, c1, c2, Gm, hmo);
+    hipLaunchKernelGGL(cas_column_kernel, dim3(N, batch), dim3(COL_THREADS), lds_bytes, st, U, h_ao, C,
+                       gamma, Gamma, nrdm, N, n_occ, ncas, Fcol, Epart, Cpart, c1, c2, Gm, hmo,
+                       out_stride);
     OOVQE_CHECK_LAUNCH("cas_eval/column");
-    hipLaunchKernelGGL(cas_final_kernel, dim3(1), dim3(512), 0, st, Fcol, Epart, Cpart, nuc, nrdm, N,
-                       M, kap_row, kap_col, n_kappa, c0, E, gvec, dE, fock, gmat);
+    hipLaunchKernelGGL(cas_final_kernel, dim3(batch), dim3(512), 0, st, Fcol, Epart, Cpart, nuc, nrdm,
+                       N, M, kap_row, kap_col, n_kappa, c0, E, gvec, dE, fock, gmat, nuc_arr,
+                       out_stride);
     OOVQE_CHECK_LAUNCH("cas_eval/final");
     return 0;
+}
+
+extern "C" int oovqe_cas_eval(const double* g_ao, const double* h_ao, const double* C,
+                              const double* gamma, const double* Gamma, int nrdm, double nuc, int N,
+                              int n_occ, int ncas, const int32_t* kap_row, const int32_t* kap_col,
+                              int n_kappa, double* work, double* c0, double* c1, double* c2,
+                              double* E, double* gvec, double* dE, double* fock, double* gmat,
+                              double* Gm, double* hmo, oovqe_stream_t stream)
+{
+    return cas_eval_batched(g_ao, h_ao, C, gamma, Gamma, nrdm, nuc, nullptr, N, n_occ, ncas, kap_row,
+                            kap_col, n_kappa, work, c0, c1, c2, E, gvec, dE, fock, gmat, Gm, hmo, 1, 0,
+                            stream);
 }
 
 extern "C" int64_t oovqe_cas_eval_work_size(int N, int n_occ, int ncas, int nrdm)
@@ -716,7 +848,58 @@ extern "C" int64_t oovqe_oo_eval_work_size(int n_theta, int n_gates, int n_qubit
     w += oovqe_cas_eval_work_size(N, n_occ, ncas, (int)nvec);
     if (!oovqe_circuit_rdms_is_small(n_qubits, ncas, (int)nvec, n_gates))
         w += nvec * D + nvec * na2 * D;                        // psi | dpsi, V
-    return w;
+    return w;   // per geometry; a batch of G geometries needs G times this
+}
+
+extern "C" int64_t oovqe_oo_eval_out_size(int n_theta, int n_kappa, int ncas, int derivatives)
+{
+    const int64_t nvec = derivatives ? 1 + n_theta : 1;
+    const int64_t n_t = nvec > 1 ? nvec - 1 : 1;
+    return 2 + n_t + nvec * n_kappa + (int64_t)ncas * ncas + (int64_t)ncas * ncas * ncas * ncas;
+}
+
+// One call = one OO-VQE evaluation for each of `batch` geometries (same circuit, same shapes):
+// circuit (+tangents) -> RDM sets -> CAS path; 5 launches in total, whatever the batch size.
+static int oo_eval_batched(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
+                           int n_qubits, uint32_t init_index, const double* g_ao, const double* h_ao,
+                           const double* C, double nuc, const double* nuc_arr, int N, int n_occ,
+                           int ncas, const int32_t* kap_row, const int32_t* kap_col, int n_kappa,
+                           int derivatives, int batch, double* work, double* out,
+                           oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(theta && gates && g_ao && h_ao && C && work && out, "oo_eval: null pointer");
+    OOVQE_REQUIRE(n_qubits == 2 * ncas, "oo_eval: n_qubits != 2*ncas");
+    OOVQE_REQUIRE(batch >= 1, "oo_eval: batch=%d", batch);
+    const int nvec = derivatives ? 1 + n_theta : 1;
+    const size_t nb = (size_t)batch;
+    const size_t D = (size_t)1 << n_qubits;
+    const size_t na2 = (size_t)ncas * ncas, na4 = na2 * na2;
+    double* gamma = work;                                  // [G][nvec][a^2]
+    double* Gamma = gamma + nb * nvec * na2;               // [G][nvec][a^4]
+    double* cas_work = Gamma + nb * nvec * na4;
+    double* rest = cas_work + nb * oovqe_cas_eval_work_size(N, n_occ, ncas, nvec);
+    double *psi = nullptr, *dpsi = nullptr, *rwork = nullptr;
+    if (!oovqe_circuit_rdms_is_small(n_qubits, ncas, nvec, n_gates)) {
+        psi = rest;                                        // [G][D]
+        dpsi = psi + nb * D;                               // [G][n_theta][D]
+        rwork = psi + nb * nvec * D;
+    }
+    int rc = oovqe_circuit_rdms(theta, n_theta, gates, n_gates, n_qubits, ncas, init_index,
+                                derivatives, batch, psi, derivatives ? dpsi : nullptr, gamma, Gamma,
+                                rwork, stream);
+    if (rc) return rc;
+    // packed output per geometry: [c0 | E | dE (max(nvec-1,1)) | gvec (nvec x n_kappa) | c1 | c2]
+    const size_t out_stride = (size_t)oovqe_oo_eval_out_size(n_theta, n_kappa, ncas, derivatives);
+    const int n_t = nvec > 1 ? nvec - 1 : 1;
+    double* c0 = out;
+    double* E = out + 1;
+    double* dE = out + 2;
+    double* gvec = dE + n_t;
+    double* c1 = gvec + (size_t)nvec * n_kappa;
+    double* c2 = c1 + na2;
+    return cas_eval_batched(g_ao, h_ao, C, gamma, Gamma, nvec, nuc, nuc_arr, N, n_occ, ncas, kap_row,
+                            kap_col, n_kappa, cas_work, c0, c1, c2, E, gvec, dE, nullptr, nullptr,
+                            nullptr, nullptr, batch, out_stride, stream);
 }
 
 extern "C" int oovqe_oo_eval(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
@@ -725,34 +908,20 @@ extern "C" int oovqe_oo_eval(const double* theta, int n_theta, const oovqe_gate_
                              int ncas, const int32_t* kap_row, const int32_t* kap_col, int n_kappa,
                              int derivatives, double* work, double* out, oovqe_stream_t stream)
 {
-    OOVQE_REQUIRE(theta && gates && g_ao && h_ao && C && work && out, "oo_eval: null pointer");
-    OOVQE_REQUIRE(n_qubits == 2 * ncas, "oo_eval: n_qubits != 2*ncas");
-    const int nvec = derivatives ? 1 + n_theta : 1;
-    const size_t D = (size_t)1 << n_qubits;
-    const size_t na2 = (size_t)ncas * ncas, na4 = na2 * na2;
-    double* gamma = work;
-    double* Gamma = gamma + (size_t)nvec * na2;
-    double* cas_work = Gamma + (size_t)nvec * na4;
-    double* rest = cas_work + oovqe_cas_eval_work_size(N, n_occ, ncas, nvec);
-    double *psi = nullptr, *dpsi = nullptr, *rwork = nullptr;
-    if (!oovqe_circuit_rdms_is_small(n_qubits, ncas, nvec, n_gates)) {
-        psi = rest;
-        dpsi = psi + D;
-        rwork = psi + (size_t)nvec * D;
-    }
-    int rc = oovqe_circuit_rdms(theta, n_theta, gates, n_gates, n_qubits, ncas, init_index,
-                                derivatives, 1, psi, derivatives ? dpsi : nullptr, gamma, Gamma,
-                                rwork, stream);
-    if (rc) return rc;
-    // packed output: [c0 | E | dE (max(nvec-1,1)) | gvec (nvec x n_kappa) | c1 (a^2) | c2 (a^4)]
-    const int n_t = nvec > 1 ? nvec - 1 : 1;
-    double* c0 = out;
-    double* E = out + 1;
-    double* dE = out + 2;
-    double* gvec = dE + n_t;
-    double* c1 = gvec + (size_t)nvec * n_kappa;
-    double* c2 = c1 + na2;
-    return oovqe_cas_eval(g_ao, h_ao, C, gamma, Gamma, nvec, nuc, N, n_occ, ncas, kap_row, kap_col,
-                          n_kappa, cas_work, c0, c1, c2, E, gvec, dE, nullptr, nullptr, nullptr,
-                          nullptr, stream);
+    return oo_eval_batched(theta, n_theta, gates, n_gates, n_qubits, init_index, g_ao, h_ao, C, nuc,
+                           nullptr, N, n_occ, ncas, kap_row, kap_col, n_kappa, derivatives, 1, work,
+                           out, stream);
+}
+
+extern "C" int oovqe_oo_eval_batch(const double* theta, int n_theta, const oovqe_gate_t* gates,
+                                   int n_gates, int n_qubits, uint32_t init_index, const double* g_ao,
+                                   const double* h_ao, const double* C, const double* nuc, int N,
+                                   int n_occ, int ncas, const int32_t* kap_row, const int32_t* kap_col,
+                                   int n_kappa, int derivatives, int batch, double* work, double* out,
+                                   oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(nuc, "oo_eval_batch: null nuc");
+    return oo_eval_batched(theta, n_theta, gates, n_gates, n_qubits, init_index, g_ao, h_ao, C, 0.0,
+                           nuc, N, n_occ, ncas, kap_row, kap_col, n_kappa, derivatives, batch, work,
+                           out, stream);
 }

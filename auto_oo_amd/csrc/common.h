@@ -8,6 +8,9 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
+// two adjacent doubles fetched with one 16-byte load from an address that is only 8-byte aligned
+// (gfx950 global loads need dword alignment only)
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 
 #define OOVQE_ERR_ARG   (-1)
 #define OOVQE_ERR_HIP   (-2)

@@ -33,8 +33,12 @@ template <int NT, bool LAST, int KSTEPS>
 __global__ __launch_bounds__(NTHREADS, 2)
 void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm,
                      double* __restrict__ out, long A, int K, int J, long B, int ldc,
-                     long n_items, int nbt)
+                     long n_items, int nbt, long t_bs, long c_bs, long o_bs)
 {
+    // blockIdx.z = batch element (independent problems of identical shape)
+    T += (long)blockIdx.z * t_bs;
+    Cm += (long)blockIdx.z * c_bs;
+    out += (long)blockIdx.z * o_bs;
     const int j0 = blockIdx.y * (NT * 16);   // this workgroup's j-group
     constexpr int KC = 4 * KSTEPS;
     constexpr int LDJ = 16 * (NT | 1);
@@ -177,7 +181,8 @@ void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm
 
 template <int NT, bool LAST, int KS>
 int launch_nt(const double* T, const double* Cm, double* out, long A, int K, int J, long B,
-              int ldc, int ngroups, long n_items, int nbt, hipStream_t st)
+              int ldc, int ngroups, long n_items, int nbt, int batch, long t_bs, long c_bs, long o_bs,
+              hipStream_t st)
 {
     constexpr int LDJ = 16 * (NT | 1);
     constexpr int KC = 4 * KS;
@@ -199,19 +204,23 @@ int launch_nt(const double* T, const double* Cm, double* out, long A, int K, int
         oovqe_set_error("mode_contract: grid too large");
         return OOVQE_ERR_SIZE;
     }
-    hipLaunchKernelGGL((contract_kernel<NT, LAST, KS>), dim3((unsigned)nblocks, (unsigned)ngroups),
-                       dim3(NTHREADS), lds_bytes, st, T, Cm, out, A, K, J, B, ldc, n_items, nbt);
+    hipLaunchKernelGGL((contract_kernel<NT, LAST, KS>),
+                       dim3((unsigned)nblocks, (unsigned)ngroups, (unsigned)batch), dim3(NTHREADS),
+                       lds_bytes, st, T, Cm, out, A, K, J, B, ldc, n_items, nbt, t_bs, c_bs, o_bs);
     OOVQE_CHECK_LAUNCH("mode_contract");
     return 0;
 }
 
 template <bool LAST, int KS>
 int launch_group(int nt, const double* T, const double* Cm, double* out, long A, int K, int J,
-                 long B, int ldc, int ngroups, long n_items, int nbt, hipStream_t st)
+                 long B, int ldc, int ngroups, long n_items, int nbt, int batch, long t_bs, long c_bs,
+                 long o_bs, hipStream_t st)
 {
     switch (nt) {
 #define OOVQE_CASE(n) \
-    case n: return launch_nt<n, LAST, KS>(T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, st);
+    case n:                                                                                    \
+        return launch_nt<n, LAST, KS>(T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, batch, t_bs, \
+                                      c_bs, o_bs, st);
         OOVQE_CASE(1) OOVQE_CASE(2) OOVQE_CASE(3) OOVQE_CASE(4) OOVQE_CASE(5) OOVQE_CASE(6)
         OOVQE_CASE(7) OOVQE_CASE(8) OOVQE_CASE(9) OOVQE_CASE(10) OOVQE_CASE(11) OOVQE_CASE(12)
         OOVQE_CASE(13)
@@ -223,9 +232,21 @@ int launch_group(int nt, const double* T, const double* Cm, double* out, long A,
 
 }  // namespace
 
+int oovqe_mode_contract_batched(const double* T, const double* Cm, double* out, long A, int K, int J,
+                                long B, int ldc, int last, int batch, long t_bs, long c_bs, long o_bs,
+                                hipStream_t st);
+
 int oovqe_mode_contract_impl(const double* T, const double* Cm, double* out, long A, int K, int J,
                              long B, int ldc, int last, hipStream_t st)
 {
+    return oovqe_mode_contract_batched(T, Cm, out, A, K, J, B, ldc, last, 1, 0, 0, 0, st);
+}
+
+int oovqe_mode_contract_batched(const double* T, const double* Cm, double* out, long A, int K, int J,
+                                long B, int ldc, int last, int batch, long t_bs, long c_bs, long o_bs,
+                                hipStream_t st)
+{
+    OOVQE_REQUIRE(batch >= 1 && batch <= 65535, "mode_contract: batch=%d", batch);
     OOVQE_REQUIRE(T && Cm && out, "mode_contract: null pointer");
     OOVQE_REQUIRE(A >= 1 && K >= 1 && J >= 1 && B >= 1 && ldc >= J,
                   "mode_contract: bad dims A=%ld K=%d J=%d B=%ld ldc=%d", A, K, J, B, ldc);
@@ -245,7 +266,7 @@ int oovqe_mode_contract_impl(const double* T, const double* Cm, double* out, lon
     // small to fill 256 CUs with 8-wave workgroups.  The j-groups are grid.y of ONE launch.
     int nt = JT < 13 ? JT : 13;
     const long wgs = (n_items + NWAVES - 1) / NWAVES;
-    while (nt > 1 && wgs * ((JT + nt - 1) / nt) < 512) nt = (nt + 1) / 2;
+    while (nt > 1 && wgs * ((JT + nt - 1) / nt) * batch < 512) nt = (nt + 1) / 2;
     const int ngroups = (JT + nt - 1) / nt;
     nt = (JT + ngroups - 1) / ngroups;   // even split
     OOVQE_REQUIRE(ngroups <= 65535, "mode_contract: J too large");
@@ -254,11 +275,15 @@ int oovqe_mode_contract_impl(const double* T, const double* Cm, double* out, lon
     const bool deep = pad20 <= pad12 || pad20 * 100 <= K * 105;
     int rc;
     if (deep)
-        rc = last ? launch_group<true, 5>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, st)
-                  : launch_group<false, 5>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, st);
+        rc = last ? launch_group<true, 5>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, batch,
+                                     t_bs, c_bs, o_bs, st)
+                  : launch_group<false, 5>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, batch,
+                                     t_bs, c_bs, o_bs, st);
     else
-        rc = last ? launch_group<true, 3>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, st)
-                  : launch_group<false, 3>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, st);
+        rc = last ? launch_group<true, 3>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, batch,
+                                     t_bs, c_bs, o_bs, st)
+                  : launch_group<false, 3>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, batch,
+                                     t_bs, c_bs, o_bs, st);
     if (rc) return rc;
     return 0;
 }

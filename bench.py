@@ -8,10 +8,12 @@ Workload (BASELINE.json configs[1], SURVEY.md section 8(d) "C2"): formaldimine C
 SHAPE on synthetic tensors -- N=43 AOs, 6 doubly occupied, 3 active orbitals, UCCD (4 thetas),
 327 non-redundant kappas.  A step is ONE evaluation: E = energy_from_parameters(theta) and the
 full gradient (dE/dtheta, dE/dkappa) for one molecular geometry whose AO integrals are already
-resident in HBM.  Each rank cycles through its shard of 64 synthetic geometries (geometry g lives
-on rank g mod N: the Berry-phase-loop partition of the north star), so successive steps read a
-different 27 MB integral tensor.  Per-GPU work is fixed ("scaling": "weak"); the only collective
-is one all_gather of the per-geometry energies/gradients at the end of the timed region.
+resident in HBM.  Each rank owns its shard of 64 synthetic geometries (geometry g lives on rank
+g mod N: the Berry-phase-loop partition of the north star) and evaluates them in batched calls
+(OO_pqc_batch: the geometry index is a grid dimension of every kernel), so K steps are
+ceil(K / shard) calls, each reading a different 27 MB integral tensor per evaluation.  Per-GPU
+work is fixed ("scaling": "weak"); the only collective is one all_gather of the per-geometry
+energies/gradients at the end of the timed region.
 
 The JSON line also carries
   roofline      -- dominant kernel (the N^4 half-transform sweep) against the HBM roofline,
@@ -44,8 +46,8 @@ FP64_PEAK_TFLOPS = 78.6        # AMD spec, vector = matrix fp64 (SURVEY.md secti
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=6400)
+    ap.add_argument("--warmup", type=int, default=640)
     ap.add_argument("--geoms", type=int, default=N_GEOM)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-transform", action="store_true")
@@ -57,14 +59,17 @@ def build_geometries(my_geoms):
     import auto_oo_amd as aoo
     from auto_oo_amd.synthetic import synthetic_problem
     pqc = aoo.Parameterized_circuit(NCAS, NELECAS, None, ansatz="ucc")
-    objs, thetas = [], []
+    mols, coeffs, thetas = [], [], []
     for g in my_geoms:
         P = synthetic_problem(NAO, 20260 + 2 + 1000 * g)
-        mol = aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], NELEC)
-        objs.append(aoo.OO_pqc(pqc, mol, NCAS, NELECAS, oao_mo_coeff=P["oao_mo_coeff"]))
+        mols.append(aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], NELEC))
+        coeffs.append(P["oao_mo_coeff"])
         rng = np.random.default_rng(777 + g)
-        thetas.append(torch.tensor(rng.uniform(0, 2 * np.pi, pqc.theta_shape), device="cuda"))
-    return pqc, objs, thetas
+        thetas.append(rng.uniform(0, 2 * np.pi, pqc.theta_shape))
+    batch = aoo.OO_pqc_batch(pqc, mols, NCAS, NELECAS, oao_mo_coeffs=coeffs)
+    single = aoo.OO_pqc(pqc, mols[0], NCAS, NELECAS, oao_mo_coeff=coeffs[0])
+    thetas = torch.tensor(np.stack(thetas), device="cuda")
+    return pqc, batch, single, thetas
 
 
 def cpu_baseline(seconds_budget=20.0):
@@ -157,30 +162,29 @@ def main():
     from auto_oo_amd.parallel import shard_geometries, gather_results
 
     my_geoms = shard_geometries(args.geoms, rank, world)
-    pqc, objs, thetas = build_geometries(my_geoms)
-    n_out = 1 + int(np.prod(pqc.theta_shape)) + objs[0].n_kappa
-    results = torch.zeros((len(objs), n_out), dtype=torch.float64, device="cuda")
+    pqc, batch, single, thetas = build_geometries(my_geoms)
+    G = batch.G
+    n_out = 1 + batch.n_theta + batch.n_kappa
+    results = torch.zeros((G, n_out), dtype=torch.float64, device="cuda")
 
-    latest = [None] * len(objs)
+    def run(n_evals):
+        """n_evals evaluations as batched calls over this rank's shard (last call partial)."""
+        done, calls = 0, 0
+        while done < n_evals:
+            b = min(G, n_evals - done)
+            results[:b] = batch.energy_and_gradient(thetas, count=b)
+            done += b
+            calls += 1
+        return calls
 
-    def step(i):
-        j = i % len(objs)
-        latest[j] = objs[j].energy_and_gradient(thetas[j])   # (E, full gradient) on the device
-
-    for i in range(args.warmup):
-        step(i)
+    run(args.warmup)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     ops.profile_begin()   # HIP events around every half-transform launch, on its stream
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    for j, eg in enumerate(latest):
-        if eg is not None:
-            results[j, 0] = eg[0]
-            results[j, 1:] = eg[1]
+    n_calls = run(args.steps)
     gathered = gather_results(results, my_geoms, args.geoms, dist)   # the one exchange step
     torch.cuda.synchronize()
     if dist is not None:
@@ -194,8 +198,9 @@ def main():
 
     kern_total_ms, kern_count = ops.profile_end()
     kern_s = kern_total_ms * 1e-3 / kern_count if kern_count else float("nan")
-    M = objs[0]._M
-    alg_bytes = 8.0 * NAO ** 4 + 8.0 * NAO ** 2 * M ** 2
+    M = batch._n_occ + NCAS
+    bytes_per_eval = 8.0 * NAO ** 4 + 8.0 * NAO ** 2 * M ** 2       # g_ao read once + T2 written
+    alg_bytes = bytes_per_eval * args.steps / max(kern_count, 1)   # per launch (batched)
     achieved = alg_bytes / kern_s / 1e9
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_half_transform.json")
@@ -221,9 +226,11 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": (f"configs[1] shape: N={NAO} AOs, n_occ=6, CAS(4e,3o), UCCD n_theta=4, "
-                         f"n_kappa={objs[0].n_kappa}; one energy + full-gradient evaluation per "
-                         f"step; {args.geoms} synthetic geometries sharded g mod n_gpus and cycled"),
-            "geometries_per_rank": len(objs),
+                         f"n_kappa={batch.n_kappa}; one energy + full-gradient evaluation per "
+                         f"step; {args.geoms} synthetic geometries sharded g mod n_gpus, evaluated "
+                         f"in batched calls of up to {G} geometries"),
+            "geometries_per_rank": G,
+            "batched_calls": n_calls,
             "parallelism": f"geometry-sharded x{world}, one all_gather at the end",
         },
         "roofline": {
@@ -235,10 +242,23 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes,
+            "algorithmic_bytes_per_eval": bytes_per_eval,
+            "evals_per_launch": args.steps / max(kern_count, 1),
             "avg_launch_us": kern_s * 1e6,
             "launches_timed": kern_count,
         },
     }
+    if rank == 0 and world == 1:
+        # latency of ONE un-batched evaluation through the drop-in API (not the headline)
+        th0 = thetas[0].contiguous()
+        for _ in range(50):
+            single.energy_and_gradient(th0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(500):
+            single.energy_and_gradient(th0)
+        torch.cuda.synchronize()
+        out["single_eval_us"] = (time.perf_counter() - t1) / 500 * 1e6
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             cb, e_ref, g_ref = cpu_baseline()

@@ -186,6 +186,17 @@ int oovqe_oo_eval(const double* theta, int n_theta, const oovqe_gate_t* gates, i
                   oovqe_stream_t stream);
 int64_t oovqe_oo_eval_work_size(int n_theta, int n_gates, int n_qubits, int N, int n_occ, int ncas,
                                 int derivatives);
+int64_t oovqe_oo_eval_out_size(int n_theta, int n_kappa, int ncas, int derivatives);
+/* The same for a BATCH of geometries in one call (the Berry-phase-loop batch of the north star;
+ * examples/Tutorial_Berry_phase.ipynb): every per-geometry array is stacked along a leading batch
+ * axis -- theta [G,n_theta], g_ao [G,N^4], h_ao [G,N^2], C [G,N^2], nuc [G] (device), work
+ * G * oovqe_oo_eval_work_size(), out [G, oovqe_oo_eval_out_size()].  Still 5 launches: the batch is a
+ * grid dimension of every kernel, so small geometries fill the 256 CUs together. */
+int oovqe_oo_eval_batch(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
+                        int n_qubits, uint32_t init_index, const double* g_ao, const double* h_ao,
+                        const double* C, const double* nuc, int N, int n_occ, int ncas,
+                        const int32_t* kap_row, const int32_t* kap_col, int n_kappa, int derivatives,
+                        int batch, double* work, double* out, oovqe_stream_t stream);
 /* 1 when oovqe_circuit_rdms takes its one-workgroup LDS path for these sizes */
 int oovqe_circuit_rdms_is_small(int n_qubits, int ncas, int nvec, int n_gates);
 
