@@ -80,6 +80,18 @@ SIGNATURES = {
                                                         c_int32_p, ctypes.c_int]
                        + [c_double_p] * 11 + [c_stream]),
     "oovqe_cas_eval_work_size": (ctypes.c_int64, [ctypes.c_int] * 4),
+    "oovqe_orbital_hessian": (ctypes.c_int, [c_double_p] * 6 + [ctypes.c_int, ctypes.c_int,
+                                                               ctypes.c_int, c_int32_p, c_int32_p,
+                                                               ctypes.c_int, c_double_p, c_double_p,
+                                                               c_double_p, c_stream]),
+    "oovqe_orbital_hessian_work_size": (ctypes.c_int64, [ctypes.c_int] * 3),
+    "oovqe_circuit_second_tangents": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_void_p,
+                                                     ctypes.c_int, ctypes.c_int, ctypes.c_uint32,
+                                                     c_int32_p, ctypes.c_int, c_double_p, c_double_p,
+                                                     c_stream]),
+    "oovqe_circuit_hessian_assemble": (ctypes.c_int, [c_double_p, c_double_p, c_double_p, c_double_p,
+                                                      ctypes.c_int, c_int32_p, ctypes.c_int,
+                                                      ctypes.c_int, c_double_p, c_stream]),
     "oovqe_oo_eval": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                      ctypes.c_int, ctypes.c_uint32, c_double_p, c_double_p, c_double_p,
                                      ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int,

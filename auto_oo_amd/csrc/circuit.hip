@@ -515,6 +515,106 @@ void circuit_rdm_small_kernel(const double* __restrict__ theta, int n_theta,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Second tangents d^2 psi / d theta_j d theta_k (for the circuit-circuit Hessian, reference
+// oo_pqc.py:103-111 = torch.autograd.functional.hessian through the simulator).
+// mode 0: gate, 1: d/dtheta, 2: d^2/dtheta^2 = -(1/4) gate on the pair subspace, 0 elsewhere.
+// ------------------------------------------------------------------------------------------
+__device__ void apply_gate_mode(double* st, uint32_t D, const oovqe_gate_t& g, double c, double s,
+                                int mode)
+{
+    const uint32_t fm = g.mask_hi | g.mask_lo;
+    const uint32_t npairs = D >> g.nfix;
+    const double h = 0.5 * (double)g.sign;
+    for (uint32_t t = threadIdx.x; t < npairs; t += CIRC_THREADS) {
+        const uint32_t x = deposit(t, g) | g.mask_hi;
+        const uint32_t y = x ^ fm;
+        const double pi = (__popc(x & g.mask_par) & 1) ? -1.0 : 1.0;
+        const double ax = st[x], ay = st[y];
+        const double nx = c * ax + pi * s * ay, ny = c * ay - pi * s * ax;
+        if (mode == 0) {
+            st[x] = nx;
+            st[y] = ny;
+        } else if (mode == 1) {
+            st[x] = h * (-s * ax + pi * c * ay);
+            st[y] = h * (-s * ay - pi * c * ax);
+        } else {
+            st[x] = -0.25 * nx;
+            st[y] = -0.25 * ny;
+        }
+    }
+    if (mode != 0) {
+        for (uint32_t x = threadIdx.x; x < D; x += CIRC_THREADS) {
+            const uint32_t f = x & fm;
+            if (f != g.mask_hi && f != g.mask_lo) st[x] = 0.0;
+        }
+    }
+}
+
+// grid = npairs; pair (j,k): out[pair] = sum over gates g1 driven by theta_j, g2 driven by theta_k
+// of the circuit with g1 and g2 differentiated (g1 == g2: second derivative of that gate).
+__global__ __launch_bounds__(CIRC_THREADS)
+void circuit_second_tangent_kernel(const double* __restrict__ theta,
+                                   const oovqe_gate_t* __restrict__ gates, int n_gates, int n_qubits,
+                                   uint32_t init_index, const int32_t* __restrict__ pairs,
+                                   double* __restrict__ out, double* __restrict__ scratch)
+{
+    const uint32_t D = 1u << n_qubits;
+    const int j = pairs[2 * blockIdx.x], k = pairs[2 * blockIdx.x + 1];
+    double* dst = out + (size_t)blockIdx.x * D;
+    double* w = scratch + (size_t)blockIdx.x * D;
+    for (uint32_t x = threadIdx.x; x < D; x += CIRC_THREADS) dst[x] = 0.0;
+    __syncthreads();
+    for (int g1 = 0; g1 < n_gates; ++g1) {
+        if (gates[g1].theta_idx != j) continue;
+        for (int g2 = 0; g2 < n_gates; ++g2) {
+            if (gates[g2].theta_idx != k) continue;
+            for (uint32_t x = threadIdx.x; x < D; x += CIRC_THREADS) w[x] = (x == init_index) ? 1.0 : 0.0;
+            __syncthreads();
+            for (int g = 0; g < n_gates; ++g) {
+                const oovqe_gate_t gt = gates[g];
+                if (gt.theta_idx < 0) continue;
+                double sn, cs;
+                sincos(0.5 * (double)gt.sign * theta[gt.theta_idx], &sn, &cs);
+                const int mode = (g == g1 && g == g2) ? 2 : ((g == g1 || g == g2) ? 1 : 0);
+                apply_gate_mode(w, D, gt, cs, sn, mode);
+                __syncthreads();
+            }
+            for (uint32_t x = threadIdx.x; x < D; x += CIRC_THREADS) dst[x] += w[x];
+            __syncthreads();
+        }
+    }
+}
+
+// H[j,k] = H[k,j] = sum over the 4 transition-RDM sets of pair (j,k) of c1.gamma + c2.Gamma
+__global__ __launch_bounds__(256)
+void circuit_hessian_kernel(const double* __restrict__ gamma, const double* __restrict__ Gamma,
+                            const double* __restrict__ c1, const double* __restrict__ c2, int ncas,
+                            const int32_t* __restrict__ pairs, int n_theta, double* __restrict__ H)
+{
+    __shared__ double red[256];
+    const int na2 = ncas * ncas, na4 = na2 * na2;
+    const int pr = blockIdx.x, tid = threadIdx.x;
+    double acc = 0.0;
+    for (int set = 0; set < 4; ++set) {
+        const double* g1 = gamma + ((size_t)pr * 4 + set) * na2;
+        const double* g2 = Gamma + ((size_t)pr * 4 + set) * na4;
+        for (int i = tid; i < na2; i += 256) acc += c1[i] * g1[i];
+        for (int i = tid; i < na4; i += 256) acc += c2[i] * g2[i];
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int j = pairs[2 * pr], k = pairs[2 * pr + 1];
+        H[(size_t)j * n_theta + k] = red[0];
+        H[(size_t)k * n_theta + j] = red[0];
+    }
+}
+
 }  // namespace
 
 extern "C" int oovqe_circuit_state(const double* theta, int n_theta, const oovqe_gate_t* gates,
@@ -642,4 +742,31 @@ extern "C" int oovqe_circuit_rdms(const double* theta, int n_theta, const oovqe_
     if (rc) return rc;
     return oovqe_rdms_tangent(psi, want_tangents ? dpsi : nullptr, n_qubits, ncas, n_tan, batch,
                               gamma, Gamma, work, stream);
+}
+
+extern "C" int oovqe_circuit_second_tangents(const double* theta, int n_theta,
+                                             const oovqe_gate_t* gates, int n_gates, int n_qubits,
+                                             uint32_t init_index, const int32_t* pairs, int n_pairs,
+                                             double* out, double* scratch, oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(theta && gates && pairs && out && scratch, "second_tangents: null pointer");
+    OOVQE_REQUIRE(n_qubits >= 2 && n_qubits <= 26 && n_pairs >= 1 && n_gates >= 1 && n_theta >= 1,
+                  "second_tangents: bad sizes");
+    hipLaunchKernelGGL(circuit_second_tangent_kernel, dim3(n_pairs), dim3(CIRC_THREADS), 0,
+                       (hipStream_t)stream, theta, gates, n_gates, n_qubits, init_index, pairs, out,
+                       scratch);
+    OOVQE_CHECK_LAUNCH("second_tangents");
+    return 0;
+}
+
+extern "C" int oovqe_circuit_hessian_assemble(const double* gamma, const double* Gamma,
+                                              const double* c1, const double* c2, int ncas,
+                                              const int32_t* pairs, int n_pairs, int n_theta,
+                                              double* H, oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(gamma && Gamma && c1 && c2 && pairs && H, "circuit_hessian: null pointer");
+    hipLaunchKernelGGL(circuit_hessian_kernel, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream,
+                       gamma, Gamma, c1, c2, ncas, pairs, n_theta, H);
+    OOVQE_CHECK_LAUNCH("circuit_hessian");
+    return 0;
 }

@@ -221,6 +221,63 @@ class OO_energy:
         g1, g2 = self._rdm_stack(one_rdm, two_rdm)
         return self._cas_eval(mo_coeff, g1, g2, want_matrices=True)["gmat"]
 
+    # ---- Hessian ------------------------------------------------------------------------------------
+    def full_rdms(self, one_rdm, two_rdm):
+        """oo_energy.py:342-379: dense full-space RDMs (API helper; the Hessian kernels use the
+        closed-form block structure directly and never build these).  Index scatter of constants and
+        of the active RDMs only."""
+        n, occ, act = self.nao, self.occ_idx, self.act_idx
+        no = len(occ)
+        g1, g2 = self._t(one_rdm), self._t(two_rdm)
+        one_full = torch.zeros((n, n), dtype=F64, device=self.device)
+        two_full = torch.zeros((n, n, n, n), dtype=F64, device=self.device)
+        eye = torch.eye(no, dtype=F64, device=self.device)
+        o = torch.as_tensor(occ, device=self.device)
+        a = torch.as_tensor(act, device=self.device)
+        one_full[o, o] = 2.0
+        one_full[a[:, None], a[None, :]] = g1
+        ix = lambda *v: tuple(x.reshape([-1 if i == k else 1 for i in range(4)])  # noqa: E731
+                              for k, x in enumerate(v))
+        two_full[ix(o, o, o, o)] = (4 * torch.einsum('ij,kl->ijkl', eye, eye)
+                                    - 2 * torch.einsum('il,jk->ijkl', eye, eye))
+        two_full[ix(o, o, a, a)] = 2 * torch.einsum('wv,ij->ijwv', g1, eye)
+        two_full[ix(a, a, o, o)] = 2 * torch.einsum('wv,ij->wvij', g1, eye)
+        two_full[ix(o, a, a, o)] = -torch.einsum('wv,ij->iwvj', g1, eye)
+        two_full[ix(a, o, o, a)] = -torch.einsum('wv,ij->vjiw', g1, eye)
+        two_full[ix(a, a, a, a)] = g2
+        return one_full, two_full
+
+    def _hessian(self, mo_coeff, one_rdm, two_rdm, g_ao=None, h_ao=None, want_matrix=False,
+                 want_full=True):
+        g_ao = self.int2e_ao if g_ao is None else g_ao
+        h_ao = self.int1e_ao if h_ao is None else h_ao
+        C = self._t(mo_coeff)
+        g1, g2 = self._rdm_stack(one_rdm, two_rdm)
+        res = ops.cas_eval(g_ao, h_ao, C, g1, g2, self.nuc, self._n_occ, self.ncas, self._kap_row,
+                           self._kap_col, want_matrices=True)
+        return ops.orbital_hessian(g_ao, h_ao, C, g1[0].contiguous(), g2[0].contiguous(),
+                                   res["fock"], self._n_occ, self.ncas, self._kap_row, self._kap_col,
+                                   want_matrix=want_matrix, want_full=want_full)
+
+    def analytic_hessian_from_integrals(self, int1e_mo, int2e_mo, one_rdm, two_rdm):
+        """oo_energy.py:311-340: full [N,N,N,N] orbital Hessian from MO integrals (evaluated by the
+        same kernels with the identity as orbital matrix)."""
+        eye = torch.eye(self.nao, dtype=F64, device=self.device)
+        return self._hessian(eye, one_rdm, two_rdm, g_ao=self._t(int2e_mo), h_ao=self._t(int1e_mo))[1]
+
+    def analytic_hessian(self, one_rdm, two_rdm, mo_coeff=None):
+        """oo_energy.py:415-424: full [N,N,N,N] orbital Hessian (``oovqe_orbital_hessian``)."""
+        if mo_coeff is None:
+            mo_coeff = self.mo_coeff
+        return self._hessian(mo_coeff, one_rdm, two_rdm)[1]
+
+    def analytic_hessian_matrix(self, one_rdm, two_rdm, mo_coeff=None):
+        """Extension: the non-redundant [n_kappa, n_kappa] Hessian directly (what
+        ``full_hessian_to_matrix(analytic_hessian(...))`` returns, without the N^4 tensor)."""
+        if mo_coeff is None:
+            mo_coeff = self.mo_coeff
+        return self._hessian(mo_coeff, one_rdm, two_rdm, want_matrix=True, want_full=False)[0]
+
     def full_hessian_to_matrix(self, full_hess):
         """oo_energy.py:395-402 (index gathers)"""
         r, c = self._kap_row.long(), self._kap_col.long()
@@ -238,7 +295,7 @@ class OO_energy:
         for n in range(max_iterations):
             kappa = torch.zeros(self.n_kappa, dtype=F64, device=self.device)
             gradient = self.kappa_matrix_to_vector(self.analytic_gradient(one_rdm, two_rdm))
-            hessian = self.full_hessian_to_matrix(self.analytic_hessian(one_rdm, two_rdm))
+            hessian = self.analytic_hessian_matrix(one_rdm, two_rdm)
             kappa, lowest_eigenvalue = opt.damped_newton_step(objective_fn, (kappa,), gradient,
                                                               hessian)
             self.oao_mo_coeff = ops.matmul_nn(self._t(self.oao_mo_coeff),

@@ -81,6 +81,29 @@ class OO_pqc(OO_energy):
         res = self._evaluate(theta)
         return res["gvec"][1:].T.contiguous()
 
+    def circuit_circuit_hessian(self, theta):
+        """oo_pqc.py:103-111: d^2E/dtheta^2 (second tangent states + transition RDMs contracted
+        with the CAS coefficients, ``oovqe_circuit_second_tangents`` / ``_hessian_assemble``)."""
+        pqc = self.pqc
+        c0, c1, c2 = self.get_active_integrals(self.mo_coeff)
+        th = pqc._theta2d(theta).reshape(-1)
+        n = self._n_theta()
+        return ops.circuit_hessian(th, pqc._gates_dev, pqc._n_gates, pqc.n_qubits, self.ncas,
+                                   pqc._init_index, c1, c2).reshape(n, n)
+
+    def orbital_orbital_hessian(self, theta):
+        """oo_pqc.py:127-130: orbital-orbital Hessian on the non-redundant kappa pairs."""
+        one_rdm, two_rdm = self.pqc.get_rdms(theta)
+        return self.analytic_hessian_matrix(one_rdm, two_rdm)
+
+    def full_hessian(self, theta):
+        """oo_pqc.py:136-148: [[theta-theta, (kappa-theta)^T], [kappa-theta, kappa-kappa]]."""
+        hessian_vqe_vqe = self.circuit_circuit_hessian(theta)
+        hessian_vqe_oo = self.orbital_circuit_hessian(theta)
+        hessian_oo_oo = self.orbital_orbital_hessian(theta)
+        return torch.cat((torch.cat((hessian_vqe_vqe, hessian_vqe_oo.T), dim=1),
+                          torch.cat((hessian_vqe_oo, hessian_oo_oo), dim=1)), dim=0)
+
     def full_gradient(self, theta):
         """oo_pqc.py:132-134"""
         return self.energy_and_gradient(theta)[1]

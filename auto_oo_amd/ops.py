@@ -313,3 +313,55 @@ class OoEvalPlan:
         packed = out[1:2 + (self.nvec - 1) + nk] if self.nvec > 1 else None
         return dict(c0=out[0:1], E=out[1:2], dE=out[2:2 + self.nvec - 1], gvec=gvec, c1=c1, c2=c2,
                     packed=packed, fock=None, gmat=None, Gm=None, hmo=None)
+
+
+def orbital_hessian(g_ao, h_ao, C, gamma, Gamma, fock, n_occ, ncas, kap_row, kap_col,
+                    want_matrix=True, want_full=False):
+    """Orbital-orbital Hessian (oovqe_orbital_hessian): [n_kappa, n_kappa] and/or [N,N,N,N]."""
+    lib = _lib.load()
+    dev = _dev(g_ao)
+    N = C.shape[0]
+    n_kappa = kap_row.numel()
+    work = torch.empty(lib.oovqe_orbital_hessian_work_size(N, n_occ, ncas), dtype=F64, device=dev)
+    Hm = torch.empty((n_kappa, n_kappa), dtype=F64, device=dev) if want_matrix else None
+    Hf = torch.empty((N, N, N, N), dtype=F64, device=dev) if want_full else None
+    check(lib.oovqe_orbital_hessian(dptr(g_ao), dptr(h_ao), dptr(C), dptr(gamma), dptr(Gamma),
+                                    dptr(fock), N, n_occ, ncas, dptr(kap_row, torch.int32),
+                                    dptr(kap_col, torch.int32), n_kappa, dptr(work), dptr(Hm),
+                                    dptr(Hf), stream_ptr()), "oovqe_orbital_hessian")
+    return Hm, Hf
+
+
+def circuit_hessian(theta, gates_dev, n_gates, n_qubits, ncas, init_index, c1, c2):
+    """d^2E/dtheta^2 for E = c0 + c1.gamma(theta) + c2.Gamma(theta)  (oo_pqc.py:103-111):
+    second tangents + transition RDMs + contraction; theta [n_theta]."""
+    lib = _lib.load()
+    dev = _dev(theta)
+    n_theta = theta.numel()
+    D = 1 << n_qubits
+    th2 = theta.reshape(1, n_theta).contiguous()
+    psi, dpsi = circuit_state(th2, gates_dev, n_gates, n_qubits, init_index, tangents=True)
+    psi, dpsi = psi[0], dpsi[0]
+    pairs = [(j, k) for j in range(n_theta) for k in range(j, n_theta)]
+    n_pairs = len(pairs)
+    pairs_dev = torch.tensor(pairs, dtype=torch.int32, device=dev).contiguous()
+    psi2 = torch.empty((n_pairs, D), dtype=F64, device=dev)
+    scratch = torch.empty((n_pairs, D), dtype=F64, device=dev)
+    check(lib.oovqe_circuit_second_tangents(dptr(th2), n_theta, dptr(gates_dev, torch.uint8), n_gates,
+                                            n_qubits, ctypes.c_uint32(init_index),
+                                            dptr(pairs_dev, torch.int32), n_pairs, dptr(psi2),
+                                            dptr(scratch), stream_ptr()),
+          "oovqe_circuit_second_tangents")
+    # transition-RDM operand lists (pure data movement): per pair the four (bra, ket) combinations
+    jj = torch.tensor([p[0] for p in pairs], device=dev)
+    kk = torch.tensor([p[1] for p in pairs], device=dev)
+    psi_rep = psi.unsqueeze(0).expand(n_pairs, D)
+    bra = torch.stack((psi2, dpsi[jj], dpsi[kk], psi_rep), dim=1).reshape(4 * n_pairs, D).contiguous()
+    ket = torch.stack((psi_rep, dpsi[kk], dpsi[jj], psi2), dim=1).reshape(4 * n_pairs, D).contiguous()
+    g1, g2 = rdms(bra, ket, ncas)
+    H = torch.empty((n_theta, n_theta), dtype=F64, device=dev)
+    check(lib.oovqe_circuit_hessian_assemble(dptr(g1), dptr(g2), dptr(c1.contiguous()),
+                                             dptr(c2.contiguous()), ncas,
+                                             dptr(pairs_dev, torch.int32), n_pairs, n_theta, dptr(H),
+                                             stream_ptr()), "oovqe_circuit_hessian_assemble")
+    return H

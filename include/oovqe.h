@@ -171,6 +171,31 @@ int oovqe_cas_eval(const double* g_ao, const double* h_ao, const double* C, cons
                    double* fock, double* gmat, double* Gm, double* hmo, oovqe_stream_t stream);
 int64_t oovqe_cas_eval_work_size(int N, int n_occ, int ncas, int nrdm);
 
+/* ---- a15: orbital-orbital Hessian -----------------------------------------------------------------
+ * replaces full_rdms / y_matrix / analytic_hessian_from_integrals / full_hessian_to_matrix
+ * (src/auto_oo/oo_energy.py:311-402) and OO_pqc.orbital_orbital_hessian (oo_pqc.py:127-130).
+ * fock [N,N] = generalized Fock matrix (output of oovqe_cas_eval for the same RDMs).
+ * H_matrix [n_kappa, n_kappa] (non-redundant pairs) and/or H_full [N,N,N,N]; either may be NULL.
+ * work: oovqe_orbital_hessian_work_size() doubles. */
+int oovqe_orbital_hessian(const double* g_ao, const double* h_ao, const double* C, const double* gamma,
+                          const double* Gamma, const double* fock, int N, int n_occ, int ncas,
+                          const int32_t* kap_row, const int32_t* kap_col, int n_kappa, double* work,
+                          double* H_matrix, double* H_full, oovqe_stream_t stream);
+int64_t oovqe_orbital_hessian_work_size(int N, int n_occ, int ncas);
+
+/* ---- a16: circuit-circuit Hessian pieces (oo_pqc.py:103-111) ------------------------------------
+ * second tangents d^2 psi/d theta_j d theta_k for the listed (j,k) pairs: out [n_pairs, D],
+ * scratch [n_pairs, D]; pairs int32 [n_pairs, 2]. */
+int oovqe_circuit_second_tangents(const double* theta, int n_theta, const oovqe_gate_t* gates,
+                                  int n_gates, int n_qubits, uint32_t init_index,
+                                  const int32_t* pairs, int n_pairs, double* out, double* scratch,
+                                  oovqe_stream_t stream);
+/* H[j,k] = H[k,j] = sum_{set<4} c1 . gamma[pair,set] + c2 . Gamma[pair,set], the four sets being the
+ * transition RDMs T(psi_jk,psi), T(psi_j,psi_k), T(psi_k,psi_j), T(psi,psi_jk). */
+int oovqe_circuit_hessian_assemble(const double* gamma, const double* Gamma, const double* c1,
+                                   const double* c2, int ncas, const int32_t* pairs, int n_pairs,
+                                   int n_theta, double* H, oovqe_stream_t stream);
+
 /* ---- a12/a13/a14/a16: one evaluation of the hybrid cost function in ONE call ---------------------
  * OO_pqc.energy_from_parameters / circuit_gradient / orbital_gradient / orbital_circuit_hessian
  * (src/auto_oo/oo_pqc.py:64-125) for a single geometry: circuit (+ tangents when derivatives != 0)
