@@ -1,0 +1,502 @@
+// Particle-number-sector statevector engine with reverse-mode (adjoint) theta-gradients.
+//
+// UCCD / kUpCCD circuits conserve N_alpha and N_beta, so |psi(theta)> lives in the
+// (N_alpha, N_beta) sector of the 2^n register: C(a,N_alpha) * C(a,N_beta) determinants
+// (4 900 of 65 536 for CAS(8e,8o)).  The whole sector vector (39 KB) fits
+// one workgroup's LDS, so a full kUpCCD circuit (56..112 Givens passes, reference
+// src/auto_oo/ansatze/kUpCCD.py:118-130) runs in ONE launch without touching HBM between gates,
+// one workgroup per batch element (theta set / geometry).
+//
+// Compressed index c = ia * nb + ib  <->  (alpha string, beta string)  <->  full basis index x
+// (spin orbital 2p = alpha_p = qubit 2p = bit n-1-2p; strings keep orbital p at bit a-1-p):
+//     x = spread(alpha) << 1 | spread(beta)
+// Gates keep their full-register masks (include/oovqe.h, oovqe_gate_t): a thread owning
+// determinant c applies the 2x2 rotation iff (x & (hi|lo)) == hi, partner = rank(x ^ (hi|lo)).
+//
+// Reverse mode (what torch autograd does for the reference, src/auto_oo/oo_pqc.py:86-95):
+//   E(theta) = c0 + sum c1_pq gam_pq + sum c2_pqrs Gam_pqrs = c0 + psi^T Hop psi
+//   lambda   = (Hop + Hop^T) psi                                   (sector_lambda_kernel)
+//   walking the gates backwards:  dE/dtheta_k = (sign_k/2) lambda^T A_k psi,
+//                                 psi <- U_k^T psi, lambda <- U_k^T lambda   (sector_adjoint_kernel)
+// i.e. 2 vectors and 2*n_gates Givens passes instead of n_theta tangent states.
+#include "common.h"
+
+int oovqe_mode_contract_batched(const double* T, const double* Cm, double* out, long A, int K, int J,
+                                long B, int ldc, int last, int batch, long t_bs, long c_bs, long o_bs,
+                                hipStream_t st);
+
+namespace {
+
+constexpr int SEC_THREADS = 1024;
+
+struct Sector {
+    const uint32_t* unrank_a;   // [na]  alpha strings (orbital p at bit a-1-p)
+    const uint32_t* unrank_b;   // [nb]
+    const int32_t* rank_a;      // [2^a] string -> index or -1
+    const int32_t* rank_b;      // [2^a]
+    int na, nb, ncas;
+};
+
+__device__ __forceinline__ uint32_t spread16(uint32_t v)
+{
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+__device__ __forceinline__ uint32_t compact16(uint32_t v)
+{
+    v &= 0x55555555u;
+    v = (v | (v >> 1)) & 0x33333333u;
+    v = (v | (v >> 2)) & 0x0F0F0F0Fu;
+    v = (v | (v >> 4)) & 0x00FF00FFu;
+    v = (v | (v >> 8)) & 0x0000FFFFu;
+    return v;
+}
+
+__device__ __forceinline__ uint32_t sec_full(const Sector& s, int c)
+{
+    const int ia = c / s.nb, ib = c - ia * s.nb;
+    return (spread16(s.unrank_a[ia]) << 1) | spread16(s.unrank_b[ib]);
+}
+
+__device__ __forceinline__ int sec_rank(const Sector& s, uint32_t x)
+{
+    return s.rank_a[compact16(x >> 1)] * s.nb + s.rank_b[compact16(x)];
+}
+
+// one Givens pass on a sector vector; transpose = apply U^T (adjoint sweep)
+__device__ __forceinline__ void sec_gate(double* st, const Sector& s, int Dc, const oovqe_gate_t& g,
+                                         double c, double sn, bool transpose)
+{
+    const uint32_t fm = g.mask_hi | g.mask_lo;
+    const double sg = transpose ? -sn : sn;
+    for (int d = threadIdx.x; d < Dc; d += SEC_THREADS) {
+        const uint32_t x = sec_full(s, d);
+        if ((x & fm) == g.mask_hi) {
+            const int e = sec_rank(s, x ^ fm);
+            const double pi = (__popc(x & g.mask_par) & 1) ? -1.0 : 1.0;
+            const double ax = st[d], ay = st[e];
+            st[d] = c * ax + pi * sg * ay;
+            st[e] = c * ay - pi * sg * ax;
+        }
+    }
+}
+
+// ---- forward circuit: grid = batch -------------------------------------------------------------
+__global__ __launch_bounds__(SEC_THREADS)
+void sector_circuit_kernel(const double* __restrict__ theta, int n_theta,
+                           const oovqe_gate_t* __restrict__ gates, int n_gates, Sector s,
+                           uint32_t init_index, double* __restrict__ psi_c)
+{
+    extern __shared__ double lds[];
+    const int Dc = s.na * s.nb;
+    double* st = lds;                                   // [Dc]
+    double* cs = st + Dc;                               // [n_gates][2]
+    oovqe_gate_t* gl = reinterpret_cast<oovqe_gate_t*>(cs + 2 * n_gates);
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const double* th = theta + (size_t)b * n_theta;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(gates);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(gl);
+        for (int i = tid; i < n_gates * (int)(sizeof(oovqe_gate_t) / 4); i += SEC_THREADS) dst[i] = src[i];
+        for (int g = tid; g < n_gates; g += SEC_THREADS) {
+            const int ti = gates[g].theta_idx;
+            double sn = 0.0, c = 1.0;
+            if (ti >= 0) sincos(0.5 * (double)gates[g].sign * th[ti], &sn, &c);
+            cs[2 * g] = c;
+            cs[2 * g + 1] = sn;
+        }
+        const int c0 = sec_rank(s, init_index);
+        for (int d = tid; d < Dc; d += SEC_THREADS) st[d] = (d == c0) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int g = 0; g < n_gates; ++g) {
+        if (gl[g].theta_idx < 0) continue;
+        sec_gate(st, s, Dc, gl[g], cs[2 * g], cs[2 * g + 1], false);
+        __syncthreads();
+    }
+    for (int d = tid; d < Dc; d += SEC_THREADS) psi_c[(size_t)b * Dc + d] = st[d];
+}
+
+// sector vector -> dense 2^n vector (zeros outside the sector)
+__global__ void sector_to_dense_kernel(const double* __restrict__ psi_c, Sector s, uint32_t D,
+                                       double* __restrict__ psi)
+{
+    const int Dc = s.na * s.nb;
+    const size_t b = blockIdx.y;
+    for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < D; x += gridDim.x * blockDim.x) {
+        const int ia = s.rank_a[compact16(x >> 1)], ib = s.rank_b[compact16(x)];
+        psi[b * D + x] = (ia >= 0 && ib >= 0) ? psi_c[b * Dc + ia * s.nb + ib] : 0.0;
+    }
+}
+
+// ---- E_pq applications in the sector: V[vec][pq][c] ---------------------------------------------
+__device__ __forceinline__ double sec_epq(const double* __restrict__ src, const Sector& s, int n,
+                                          int p, int q, uint32_t x, int c)
+{
+    double acc = 0.0;
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp) {
+        const int P = 2 * p + sp, Q = 2 * q + sp;
+        const uint32_t bP = 1u << (n - 1 - P), bQ = 1u << (n - 1 - Q);
+        if (p == q) {
+            if (x & bP) acc += src[c];
+        } else if ((x & bP) && !(x & bQ)) {
+            const uint32_t hi = bP > bQ ? bP : bQ, lo = bP > bQ ? bQ : bP;
+            const uint32_t between = (hi - 1u) & ~((lo << 1) - 1u);
+            const double sgn = (__popc(x & between) & 1) ? -1.0 : 1.0;
+            acc += sgn * src[sec_rank(s, x ^ (bP | bQ))];
+        }
+    }
+    return acc;
+}
+
+// grid: (ceil(Dc/256), a^2, nvec_total); vec [nvec_total][Dc] -> V [nvec_total][a^2][Dc]
+__global__ __launch_bounds__(256)
+void sector_epq_kernel(const double* __restrict__ vec, Sector s, double* __restrict__ V)
+{
+    const int Dc = s.na * s.nb, n = 2 * s.ncas, na2 = s.ncas * s.ncas;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Dc) return;
+    const int pq = blockIdx.y, p = pq / s.ncas, q = pq - p * s.ncas;
+    const size_t v = blockIdx.z;
+    const uint32_t x = sec_full(s, c);
+    V[(v * na2 + pq) * Dc + c] = sec_epq(vec + v * Dc, s, n, p, q, x, c);
+}
+
+// ---- RDM Gram on the f64 MFMA -----------------------------------------------------------------
+// G[m][n] = sum_c A[m][c] B[n][c];  A rows m < a^2: V[qp] (m = pq), row a^2: psi;  B rows: V[rs].
+// grid: (MT*NT tiles, batch); 4 waves split the c range, fixed-order LDS reduction.
+__global__ __launch_bounds__(256)
+void sector_gram_kernel(const double* __restrict__ psi_c, const double* __restrict__ V, int ncas,
+                        int Dc, double* __restrict__ R)
+{
+    __shared__ double red[4][256];
+    const int na2 = ncas * ncas, nrow = na2 + 1;
+    const int MT = (nrow + 15) / 16, NT = (na2 + 15) / 16;
+    const int tile = blockIdx.x, mt = tile / NT, nt = tile - mt * NT;
+    const size_t b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane >> 4, lr = lane & 15;
+    const double* Vb = V + b * (size_t)na2 * Dc;
+    const int m = mt * 16 + lr, nn = nt * 16 + lr;
+    const double* arow = nullptr;
+    if (m < na2) {
+        const int p = m / ncas, q = m - p * ncas;
+        arow = Vb + (size_t)(q * ncas + p) * Dc;
+    } else if (m == na2) {
+        arow = psi_c + b * (size_t)Dc;
+    }
+    const double* brow = nn < na2 ? Vb + (size_t)nn * Dc : nullptr;
+    const int ksteps = (Dc + 3) / 4;
+    const int per = (ksteps + 3) / 4;
+    const int k0 = wave * per, k1 = (k0 + per < ksteps) ? k0 + per : ksteps;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int ks = k0; ks < k1; ++ks) {
+        const int c = 4 * ks + lq;
+        const double av = (arow && c < Dc) ? arow[c] : 0.0;
+        const double bv = (brow && c < Dc) ? brow[c] : 0.0;
+        acc = mfma_f64(av, bv, acc);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][(lq + 4 * i) * 16 + lr] = acc[i];
+    __syncthreads();
+    const double v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    const int row = mt * 16 + tid / 16, col = nt * 16 + (tid & 15);
+    R[(b * (size_t)(MT * 16) + row) * (NT * 16) + col] = v;
+}
+
+// gamma[rs] = R[a^2][rs];  Gamma[pq,rs] = R[pq][rs] - delta_qr gamma[ps]
+__global__ void sector_rdm_finish_kernel(const double* __restrict__ R, int ncas,
+                                         double* __restrict__ gamma, double* __restrict__ Gamma)
+{
+    const int na2 = ncas * ncas, nrow = na2 + 1;
+    const int MT = (nrow + 15) / 16, NT = (na2 + 15) / 16, ldr = NT * 16;
+    const size_t b = blockIdx.y;
+    const double* Rb = R + b * (size_t)(MT * 16) * ldr;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < na2 * na2 + na2;
+         idx += gridDim.x * blockDim.x) {
+        if (idx < na2) {
+            gamma[b * na2 + idx] = Rb[na2 * ldr + idx];
+        } else {
+            const int rem = idx - na2;
+            const int pq = rem / na2, rs = rem - pq * na2;
+            const int p = pq / ncas, q = pq - p * ncas, r = rs / ncas, s2 = rs - r * ncas;
+            double g = Rb[pq * ldr + rs];
+            if (q == r) g -= Rb[na2 * ldr + p * ncas + s2];
+            Gamma[b * (size_t)na2 * na2 + rem] = g;
+        }
+    }
+}
+
+// ---- lambda = (Hop + Hop^T) psi -------------------------------------------------------------------
+// coefficient matrices for the two GEMMs:  M1[(rs),(pq)] = c2[pq,rs]  (W_pq  = sum_rs c2 V_rs)
+//                                           M2[(k),(rs)]  = c2[swap(k),rs], swap(q*a+p) = p*a+q
+//                                                            (W'_rs = sum_pq c2[pq,rs] V_qp)
+// c1e[ps] = c1[ps] - sum_q c2[p,q,q,s]
+__global__ void sector_coeff_kernel(const double* __restrict__ c1, const double* __restrict__ c2,
+                                    int ncas, double* __restrict__ M1, double* __restrict__ M2,
+                                    double* __restrict__ c1e)
+{
+    const int na2 = ncas * ncas;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < na2 * na2;
+         idx += gridDim.x * blockDim.x) {
+        const int k = idx / na2, j = idx - k * na2;
+        M1[idx] = c2[(size_t)j * na2 + k];
+        const int kq = k / ncas, kp = k - kq * ncas;          // k = q*a + p  ->  pq = p*a + q
+        M2[idx] = c2[(size_t)(kp * ncas + kq) * na2 + j];
+        if (idx < na2) {
+            const int p = idx / ncas, s2 = idx - p * ncas;
+            double v = c1[idx];
+            for (int q = 0; q < ncas; ++q) v -= c2[((size_t)(p * ncas + q) * ncas + q) * ncas + s2];
+            c1e[idx] = v;
+        }
+    }
+}
+
+// grid: (ceil(Dc/256), batch)
+__global__ __launch_bounds__(256)
+void sector_lambda_kernel(const double* __restrict__ V, const double* __restrict__ W1,
+                          const double* __restrict__ W2, const double* __restrict__ c1e, Sector s,
+                          double* __restrict__ lam)
+{
+    const int Dc = s.na * s.nb, n = 2 * s.ncas, a = s.ncas, na2 = a * a;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Dc) return;
+    const size_t b = blockIdx.y;
+    const double* Vb = V + b * (size_t)na2 * Dc;
+    const double* W1b = W1 + b * (size_t)na2 * Dc;
+    const double* W2b = W2 + b * (size_t)na2 * Dc;
+    const uint32_t x = sec_full(s, c);
+    double acc = 0.0;
+    for (int p = 0; p < a; ++p)
+        for (int q = 0; q < a; ++q) {
+            const int pq = p * a + q, qp = q * a + p;
+            acc += c1e[pq] * (Vb[(size_t)pq * Dc + c] + Vb[(size_t)qp * Dc + c]);
+            acc += sec_epq(W1b + (size_t)pq * Dc, s, n, p, q, x, c);      // E_pq W_pq
+            acc += sec_epq(W2b + (size_t)pq * Dc, s, n, q, p, x, c);      // E_sr W'_rs (r=p, s=q)
+        }
+    lam[b * Dc + c] = acc;
+}
+
+// ---- adjoint sweep: grid = batch --------------------------------------------------------------------
+__global__ __launch_bounds__(SEC_THREADS)
+void sector_adjoint_kernel(const double* __restrict__ theta, int n_theta,
+                           const oovqe_gate_t* __restrict__ gates, int n_gates, Sector s,
+                           const double* __restrict__ psi_c, const double* __restrict__ lam,
+                           double* __restrict__ dtheta)
+{
+    extern __shared__ double lds[];
+    const int Dc = s.na * s.nb;
+    double* ps = lds;                                   // [Dc]
+    double* lm = ps + Dc;                               // [Dc]
+    double* cs = lm + Dc;                               // [n_gates][2]
+    double* part = cs + 2 * n_gates;                    // [16 waves]
+    double* gth = part + SEC_THREADS / 64;              // [n_theta]
+    oovqe_gate_t* gl = reinterpret_cast<oovqe_gate_t*>(gth + n_theta);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const double* th = theta + (size_t)b * n_theta;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(gates);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(gl);
+        for (int i = tid; i < n_gates * (int)(sizeof(oovqe_gate_t) / 4); i += SEC_THREADS) dst[i] = src[i];
+        for (int g = tid; g < n_gates; g += SEC_THREADS) {
+            const int ti = gates[g].theta_idx;
+            double sn = 0.0, c = 1.0;
+            if (ti >= 0) sincos(0.5 * (double)gates[g].sign * th[ti], &sn, &c);
+            cs[2 * g] = c;
+            cs[2 * g + 1] = sn;
+        }
+        for (int k = tid; k < n_theta; k += SEC_THREADS) gth[k] = 0.0;
+        for (int d = tid; d < Dc; d += SEC_THREADS) {
+            ps[d] = psi_c[(size_t)b * Dc + d];
+            lm[d] = lam[(size_t)b * Dc + d];
+        }
+    }
+    __syncthreads();
+    for (int g = n_gates - 1; g >= 0; --g) {
+        const oovqe_gate_t gt = gl[g];
+        if (gt.theta_idx < 0) continue;
+        const uint32_t fm = gt.mask_hi | gt.mask_lo;
+        const double c = cs[2 * g], sn = cs[2 * g + 1];
+        double acc = 0.0;
+        for (int d = tid; d < Dc; d += SEC_THREADS) {
+            const uint32_t x = sec_full(s, d);
+            if ((x & fm) == gt.mask_hi) {
+                const int e = sec_rank(s, x ^ fm);
+                const double pi = (__popc(x & gt.mask_par) & 1) ? -1.0 : 1.0;
+                const double px = ps[d], py = ps[e], lx = lm[d], ly = lm[e];
+                acc += pi * (lx * py - ly * px);            // lambda^T A psi on this pair
+                ps[d] = c * px - pi * sn * py;              // U^T
+                ps[e] = c * py + pi * sn * px;
+                lm[d] = c * lx - pi * sn * ly;
+                lm[e] = c * ly + pi * sn * lx;
+            }
+        }
+        // deterministic reduction: wave shuffle tree, then the 16 wave partials in fixed order
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) part[wave] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int w = 0; w < SEC_THREADS / 64; ++w) tot += part[w];
+            gth[gt.theta_idx] += 0.5 * (double)gt.sign * tot;
+        }
+        __syncthreads();
+    }
+    for (int k = tid; k < n_theta; k += SEC_THREADS) dtheta[(size_t)b * n_theta + k] = gth[k];
+}
+
+Sector make_sector(const uint32_t* ua, const uint32_t* ub, const int32_t* ra, const int32_t* rb, int na,
+                   int nb, int ncas)
+{
+    Sector s;
+    s.unrank_a = ua; s.unrank_b = ub; s.rank_a = ra; s.rank_b = rb;
+    s.na = na; s.nb = nb; s.ncas = ncas;
+    return s;
+}
+
+size_t circuit_lds(int Dc, int n_gates)
+{
+    return ((size_t)Dc + 2 * n_gates) * sizeof(double) + (size_t)n_gates * sizeof(oovqe_gate_t);
+}
+
+size_t adjoint_lds(int Dc, int n_gates, int n_theta)
+{
+    return ((size_t)2 * Dc + 2 * n_gates + SEC_THREADS / 64 + n_theta) * sizeof(double) +
+           (size_t)n_gates * sizeof(oovqe_gate_t);
+}
+
+}  // namespace
+
+extern "C" int oovqe_sector_state(const double* theta, int n_theta, const oovqe_gate_t* gates,
+                                  int n_gates, int ncas, uint32_t init_index, const uint32_t* unrank_a,
+                                  const uint32_t* unrank_b, const int32_t* rank_a, const int32_t* rank_b,
+                                  int na, int nb, int batch, double* psi_c, double* psi_dense,
+                                  oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(theta && gates && unrank_a && unrank_b && rank_a && rank_b && psi_c,
+                  "sector_state: null pointer");
+    OOVQE_REQUIRE(ncas >= 1 && ncas <= 13 && na >= 1 && nb >= 1 && batch >= 1 && n_gates >= 1,
+                  "sector_state: bad sizes");
+    const int Dc = na * nb;
+    const size_t lds_bytes = circuit_lds(Dc, n_gates);
+    OOVQE_REQUIRE(lds_bytes <= 160 * 1024, "sector_state: sector of %d determinants needs %zu B LDS", Dc,
+                  lds_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)sector_circuit_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            oovqe_set_error("sector_state: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return OOVQE_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    Sector s = make_sector(unrank_a, unrank_b, rank_a, rank_b, na, nb, ncas);
+    hipLaunchKernelGGL(sector_circuit_kernel, dim3(batch), dim3(SEC_THREADS), lds_bytes, st, theta,
+                       n_theta, gates, n_gates, s, init_index, psi_c);
+    OOVQE_CHECK_LAUNCH("sector_state");
+    if (psi_dense) {
+        const uint32_t D = 1u << (2 * ncas);
+        OOVQE_REQUIRE(batch <= 65535, "sector_state: batch too large for dense output");
+        hipLaunchKernelGGL(sector_to_dense_kernel, dim3((D + 255) / 256 < 1024 ? (D + 255) / 256 : 1024,
+                                                        batch), dim3(256), 0, st, psi_c, s, D, psi_dense);
+        OOVQE_CHECK_LAUNCH("sector_state/dense");
+    }
+    return 0;
+}
+
+extern "C" int64_t oovqe_sector_work_size(int ncas, int na, int nb, int batch)
+{
+    const int64_t Dc = (int64_t)na * nb, na2 = (int64_t)ncas * ncas;
+    const int64_t MT = (na2 + 1 + 15) / 16, NT = (na2 + 15) / 16;
+    // V, W1, W2 [batch][a^2][Dc] | lam [batch][Dc] | R [batch][MT*16][NT*16] | M1, M2 [a^4] | c1e [a^2]
+    return (int64_t)batch * (3 * na2 * Dc + Dc + MT * 16 * NT * 16) + 2 * na2 * na2 + na2;
+}
+
+extern "C" int oovqe_sector_rdms(const double* psi_c, int ncas, const uint32_t* unrank_a,
+                                 const uint32_t* unrank_b, const int32_t* rank_a, const int32_t* rank_b,
+                                 int na, int nb, int batch, double* gamma, double* Gamma, double* work,
+                                 oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(psi_c && unrank_a && unrank_b && rank_a && rank_b && gamma && Gamma && work,
+                  "sector_rdms: null pointer");
+    OOVQE_REQUIRE(ncas >= 1 && ncas <= 13 && batch >= 1 && batch <= 65535, "sector_rdms: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const int Dc = na * nb, na2 = ncas * ncas;
+    const int MT = (na2 + 1 + 15) / 16, NT = (na2 + 15) / 16;
+    Sector s = make_sector(unrank_a, unrank_b, rank_a, rank_b, na, nb, ncas);
+    double* V = work;                                              // [batch][a^2][Dc]
+    double* R = work + (size_t)batch * (3 * (size_t)na2 * Dc + Dc); // [batch][MT*16][NT*16]
+    hipLaunchKernelGGL(sector_epq_kernel, dim3((Dc + 255) / 256, na2, batch), dim3(256), 0, st, psi_c, s,
+                       V);
+    OOVQE_CHECK_LAUNCH("sector_rdms/epq");
+    hipLaunchKernelGGL(sector_gram_kernel, dim3(MT * NT, batch), dim3(256), 0, st, psi_c, V, ncas, Dc, R);
+    OOVQE_CHECK_LAUNCH("sector_rdms/gram");
+    hipLaunchKernelGGL(sector_rdm_finish_kernel, dim3((na2 * na2 + na2 + 255) / 256, batch), dim3(256),
+                       0, st, R, ncas, gamma, Gamma);
+    OOVQE_CHECK_LAUNCH("sector_rdms/finish");
+    return 0;
+}
+
+// dtheta[b,k] = d/dtheta_k ( c1 . gamma(theta_b) + c2 . Gamma(theta_b) ).  psi_c and the V block of
+// `work` must be those of oovqe_sector_state / oovqe_sector_rdms for the same theta (same work).
+// c1 [a,a], c2 [a,a,a,a] shared by the batch (c_stride = 0) or per element (c_stride = a^2+a^4 ...).
+extern "C" int oovqe_sector_adjoint(const double* theta, int n_theta, const oovqe_gate_t* gates,
+                                    int n_gates, int ncas, const uint32_t* unrank_a,
+                                    const uint32_t* unrank_b, const int32_t* rank_a,
+                                    const int32_t* rank_b, int na, int nb, int batch,
+                                    const double* psi_c, const double* c1, const double* c2,
+                                    double* work, double* dtheta, oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(theta && gates && psi_c && c1 && c2 && work && dtheta, "sector_adjoint: null pointer");
+    OOVQE_REQUIRE(ncas >= 1 && ncas <= 13 && batch >= 1 && batch <= 65535, "sector_adjoint: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const int Dc = na * nb, na2 = ncas * ncas;
+    const int MT = (na2 + 1 + 15) / 16, NT = (na2 + 15) / 16;
+    const size_t lds_bytes = adjoint_lds(Dc, n_gates, n_theta);
+    OOVQE_REQUIRE(lds_bytes <= 160 * 1024, "sector_adjoint: needs %zu B LDS", lds_bytes);
+    Sector s = make_sector(unrank_a, unrank_b, rank_a, rank_b, na, nb, ncas);
+    const size_t nb_ = (size_t)batch;
+    double* V = work;
+    double* W1 = V + nb_ * na2 * Dc;
+    double* W2 = W1 + nb_ * na2 * Dc;
+    double* lam = W2 + nb_ * na2 * Dc;
+    double* R = lam + nb_ * Dc;
+    double* M1 = R + nb_ * (size_t)(MT * 16) * (NT * 16);
+    double* M2 = M1 + (size_t)na2 * na2;
+    double* c1e = M2 + (size_t)na2 * na2;
+    hipLaunchKernelGGL(sector_coeff_kernel, dim3((na2 * na2 + 255) / 256), dim3(256), 0, st, c1, c2, ncas,
+                       M1, M2, c1e);
+    OOVQE_CHECK_LAUNCH("sector_adjoint/coeff");
+    int rc;
+    // W1[b][pq][c] = sum_rs M1[(rs),(pq)] V[b][rs][c]   ;   W2[b][rs][c] = sum_k M2[k,(rs)] V[b][k][c]
+    if ((rc = oovqe_mode_contract_batched(V, M1, W1, 1, na2, na2, Dc, na2, 0, batch, (long)na2 * Dc, 0,
+                                          (long)na2 * Dc, st)))
+        return rc;
+    if ((rc = oovqe_mode_contract_batched(V, M2, W2, 1, na2, na2, Dc, na2, 0, batch, (long)na2 * Dc, 0,
+                                          (long)na2 * Dc, st)))
+        return rc;
+    hipLaunchKernelGGL(sector_lambda_kernel, dim3((Dc + 255) / 256, batch), dim3(256), 0, st, V, W1, W2,
+                       c1e, s, lam);
+    OOVQE_CHECK_LAUNCH("sector_adjoint/lambda");
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)sector_adjoint_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            oovqe_set_error("sector_adjoint: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return OOVQE_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(sector_adjoint_kernel, dim3(batch), dim3(SEC_THREADS), lds_bytes, st, theta,
+                       n_theta, gates, n_gates, s, psi_c, lam, dtheta);
+    OOVQE_CHECK_LAUNCH("sector_adjoint/sweep");
+    return 0;
+}

@@ -27,10 +27,26 @@ class OO_pqc(OO_energy):
         return int(np.prod(self.pqc.theta_shape))
 
     # ---- fused evaluation (one pass: state + tangents, RDMs + derivative RDMs, one N^4 sweep) -----
+    def _evaluate_adjoint(self, theta, mo_coeff):
+        """Large circuits (sector engine): RDMs -> CAS path (E, orbital gradient, c1, c2) ->
+        reverse-mode theta-gradient with c1, c2 as cotangents (3 + 5 + 5 launches)."""
+        pqc = self.pqc
+        eng = pqc._sector
+        th = pqc._theta2d(theta)
+        psi_c = eng.state(th)
+        gamma, Gamma = eng.rdms(psi_c)
+        res = self._cas_eval(mo_coeff, gamma, Gamma)
+        res["dE"] = eng.adjoint(th, psi_c, res["c1"], res["c2"])[0]
+        res["packed"] = torch.cat((res["E"], res["dE"], res["gvec"][0]))
+        return res
+
     def _evaluate(self, theta, mo_coeff=None, derivatives=True, want_matrices=False):
         if mo_coeff is None:
             mo_coeff = self.mo_coeff
-        if not want_matrices:
+        if derivatives == "adjoint" or (derivatives is True and getattr(self.pqc, "_use_sector", False)
+                                        and not want_matrices):
+            return self._evaluate_adjoint(theta, mo_coeff)
+        if not want_matrices and not getattr(self.pqc, "_use_sector", False):
             # one C call: circuit (+tangents) -> RDM sets -> CAS path, persistent workspace
             plans = self.__dict__.setdefault("_plans2", {})
             key = (bool(derivatives), id(self.pqc), id(self.int2e_ao), id(self.int1e_ao))
@@ -77,8 +93,10 @@ class OO_pqc(OO_energy):
         return self._evaluate(theta, derivatives=False)["gvec"][0]
 
     def orbital_circuit_hessian(self, theta):
-        """oo_pqc.py:113-125: d(orbital gradient)/d theta, shape [n_kappa, n_theta]."""
-        res = self._evaluate(theta)
+        """oo_pqc.py:113-125: d(orbital gradient)/d theta, shape [n_kappa, n_theta] (forward-mode
+        tangent RDMs through the linear Fock map)."""
+        gamma, Gamma = self.pqc.rdms_with_derivatives(theta)
+        res = self._cas_eval(self.mo_coeff, gamma, Gamma)
         return res["gvec"][1:].T.contiguous()
 
     def circuit_circuit_hessian(self, theta):

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib, excitations as X, ops
+from .sector import SectorEngine
 
 
 class Parameterized_circuit():
@@ -65,6 +66,11 @@ class Parameterized_circuit():
         self._init_index = X.basis_index(self.hfstate)
         self._n_gates = len(self._gates)
         self._gates_dev = torch.as_tensor(X.gates_to_numpy(self._gates)).to(self.device)
+        # (N_alpha, N_beta)-sector engine: one-launch circuits + reverse-mode gradients for active
+        # spaces beyond the small one-workgroup kernel (e.g. kUpCCD CAS(8e,8o), 16 qubits)
+        self._sector = SectorEngine(ncas, self.hfstate, self._gates_dev, self._n_gates,
+                                    int(np.prod(self.theta_shape)), self._init_index, self.device)
+        self._use_sector = self.n_qubits > 10 and self._sector.fits()
         self.qnode = self._qnode
 
     # ---- internal real-amplitude entry points ---------------------------------------------------
@@ -84,6 +90,8 @@ class Parameterized_circuit():
     def state_real(self, theta, tangents=False):
         """Real amplitudes psi [D] (and tangents d psi/d theta [n_theta, D]) on the device."""
         th = self._theta2d(theta)
+        if self._use_sector and not tangents:
+            return self._sector.state(th, dense=True)[1][0]
         res = ops.circuit_state(th, self._gates_dev, self._n_gates, self.n_qubits,
                                 self._init_index, tangents=tangents)
         if tangents:
@@ -135,6 +143,9 @@ class Parameterized_circuit():
         if not restricted:
             raise NotImplementedError("unrestricted RDMs are not built (never used on the hot path)")
         th = self._theta2d(theta)
+        if self._use_sector:
+            g1, g2 = self._sector.rdms(self._sector.state(th))
+            return g1[0], g2[0]
         g1, g2 = ops.circuit_rdms(th, self._gates_dev, self._n_gates, self.n_qubits, self.ncas,
                                   self._init_index, tangents=False)
         return g1[0, 0], g2[0, 0]

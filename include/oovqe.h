@@ -196,6 +196,33 @@ int oovqe_circuit_hessian_assemble(const double* gamma, const double* Gamma, con
                                    const double* c2, int ncas, const int32_t* pairs, int n_pairs,
                                    int n_theta, double* H, oovqe_stream_t stream);
 
+/* ---- a10/a11/a13 at scale: particle-number-sector engine with reverse-mode gradients -------------
+ * For circuits that conserve (N_alpha, N_beta) -- UCCD, UCCSD, kUpCCD -- the state lives in a
+ * sector of C(a,N_alpha)*C(a,N_beta) determinants (4 900 of 65 536 for CAS(8e,8o)); the sector
+ * vector fits one workgroup's LDS, so the whole circuit is ONE launch per batch.
+ * Sector tables (device): unrank_a [na] / unrank_b [nb] = occupation strings (orbital p at bit
+ * ncas-1-p), rank_a / rank_b [2^ncas] = string -> index or -1.  Compressed index c = ia*nb + ib.
+ *   oovqe_sector_state   : theta [batch,n_theta] -> psi_c [batch, na*nb] (and, if not NULL, the
+ *                          dense psi [batch, 2^n]: Parameterized_circuit.qnode, pqc.py:165-172)
+ *   oovqe_sector_rdms    : gamma [batch,a,a], Gamma [batch,a,a,a,a] (pqc.py:192-221); MFMA Gram
+ *   oovqe_sector_adjoint : dtheta [batch,n_theta] = d/dtheta (c1.gamma + c2.Gamma): the reverse
+ *                          sweep torch autograd performs for the reference (oo_pqc.py:86-95);
+ *                          must follow oovqe_sector_rdms on the same `work` (reuses E_pq psi)
+ * work: oovqe_sector_work_size() doubles. */
+int oovqe_sector_state(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
+                       int ncas, uint32_t init_index, const uint32_t* unrank_a, const uint32_t* unrank_b,
+                       const int32_t* rank_a, const int32_t* rank_b, int na, int nb, int batch,
+                       double* psi_c, double* psi_dense, oovqe_stream_t stream);
+int oovqe_sector_rdms(const double* psi_c, int ncas, const uint32_t* unrank_a, const uint32_t* unrank_b,
+                      const int32_t* rank_a, const int32_t* rank_b, int na, int nb, int batch,
+                      double* gamma, double* Gamma, double* work, oovqe_stream_t stream);
+int oovqe_sector_adjoint(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
+                         int ncas, const uint32_t* unrank_a, const uint32_t* unrank_b,
+                         const int32_t* rank_a, const int32_t* rank_b, int na, int nb, int batch,
+                         const double* psi_c, const double* c1, const double* c2, double* work,
+                         double* dtheta, oovqe_stream_t stream);
+int64_t oovqe_sector_work_size(int ncas, int na, int nb, int batch);
+
 /* ---- a12/a13/a14/a16: one evaluation of the hybrid cost function in ONE call ---------------------
  * OO_pqc.energy_from_parameters / circuit_gradient / orbital_gradient / orbital_circuit_hessian
  * (src/auto_oo/oo_pqc.py:64-125) for a single geometry: circuit (+ tangents when derivatives != 0)

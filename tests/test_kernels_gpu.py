@@ -288,3 +288,46 @@ def test_circuit_rdms_fused_matches_staged(ncas, nelecas, kind):
     assert (f1 - g1).abs().max() < 1e-12 and (f2 - g2).abs().max() < 1e-12
     n1, n2 = ops.circuit_rdms(th, gd, len(gates), n, ncas, init, tangents=False)
     assert (n1[:, 0] - g1[:, 0]).abs().max() < 1e-12 and (n2[:, 0] - g2[:, 0]).abs().max() < 1e-12
+
+
+@pytest.mark.parametrize("ncas,nelecas,kind,k", [(4, 4, "kupccd", 1), (4, 4, "kupccd", 2),
+                                                 (3, 4, "uccd", 1), (3, 4, "uccsd", 1),
+                                                 (3, 2, "kupccd", 1), (4, 6, "uccd", 1)])
+def test_sector_engine_state_rdms_adjoint(ncas, nelecas, kind, k):
+    """(N_alpha,N_beta)-sector engine: state and RDMs against the dense kernels, reverse-mode
+    theta-gradient against forward-mode tangent RDMs and against the oracle's autograd."""
+    from auto_oo_amd.sector import SectorEngine
+    n = 2 * ncas
+    if kind == "kupccd":
+        gates, n_theta = X.kupccd_gates(ncas, k)
+    else:
+        gates, n_theta = X.uccd_gates(ncas, nelecas, kind == "uccsd")
+    hf = X.hf_state(nelecas, n)
+    init = X.basis_index(hf)
+    gd = _gates_dev(gates)
+    eng = SectorEngine(ncas, hf, gd, len(gates), n_theta, init, torch.device(DEV))
+    assert eng.fits()
+    rng = np.random.default_rng(31)
+    th = torch.tensor(rng.uniform(0, 2 * np.pi, (3, n_theta))).to(DEV)
+    psi_c, psi = eng.state(th, dense=True)
+    ref_psi, dpsi = ops.circuit_state(th, gd, len(gates), n, init, tangents=True)
+    assert (psi - ref_psi).abs().max() < 1e-13
+    assert abs(float((psi_c ** 2).sum(dim=1).min()) - 1.0) < 1e-12     # all weight in the sector
+    g1, g2 = eng.rdms(psi_c)
+    r1, r2 = ops.rdms_tangent(ref_psi, dpsi, ncas)
+    assert (g1 - r1[:, 0]).abs().max() < 1e-12 and (g2 - r2[:, 0]).abs().max() < 1e-12
+    # random, deliberately NON-symmetric cotangents
+    c1 = torch.tensor(rng.standard_normal((ncas, ncas))).to(DEV)
+    c2 = torch.tensor(rng.standard_normal((ncas,) * 4)).to(DEV)
+    dth = eng.adjoint(th, psi_c, c1, c2).cpu()
+    fwd = (torch.einsum("pq,bkpq->bk", c1, r1[:, 1:]) + torch.einsum("pqrs,bkpqrs->bk", c2, r2[:, 1:])).cpu()
+    assert (dth - fwd).abs().max() < 1e-11
+    if ncas <= 3 or kind == "kupccd" and k == 1:
+        pqc = (R.OraclePQC(ncas, nelecas, "kupccd", k=k) if kind == "kupccd"
+               else R.OraclePQC(ncas, nelecas, "ucc", add_singles=(kind == "uccsd")))
+
+        def f(t):
+            a, b = pqc.get_rdms(t)
+            return (c1.cpu() * a).sum() + (c2.cpu() * b).sum()
+        ref = torch.autograd.functional.jacobian(f, th[0].cpu())
+        assert (dth[0] - ref).abs().max() < 1e-10
