@@ -440,7 +440,8 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
                        const double* __restrict__ Gamma, int nrdm, int N, int no, int na,
                        double* __restrict__ Fcol, double* __restrict__ Epart,
                        double* __restrict__ Cpart, double* __restrict__ c1, double* __restrict__ c2,
-                       double* __restrict__ Gm_out, double* __restrict__ hmo_out, size_t out_stride)
+                       double* __restrict__ Gm_out, double* __restrict__ hmo_out, size_t out_stride,
+                       int rdm_chunk)
 {
     extern __shared__ double lds[];
     const int M = no + na, M2 = M * M, M3 = M2 * M;
@@ -453,8 +454,8 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
     double* FIn = hn + M;                // [M]
     double* cn = FIn + M;                // [N]      C[:, n]
     double* hl = cn + N;                 // [N][N]   h_ao
-    double* gml = hl + (size_t)N * N;    // [nrdm][na2]
-    double* Gml = gml + (size_t)nrdm * na2;   // [nrdm][na4]
+    double* gml = hl + (size_t)N * N;    // [rdm_chunk][na2]   (RDM sets are staged chunk by chunk)
+    double* Gml = gml + (size_t)rdm_chunk * na2;   // [rdm_chunk][na4]
     const int tid = threadIdx.x;
     const int n = blockIdx.x;
     {   // blockIdx.y = geometry of a batch: every per-geometry array is stacked
@@ -473,8 +474,6 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
         if (hmo_out) hmo_out += gi * (size_t)N * M;
     }
     for (int idx = tid; idx < N * N; idx += COL_THREADS) hl[idx] = h_ao[idx];
-    for (int idx = tid; idx < nrdm * na2; idx += COL_THREADS) gml[idx] = gamma[idx];
-    for (int idx = tid; idx < nrdm * na4; idx += COL_THREADS) Gml[idx] = Gamma[idx];
 
     const double* Usrc = U + (size_t)n * N * M2;
     for (int idx = tid; idx < N * M2; idx += COL_THREADS) Un[idx] = Usrc[idx];
@@ -509,37 +508,9 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
     __syncthreads();
     if (hmo_out && tid < M) hmo_out[(size_t)n * M + tid] = hn[tid];
 
-    // Fock columns: one thread per (set k, row m)
-    for (int idx = tid; idx < nrdm * M; idx += COL_THREADS) {
-        const int k = idx / M, m = idx - k * M;
-        const double* gam = gml + (size_t)k * na2;
-        double val;
-        if (m < no) {
-            double fa = 0.0;
-            for (int v = 0; v < na; ++v)
-                for (int w = 0; w < na; ++w) {
-                    const int V = no + v, W = no + w;
-                    fa += gam[v * na + w] * (Gn[m * M2 + V * M + W] - 0.5 * Gn[W * M2 + V * M + m]);
-                }
-            val = 2.0 * ((k == 0 ? FIn[m] : 0.0) + fa);
-        } else {
-            const int v = m - no;
-            const double* Gv = Gml + (size_t)k * na4 + (size_t)v * na3;
-            double acc = 0.0;
-            for (int w = 0; w < na; ++w) acc += FIn[no + w] * gam[v * na + w];
-            for (int w = 0; w < na; ++w)
-                for (int x = 0; x < na; ++x)
-                    for (int y = 0; y < na; ++y)
-                        acc += Gv[(w * na + x) * na + y] * Gn[(no + w) * M2 + (no + x) * M + no + y];
-            val = acc;
-        }
-        Fcol[((size_t)k * M + m) * N + n] = val;
-    }
-
-    // per-n pieces of the CAS coefficients and of the energy
+    // per-n pieces of the CAS coefficients (independent of the RDM sets)
     if (n < no) {
         if (tid == 0) Cpart[n] = hn[n] + FIn[n];
-        for (int k = tid; k < nrdm; k += COL_THREADS) Epart[(size_t)k * N + n] = 0.0;
     } else if (n < M) {
         const int p = n - no;
         if (tid == 0) Cpart[n] = 0.0;
@@ -551,23 +522,59 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
             const int q = t;
             c2[(size_t)p * na3 + idx] = 0.5 * Gn[(no + q) * M2 + (no + r) * M + no + s];
         }
-        // E_k contribution of row p: sum_q FI[P,Q] gam_k[p,q] + sum_qrs 1/2 g[P,Q,R,S] Gam_k[p,q,r,s]
-        // (serial per set in a fixed order: deterministic)
-        for (int k = tid; k < nrdm; k += COL_THREADS) {
-            const double* gam = gml + (size_t)k * na2 + (size_t)p * na;
-            const double* Gp = Gml + (size_t)k * na4 + (size_t)p * na3;
-            double acc = 0.0;
-            for (int q = 0; q < na; ++q) acc += FIn[no + q] * gam[q];
-            for (int q = 0; q < na; ++q)
-                for (int r = 0; r < na; ++r)
-                    for (int s2 = 0; s2 < na; ++s2)
-                        acc += 0.5 * Gn[(no + q) * M2 + (no + r) * M + no + s2]
-                               * Gp[(q * na + r) * na + s2];
-            Epart[(size_t)k * N + n] = acc;
+    } else if (tid == 0) {
+        Cpart[n] = 0.0;
+    }
+
+    // RDM sets, rdm_chunk at a time through LDS
+    for (int k0 = 0; k0 < nrdm; k0 += rdm_chunk) {
+        const int kc = (nrdm - k0) < rdm_chunk ? (nrdm - k0) : rdm_chunk;
+        __syncthreads();
+        for (int idx = tid; idx < kc * na2; idx += COL_THREADS) gml[idx] = gamma[(size_t)k0 * na2 + idx];
+        for (int idx = tid; idx < kc * na4; idx += COL_THREADS) Gml[idx] = Gamma[(size_t)k0 * na4 + idx];
+        __syncthreads();
+        // Fock columns: one thread per (set k, row m)
+        for (int idx = tid; idx < kc * M; idx += COL_THREADS) {
+            const int kl = idx / M, m = idx - kl * M, k = k0 + kl;
+            const double* gam = gml + (size_t)kl * na2;
+            double val;
+            if (m < no) {
+                double fa = 0.0;
+                for (int v = 0; v < na; ++v)
+                    for (int w = 0; w < na; ++w) {
+                        const int V = no + v, W = no + w;
+                        fa += gam[v * na + w] * (Gn[m * M2 + V * M + W] - 0.5 * Gn[W * M2 + V * M + m]);
+                    }
+                val = 2.0 * ((k == 0 ? FIn[m] : 0.0) + fa);
+            } else {
+                const int v = m - no;
+                const double* Gv = Gml + (size_t)kl * na4 + (size_t)v * na3;
+                double acc = 0.0;
+                for (int w = 0; w < na; ++w) acc += FIn[no + w] * gam[v * na + w];
+                for (int w = 0; w < na; ++w)
+                    for (int x = 0; x < na; ++x)
+                        for (int y = 0; y < na; ++y)
+                            acc += Gv[(w * na + x) * na + y] * Gn[(no + w) * M2 + (no + x) * M + no + y];
+                val = acc;
+            }
+            Fcol[((size_t)k * M + m) * N + n] = val;
         }
-    } else {
-        if (tid == 0) Cpart[n] = 0.0;
-        for (int k = tid; k < nrdm; k += COL_THREADS) Epart[(size_t)k * N + n] = 0.0;
+        // E_k contribution of row p = n - no (active n only), serial per set: deterministic
+        for (int kl = tid; kl < kc; kl += COL_THREADS) {
+            double acc = 0.0;
+            if (n >= no && n < M) {
+                const int p = n - no;
+                const double* gam = gml + (size_t)kl * na2 + (size_t)p * na;
+                const double* Gp = Gml + (size_t)kl * na4 + (size_t)p * na3;
+                for (int q = 0; q < na; ++q) acc += FIn[no + q] * gam[q];
+                for (int q = 0; q < na; ++q)
+                    for (int r = 0; r < na; ++r)
+                        for (int s2 = 0; s2 < na; ++s2)
+                            acc += 0.5 * Gn[(no + q) * M2 + (no + r) * M + no + s2]
+                                   * Gp[(q * na + r) * na + s2];
+            }
+            Epart[(size_t)(k0 + kl) * N + n] = acc;
+        }
     }
 }
 
@@ -792,10 +799,14 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
                                           (long)N * N * m2, (long)N * N, (long)N * N * m2, st)))
         return rc;
     const size_t na2 = (size_t)ncas * ncas;
-    const size_t lds_bytes = ((size_t)N * m2 + (size_t)N * M + m3 + N + M + M + N + (size_t)N * N +
-                              (size_t)nrdm * (na2 + na2 * na2)) * sizeof(double);
-    OOVQE_REQUIRE(lds_bytes <= 160 * 1024, "cas_eval: N=%d M=%d nrdm=%d needs %zu B of LDS", N, M,
-                  nrdm, lds_bytes);
+    const size_t base_bytes = ((size_t)N * m2 + (size_t)N * M + m3 + N + M + M + N + (size_t)N * N) *
+                              sizeof(double);
+    const size_t set_bytes = (na2 + na2 * na2) * sizeof(double);
+    OOVQE_REQUIRE(base_bytes + set_bytes <= 160 * 1024, "cas_eval: N=%d M=%d needs %zu B of LDS", N, M,
+                  base_bytes + set_bytes);
+    int rdm_chunk = (int)((160 * 1024 - base_bytes) / set_bytes);
+    if (rdm_chunk > nrdm) rdm_chunk = nrdm;
+    const size_t lds_bytes = base_bytes + (size_t)rdm_chunk * set_bytes;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)cas_column_kernel,
@@ -808,7 +819,7 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
     }
     hipLaunchKernelGGL(cas_column_kernel, dim3(N, batch), dim3(COL_THREADS), lds_bytes, st, U, h_ao, C,
                        gamma, Gamma, nrdm, N, n_occ, ncas, Fcol, Epart, Cpart, c1, c2, Gm, hmo,
-                       out_stride);
+                       out_stride, rdm_chunk);
     OOVQE_CHECK_LAUNCH("cas_eval/column");
     hipLaunchKernelGGL(cas_final_kernel, dim3(batch), dim3(512), 0, st, Fcol, Epart, Cpart, nuc, nrdm,
                        N, M, kap_row, kap_col, n_kappa, c0, E, gvec, dE, fock, gmat, nuc_arr,
