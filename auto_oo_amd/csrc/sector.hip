@@ -67,25 +67,70 @@ __device__ __forceinline__ int sec_rank(const Sector& s, uint32_t x)
     return s.rank_a[compact16(x >> 1)] * s.nb + s.rank_b[compact16(x)];
 }
 
-// one Givens pass on a sector vector; transpose = apply U^T (adjoint sweep)
-__device__ __forceinline__ void sec_gate(double* st, const Sector& s, int Dc, const oovqe_gate_t& g,
-                                         double c, double sn, bool transpose)
+// Stage the string tables and the full basis index of every determinant in LDS (the gate loops
+// touch them 5 times per gate per thread; from global memory that is an L2 round trip each).
+// `buf` must hold na + nb + 2*2^ncas + na*nb 32-bit words.  Returns the sector with LDS tables.
+__device__ Sector sec_stage_lds(const Sector& g, uint32_t* buf, uint32_t** xfull, int nthreads)
+{
+    const int ns = 1 << g.ncas, Dc = g.na * g.nb;
+    uint32_t* ua = buf;
+    uint32_t* ub = ua + g.na;
+    int32_t* ra = reinterpret_cast<int32_t*>(ub + g.nb);
+    int32_t* rb = ra + ns;
+    uint32_t* xf = reinterpret_cast<uint32_t*>(rb + ns);
+    for (int i = threadIdx.x; i < g.na; i += nthreads) ua[i] = g.unrank_a[i];
+    for (int i = threadIdx.x; i < g.nb; i += nthreads) ub[i] = g.unrank_b[i];
+    for (int i = threadIdx.x; i < ns; i += nthreads) { ra[i] = g.rank_a[i]; rb[i] = g.rank_b[i]; }
+    for (int d = threadIdx.x; d < Dc; d += nthreads) xf[d] = sec_full(g, d);
+    Sector l = g;
+    l.unrank_a = ua; l.unrank_b = ub; l.rank_a = ra; l.rank_b = rb;
+    *xfull = xf;
+    return l;
+}
+
+__host__ __device__ inline size_t sec_lds_words(int na, int nb, int ncas)
+{
+    return (size_t)na + nb + 2 * ((size_t)1 << ncas) + (size_t)na * nb;
+}
+
+// one Givens pass on a sector vector; transpose = apply U^T (adjoint sweep).  Up to SEC_MAXIT
+// determinants per thread, processed as one unrolled batch so that the dependent LDS lookups
+// (full index -> partner rank -> amplitudes) of different determinants overlap.
+constexpr int SEC_MAXIT = 8;   // Dc <= SEC_MAXIT * SEC_THREADS (checked on the host)
+
+template <int MAXIT>
+__device__ __forceinline__ void sec_gate(double* st, const Sector& s, const uint32_t* xfull, int Dc,
+                                         const oovqe_gate_t& g, double c, double sn, bool transpose)
 {
     const uint32_t fm = g.mask_hi | g.mask_lo;
     const double sg = transpose ? -sn : sn;
-    for (int d = threadIdx.x; d < Dc; d += SEC_THREADS) {
-        const uint32_t x = sec_full(s, d);
-        if ((x & fm) == g.mask_hi) {
-            const int e = sec_rank(s, x ^ fm);
-            const double pi = (__popc(x & g.mask_par) & 1) ? -1.0 : 1.0;
-            const double ax = st[d], ay = st[e];
-            st[d] = c * ax + pi * sg * ay;
-            st[e] = c * ay - pi * sg * ax;
+    int e[MAXIT];
+    double pi[MAXIT];
+#pragma unroll
+    for (int i = 0; i < MAXIT; ++i) {
+        const int d = threadIdx.x + i * SEC_THREADS;
+        e[i] = -1;
+        if (d < Dc) {
+            const uint32_t x = xfull[d];
+            if ((x & fm) == g.mask_hi) {
+                e[i] = sec_rank(s, x ^ fm);
+                pi[i] = (__popc(x & g.mask_par) & 1) ? -sg : sg;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXIT; ++i) {
+        if (e[i] >= 0) {
+            const int d = threadIdx.x + i * SEC_THREADS;
+            const double ax = st[d], ay = st[e[i]];
+            st[d] = c * ax + pi[i] * ay;
+            st[e[i]] = c * ay - pi[i] * ax;
         }
     }
 }
 
 // ---- forward circuit: grid = batch -------------------------------------------------------------
+template <int MAXIT>
 __global__ __launch_bounds__(SEC_THREADS)
 void sector_circuit_kernel(const double* __restrict__ theta, int n_theta,
                            const oovqe_gate_t* __restrict__ gates, int n_gates, Sector s,
@@ -96,6 +141,9 @@ void sector_circuit_kernel(const double* __restrict__ theta, int n_theta,
     double* st = lds;                                   // [Dc]
     double* cs = st + Dc;                               // [n_gates][2]
     oovqe_gate_t* gl = reinterpret_cast<oovqe_gate_t*>(cs + 2 * n_gates);
+    uint32_t* xfull;
+    const Sector sg = s;
+    s = sec_stage_lds(sg, reinterpret_cast<uint32_t*>(gl + n_gates), &xfull, SEC_THREADS);
     const int tid = threadIdx.x, b = blockIdx.x;
     const double* th = theta + (size_t)b * n_theta;
     {
@@ -109,13 +157,13 @@ void sector_circuit_kernel(const double* __restrict__ theta, int n_theta,
             cs[2 * g] = c;
             cs[2 * g + 1] = sn;
         }
-        const int c0 = sec_rank(s, init_index);
+        const int c0 = sec_rank(sg, init_index);
         for (int d = tid; d < Dc; d += SEC_THREADS) st[d] = (d == c0) ? 1.0 : 0.0;
     }
     __syncthreads();
     for (int g = 0; g < n_gates; ++g) {
         if (gl[g].theta_idx < 0) continue;
-        sec_gate(st, s, Dc, gl[g], cs[2 * g], cs[2 * g + 1], false);
+        sec_gate<MAXIT>(st, s, xfull, Dc, gl[g], cs[2 * g], cs[2 * g + 1], false);
         __syncthreads();
     }
     for (int d = tid; d < Dc; d += SEC_THREADS) psi_c[(size_t)b * Dc + d] = st[d];
@@ -169,64 +217,84 @@ void sector_epq_kernel(const double* __restrict__ vec, Sector s, double* __restr
 
 // ---- RDM Gram on the f64 MFMA -----------------------------------------------------------------
 // G[m][n] = sum_c A[m][c] B[n][c];  A rows m < a^2: V[qp] (m = pq), row a^2: psi;  B rows: V[rs].
-// grid: (MT*NT tiles, batch); 4 waves split the c range, fixed-order LDS reduction.
+// grid: (MT*NT tiles, batch, ksplit); the 4 waves of a block split their c range again; operands
+// are fetched 8 k-steps at a time so the L2 latency is paid once per 8 MFMAs; partial results of
+// the ksplit slices land in R[split] and are summed in fixed order by the finish kernel.
 __global__ __launch_bounds__(256)
 void sector_gram_kernel(const double* __restrict__ psi_c, const double* __restrict__ V, int ncas,
-                        int Dc, double* __restrict__ R)
+                        int Dc, int batch, double* __restrict__ R)
 {
     __shared__ double red[4][256];
     const int na2 = ncas * ncas, nrow = na2 + 1;
     const int MT = (nrow + 15) / 16, NT = (na2 + 15) / 16;
     const int tile = blockIdx.x, mt = tile / NT, nt = tile - mt * NT;
     const size_t b = blockIdx.y;
+    const int split = blockIdx.z, nsplit = gridDim.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
     const double* Vb = V + b * (size_t)na2 * Dc;
     const int m = mt * 16 + lr, nn = nt * 16 + lr;
-    const double* arow = nullptr;
+    const double* arow = psi_c + b * (size_t)Dc;    // dummy valid pointer for padded rows
+    double amask = 0.0, bmask = 0.0;
     if (m < na2) {
         const int p = m / ncas, q = m - p * ncas;
         arow = Vb + (size_t)(q * ncas + p) * Dc;
+        amask = 1.0;
     } else if (m == na2) {
-        arow = psi_c + b * (size_t)Dc;
+        amask = 1.0;
     }
-    const double* brow = nn < na2 ? Vb + (size_t)nn * Dc : nullptr;
+    const double* brow = Vb;
+    if (nn < na2) { brow = Vb + (size_t)nn * Dc; bmask = 1.0; }
     const int ksteps = (Dc + 3) / 4;
-    const int per = (ksteps + 3) / 4;
-    const int k0 = wave * per, k1 = (k0 + per < ksteps) ? k0 + per : ksteps;
+    const int nslice = 4 * nsplit;
+    const int per = (ksteps + nslice - 1) / nslice;
+    const int sl = split * 4 + wave;
+    const int k0 = sl * per, k1 = (k0 + per < ksteps) ? k0 + per : ksteps;
     d4 acc = {0.0, 0.0, 0.0, 0.0};
-    for (int ks = k0; ks < k1; ++ks) {
-        const int c = 4 * ks + lq;
-        const double av = (arow && c < Dc) ? arow[c] : 0.0;
-        const double bv = (brow && c < Dc) ? brow[c] : 0.0;
-        acc = mfma_f64(av, bv, acc);
+    for (int ks = k0; ks < k1; ks += 8) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = 4 * (ks + u) + lq;
+            const int cc = c < Dc ? c : Dc - 1;
+            const double ok = (ks + u < k1 && c < Dc) ? 1.0 : 0.0;
+            av[u] = arow[cc] * (ok * amask);
+            bv[u] = brow[cc] * (ok * bmask);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = mfma_f64(av[u], bv[u], acc);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) red[wave][(lq + 4 * i) * 16 + lr] = acc[i];
     __syncthreads();
     const double v = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
     const int row = mt * 16 + tid / 16, col = nt * 16 + (tid & 15);
-    R[(b * (size_t)(MT * 16) + row) * (NT * 16) + col] = v;
+    R[(((size_t)split * batch + b) * (MT * 16) + row) * (NT * 16) + col] = v;
 }
 
 // gamma[rs] = R[a^2][rs];  Gamma[pq,rs] = R[pq][rs] - delta_qr gamma[ps]
-__global__ void sector_rdm_finish_kernel(const double* __restrict__ R, int ncas,
+__global__ void sector_rdm_finish_kernel(const double* __restrict__ R, int ncas, int batch, int nsplit,
                                          double* __restrict__ gamma, double* __restrict__ Gamma)
 {
     const int na2 = ncas * ncas, nrow = na2 + 1;
     const int MT = (nrow + 15) / 16, NT = (na2 + 15) / 16, ldr = NT * 16;
     const size_t b = blockIdx.y;
-    const double* Rb = R + b * (size_t)(MT * 16) * ldr;
+    const size_t tile_sz = (size_t)(MT * 16) * ldr;
+    auto Rsum = [&](int off) -> double {
+        double v = 0.0;
+        for (int sp = 0; sp < nsplit; ++sp) v += R[((size_t)sp * batch + b) * tile_sz + off];
+        return v;
+    };
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < na2 * na2 + na2;
          idx += gridDim.x * blockDim.x) {
         if (idx < na2) {
-            gamma[b * na2 + idx] = Rb[na2 * ldr + idx];
+            gamma[b * na2 + idx] = Rsum(na2 * ldr + idx);
         } else {
             const int rem = idx - na2;
             const int pq = rem / na2, rs = rem - pq * na2;
             const int p = pq / ncas, q = pq - p * ncas, r = rs / ncas, s2 = rs - r * ncas;
-            double g = Rb[pq * ldr + rs];
-            if (q == r) g -= Rb[na2 * ldr + p * ncas + s2];
+            double g = Rsum(pq * ldr + rs);
+            if (q == r) g -= Rsum(na2 * ldr + p * ncas + s2);
             Gamma[b * (size_t)na2 * na2 + rem] = g;
         }
     }
@@ -257,32 +325,49 @@ __global__ void sector_coeff_kernel(const double* __restrict__ c1, const double*
     }
 }
 
-// grid: (ceil(Dc/256), batch)
+// grid: (ceil(Dc/64), batch); block = 64 determinants x 4 slices of the (p,q) loop, summed in LDS
+// in fixed order; string tables staged in LDS.
 __global__ __launch_bounds__(256)
 void sector_lambda_kernel(const double* __restrict__ V, const double* __restrict__ W1,
                           const double* __restrict__ W2, const double* __restrict__ c1e, Sector s,
                           double* __restrict__ lam)
 {
+    extern __shared__ double lds[];
+    double* part = lds;                                         // [4][64]
+    uint32_t* tb = reinterpret_cast<uint32_t*>(part + 256);
+    const int ns = 1 << s.ncas;
+    int32_t* ra = reinterpret_cast<int32_t*>(tb);
+    int32_t* rb = ra + ns;
+    for (int i = threadIdx.x; i < ns; i += 256) { ra[i] = s.rank_a[i]; rb[i] = s.rank_b[i]; }
+    const Sector sg = s;
+    s.rank_a = ra;
+    s.rank_b = rb;
+    __syncthreads();
     const int Dc = s.na * s.nb, n = 2 * s.ncas, a = s.ncas, na2 = a * a;
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= Dc) return;
+    const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     const size_t b = blockIdx.y;
-    const double* Vb = V + b * (size_t)na2 * Dc;
-    const double* W1b = W1 + b * (size_t)na2 * Dc;
-    const double* W2b = W2 + b * (size_t)na2 * Dc;
-    const uint32_t x = sec_full(s, c);
     double acc = 0.0;
-    for (int p = 0; p < a; ++p)
-        for (int q = 0; q < a; ++q) {
-            const int pq = p * a + q, qp = q * a + p;
+    if (c < Dc) {
+        const double* Vb = V + b * (size_t)na2 * Dc;
+        const double* W1b = W1 + b * (size_t)na2 * Dc;
+        const double* W2b = W2 + b * (size_t)na2 * Dc;
+        const uint32_t x = sec_full(sg, c);
+        for (int pq = slice; pq < na2; pq += 4) {
+            const int p = pq / a, q = pq - p * a, qp = q * a + p;
             acc += c1e[pq] * (Vb[(size_t)pq * Dc + c] + Vb[(size_t)qp * Dc + c]);
             acc += sec_epq(W1b + (size_t)pq * Dc, s, n, p, q, x, c);      // E_pq W_pq
             acc += sec_epq(W2b + (size_t)pq * Dc, s, n, q, p, x, c);      // E_sr W'_rs (r=p, s=q)
         }
-    lam[b * Dc + c] = acc;
+    }
+    part[slice * 64 + cl] = acc;
+    __syncthreads();
+    if (slice == 0 && c < Dc)
+        lam[b * Dc + c] = part[cl] + part[64 + cl] + part[128 + cl] + part[192 + cl];
 }
 
 // ---- adjoint sweep: grid = batch --------------------------------------------------------------------
+template <int MAXIT>
 __global__ __launch_bounds__(SEC_THREADS)
 void sector_adjoint_kernel(const double* __restrict__ theta, int n_theta,
                            const oovqe_gate_t* __restrict__ gates, int n_gates, Sector s,
@@ -297,6 +382,8 @@ void sector_adjoint_kernel(const double* __restrict__ theta, int n_theta,
     double* part = cs + 2 * n_gates;                    // [16 waves]
     double* gth = part + SEC_THREADS / 64;              // [n_theta]
     oovqe_gate_t* gl = reinterpret_cast<oovqe_gate_t*>(gth + n_theta);
+    uint32_t* xfull;
+    s = sec_stage_lds(s, reinterpret_cast<uint32_t*>(gl + n_gates), &xfull, SEC_THREADS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
     const double* th = theta + (size_t)b * n_theta;
     {
@@ -323,17 +410,31 @@ void sector_adjoint_kernel(const double* __restrict__ theta, int n_theta,
         const uint32_t fm = gt.mask_hi | gt.mask_lo;
         const double c = cs[2 * g], sn = cs[2 * g + 1];
         double acc = 0.0;
-        for (int d = tid; d < Dc; d += SEC_THREADS) {
-            const uint32_t x = sec_full(s, d);
-            if ((x & fm) == gt.mask_hi) {
-                const int e = sec_rank(s, x ^ fm);
-                const double pi = (__popc(x & gt.mask_par) & 1) ? -1.0 : 1.0;
-                const double px = ps[d], py = ps[e], lx = lm[d], ly = lm[e];
-                acc += pi * (lx * py - ly * px);            // lambda^T A psi on this pair
-                ps[d] = c * px - pi * sn * py;              // U^T
-                ps[e] = c * py + pi * sn * px;
-                lm[d] = c * lx - pi * sn * ly;
-                lm[e] = c * ly + pi * sn * lx;
+        int e[MAXIT];
+        double pi[MAXIT];
+#pragma unroll
+        for (int i = 0; i < MAXIT; ++i) {
+            const int d = tid + i * SEC_THREADS;
+            e[i] = -1;
+            if (d < Dc) {
+                const uint32_t x = xfull[d];
+                if ((x & fm) == gt.mask_hi) {
+                    e[i] = sec_rank(s, x ^ fm);
+                    pi[i] = (__popc(x & gt.mask_par) & 1) ? -1.0 : 1.0;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXIT; ++i) {
+            if (e[i] >= 0) {
+                const int d = tid + i * SEC_THREADS, ee = e[i];
+                const double px = ps[d], py = ps[ee], lx = lm[d], ly = lm[ee];
+                acc += pi[i] * (lx * py - ly * px);          // lambda^T A psi on this pair
+                const double ps_ = pi[i] * sn;
+                ps[d] = c * px - ps_ * py;                   // U^T
+                ps[ee] = c * py + ps_ * px;
+                lm[d] = c * lx - ps_ * ly;
+                lm[ee] = c * ly + ps_ * lx;
             }
         }
         // deterministic reduction: wave shuffle tree, then the 16 wave partials in fixed order
@@ -359,15 +460,16 @@ Sector make_sector(const uint32_t* ua, const uint32_t* ub, const int32_t* ra, co
     return s;
 }
 
-size_t circuit_lds(int Dc, int n_gates)
+size_t circuit_lds(int na, int nb, int ncas, int n_gates)
 {
-    return ((size_t)Dc + 2 * n_gates) * sizeof(double) + (size_t)n_gates * sizeof(oovqe_gate_t);
+    return ((size_t)na * nb + 2 * n_gates) * sizeof(double) + (size_t)n_gates * sizeof(oovqe_gate_t) +
+           sec_lds_words(na, nb, ncas) * 4;
 }
 
-size_t adjoint_lds(int Dc, int n_gates, int n_theta)
+size_t adjoint_lds(int na, int nb, int ncas, int n_gates, int n_theta)
 {
-    return ((size_t)2 * Dc + 2 * n_gates + SEC_THREADS / 64 + n_theta) * sizeof(double) +
-           (size_t)n_gates * sizeof(oovqe_gate_t);
+    return ((size_t)2 * na * nb + 2 * n_gates + SEC_THREADS / 64 + n_theta) * sizeof(double) +
+           (size_t)n_gates * sizeof(oovqe_gate_t) + sec_lds_words(na, nb, ncas) * 4;
 }
 
 }  // namespace
@@ -383,23 +485,33 @@ extern "C" int oovqe_sector_state(const double* theta, int n_theta, const oovqe_
     OOVQE_REQUIRE(ncas >= 1 && ncas <= 13 && na >= 1 && nb >= 1 && batch >= 1 && n_gates >= 1,
                   "sector_state: bad sizes");
     const int Dc = na * nb;
-    const size_t lds_bytes = circuit_lds(Dc, n_gates);
-    OOVQE_REQUIRE(lds_bytes <= 160 * 1024, "sector_state: sector of %d determinants needs %zu B LDS", Dc,
-                  lds_bytes);
+    const size_t lds_bytes = circuit_lds(na, nb, ncas, n_gates);
+    OOVQE_REQUIRE(lds_bytes <= 160 * 1024 && Dc <= SEC_MAXIT * SEC_THREADS,
+                  "sector_state: sector of %d determinants needs %zu B LDS", Dc, lds_bytes);
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)sector_circuit_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            oovqe_set_error("sector_state: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return OOVQE_ERR_HIP;
-        }
-        attr_done = true;
-    }
     Sector s = make_sector(unrank_a, unrank_b, rank_a, rank_b, na, nb, ncas);
-    hipLaunchKernelGGL(sector_circuit_kernel, dim3(batch), dim3(SEC_THREADS), lds_bytes, st, theta,
-                       n_theta, gates, n_gates, s, init_index, psi_c);
+    const int nit = (Dc + SEC_THREADS - 1) / SEC_THREADS;
+#define OOVQE_SEC_CIRC(MI)                                                                         \
+    do {                                                                                           \
+        static bool attr_done = false;                                                             \
+        if (!attr_done) {                                                                          \
+            hipError_t e = hipFuncSetAttribute((const void*)sector_circuit_kernel<MI>,             \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                               160 * 1024);                                        \
+            if (e != hipSuccess) {                                                                 \
+                oovqe_set_error("sector_state: hipFuncSetAttribute: %s", hipGetErrorString(e));    \
+                return OOVQE_ERR_HIP;                                                              \
+            }                                                                                      \
+            attr_done = true;                                                                      \
+        }                                                                                          \
+        hipLaunchKernelGGL(sector_circuit_kernel<MI>, dim3(batch), dim3(SEC_THREADS), lds_bytes,   \
+                           st, theta, n_theta, gates, n_gates, s, init_index, psi_c);              \
+    } while (0)
+    if (nit <= 1) OOVQE_SEC_CIRC(1);
+    else if (nit <= 2) OOVQE_SEC_CIRC(2);
+    else if (nit <= 5) OOVQE_SEC_CIRC(5);
+    else OOVQE_SEC_CIRC(8);
+#undef OOVQE_SEC_CIRC
     OOVQE_CHECK_LAUNCH("sector_state");
     if (psi_dense) {
         const uint32_t D = 1u << (2 * ncas);
@@ -415,8 +527,9 @@ extern "C" int64_t oovqe_sector_work_size(int ncas, int na, int nb, int batch)
 {
     const int64_t Dc = (int64_t)na * nb, na2 = (int64_t)ncas * ncas;
     const int64_t MT = (na2 + 1 + 15) / 16, NT = (na2 + 15) / 16;
-    // V, W1, W2 [batch][a^2][Dc] | lam [batch][Dc] | R [batch][MT*16][NT*16] | M1, M2 [a^4] | c1e [a^2]
-    return (int64_t)batch * (3 * na2 * Dc + Dc + MT * 16 * NT * 16) + 2 * na2 * na2 + na2;
+    // V, W1, W2 [batch][a^2][Dc] | lam [batch][Dc] | R [8 splits][batch][MT*16][NT*16]
+    // | M1, M2 [a^4] | c1e [a^2]
+    return (int64_t)batch * (3 * na2 * Dc + Dc + 8 * MT * 16 * NT * 16) + 2 * na2 * na2 + na2;
 }
 
 extern "C" int oovqe_sector_rdms(const double* psi_c, int ncas, const uint32_t* unrank_a,
@@ -436,10 +549,12 @@ extern "C" int oovqe_sector_rdms(const double* psi_c, int ncas, const uint32_t* 
     hipLaunchKernelGGL(sector_epq_kernel, dim3((Dc + 255) / 256, na2, batch), dim3(256), 0, st, psi_c, s,
                        V);
     OOVQE_CHECK_LAUNCH("sector_rdms/epq");
-    hipLaunchKernelGGL(sector_gram_kernel, dim3(MT * NT, batch), dim3(256), 0, st, psi_c, V, ncas, Dc, R);
+    const int nsplit = batch >= 32 ? 1 : (batch >= 8 ? 2 : 8);   // fill the chip at small batch
+    hipLaunchKernelGGL(sector_gram_kernel, dim3(MT * NT, batch, nsplit), dim3(256), 0, st, psi_c, V, ncas,
+                       Dc, batch, R);
     OOVQE_CHECK_LAUNCH("sector_rdms/gram");
     hipLaunchKernelGGL(sector_rdm_finish_kernel, dim3((na2 * na2 + na2 + 255) / 256, batch), dim3(256),
-                       0, st, R, ncas, gamma, Gamma);
+                       0, st, R, ncas, batch, nsplit, gamma, Gamma);
     OOVQE_CHECK_LAUNCH("sector_rdms/finish");
     return 0;
 }
@@ -459,7 +574,7 @@ extern "C" int oovqe_sector_adjoint(const double* theta, int n_theta, const oovq
     hipStream_t st = (hipStream_t)stream;
     const int Dc = na * nb, na2 = ncas * ncas;
     const int MT = (na2 + 1 + 15) / 16, NT = (na2 + 15) / 16;
-    const size_t lds_bytes = adjoint_lds(Dc, n_gates, n_theta);
+    const size_t lds_bytes = adjoint_lds(na, nb, ncas, n_gates, n_theta);
     OOVQE_REQUIRE(lds_bytes <= 160 * 1024, "sector_adjoint: needs %zu B LDS", lds_bytes);
     Sector s = make_sector(unrank_a, unrank_b, rank_a, rank_b, na, nb, ncas);
     const size_t nb_ = (size_t)batch;
@@ -468,7 +583,7 @@ extern "C" int oovqe_sector_adjoint(const double* theta, int n_theta, const oovq
     double* W2 = W1 + nb_ * na2 * Dc;
     double* lam = W2 + nb_ * na2 * Dc;
     double* R = lam + nb_ * Dc;
-    double* M1 = R + nb_ * (size_t)(MT * 16) * (NT * 16);
+    double* M1 = R + 8 * nb_ * (size_t)(MT * 16) * (NT * 16);
     double* M2 = M1 + (size_t)na2 * na2;
     double* c1e = M2 + (size_t)na2 * na2;
     hipLaunchKernelGGL(sector_coeff_kernel, dim3((na2 * na2 + 255) / 256), dim3(256), 0, st, c1, c2, ncas,
@@ -482,21 +597,32 @@ extern "C" int oovqe_sector_adjoint(const double* theta, int n_theta, const oovq
     if ((rc = oovqe_mode_contract_batched(V, M2, W2, 1, na2, na2, Dc, na2, 0, batch, (long)na2 * Dc, 0,
                                           (long)na2 * Dc, st)))
         return rc;
-    hipLaunchKernelGGL(sector_lambda_kernel, dim3((Dc + 255) / 256, batch), dim3(256), 0, st, V, W1, W2,
+    hipLaunchKernelGGL(sector_lambda_kernel, dim3((Dc + 63) / 64, batch), dim3(256),
+                       256 * sizeof(double) + 2 * ((size_t)1 << ncas) * sizeof(int32_t), st, V, W1, W2,
                        c1e, s, lam);
     OOVQE_CHECK_LAUNCH("sector_adjoint/lambda");
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)sector_adjoint_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            oovqe_set_error("sector_adjoint: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return OOVQE_ERR_HIP;
-        }
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(sector_adjoint_kernel, dim3(batch), dim3(SEC_THREADS), lds_bytes, st, theta,
-                       n_theta, gates, n_gates, s, psi_c, lam, dtheta);
+    const int nit = (Dc + SEC_THREADS - 1) / SEC_THREADS;
+#define OOVQE_SEC_ADJ(MI)                                                                          \
+    do {                                                                                           \
+        static bool attr_done = false;                                                             \
+        if (!attr_done) {                                                                          \
+            hipError_t e = hipFuncSetAttribute((const void*)sector_adjoint_kernel<MI>,             \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                               160 * 1024);                                        \
+            if (e != hipSuccess) {                                                                 \
+                oovqe_set_error("sector_adjoint: hipFuncSetAttribute: %s", hipGetErrorString(e));  \
+                return OOVQE_ERR_HIP;                                                              \
+            }                                                                                      \
+            attr_done = true;                                                                      \
+        }                                                                                          \
+        hipLaunchKernelGGL(sector_adjoint_kernel<MI>, dim3(batch), dim3(SEC_THREADS), lds_bytes,   \
+                           st, theta, n_theta, gates, n_gates, s, psi_c, lam, dtheta);             \
+    } while (0)
+    if (nit <= 1) OOVQE_SEC_ADJ(1);
+    else if (nit <= 2) OOVQE_SEC_ADJ(2);
+    else if (nit <= 5) OOVQE_SEC_ADJ(5);
+    else OOVQE_SEC_ADJ(8);
+#undef OOVQE_SEC_ADJ
     OOVQE_CHECK_LAUNCH("sector_adjoint/sweep");
     return 0;
 }

@@ -55,7 +55,9 @@ class SectorEngine:
 
     def fits(self):
         """The sector vector (+ gate table) must fit one workgroup's LDS twice (adjoint sweep)."""
-        return (2 * self.Dc + 2 * self.n_gates + 16 + self.n_theta) * 8 + 40 * self.n_gates <= 160 * 1024
+        words = self.na + self.nb + 2 * (1 << self.ncas) + self.Dc
+        return ((2 * self.Dc + 2 * self.n_gates + 16 + self.n_theta) * 8 + 40 * self.n_gates
+                + 4 * words) <= 160 * 1024
 
     def _tabs(self):
         i32 = torch.int32
