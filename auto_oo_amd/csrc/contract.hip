@@ -50,29 +50,48 @@ void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
-    const long item = (long)blockIdx.x * NWAVES + wave;
-    const bool active = item < n_items;
-
-    // ---- decode this wave's strip of T ------------------------------------------------------
-    long a = 0, tbase = 0, tstride = 0;
-    bool tvalid = false;
-    long bcol = 0;
-    if (LAST) {
-        a = item * 16;                       // first row of the strip
-        const long row = a + lr;
-        tvalid = active && row < A;
-        tbase = row * (long)K;               // + k
-        tstride = 1;
-    } else {
-        a = item / nbt;
-        const long bt = item - a * nbt;
-        bcol = bt * 16 + lr;
-        tvalid = active && bcol < B;
-        tbase = a * (long)K * B + bcol;      // + k * B
-        tstride = B;
-    }
-
     const int nchunks = (K + KC - 1) / KC;
+    const long n_groups = (n_items + NWAVES - 1) / NWAVES;
+
+    // One wave = one 16-wide strip of T ("item"); a workgroup walks the item groups
+    // blockIdx.x, blockIdx.x + gridDim.x, ... (persistent), and the chunk pipeline runs ACROSS
+    // items: while the last K-chunk of item i is in the MFMA pipe, chunk 0 of item i+1 is already
+    // being fetched, so neither the workgroup launch nor the first HBM round trip of an item is
+    // ever exposed.
+    struct Strip {
+        const double* tp;   // base of this lane's T column / row (clamped to a valid address)
+        long a, bcol;
+        bool active;
+    };
+    auto decode = [&](long group) -> Strip {
+        Strip st;
+        const long item = group * NWAVES + wave;
+        st.active = group < n_groups && item < n_items;
+        st.a = 0;
+        st.bcol = 0;
+        long tbase = 0;
+        bool tvalid = false;
+        if (LAST) {
+            st.a = item * 16;
+            const long row = st.a + lr;
+            tvalid = st.active && row < A;
+            tbase = row * (long)K;
+        } else {
+            // 32-bit division (n_items < 2^31 is checked on the host): the 64-bit one costs ~40
+            // live VGPRs at this point and pushes the NT = 13 instantiation into scratch
+            const unsigned ai = (unsigned)item / (unsigned)nbt;
+            st.a = ai;
+            const long bt = (long)((unsigned)item - ai * (unsigned)nbt);
+            st.bcol = bt * 16 + lr;
+            tvalid = st.active && st.bcol < B;
+            tbase = st.a * (long)K * B + st.bcol;
+        }
+        // T needs no mask: a lane outside the tensor only feeds output columns / rows that are
+        // never stored, and rows k >= K meet zero rows of Cm; its address is clamped to T[0].
+        st.tp = T + (tvalid ? tbase : 0);
+        return st;
+    };
+    const long tstride = LAST ? 1 : B;
 
     d4 acc[NT];
 #pragma unroll
@@ -85,9 +104,6 @@ void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm
     // same basic block as its use: nothing for the compiler to sink behind a branch, so the loads
     // of a chunk stay in flight together and vmcnt is counted, not drained.  Masks are
     // multiplicative (a select on a loaded value is turned back into a branch around the load).
-    // T needs no mask: a lane outside the tensor (bcol >= B / row >= A) only feeds output columns
-    // / rows that are never stored, and rows k >= K meet zero rows of Cm.
-    const double* tp = T + (tvalid ? tbase : 0);
     auto stage_load = [&](int kbase) {
 #pragma unroll
         for (int i = 0; i < CREG; ++i) {
@@ -106,7 +122,7 @@ void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm
             buf[idx] = creg[i] * (ok ? 1.0 : 0.0);
         }
     };
-    auto load_t = [&](int kbase, double* dst) {
+    auto load_t = [&](const double* tp, int kbase, double* dst) {
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             const int k = kbase + s * 4 + lq;
@@ -114,68 +130,90 @@ void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm
         }
     };
 
-    // ---- prologue ---------------------------------------------------------------------------
+    // ---- prologue (once per workgroup) -------------------------------------------------------
+    long group = blockIdx.x;
+    Strip cur = decode(group);
     stage_load(0);
-    load_t(0, tcur);
+    load_t(cur.tp, 0, tcur);
     stage_store(0, lds);
     __syncthreads();
+    int par = 0;   // LDS buffer holding the chunk being consumed
 
-    for (int c = 0; c < nchunks; ++c) {
-        const int kbase = c * KC;
-        // prefetch the next chunk (on the last iteration: a harmless re-read of row K-1)
-        const int knext = (c + 1 < nchunks) ? kbase + KC : K - 1;
-        stage_load(knext);
-        load_t(knext, tnext);
-        // One straight-line code path for every chunk (rows k >= K of the staged Cm are zero, so
-        // the padded k-steps of the last chunk add nothing).  The Cm fragments of k-step s+1 are
-        // read from LDS while the MFMAs of k-step s issue: an explicit two-stage pipeline,
-        // because letting the scheduler hoist all fragment reads of the chunk costs 2*KS*NT
-        // registers, and a second (tail) code path makes the compiler keep two copies of acc.
-        const double* buf = lds + (c & 1) * BUF + lq * LDJ + lr;
-        double cv[2][NT];
+    while (group < n_groups) {
+        const Strip nxt = decode(group + gridDim.x);
+        for (int c = 0; c < nchunks; ++c) {
+            const int kbase = c * KC;
+            const bool last = (c + 1 == nchunks);
+            // next chunk in the pipeline: chunk c+1 of this item, or chunk 0 of the next item
+            const int knext = last ? 0 : kbase + KC;
+            const double* tpn = last ? nxt.tp : cur.tp;
+            // One straight-line code path for every chunk (rows k >= K of the staged Cm are zero,
+            // so the padded k-steps of the last chunk add nothing).  The Cm fragments of k-step
+            // s+1 are read from LDS while the MFMAs of k-step s issue (two-stage pipeline).  The
+            // global prefetch (address arithmetic + loads) sits in the SAME scheduling region as
+            // the MFMAs of k-step 0, and the LDS staging stores in the region of the last k-step,
+            // so their VALU work fills the 64-cycle MFMA issue gaps instead of running ahead of
+            // the first MFMA after every barrier.
+            const double* buf = lds + par * BUF + lq * LDJ + lr;
+            double cv[2][NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) cv[0][t] = buf[t * 16];
+            for (int t = 0; t < NT; ++t) cv[0][t] = buf[t * 16];
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            if (s + 1 < KSTEPS) {
+            for (int s = 0; s < KSTEPS; ++s) {
+                if (s + 1 < KSTEPS) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) cv[(s + 1) & 1][t] = buf[(s + 1) * 4 * LDJ + t * 16];
+                    for (int t = 0; t < NT; ++t) cv[(s + 1) & 1][t] = buf[(s + 1) * 4 * LDJ + t * 16];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = LAST ? mfma_f64(tcur[s], cv[s & 1][t], acc[t])
+                                  : mfma_f64(cv[s & 1][t], tcur[s], acc[t]);
+                if (s == 0) {
+                    stage_load(knext);
+                    load_t(tpn, knext, tnext);
+                }
+                if (s == KSTEPS - 1) stage_store(knext, lds + (par ^ 1) * BUF);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            par ^= 1;
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                acc[t] = LAST ? mfma_f64(tcur[s], cv[s & 1][t], acc[t])
-                              : mfma_f64(cv[s & 1][t], tcur[s], acc[t]);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int s = 0; s < KSTEPS; ++s) tcur[s] = tnext[s];
         }
-        stage_store(knext, lds + ((c + 1) & 1) * BUF);
-        __syncthreads();
+        // ---- epilogue of this item (stores drain while the next item's MFMAs run) -------------
+        // one running pointer + a scheduling fence per tile: otherwise all 4*NT 64-bit store
+        // addresses are materialised at once (2 VGPRs each) on top of the accumulators
+        if (cur.active) {
+            if (LAST) {
+                double* op = out + (cur.a + lq) * (long)J + j0 + lr;
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) tcur[s] = tnext[s];
-    }
-
-    // ---- epilogue ---------------------------------------------------------------------------
-    if (!active) return;
-    if (LAST) {
+                for (int t = 0; t < NT; ++t) {
+                    const int col = j0 + t * 16 + lr;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int col = j0 + t * 16 + lr;
+                    for (int i = 0; i < 4; ++i) {
+                        const long row = cur.a + lq + 4 * i;
+                        if (row < A && col < J) op[(long)(4 * i) * J + t * 16] = acc[t][i];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if (cur.bcol < B) {
+                double* op = out + (cur.a * (long)J + j0 + lq) * B + cur.bcol;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const long row = a + lq + 4 * i;
-                if (row < A && col < J) out[row * (long)J + col] = acc[t][i];
+                for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int j = j0 + t * 16 + lq + 4 * i;
+                        if (j < J) op[(long)(t * 16 + 4 * i) * B] = acc[t][i];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
-    } else {
-        if (bcol >= B) return;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int j = j0 + t * 16 + lq + 4 * i;
-                if (j < J) out[(a * (long)J + j) * B + bcol] = acc[t][i];
-            }
-        }
+        for (int t = 0; t < NT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+        cur = nxt;
+        group += gridDim.x;
     }
 }
 
@@ -199,11 +237,11 @@ int launch_nt(const double* T, const double* Cm, double* out, long A, int K, int
         }
         attr_done = true;
     }
-    const long nblocks = (n_items + NWAVES - 1) / NWAVES;
-    if (nblocks > 0x7fffffffL) {
-        oovqe_set_error("mode_contract: grid too large");
-        return OOVQE_ERR_SIZE;
-    }
+    // persistent grid: at most ~2 workgroups per CU in total, each walks many item groups
+    const long ngroups_items = (n_items + NWAVES - 1) / NWAVES;
+    long per_slice = 512 / ((long)ngroups * batch);
+    if (per_slice < 1) per_slice = 1;
+    const long nblocks = ngroups_items < per_slice ? ngroups_items : per_slice;
     hipLaunchKernelGGL((contract_kernel<NT, LAST, KS>),
                        dim3((unsigned)nblocks, (unsigned)ngroups, (unsigned)batch), dim3(NTHREADS),
                        lds_bytes, st, T, Cm, out, A, K, J, B, ldc, n_items, nbt, t_bs, c_bs, o_bs);
@@ -247,6 +285,7 @@ int oovqe_mode_contract_batched(const double* T, const double* Cm, double* out, 
                                 hipStream_t st)
 {
     OOVQE_REQUIRE(batch >= 1 && batch <= 65535, "mode_contract: batch=%d", batch);
+    OOVQE_REQUIRE((double)A * (double)((B + 15) / 16) < 2.0e9, "mode_contract: too many strips");
     OOVQE_REQUIRE(T && Cm && out, "mode_contract: null pointer");
     OOVQE_REQUIRE(A >= 1 && K >= 1 && J >= 1 && B >= 1 && ldc >= J,
                   "mode_contract: bad dims A=%ld K=%d J=%d B=%ld ldc=%d", A, K, J, B, ldc);
