@@ -134,6 +134,61 @@ def kupccd_gates(ncas, k=1):
     return gates, k * len(d_wires)
 
 
+def double_excitation_gate(wires, n, theta_idx):
+    """qml.DoubleExcitation(phi) on four wires: |0011> -> c|0011> + s|1100>,
+    |1100> -> c|1100> - s|0011>  (c, s = cos, sin of phi/2); no fermionic sign."""
+    w0, w1, w2, w3 = wires
+    return _gate(_bit(w0, n) | _bit(w1, n), _bit(w2, n) | _bit(w3, n), 0, theta_idx, +1)
+
+
+def orbital_rotation_gates(wires, n, theta_idx):
+    """qml.OrbitalRotation(phi) on (q0,q1,q2,q3) = fSWAP[q1,q2] SingleExcitation(phi)[q0,q1]
+    SingleExcitation(phi)[q2,q3] fSWAP[q1,q2].  Conjugating an adjacent-qubit Givens rotation by the
+    fermionic swap turns it into a Givens rotation between q0 and q2 (resp. q1 and q3) that picks
+    up the Jordan-Wigner sign of the qubit in between, so the whole gate is two commuting entries
+    of the ordinary gate table, both driven by the same parameter."""
+    q0, q1, q2, q3 = wires
+    return [_gate(_bit(q0, n), _bit(q2, n), _bit(q1, n), theta_idx, +1),
+            _gate(_bit(q1, n), _bit(q3, n), _bit(q2, n), theta_idx, +1)]
+
+
+def gatefabric_redundant_idx(ncas, nelecas):
+    """src/auto_oo/pqc.py:147-153: leading GateFabric parameters that only rotate all-occupied or
+    all-virtual orbital pairs of the HF state."""
+    n_qubits = 2 * ncas
+    if n_qubits > 4:
+        red = list(range(0, 2 * (nelecas // 4)))
+        if ncas % 2 == 0:
+            red += list(range(2 * ((n_qubits - nelecas) // 4), 2 * (n_qubits // 4)))
+    else:
+        red = []
+    return red
+
+
+def gatefabric_gates(ncas, nelecas, n_layers):
+    """Gate list of gatefabric_circuit (pqc.py:79-83,136-160,174-186; qml.GateFabric with
+    include_pi=False): per layer the 4-wire blocks [0..3],[4..7],... then [2..5],[6..9],...;
+    per block DoubleExcitation(weights[l,i,0]) then OrbitalRotation(weights[l,i,1]).  The
+    redundant leading parameters are fixed to zero (theta_idx = -1: the gate is skipped)."""
+    n = 2 * ncas
+    n_blocks = n // 2 - 1
+    full = n_layers * n_blocks * 2
+    red = set(gatefabric_redundant_idx(ncas, nelecas))
+    params = [x for x in range(full) if x not in red]
+    to_user = {f: u for u, f in enumerate(params)}
+    wires = list(range(n))
+    blocks = [wires[i:i + 4] for i in range(0, n, 4) if i + 4 <= n]
+    blocks += [wires[i:i + 4] for i in range(2, n, 4) if i + 4 <= n]
+    assert len(blocks) == n_blocks
+    gates = []
+    for layer in range(n_layers):
+        for i, bw in enumerate(blocks):
+            f0 = (layer * n_blocks + i) * 2
+            gates.append(double_excitation_gate(bw, n, to_user.get(f0, -1)))
+            gates.extend(orbital_rotation_gates(bw, n, to_user.get(f0 + 1, -1)))
+    return gates, len(params)
+
+
 def pack_gates(gates):
     """ctypes array (contiguous bytes) of oovqe_gate_t."""
     arr = (GateT * len(gates))()

@@ -1,9 +1,10 @@
 """Parameterized_circuit: statevector ansatz + RDMs on the MI355X.
 
 Drop-in for the reference's ``auto_oo.Parameterized_circuit`` (src/auto_oo/pqc.py:86-235) for
-``ansatz='ucc'`` (UCCD, and UCCSD with ``add_singles=True``) plus ``ansatz='kupccd'`` (the
-reference defines the kUpCCD operator, ansatze/kUpCCD.py:36-154, but never wires it into
-``Parameterized_circuit``).  The PennyLane device argument ``dev`` is accepted and ignored: the
+``ansatz='ucc'`` (UCCD, and UCCSD with ``add_singles=True``), ``ansatz='np_fabric'`` (GateFabric)
+plus ``ansatz='kupccd'`` (the reference defines the kUpCCD operator, ansatze/kUpCCD.py:36-154, but
+never wires it into ``Parameterized_circuit``).  A custom PennyLane QNode as ``ansatz`` is not
+supported (there is no PennyLane here).  The PennyLane device argument ``dev`` is accepted and ignored: the
 state is produced by ``oovqe_circuit_state`` and the RDMs by ``oovqe_rdms*`` (include/oovqe.h).
 """
 import warnings
@@ -26,8 +27,8 @@ class Parameterized_circuit():
             ncas: Number of active orbitals
             nelecas: Number of active electrons
             dev: ignored (kept for signature compatibility with the PennyLane-based reference)
-            ansatz: 'ucc' (UCCD / UCCSD) or 'kupccd'
-            n_layers: layers of an 'np_fabric' ansatz (not built yet)
+            ansatz: 'ucc' (UCCD / UCCSD), 'np_fabric' (GateFabric) or 'kupccd'
+            n_layers: layers of an 'np_fabric' ansatz
             add_singles: add UCC single excitations to a 'ucc' ansatz
             k: number of kUpCCD layers (``ansatz='kupccd'`` only)
         """
@@ -55,9 +56,16 @@ class Parameterized_circuit():
             self._gates, n_theta = X.kupccd_gates(ncas, k)
             self.theta_shape = n_theta
         elif ansatz == 'np_fabric':
-            raise NotImplementedError(
-                "ansatz='np_fabric' (GateFabric) is not built yet in auto_oo_amd "
-                "(SURVEY.md section 8(f) rank 2)")
+            # pqc.py:136-160: GateFabric layers; the leading parameters that are redundant when
+            # starting from the HF state are fixed to zero
+            self.n_layers = n_layers
+            self.full_theta_shape = (n_layers, self.n_qubits // 2 - 1, 2)
+            self.redundant_idx = X.gatefabric_redundant_idx(ncas, nelecas)
+            self._gates, n_theta = X.gatefabric_gates(ncas, nelecas, n_layers)
+            self.params_idx = torch.as_tensor(
+                np.array([x for x in range(int(np.prod(self.full_theta_shape)))
+                          if x not in self.redundant_idx]), device=self.device)
+            self.theta_shape = n_theta
         else:
             raise ValueError(f"unknown ansatz {ansatz!r}: expected 'ucc' or 'kupccd'")
         self.ansatz = ansatz
@@ -113,6 +121,10 @@ class Parameterized_circuit():
         return self.state_real(theta).to(torch.complex128)
 
     def uccd_state(self, theta):
+        return self._qnode(theta)
+
+    def gatefabric_state(self, theta):
+        """pqc.py:174-186"""
         return self._qnode(theta)
 
     def init_zeros(self):

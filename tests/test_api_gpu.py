@@ -33,10 +33,10 @@ def _setup(N, seed, ncas=3, nelecas=4, nelec=16, freeze_active=False, ansatz="uc
     return ooo, opqc, oo, pqc
 
 
-@pytest.mark.parametrize("case", [c for c in _load("pqc_states.json") if c["ansatz"] == "ucc"],
-                         ids=lambda c: c["source"])
+@pytest.mark.parametrize("case", _load("pqc_states.json"), ids=lambda c: c["source"])
 def test_qnode_golden(case):
-    pqc = aoo.Parameterized_circuit(case["ncas"], case["nelecas"], None, ansatz="ucc",
+    pqc = aoo.Parameterized_circuit(case["ncas"], case["nelecas"], None, ansatz=case["ansatz"],
+                                    n_layers=case["n_layers"] or 3,
                                     add_singles=bool(case["add_singles"]))
     state = pqc.qnode(torch.tensor(case["theta"], dtype=torch.float64))
     assert state.dtype == torch.complex128 and state.shape == (2 ** (2 * case["ncas"]),)
@@ -44,10 +44,10 @@ def test_qnode_golden(case):
     assert np.allclose(state.cpu().numpy(), ref, rtol=1e-5, atol=1e-8)
 
 
-@pytest.mark.parametrize("case", [c for c in _load("pqc_rdms.json") if c["ansatz"] == "ucc"],
-                         ids=lambda c: c["source"])
+@pytest.mark.parametrize("case", _load("pqc_rdms.json"), ids=lambda c: c["source"])
 def test_get_rdms_golden(case):
-    pqc = aoo.Parameterized_circuit(case["ncas"], case["nelecas"], None, ansatz="ucc",
+    pqc = aoo.Parameterized_circuit(case["ncas"], case["nelecas"], None, ansatz=case["ansatz"],
+                                    n_layers=case["n_layers"] or 3,
                                     add_singles=bool(case["add_singles"]))
     theta = torch.tensor(case["theta"], dtype=torch.float64)
     g1, g2 = pqc.get_rdms(theta)
@@ -256,3 +256,27 @@ def test_kupccd_adjoint_path_matches_oracle():
     E2, g2_ = oo2.energy_and_gradient(th2)
     assert abs(E2.item() - ooo.energy_from_parameters(th2).item()) < 1e-9
     assert (g2_.cpu() - ooo.full_gradient(th2)).abs().max() < 1e-8
+
+
+def test_np_fabric_full_derivatives_like_reference_test():
+    """The reference's test/test_oo_pqc.py::test_full_derivatives (np_fabric, CAS(2,2),
+    freeze_active) replayed on synthetic STO-3G-shaped integrals: block gradients / Hessians of the
+    engine == joint autodiff of the oracle's energy_from_parameters(theta, kappa)."""
+    from auto_oo_amd.synthetic import synthetic_problem
+    N, ncas, nelecas, nelec = 13, 2, 2, 16
+    P = synthetic_problem(N, 4242)
+    mol = aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec)
+    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="np_fabric", n_layers=1)
+    oo = aoo.OO_pqc(pqc, mol, ncas, nelecas, oao_mo_coeff=P["oao_mo_coeff"], freeze_active=True)
+    omol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec)
+    ooo = R.OracleOOPQC(R.OraclePQC(ncas, nelecas, "np_fabric", n_layers=1), omol, ncas, nelecas,
+                        P["oao_mo_coeff"], freeze_active=True)
+    theta = torch.tensor([0.8324, 0.2490], dtype=torch.float64)     # test/test_oo_pqc.py:83
+    kappa = torch.zeros(ooo.n_kappa, dtype=torch.float64)
+    J = torch.autograd.functional.jacobian(ooo.energy_from_parameters, (theta, kappa))
+    assert (oo.circuit_gradient(theta).cpu() - J[0]).abs().max() < 1e-8
+    assert (oo.orbital_gradient(theta).cpu() - J[1]).abs().max() < 1e-8
+    H = torch.autograd.functional.hessian(ooo.energy_from_parameters, (theta, kappa))
+    assert (oo.circuit_circuit_hessian(theta).cpu() - H[0][0]).abs().max() < 1e-8
+    assert (oo.orbital_circuit_hessian(theta).cpu() - H[1][0]).abs().max() < 1e-8
+    assert (oo.orbital_orbital_hessian(theta).cpu() - H[1][1]).abs().max() < 1e-7

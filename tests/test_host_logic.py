@@ -101,3 +101,21 @@ def test_synthetic_generator_matches_oracle_copy():
     a, b = synthetic_problem(9, 123), R.synthetic_problem(9, 123)
     for key in a:
         assert np.array_equal(np.asarray(a[key]), np.asarray(b[key]))
+
+
+@pytest.mark.parametrize("case", [c for c in _load("pqc_states.json") if c["ansatz"] == "np_fabric"],
+                         ids=lambda c: c["source"])
+def test_gatefabric_table_reproduces_reference_states(case):
+    """GateFabric (np_fabric) as entries of the ordinary Givens gate table against the reference's
+    own statevectors (test/test_pqc.py:137-263)."""
+    n = 2 * case["ncas"]
+    gates, n_theta = X.gatefabric_gates(case["ncas"], case["nelecas"], case["n_layers"])
+    assert n_theta == len(case["theta"])
+    psi = apply_gate_table(gates, np.array(case["theta"]), n,
+                           X.basis_index(X.hf_state(case["nelecas"], n)))
+    assert np.abs(psi - np.array(case["state_real"])).max() < 1e-8
+
+
+def test_gatefabric_redundant_idx_matches_oracle():
+    for ncas, ne in [(2, 2), (3, 4), (3, 2), (4, 4), (5, 6), (6, 6)]:
+        assert X.gatefabric_redundant_idx(ncas, ne) == R.gatefabric_redundant_idx(ncas, ne)
