@@ -29,13 +29,15 @@ def gather_results(local, my_geoms, n_geom, dist=None):
         return full
     world = dist.get_world_size()
     per = (n_geom + world - 1) // world
-    block = torch.zeros((per, n_out), dtype=local.dtype, device=local.device)
-    block[:local.shape[0]] = local
+    # gloo (CPU rehearsal) exchanges host tensors; nccl (= RCCL) exchanges device tensors over xGMI
+    xdev = torch.device("cpu") if dist.get_backend() == "gloo" else local.device
+    block = torch.zeros((per, n_out), dtype=local.dtype, device=xdev)
+    block[:local.shape[0]] = local.to(xdev)
     blocks = [torch.empty_like(block) for _ in range(world)]
     dist.all_gather(blocks, block)
     full = torch.zeros((n_geom, n_out), dtype=local.dtype, device=local.device)
     for r in range(world):
         geoms = shard_geometries(n_geom, r, world)
         if geoms:
-            full[torch.as_tensor(geoms, device=local.device)] = blocks[r][:len(geoms)]
+            full[torch.as_tensor(geoms, device=local.device)] = blocks[r][:len(geoms)].to(local.device)
     return full

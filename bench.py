@@ -51,7 +51,12 @@ def parse():
     ap.add_argument("--geoms", type=int, default=N_GEOM)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-transform", action="store_true")
+    ap.add_argument("--no-berry", action="store_true",
+                    help="skip the configs[3] extra (energy+gradient+Hessian+Newton step per geometry)")
     ap.add_argument("--transform-n", type=int, default=200)
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal of the "
+                         "N>1 path on a one-GPU box: all ranks share cuda:0)")
     return ap.parse_args()
 
 
@@ -106,6 +111,50 @@ def cpu_baseline(seconds_budget=20.0):
                        f"torch {torch.__version__} CPU, {cores} threads"), float(e), g
 
 
+def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl"):
+    """BASELINE.json configs[3]: for every geometry of this rank's shard, from a shared (theta0, C0):
+    energy + full gradient + full (n_theta+n_kappa)^2 Hessian + one damped Newton step
+    (oo_pqc.py:172-196); one all_gather of the new energies at the end.  Returns geometries/s."""
+    import auto_oo_amd as aoo
+    from auto_oo_amd.synthetic import synthetic_problem
+    from auto_oo_amd.parallel import gather_results
+    pqc = aoo.Parameterized_circuit(NCAS, NELECAS, None, ansatz="ucc")
+    objs = []
+    for g in my_geoms:
+        P = synthetic_problem(NAO, 20260 + 2 + 1000 * g)
+        mol = aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], NELEC)
+        objs.append(aoo.OO_pqc(pqc, mol, NCAS, NELECAS, oao_mo_coeff=P["oao_mo_coeff"]))
+    theta0 = torch.full((pqc.theta_shape,), 0.1, dtype=torch.float64, device="cuda")
+    opt = aoo.NewtonStep(verbose=0)
+
+    def one(oo):
+        kappa = torch.zeros(oo.n_kappa, dtype=torch.float64, device="cuda")
+        grad = oo.full_gradient(theta0)
+        hess = oo.full_hessian(theta0)
+        new, eig = opt.damped_newton_step(oo.energy_from_parameters, (theta0, kappa), grad, hess)
+        return oo.energy_from_parameters(new[0], new[1])
+
+    one(objs[0])                                   # warm-up
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    res = torch.stack([one(oo) for oo in objs]).reshape(-1, 1)
+    full = gather_results(res, my_geoms, n_geom, dist)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([el], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        el = float(tmax.item())
+    return {"geometries": n_geom, "seconds": el, "geometries_per_s": n_geom / el,
+            "per_geometry_ms": el / max(len(objs), 1) * 1e3, "hessian_dim": objs[0].n_kappa + pqc.theta_shape,
+            "scaling": "strong (fixed 64 geometries, sharded g mod n_gpus)",
+            "mean_energy_after_step": float(full.mean().item())}
+
+
 def transform_microbench(N):
     """BASELINE.json configs[2]: full 4-index transform + expm at N=200 on synthetic data."""
     from auto_oo_amd import ops
@@ -151,13 +200,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if args.backend == "gloo":
+        local_rank = 0                      # rehearsal: every rank uses the only GPU
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     from auto_oo_amd import ops
     from auto_oo_amd.parallel import shard_geometries, gather_results
 
@@ -192,7 +246,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64,
+                            device="cpu" if args.backend == "gloo" else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -259,6 +314,10 @@ def main():
             single.energy_and_gradient(th0)
         torch.cuda.synchronize()
         out["single_eval_us"] = (time.perf_counter() - t1) / 500 * 1e6
+    if not args.no_berry:
+        berry = berry_loop_extra(my_geoms, args.geoms, dist, world, args.backend)
+        if rank == 0:
+            out["berry_loop"] = berry
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             cb, e_ref, g_ref = cpu_baseline()
