@@ -231,6 +231,10 @@ def main():
             calls += 1
         return calls
 
+    # set-up: prime the pipeline (lazy code-object loading, allocator pools, GPU clock ramp from
+    # idle -- the first ~20 batched calls of a fresh process run ~1.5x slower); not part of W or K
+    run(32 * G)
+    torch.cuda.synchronize()
     run(args.warmup)
     torch.cuda.synchronize()
     if dist is not None:
@@ -239,6 +243,7 @@ def main():
     ops.profile_begin()   # HIP events around every half-transform launch, on its stream
     t0 = time.perf_counter()
     n_calls = run(args.steps)
+    t_submit = time.perf_counter() - t0                              # host time to enqueue everything
     gathered = gather_results(results, my_geoms, args.geoms, dist)   # the one exchange step
     torch.cuda.synchronize()
     if dist is not None:
@@ -257,12 +262,15 @@ def main():
     bytes_per_eval = 8.0 * NAO ** 4 + 8.0 * NAO ** 2 * M ** 2       # g_ao read once + T2 written
     alg_bytes = bytes_per_eval * args.steps / max(kern_count, 1)   # per launch (batched)
     achieved = alg_bytes / kern_s / 1e9
+    # HBM traffic of that kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 [gfx950 correction] +
+    # WRITE_SIZE, separate passes; profiles/pmc_half_transform.json), scaled to this launch size
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_half_transform.json")
     if os.path.exists(pmc_path):
         try:
             with open(pmc_path) as fh:
-                traffic = json.load(fh).get("hbm_bytes_per_launch")
+                pmc = json.load(fh)
+            traffic = pmc["hbm_bytes_per_launch"] / 64.0 * args.steps / max(kern_count, 1)
         except Exception:
             traffic = None
 
@@ -286,6 +294,7 @@ def main():
                          f"in batched calls of up to {G} geometries"),
             "geometries_per_rank": G,
             "batched_calls": n_calls,
+            "host_submit_us_per_call": t_submit / max(n_calls, 1) * 1e6,
             "parallelism": f"geometry-sharded x{world}, one all_gather at the end",
         },
         "roofline": {
