@@ -453,8 +453,8 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
     double* hn = Wn + N;                 // [M]
     double* FIn = hn + M;                // [M]
     double* cn = FIn + M;                // [N]      C[:, n]
-    double* hl = cn + N;                 // [N][N]   h_ao
-    double* gml = hl + (size_t)N * N;    // [rdm_chunk][na2]   (RDM sets are staged chunk by chunk)
+    double* hl = cn + N;                 // [4][N]   partial sums of C[:,n]^T h
+    double* gml = hl + (size_t)4 * N;    // [rdm_chunk][na2]   (RDM sets are staged chunk by chunk)
     double* Gml = gml + (size_t)rdm_chunk * na2;   // [rdm_chunk][na4]
     const int tid = threadIdx.x;
     const int n = blockIdx.x;
@@ -473,7 +473,6 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
         if (Gm_out) Gm_out += gi * (size_t)N * M3;
         if (hmo_out) hmo_out += gi * (size_t)N * M;
     }
-    for (int idx = tid; idx < N * N; idx += COL_THREADS) hl[idx] = h_ao[idx];
 
     const double* Usrc = U + (size_t)n * N * M2;
     for (int idx = tid; idx < N * M2; idx += COL_THREADS) Un[idx] = Usrc[idx];
@@ -483,17 +482,51 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
     }
     for (int p = tid; p < N; p += COL_THREADS) cn[p] = C[(size_t)p * N + n];
     __syncthreads();
-    for (int q = tid; q < N; q += COL_THREADS) {
-        double acc = 0.0;
-        for (int p = 0; p < N; ++p) acc += cn[p] * hl[p * N + q];
-        Wn[q] = acc;
+    // W[n,q] = sum_p C[p,n] h[p,q]: 4 thread groups split the p range (coalesced rows of h),
+    // partial sums combined in fixed order
+    {
+        double* wpart = hl;                      // [4][N] scratch (hl is only used here)
+        const int q = tid & 63, part = tid >> 6;
+        for (int q0 = 0; q0 < N; q0 += 64) {
+            const int qq = q0 + q;
+            if (qq < N) {
+                const int p0 = (N * part) / 4, p1 = (N * (part + 1)) / 4;
+                double a0 = 0.0, a1 = 0.0;
+                int pp = p0;
+                for (; pp + 1 < p1; pp += 2) {
+                    a0 += cn[pp] * h_ao[(size_t)pp * N + qq];
+                    a1 += cn[pp + 1] * h_ao[(size_t)(pp + 1) * N + qq];
+                }
+                if (pp < p1) a0 += cn[pp] * h_ao[(size_t)pp * N + qq];
+                wpart[part * N + qq] = a0 + a1;
+            }
+        }
     }
-    for (int idx = tid; idx < M3; idx += COL_THREADS) {
-        const int x = idx / M2, yz = idx - x * M2;
-        double acc = 0.0;
-        for (int q = 0; q < N; ++q) acc += Cl[q * M + x] * Un[q * M2 + yz];
-        Gn[idx] = acc;
+    // Gn[x,yz] = sum_q C[q,x] U[n,q,yz]: four outputs per thread share one q loop (independent
+    // LDS reads in flight instead of one dependent chain per output)
+    for (int base = 0; base < M3; base += 4 * COL_THREADS) {
+        int xo[4], yo[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * COL_THREADS + tid;
+            ok[u] = idx < M3;
+            const int ii = ok[u] ? idx : 0;
+            xo[u] = ii / M2;
+            yo[u] = ii - xo[u] * M2;
+        }
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int q = 0; q < N; ++q) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] += Cl[q * M + xo[u]] * Un[q * M2 + yo[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (ok[u]) Gn[base + u * COL_THREADS + tid] = acc[u];
     }
+    __syncthreads();
+    for (int q = tid; q < N; q += COL_THREADS)
+        Wn[q] = hl[q] + hl[N + q] + hl[2 * N + q] + hl[3 * N + q];
     __syncthreads();
     if (tid < M) {
         double acc = 0.0;
@@ -799,7 +832,7 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
                                           (long)N * N * m2, (long)N * N, (long)N * N * m2, st)))
         return rc;
     const size_t na2 = (size_t)ncas * ncas;
-    const size_t base_bytes = ((size_t)N * m2 + (size_t)N * M + m3 + N + M + M + N + (size_t)N * N) *
+    const size_t base_bytes = ((size_t)N * m2 + (size_t)N * M + m3 + N + M + M + N + (size_t)4 * N) *
                               sizeof(double);
     const size_t set_bytes = (na2 + na2 * na2) * sizeof(double);
     OOVQE_REQUIRE(base_bytes + set_bytes <= 160 * 1024, "cas_eval: N=%d M=%d needs %zu B of LDS", N, M,
