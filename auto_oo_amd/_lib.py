@@ -80,6 +80,9 @@ SIGNATURES = {
                                                         c_int32_p, ctypes.c_int]
                        + [c_double_p] * 11 + [c_stream]),
     "oovqe_cas_eval_work_size": (ctypes.c_int64, [ctypes.c_int] * 4),
+    "oovqe_fock_core_active": (ctypes.c_int, [c_double_p, c_double_p, c_double_p, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
+                                              c_stream]),
     "oovqe_orbital_hessian": (ctypes.c_int, [c_double_p] * 6 + [ctypes.c_int, ctypes.c_int,
                                                                ctypes.c_int, c_int32_p, c_int32_p,
                                                                ctypes.c_int, c_double_p, c_double_p,

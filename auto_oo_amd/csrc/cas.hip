@@ -969,3 +969,52 @@ extern "C" int oovqe_oo_eval_batch(const double* theta, int n_theta, const oovqe
                            nuc, N, n_occ, ncas, kap_row, kap_col, n_kappa, derivatives, batch, work,
                            out, stream);
 }
+
+// ------------------------------------------------------------------------------------------
+// Inactive / active Fock matrices from FULL MO integrals (API helpers OO_energy.fock_core /
+// fock_active, reference oo_energy.py:272-298).  The evaluation path never needs them in full
+// (only the columns < M, formed in cas_column_kernel); these kernels exist so that the two public
+// methods return the same N x N matrices as the reference.
+//   FI[m,n] = h[m,n] + sum_i (2 g[m,n,i,i] - g[m,i,i,n])
+//   FA[m,n] = sum_vw gam[v,w] (g[m,n,V,W] - 1/2 g[m,W,V,n])
+// ------------------------------------------------------------------------------------------
+__global__ void fock_core_active_kernel(const double* __restrict__ h, const double* __restrict__ g,
+                                        const double* __restrict__ gam, int N, int no, int na,
+                                        double* __restrict__ FI, double* __restrict__ FA)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * N) return;
+    const int m = idx / N, n = idx - m * N;
+    const size_t n2 = (size_t)N * N, n3 = n2 * N;
+    const double* gm = g + (size_t)m * n3;
+    if (FI) {
+        double acc = h[idx];
+        for (int i = 0; i < no; ++i)
+            acc += 2.0 * gm[(size_t)n * n2 + (size_t)i * N + i] - gm[(size_t)i * n2 + (size_t)i * N + n];
+        FI[idx] = acc;
+    }
+    if (FA) {
+        double acc = 0.0;
+        for (int v = 0; v < na; ++v)
+            for (int w = 0; w < na; ++w) {
+                const int V = no + v, W = no + w;
+                acc += gam[v * na + w] * (gm[(size_t)n * n2 + (size_t)V * N + W] -
+                                          0.5 * gm[(size_t)W * n2 + (size_t)V * N + n]);
+            }
+        FA[idx] = acc;
+    }
+}
+
+extern "C" int oovqe_fock_core_active(const double* h_mo, const double* g_mo, const double* gamma, int N,
+                                      int n_occ, int ncas, double* fock_core, double* fock_active,
+                                      oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(g_mo && (fock_core || fock_active), "fock_core_active: null pointer");
+    OOVQE_REQUIRE(!fock_core || h_mo, "fock_core_active: h_mo required for fock_core");
+    OOVQE_REQUIRE(!fock_active || gamma, "fock_core_active: gamma required for fock_active");
+    OOVQE_REQUIRE(N >= 1 && n_occ >= 0 && ncas >= 1 && n_occ + ncas <= N, "fock_core_active: sizes");
+    hipLaunchKernelGGL(fock_core_active_kernel, dim3((N * N + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, h_mo, g_mo, gamma, N, n_occ, ncas, fock_core, fock_active);
+    OOVQE_CHECK_LAUNCH("fock_core_active");
+    return 0;
+}

@@ -204,6 +204,43 @@ class OO_energy:
         return ops.cas_energy_gradient(Gm, hmo, g1, g2, self.nuc, self._n_occ, self.ncas,
                                        self._kap_row, self._kap_col, want_matrices=True)
 
+    def _fock_ca(self, int1e_mo, int2e_mo, one_rdm, core, active):
+        lib = _lib.load()
+        N = self.nao
+        g = self._t(int2e_mo)
+        h = self._t(int1e_mo) if int1e_mo is not None else None
+        gam = self._t(one_rdm) if one_rdm is not None else None
+        FI = torch.empty((N, N), dtype=F64, device=self.device) if core else None
+        FA = torch.empty((N, N), dtype=F64, device=self.device) if active else None
+        _lib.check(lib.oovqe_fock_core_active(_lib.dptr(h), _lib.dptr(g), _lib.dptr(gam), N,
+                                              self._n_occ, self.ncas, _lib.dptr(FI), _lib.dptr(FA),
+                                              _lib.stream_ptr()), "oovqe_fock_core_active")
+        return FI, FA
+
+    def fock_core(self, int1e_mo, int2e_mo):
+        """oo_energy.py:272-284: F^I_mn = h_mn + sum_i (2 g_mnii - g_miin)"""
+        return self._fock_ca(int1e_mo, int2e_mo, None, True, False)[0]
+
+    def fock_active(self, int2e_mo, one_rdm):
+        """oo_energy.py:286-298: F^A_mn = sum_vw gamma_vw (g_mnvw - 1/2 g_mwvn)"""
+        return self._fock_ca(None, int2e_mo, one_rdm, False, True)[1]
+
+    def y_matrix(self, int2e_mo, two_full):
+        """oo_energy.py:381-393: Y_pqrs = sum_mn [(G_pmrn + G_pmnr) g_qmns + G_prmn g_qsmn] for an
+        arbitrary dense two_full (API helper): three N^2 x N^2 x N^2 products on the fp64 MFMA
+        contraction kernel after index permutations (data movement only).  The Hessian path itself
+        uses the block structure of the full-space RDM and never forms these N^4 operands."""
+        n = self.nao
+        g = self._t(int2e_mo)
+        G = self._t(two_full)
+        n2 = n * n
+        a01 = (G.permute(0, 2, 1, 3) + G.permute(0, 3, 1, 2)).reshape(n2, n2).contiguous()  # [(p,r),(m,n)]
+        b0 = g.permute(1, 2, 0, 3).reshape(n2, n2).contiguous()                              # [(m,n),(q,s)]
+        a2 = G.reshape(n2, n2)                                                               # [(p,r),(m,n)]
+        b2 = g.permute(2, 3, 0, 1).reshape(n2, n2).contiguous()                              # [(m,n),(q,s)]
+        y = ops.matmul_nn(a01, b0) + ops.matmul_nn(a2.contiguous(), b2)     # [(p,r),(q,s)]
+        return y.reshape(n, n, n, n).permute(0, 2, 1, 3).contiguous()
+
     def fock_generalized(self, int1e_mo, int2e_mo, one_rdm, two_rdm):
         """oo_energy.py:238-270: generalized Fock matrix from MO integrals (only the slices
         g_mo[:, :M, :M, :M] and h_mo[:, :M] are ever read)."""

@@ -171,6 +171,12 @@ int oovqe_cas_eval(const double* g_ao, const double* h_ao, const double* C, cons
                    double* fock, double* gmat, double* Gm, double* hmo, oovqe_stream_t stream);
 int64_t oovqe_cas_eval_work_size(int N, int n_occ, int ncas, int nrdm);
 
+/* Inactive / active Fock matrices from FULL MO integrals h_mo [N,N], g_mo [N,N,N,N]: the public
+ * helpers OO_energy.fock_core / fock_active (src/auto_oo/oo_energy.py:272-298).  Either output may
+ * be NULL. */
+int oovqe_fock_core_active(const double* h_mo, const double* g_mo, const double* gamma, int N, int n_occ,
+                           int ncas, double* fock_core, double* fock_active, oovqe_stream_t stream);
+
 /* ---- a15: orbital-orbital Hessian -----------------------------------------------------------------
  * replaces full_rdms / y_matrix / analytic_hessian_from_integrals / full_hessian_to_matrix
  * (src/auto_oo/oo_energy.py:311-402) and OO_pqc.orbital_orbital_hessian (oo_pqc.py:127-130).

@@ -190,6 +190,9 @@ def test_hessian_blocks(N, seed, freeze):
     f1, f2 = oo.full_rdms(g1, g2)
     r1, r2 = ooo.full_rdms(g1, g2)
     assert torch.equal(f1.cpu(), r1) and torch.equal(f2.cpu(), r2)
+    assert (oo.fock_core(h_mo, g_mo).cpu() - ooo.fock_core(h_mo, g_mo)).abs().max() < 1e-11
+    assert (oo.fock_active(g_mo, g1).cpu() - ooo.fock_active(g_mo, g1)).abs().max() < 1e-11
+    assert (oo.y_matrix(g_mo, r2).cpu() - ooo.y_matrix(g_mo, r2)).abs().max() < 1e-9
 
 
 def test_orbital_hessian_cc_pvdz_shape():
@@ -280,3 +283,23 @@ def test_np_fabric_full_derivatives_like_reference_test():
     assert (oo.circuit_circuit_hessian(theta).cpu() - H[0][0]).abs().max() < 1e-8
     assert (oo.orbital_circuit_hessian(theta).cpu() - H[1][0]).abs().max() < 1e-8
     assert (oo.orbital_orbital_hessian(theta).cpu() - H[1][1]).abs().max() < 1e-7
+
+
+def test_orbital_optimization_fixed_rdms():
+    """OO_energy.orbital_optimization (oo_energy.py:426-474) with fixed RDMs: the first damped
+    Newton step reproduces the oracle's, the energy decreases monotonically."""
+    ooo, opqc, oo, pqc = _setup(13, 20261)
+    theta = torch.tensor(np.random.default_rng(2).uniform(0, 2 * np.pi, pqc.theta_shape))
+    g1, g2 = opqc.get_rdms(theta)
+    e0 = oo.energy_from_mo_coeff(oo.mo_coeff, g1, g2).item()
+    energy_l = oo.orbital_optimization(g1, g2, conv_tol=1e-9, max_iterations=6, verbose=None)
+    assert energy_l[0] < e0 and all(b <= a + 1e-10 for a, b in zip(energy_l, energy_l[1:]))
+    from auto_oo_amd.newton_raphson import NewtonStep
+    from functools import partial
+    opt = NewtonStep(verbose=0)
+    kappa0 = torch.zeros(ooo.n_kappa, dtype=torch.float64)
+    grad = ooo.kappa_matrix_to_vector(ooo.analytic_gradient(g1, g2))
+    hess = ooo.full_hessian_to_matrix(ooo.analytic_hessian(g1, g2))
+    newk, _ = opt.damped_newton_step(partial(ooo.energy_from_kappa, one_rdm=g1, two_rdm=g2),
+                                     (kappa0,), grad, hess)
+    assert abs(ooo.energy_from_kappa(newk, g1, g2).item() - energy_l[0]) < 1e-8
