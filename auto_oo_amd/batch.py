@@ -79,26 +79,29 @@ class OO_pqc_batch:
         self.oao_mo_coeff[g].copy_(c)
         self.mo_coeff[g].copy_(ops.matmul_nn(self.oao_coeff[g].contiguous(), c))
 
-    def _plan(self, derivatives):
-        key = bool(derivatives)
+    def _plan(self, derivatives, slot=0):
+        key = (bool(derivatives), slot)
         if key not in self._plans:
             pqc = self.pqc
             wsz = self.lib.oovqe_oo_eval_work_size(self.n_theta, pqc._n_gates, pqc.n_qubits, self.nao,
-                                                   self._n_occ, self.ncas, int(key))
-            osz = self.lib.oovqe_oo_eval_out_size(self.n_theta, self.n_kappa, self.ncas, int(key))
+                                                   self._n_occ, self.ncas, int(key[0]))
+            osz = self.lib.oovqe_oo_eval_out_size(self.n_theta, self.n_kappa, self.ncas, int(key[0]))
             work = torch.empty(self.G * wsz, dtype=F64, device=self.device)
             self._plans[key] = (work, int(osz))
         return self._plans[key]
 
-    def evaluate(self, thetas, derivatives=True, count=None):
+    def evaluate(self, thetas, derivatives=True, count=None, slot=0):
         """thetas [G, n_theta] (device, fp64) -> packed outputs [G, out_size]
         ([c0 | E | dE/dtheta | gvec rows | c1 | c2] per geometry, include/oovqe.h).
-        ``count``: evaluate only the first ``count`` geometries of the batch."""
+        ``count``: evaluate only the first ``count`` geometries of the batch.
+        ``slot``: workspace slot -- calls issued on different HIP streams must use different slots
+        (their kernels then overlap: the HBM-bound N^4 sweep of one call runs beside the
+        latency-bound tail kernels of the other)."""
         G = self.G if count is None else int(count)
         if not 1 <= G <= self.G:
             raise ValueError(f"count must be in 1..{self.G}")
         thetas = ops.as_device(thetas, self.device).reshape(-1, self.n_theta)[:G]
-        work, osz = self._plan(derivatives)
+        work, osz = self._plan(derivatives, slot)
         out = torch.empty((G, osz), dtype=F64, device=self.device)
         pqc = self.pqc
         check(self.lib.oovqe_oo_eval_batch(
@@ -110,9 +113,9 @@ class OO_pqc_batch:
             "oovqe_oo_eval_batch")
         return out
 
-    def energy_and_gradient(self, thetas, count=None):
+    def energy_and_gradient(self, thetas, count=None, slot=0):
         """-> [G, 1 + n_theta + n_kappa]: column 0 = E, then dE/dtheta, then dE/dkappa."""
-        out = self.evaluate(thetas, derivatives=True, count=count)
+        out = self.evaluate(thetas, derivatives=True, count=count, slot=slot)
         return out[:, 1:2 + self.n_theta + self.n_kappa]
 
     def energy(self, thetas):
