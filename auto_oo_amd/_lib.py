@@ -38,8 +38,11 @@ SIGNATURES = {
     "oovqe_last_error": (ctypes.c_char_p, []),
     "oovqe_device_count": (ctypes.c_int, []),
     "oovqe_profile_begin": (ctypes.c_int, []),
+    "oovqe_profile_begin_detail": (ctypes.c_int, []),
     "oovqe_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double),
                                          ctypes.POINTER(ctypes.c_int)]),
+    "oovqe_profile_end_labels": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double),
+                                                ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
     "oovqe_general_4index_transform": (ctypes.c_int, [c_double_p] * 5 + [ctypes.c_int, c_double_p,
                                                                       c_double_p, c_stream]),
     "oovqe_matmul_nn": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,

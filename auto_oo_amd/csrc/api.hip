@@ -29,56 +29,83 @@ extern "C" int oovqe_device_count(void)
     return n;
 }
 
-// ---- optional HIP-event timing of the dominant kernel (used by bench.py for the roofline) -----
+// ---- optional HIP-event timing of the evaluation kernels (bench.py: roofline + breakdown) -------
+// Events come from a pool created in oovqe_profile_begin (nothing is allocated inside the timed
+// region); launches beyond the pool size are simply not bracketed.  Label 0 is the dominant
+// kernel (the N^4 half-transform sweep); labels 1.. are the other launches of an evaluation.
 static bool g_prof_on = false;
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
-static hipEvent_t g_prof_pending = nullptr;
+static std::vector<hipEvent_t> g_pool;          // pairs: [2i] start, [2i+1] stop
+static std::vector<int> g_label;                // label of pair i
+static size_t g_used = 0;                       // pairs handed out
+static bool g_pending = false;
+static bool g_detail = false;                   // also bracket labels > 0
 
-void oovqe_profile_mark_start(hipStream_t st)
+void oovqe_profile_mark_start_l(hipStream_t st, int label)
 {
-    if (!g_prof_on) return;
-    hipEvent_t a;
-    if (hipEventCreate(&a) != hipSuccess) return;
-    (void)hipEventRecord(a, st);
-    g_prof_pending = a;
+    if (!g_prof_on || 2 * g_used + 1 >= g_pool.size() || (label > 0 && !g_detail)) return;
+    (void)hipEventRecord(g_pool[2 * g_used], st);
+    g_label[g_used] = label;
+    g_pending = true;
 }
+
+void oovqe_profile_mark_start(hipStream_t st) { oovqe_profile_mark_start_l(st, 0); }
 
 void oovqe_profile_mark_stop(hipStream_t st)
 {
-    if (!g_prof_on || !g_prof_pending) return;
-    hipEvent_t b;
-    if (hipEventCreate(&b) != hipSuccess) return;
-    (void)hipEventRecord(b, st);
-    g_prof_events.emplace_back(g_prof_pending, b);
-    g_prof_pending = nullptr;
+    if (!g_prof_on || !g_pending) return;
+    (void)hipEventRecord(g_pool[2 * g_used + 1], st);
+    ++g_used;
+    g_pending = false;
 }
 
 extern "C" int oovqe_profile_begin(void)
 {
-    for (auto& p : g_prof_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    g_prof_events.clear();
-    g_prof_pending = nullptr;
+    const size_t want = 2 * 8192;
+    while (g_pool.size() < want) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) break;
+        g_pool.push_back(e);
+    }
+    g_label.assign(g_pool.size() / 2, 0);
+    g_used = 0;
+    g_pending = false;
     g_prof_on = true;
+    g_detail = false;
+    return 0;
+}
+
+extern "C" int oovqe_profile_begin_detail(void)
+{
+    oovqe_profile_begin();
+    g_detail = true;
+    return 0;
+}
+
+// totals per label (label < n_labels); total_ms / count refer to label 0 for compatibility
+extern "C" int oovqe_profile_end_labels(double* ms_by_label, int* count_by_label, int n_labels)
+{
+    g_prof_on = false;
+    for (int l = 0; l < n_labels; ++l) { ms_by_label[l] = 0.0; count_by_label[l] = 0; }
+    for (size_t i = 0; i < g_used; ++i) {
+        float ms = 0.f;
+        const int l = g_label[i];
+        if (l < 0 || l >= n_labels) continue;
+        if (hipEventSynchronize(g_pool[2 * i + 1]) == hipSuccess &&
+            hipEventElapsedTime(&ms, g_pool[2 * i], g_pool[2 * i + 1]) == hipSuccess) {
+            ms_by_label[l] += ms;
+            ++count_by_label[l];
+        }
+    }
+    g_used = 0;
     return 0;
 }
 
 extern "C" int oovqe_profile_end(double* total_ms, int* count)
 {
-    g_prof_on = false;
-    double tot = 0.0;
-    int n = 0;
-    for (auto& p : g_prof_events) {
-        float ms = 0.f;
-        if (hipEventSynchronize(p.second) == hipSuccess &&
-            hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
-            tot += ms;
-            ++n;
-        }
-        (void)hipEventDestroy(p.first);
-        (void)hipEventDestroy(p.second);
-    }
-    g_prof_events.clear();
-    if (total_ms) *total_ms = tot;
-    if (count) *count = n;
+    double ms[1];
+    int cnt[1];
+    oovqe_profile_end_labels(ms, cnt, 1);
+    if (total_ms) *total_ms = ms[0];
+    if (count) *count = cnt[0];
     return 0;
 }

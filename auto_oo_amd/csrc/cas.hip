@@ -828,9 +828,11 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
     int rc;
     if ((rc = half_transform_batched(g_ao, C, N, M, T2, batch, stream))) return rc;
     // U[n,(q y z)] = sum_p C[p,n] T2[p,(q y z)]
+    oovqe_profile_mark_start_l(st, 2);
     if ((rc = oovqe_mode_contract_batched(T2, C, U, 1, N, N, (long)N * m2, N, 0, batch,
                                           (long)N * N * m2, (long)N * N, (long)N * N * m2, st)))
         return rc;
+    oovqe_profile_mark_stop(st);
     const size_t na2 = (size_t)ncas * ncas;
     const size_t base_bytes = ((size_t)N * m2 + (size_t)N * M + m3 + N + M + M + N + (size_t)4 * N) *
                               sizeof(double);
@@ -850,13 +852,17 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
         }
         attr_done = true;
     }
+    oovqe_profile_mark_start_l(st, 3);
     hipLaunchKernelGGL(cas_column_kernel, dim3(N, batch), dim3(COL_THREADS), lds_bytes, st, U, h_ao, C,
                        gamma, Gamma, nrdm, N, n_occ, ncas, Fcol, Epart, Cpart, c1, c2, Gm, hmo,
                        out_stride, rdm_chunk);
+    oovqe_profile_mark_stop(st);
     OOVQE_CHECK_LAUNCH("cas_eval/column");
+    oovqe_profile_mark_start_l(st, 4);
     hipLaunchKernelGGL(cas_final_kernel, dim3(batch), dim3(512), 0, st, Fcol, Epart, Cpart, nuc, nrdm,
                        N, M, kap_row, kap_col, n_kappa, c0, E, gvec, dE, fock, gmat, nuc_arr,
                        out_stride);
+    oovqe_profile_mark_stop(st);
     OOVQE_CHECK_LAUNCH("cas_eval/final");
     return 0;
 }
@@ -928,10 +934,12 @@ static int oo_eval_batched(const double* theta, int n_theta, const oovqe_gate_t*
         dpsi = psi + nb * D;                               // [G][n_theta][D]
         rwork = psi + nb * nvec * D;
     }
+    oovqe_profile_mark_start_l((hipStream_t)stream, 1);
     int rc = oovqe_circuit_rdms(theta, n_theta, gates, n_gates, n_qubits, ncas, init_index,
                                 derivatives, batch, psi, derivatives ? dpsi : nullptr, gamma, Gamma,
                                 rwork, stream);
     if (rc) return rc;
+    oovqe_profile_mark_stop((hipStream_t)stream);
     // packed output per geometry: [c0 | E | dE (max(nvec-1,1)) | gvec (nvec x n_kappa) | c1 | c2]
     const size_t out_stride = (size_t)oovqe_oo_eval_out_size(n_theta, n_kappa, ncas, derivatives);
     const int n_t = nvec > 1 ? nvec - 1 : 1;

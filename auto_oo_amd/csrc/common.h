@@ -18,6 +18,7 @@ typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 
 void oovqe_set_error(const char* fmt, ...);
 void oovqe_profile_mark_start(hipStream_t st);
+void oovqe_profile_mark_start_l(hipStream_t st, int label);
 void oovqe_profile_mark_stop(hipStream_t st);
 
 #define OOVQE_CHECK_LAUNCH(name)                                                          \

@@ -15,16 +15,26 @@ from ._lib import check, dptr, stream_ptr
 F64 = torch.float64
 
 
-def profile_begin():
-    """Start bracketing every half-transform launch with HIP events (bench.py roofline)."""
-    _lib.load().oovqe_profile_begin()
+def profile_begin(detail=False):
+    """Start bracketing every half-transform launch with HIP events (bench.py roofline);
+    ``detail=True`` brackets the other launches of an evaluation as well (PROFILE_LABELS)."""
+    if detail:
+        _lib.load().oovqe_profile_begin_detail()
+    else:
+        _lib.load().oovqe_profile_begin()
+
+
+PROFILE_LABELS = ("half_transform", "circuit_rdms", "contract_p_to_n", "column", "final")
 
 
 def profile_end():
-    """-> (total kernel milliseconds, number of launches)"""
-    tot, cnt = ctypes.c_double(0.0), ctypes.c_int(0)
-    _lib.load().oovqe_profile_end(ctypes.byref(tot), ctypes.byref(cnt))
-    return tot.value, cnt.value
+    """-> (half-transform kernel milliseconds, launches, {label: (ms, launches)})"""
+    n = len(PROFILE_LABELS)
+    ms = (ctypes.c_double * n)()
+    cnt = (ctypes.c_int * n)()
+    _lib.load().oovqe_profile_end_labels(ms, cnt, n)
+    by = {PROFILE_LABELS[i]: (ms[i], cnt[i]) for i in range(n)}
+    return ms[0], cnt[0], by
 
 
 def _dev(t):
