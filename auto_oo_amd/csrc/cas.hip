@@ -11,6 +11,7 @@
 //   stage 2  Gm = contract q->x, p->n; hmo = C^T h C[:, :M]           (contract.hip kernels)
 //   stage 3  c0,c1,c2,E, Fock matrices, orbital gradient              (this file, fock kernel)
 #include "common.h"
+#include <stdlib.h>
 
 int oovqe_mode_contract_impl(const double* T, const double* Cm, double* out, long A, int K, int J,
                              long B, int ldc, int last, hipStream_t st);
@@ -212,7 +213,10 @@ void half_transform_kernel(const double* __restrict__ g, const double* __restric
 #pragma unroll
                 for (int i = 0; i < KCH; ++i) {
                     const double rowok = (4 * i + lq) < N ? colok : 0.0;
-                    const double av = (half == 0 ? apair[pp][i].x : apair[pp][i].y) * rowok;
+                    // odd N: the lane whose even column is the LAST one (c0 == N-1) loaded the pair
+                    // (N-2, N-1), so its value sits in .y
+                    const double ev = (c0 == N - 1) ? apair[pp][i].y : apair[pp][i].x;
+                    const double av = (half == 0 ? ev : apair[pp][i].y) * rowok;
 #pragma unroll
                     for (int y = 0; y < ZT; ++y) xt[y] = mfma_f64(av, cfr[i][y], xt[y]);
                 }
@@ -272,6 +276,351 @@ void half_transform_kernel(const double* __restrict__ g, const double* __restric
                 const int zz = z * 16 + lq + 4 * i, yy = y * 16 + lr;
                 if (yy < M && zz < M) dst[yy * M + zz] = jt[z][y][i];
             }
+}
+
+// ------------------------------------------------------------------------------------------
+// Stages 1 + 2a fused, persistent and software-pipelined (M <= 16, N <= 48: a slab is one register
+// chunk):   T3[c][p][x][y][z] = sum_{q in chunk c} C[q,x] * ( sum_rs C[r,y] g[p,q,r,s] C[s,z] )
+//
+// Why fused: written per slab, T2[p,q,:,:] (8 M^2 bytes every 8 N^2 bytes read) costs ~25 % of the
+// kernel although it is 4 % of the bytes -- a store burst per slab from every wave keeps turning the
+// HBM channels around inside the read stream (measured: identical kernel without the stores
+// 305 us, with them 385 us; store flavour, coalescing and destination make no difference, fewer
+// bursts do).  Contracting q -> x inside the workgroup shrinks the output M/N-fold (T3 is 8 N M^3
+// bytes) and leaves ONE contiguous 8 M^3-byte burst per N slabs.
+//
+// Work split: a task is (chunk c of the q range, p); a workgroup owns the tasks bx, bx+W, ... of
+// its geometry and its 8 waves take the slab positions of that task list round-robin (position j
+// = task j/qc, slot j%qc), so waves stay busy across task boundaries.  Per wave: the loads of its
+// next slab are issued before the MFMAs of the current one (two register buffers, loop unrolled by
+// two, straight-line body); C fragments are loaded once.  Per slab the 16x16 result tile goes to
+// an LDS block [slot][y*M+z] of the task (ring of nbuf blocks).  The arrival that completes a block
+// (LDS counter) opens its tile jobs: one job contracts the block with C[q,x] for 16 (y,z) on the
+// MFMA (A = C rows from LDS, B = block) and writes that part of T3.  Every wave takes at most one
+// open job per slab, so the contraction is spread over the waves (done by the completing wave
+// alone it made that wave the straggler of every following task: +9 % kernel time).  No
+// workgroup barrier after the prologue; a block is reused only after its generation counter says
+// the previous task in it has been consumed.
+// LDS ordering relies on one wave's LDS instructions executing in issue order (ds_write of the
+// tile, then ds_add of the arrival).  Rows/columns beyond N are dropped loads (descriptor range
+// check) and zeroed C fragments, so g_ao needs no masks (it must be finite).
+// nchunk > 1 (few geometries: more tasks than N per geometry) leaves partial sums per chunk; the
+// p -> n contraction that follows sums them through Cdup[(c,p)][n] = C[p][n], written here.
+// ------------------------------------------------------------------------------------------
+template <int KCH, int NST>
+__global__ __launch_bounds__(HALF_WAVES * 64)
+void half_transform_fused_kernel(const double* __restrict__ g, const double* __restrict__ C,
+                                 double* __restrict__ T3, double* __restrict__ Cdup, int N, int M,
+                                 int nchunk, int qc, int nbuf, int ldb)
+{
+    constexpr int NP = NST / 2, NS1 = NST % 2;
+    constexpr int NPA = NP > 0 ? NP : 1;
+    constexpr int NCF = NST * 4;
+    static_assert(KCH <= NCF, "C fragments must cover every k-step");
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar control flow
+    const int lq = lane >> 4, lr = lane & 15;
+    const int M2 = M * M;
+    const long nslabs = (long)N * N;
+    const size_t slab_elems = (size_t)N * N;
+    const int QR = (qc + 3) & ~3;                   // rows of a block (k-steps of the q contraction)
+    const int CR = (nchunk - 1) * qc + QR;          // rows of the LDS copy of C[:, :M]
+    double* CxL = lds;                              // [CR][16], zero padded
+    double* blk = CxL + (size_t)CR * 16;            // [nbuf][QR][ldb]
+    double* dump = blk + (size_t)nbuf * QR * ldb;   // [64] sink for lanes outside the M x M tile
+    int* cnt = reinterpret_cast<int*>(dump + 64);   // [nbuf] arrivals at the task in block b
+    int* gen = cnt + nbuf;                          // [nbuf] tasks consumed in block b
+    int* job = gen + nbuf;                          // [nbuf] next tile job of block b (>= nty: closed)
+    int* done = job + nbuf;                         // [nbuf] tile jobs finished
+    int* tsk = done + nbuf;                         // [nbuf] task held by block b
+    g += (size_t)blockIdx.y * nslabs * slab_elems;
+    C += (size_t)blockIdx.y * N * N;
+    T3 += (size_t)blockIdx.y * nchunk * N * M2 * M;
+    if (nchunk > 1) Cdup += (size_t)blockIdx.y * nchunk * N * N;
+
+    for (int idx = tid; idx < CR * 16; idx += HALF_WAVES * 64) {
+        const int r = idx >> 4, x = idx & 15;
+        CxL[idx] = (r < N && x < M) ? C[(size_t)r * N + x] : 0.0;
+    }
+    for (int idx = tid; idx < nbuf * QR * ldb + 64; idx += HALF_WAVES * 64) blk[idx] = 0.0;
+    if (tid < 5 * nbuf) cnt[tid] = (tid >= 2 * nbuf && tid < 3 * nbuf) ? (1 << 30) : 0;
+
+    // stage-1 B fragments cfr[j] = C[4j + lq][lr]; stage-2 A fragments in MFMA row order:
+    //   even/odd tile of pair pp: row m = lq + 4i <-> column pp*32 + 2(lq+4i) (+1)
+    //   single tile             : column NP*32 + lq + 4i = row (NP*8 + i)*4 + lq  (= cfr[NP*8 + i])
+    double cfr[NCF];
+#pragma unroll
+    for (int j = 0; j < NCF; ++j) {
+        const int r = 4 * j + lq;
+        cfr[j] = C[(size_t)(r < N ? r : N - 1) * N + (lr < M ? lr : M - 1)];
+    }
+    double cpr[NPA][2][4];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = pp * 32 + 2 * (lq + 4 * i) + half;
+                cpr[pp][half][i] = C[(size_t)(col < N ? col : N - 1) * N + (lr < M ? lr : M - 1)];
+            }
+#pragma unroll
+    for (int j = 0; j < NCF; ++j) cfr[j] *= ((4 * j + lq) < N && lr < M) ? 1.0 : 0.0;
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                cpr[pp][half][i] *= ((pp * 32 + 2 * (lq + 4 * i) + half) < N && lr < M) ? 1.0 : 0.0;
+    __syncthreads();   // the only workgroup barrier
+
+    // lane-invariant byte offsets inside a slab, relative to the (wave-uniform) start of the row
+    // block 4i.  Only the k-step i_last = (N-1)/4 can straddle the end of the slab: its lanes with
+    // row >= N get an out-of-range offset (the load is dropped and returns 0), and whole k-steps
+    // beyond it (KCH > ceil(N/4)) are dropped through the scalar offset.
+    constexpr int MINK = KCH == 4 ? 1 : KCH == 8 ? 5 : KCH == 11 ? 9 : KCH;   // smallest ceil(N/4) served
+    const int i_last = (N - 1) / 4;
+    const unsigned slab_bytes = (unsigned)(slab_elems * sizeof(double));
+    const unsigned total_bytes = (unsigned)(nslabs * slab_elems * sizeof(double));
+    const bool row_ok_last = 4 * i_last + lq < N;
+    unsigned offp[NPA], offp_last[NPA];
+    bool last_even[NPA];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+        const int col = pp * 32 + 2 * lr;
+        const int cc = col + 1 < N ? col : (N >= 2 ? N - 2 : 0);
+        offp[pp] = (unsigned)((lq * N + cc) * sizeof(double));
+        offp_last[pp] = row_ok_last ? offp[pp] : total_bytes;
+        last_even[pp] = col == N - 1;
+    }
+    const int col1 = NP * 32 + lr;
+    const unsigned offs = (unsigned)((lq * N + (col1 < N ? col1 : N - 1)) * sizeof(double));
+    const unsigned offs_last = row_ok_last ? offs : total_bytes;
+
+    // buffer loads: 32-bit per-lane byte offset (5 VGPRs for the whole slab) + the wave-uniform
+    // slab / row-block offset in an SGPR, instead of one 64-bit VGPR address per load
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double*>(g), 0, (int)total_bytes, 0x00020000);
+    const unsigned rowblk_bytes = (unsigned)(4 * N * sizeof(double));
+    auto soff = [&](unsigned sb, int i) -> unsigned {
+        return (i < MINK || i <= i_last) ? sb + i * rowblk_bytes : total_bytes;
+    };
+
+    // this workgroup's task list and this wave's positions in it
+    const int Tg = nchunk * N, W = gridDim.x, bx = blockIdx.x;
+    const int ntask = (Tg - bx + W - 1) / W;
+    const int npos = ntask * qc;
+    if (nchunk > 1)   // rows of the duplicated coefficient matrix that belong to this workgroup's tasks
+        for (int k = 0; k < ntask; ++k) {
+            const int t = bx + k * W, p = t % N;
+            for (int n = tid; n < N; n += HALF_WAVES * 64) Cdup[(size_t)t * N + n] = C[(size_t)p * N + n];
+        }
+    if (wave >= npos) return;
+    const int n_mine = (npos - wave + HALF_WAVES - 1) / HALF_WAVES;
+    struct Pos { int k, qi; };
+    auto advance = [&](Pos a) -> Pos {
+        a.qi += HALF_WAVES;
+        while (a.qi >= qc) { a.qi -= qc; ++a.k; }
+        return a;
+    };
+    // byte offset of the slab at a position; positions past the task list or slots past q = N-1
+    // become an out-of-range offset: the descriptor's range check drops those loads (no branch
+    // here, so the s_waitcnt counts in the loop stay exact)
+    auto slab_off = [&](Pos a) -> unsigned {
+        const int t = bx + a.k * W;
+        const int c = t / N, p = t - c * N, q = c * qc + a.qi;
+        const bool ok = a.k < ntask && q < N;
+        return __builtin_amdgcn_readfirstlane(ok ? (unsigned)(p * N + q) * slab_bytes : total_bytes);
+    };
+    auto issue = [&](Pos a, d2u (&ap)[NPA][KCH], double (&as)[KCH]) {
+        const unsigned sb = slab_off(a);
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) {
+                const v4u v = __builtin_amdgcn_raw_buffer_load_b128(
+                    rsrc, (i >= MINK - 1 && i == i_last) ? offp_last[pp] : offp[pp], soff(sb, i), 0);
+                ap[pp][i] = __builtin_bit_cast(d2u, v);
+            }
+        if constexpr (NS1) {
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) {
+                const v2u v = __builtin_amdgcn_raw_buffer_load_b64(
+                    rsrc, (i >= MINK - 1 && i == i_last) ? offs_last : offs, soff(sb, i), 0);
+                as[i] = __builtin_bit_cast(double, v);
+            }
+        }
+    };
+    // LDS destination of jt[i] = Jt[z = lq + 4i][y = lr] inside a block row: [y*M + z]
+    int tile_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int zz = lq + 4 * i;
+        tile_off[i] = (lr < M && zz < M) ? lr * M + zz : -1;
+    }
+    // T3 goes out through a descriptor with a FIXED number of store instructions per slab: lanes
+    // outside the tile, and slabs without a job, get an out-of-range offset (dropped).  A
+    // conditional store would leave the compiler unsure how many VMEM operations are younger than
+    // the prefetched loads, and its conservative s_waitcnt then waits for the stores' acknowledgement
+    // before every MFMA phase.
+    const unsigned t3_bytes = (unsigned)((size_t)nchunk * N * M * M2 * sizeof(double));
+    const __amdgpu_buffer_rsrc_t rsrc_t3 = __builtin_amdgcn_make_buffer_rsrc(T3, 0, (int)t3_bytes, 0x00020000);
+    unsigned t3_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t3_off[j] = (unsigned)(((lq + 4 * j) * M2 + lr) * sizeof(double));
+    auto store_tile = [&](d4 acc, unsigned obase, int ty) {
+        // obase = byte offset of T3[c][p][0][16 ty] (ty < 0: no job); valid lanes: x = lq + 4j < M,
+        // 16 ty + lr < M2
+        const unsigned sb = __builtin_amdgcn_readfirstlane(obase);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double v = acc[j];
+            // (ty = -1 makes the unsigned comparison fail: no short-circuit branches here)
+            const bool ok = ((unsigned)(16 * ty + lr) < (unsigned)M2) & ((lq + 4 * j) < M);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), rsrc_t3,
+                                                  ok ? t3_off[j] : t3_bytes, sb, 0);
+        }
+    };
+    // One tile job of a complete block: T3[c][p][x][yz] = sum_slot C[q0+slot][x] blk[slot][yz] for
+    // the 16 yz of tile ty (A = C rows: m = x, k = slot; B = block rows: k = slot, n = yz).  All
+    // fragments are read before the MFMA chain (QR/4 <= NCF k-steps; the ones past QR/4 re-read
+    // k-step 0 against a zero A operand).
+    const int nty = (M2 + 15) / 16, kf = QR / 4;
+    auto do_tile = [&](int k, int b, int ty, unsigned* obase, int* ty_out) -> d4 {
+        const int t = bx + k * W;
+        const int c = t / N, p = t - c * N;
+        const double* arow = CxL + (size_t)(c * qc + lq) * 16 + lr;
+        const double* brow = blk + ((size_t)b * QR + lq) * ldb + lr + 16 * ty;
+        double af[NCF], bf[NCF];
+#pragma unroll
+        for (int i = 0; i < NCF; ++i) {
+            const int ii = i < kf ? i : 0;
+            af[i] = arow[(size_t)ii * 64];
+            bf[i] = brow[(size_t)ii * 4 * ldb];
+        }
+        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < NCF; ++i) acc = mfma_f64(i < kf ? af[i] : 0.0, bf[i], acc);
+        *obase = (unsigned)((c * N + p) * M * M2 + 16 * ty) * (unsigned)sizeof(double);
+        *ty_out = ty;
+        return acc;
+    };
+    // Take at most one tile job from the blocks that are open (complete, not yet consumed).  The
+    // wave that finishes the last job of a block releases it (gen).  Returns whether a job was done.
+    auto take_job = [&](d4* acc, unsigned* obase, int* ty_out) -> bool {
+        for (int b = 0; b < nbuf; ++b) {
+            if (__hip_atomic_load(&job[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= nty)
+                continue;
+            int j = 0;
+            if (lane == 0)
+                j = __hip_atomic_fetch_add(&job[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            j = __builtin_amdgcn_readfirstlane(j);
+            if (j >= nty) continue;
+            asm volatile("" ::: "memory");
+            const int k = __builtin_amdgcn_readfirstlane(
+                __hip_atomic_load(&tsk[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            *acc = do_tile(k, b, j, obase, ty_out);
+            asm volatile("" ::: "memory");
+            int d = 0;
+            if (lane == 0)
+                d = __hip_atomic_fetch_add(&done[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            d = __builtin_amdgcn_readfirstlane(d);
+            if (d == nty - 1 && lane == 0)
+                __hip_atomic_fetch_add(&gen[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return true;
+        }
+        return false;
+    };
+    auto compute = [&](Pos a, const d2u (&ap)[NPA][KCH], const double (&as)[KCH]) {
+        d4 jt = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                d4 xt = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int i = 0; i < KCH; ++i) {
+                    // odd N: the lane whose even column is the LAST one loaded the pair
+                    // (N-2, N-1), so its value sits in .y
+                    const double ev = last_even[pp] ? ap[pp][i].y : ap[pp][i].x;
+                    xt = mfma_f64(half == 0 ? ev : ap[pp][i].y, cfr[i], xt);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) jt = mfma_f64(cpr[pp][half][i], xt[i], jt);
+            }
+        if constexpr (NS1) {
+            d4 xt = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) xt = mfma_f64(as[i], cfr[i], xt);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) jt = mfma_f64(cfr[NP * 8 + i], xt[i], jt);
+        }
+        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+        unsigned obase = t3_bytes;
+        int ty = -1;
+        if (a.k < ntask) {                            // (else: padding position of the unrolled loop)
+            const int b = a.k % nbuf, need = a.k / nbuf;
+            // the block is free once the previous task in it has been consumed
+            while (__hip_atomic_load(&gen[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+                __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+            double* row = blk + ((size_t)b * QR + a.qi) * ldb;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                double* dst = tile_off[i] >= 0 ? row + tile_off[i] : dump + lane;
+                *dst = jt[i];
+            }
+            asm volatile("" ::: "memory");
+            int old = 0;
+            if (lane == 0)
+                old = __hip_atomic_fetch_add(&cnt[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            old = __builtin_amdgcn_readfirstlane(old);
+            asm volatile("" ::: "memory");
+            if (old == qc - 1 && lane == 0) {         // block complete: open its tile jobs
+                __hip_atomic_store(&cnt[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&tsk[b], a.k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&done[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                asm volatile("" ::: "memory");
+                __hip_atomic_store(&job[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            asm volatile("" ::: "memory");
+            take_job(&acc, &obase, &ty);
+        }
+        store_tile(acc, obase, ty);                   // always 4 store instructions
+    };
+
+    d2u ap0[NPA][KCH], ap1[NPA][KCH];
+    double as0[KCH], as1[KCH];
+    // Straight-line loop body (no exit test between an issue and its use: the optimiser sinks
+    // loads below such a test, which serialises them with the MFMAs).  An odd position count
+    // costs one idle MFMA pass on dropped loads.
+    Pos p0{wave / qc, wave % qc};
+    issue(p0, ap0, as0);
+    store_tile(d4{0.0, 0.0, 0.0, 0.0}, t3_bytes, -1);   // same VMEM sequence as a loop iteration leaves
+    for (int it = 0; it < n_mine; it += 2) {
+        const Pos p1 = advance(p0);
+        issue(p1, ap1, as1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(p0, ap0, as0);
+        __builtin_amdgcn_sched_barrier(0);
+        const Pos p2 = advance(p1);
+        issue(p2, ap0, as0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(p1, ap1, as1);
+        __builtin_amdgcn_sched_barrier(0);
+        p0 = p2;
+    }
+    for (;;) {   // blocks opened by this wave's last arrivals
+        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+        unsigned obase = t3_bytes;
+        int ty = -1;
+        if (!take_job(&acc, &obase, &ty)) break;
+        store_tile(acc, obase, ty);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -424,8 +773,9 @@ void fock_kernel(const double* __restrict__ Gm, const double* __restrict__ hmo,
 
 // ------------------------------------------------------------------------------------------
 // Fused stage 2b + 3 ("column" kernel): one workgroup per general index n.
-//   in : U[n,q,y,z] = sum_p C[p,n] T2[p,q,y,z]   (from the K1 contraction kernel)
-//   Gn[x,y,z] = sum_q C[q,x] U[n,q,y,z]          (= g_mo[n,x,y,z], kept in LDS, 8 M^3 bytes)
+//   in : Gm_in[n,x,y,z] = g_mo[n,x,y,z] (fused path: T3 contracted p -> n), or
+//        U[n,q,y,z] = sum_p C[p,n] T2[p,q,y,z] (T2 path), then
+//        Gn[x,y,z] = sum_q C[q,x] U[n,q,y,z]     (= g_mo[n,x,y,z], kept in LDS, 8 M^3 bytes)
 //   hn[x]     = sum_q (sum_p C[p,n] h[p,q]) C[q,x]
 //   FI[n,x], and for every RDM set k the n-th COLUMN of the generalized Fock matrix
 //   (rows m < M only; virtual rows are zero), the per-n pieces of c0 / c1 / c2 and of the energy.
@@ -435,7 +785,8 @@ void fock_kernel(const double* __restrict__ Gm, const double* __restrict__ hmo,
 constexpr int COL_THREADS = 256;
 
 __global__ __launch_bounds__(COL_THREADS)
-void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ h_ao,
+void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ Gm_in,
+                       const double* __restrict__ h_ao,
                        const double* __restrict__ C, const double* __restrict__ gamma,
                        const double* __restrict__ Gamma, int nrdm, int N, int no, int na,
                        double* __restrict__ Fcol, double* __restrict__ Epart,
@@ -446,8 +797,8 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
     extern __shared__ double lds[];
     const int M = no + na, M2 = M * M, M3 = M2 * M;
     const int na2 = na * na, na3 = na2 * na, na4 = na2 * na2;
-    double* Un = lds;                    // [N][M2]
-    double* Cl = Un + (size_t)N * M2;    // [N][M]   C[:, :M]
+    double* Un = lds;                    // [N][M2]  (absent when Gm_in supplies g_mo[n,x,y,z])
+    double* Cl = Un + (Gm_in ? 0 : (size_t)N * M2);   // [N][M]   C[:, :M]
     double* Gn = Cl + (size_t)N * M;     // [M3]
     double* Wn = Gn + M3;                // [N]      (C^T h)[n, :]
     double* hn = Wn + N;                 // [M]
@@ -460,7 +811,8 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
     const int n = blockIdx.x;
     {   // blockIdx.y = geometry of a batch: every per-geometry array is stacked
         const size_t gi = blockIdx.y;
-        U += gi * (size_t)N * N * M2;
+        if (Gm_in) Gm_in += gi * (size_t)N * M3;
+        else U += gi * (size_t)N * N * M2;
         h_ao += gi * (size_t)N * N;
         C += gi * (size_t)N * N;
         gamma += gi * (size_t)nrdm * na2;
@@ -474,8 +826,12 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
         if (hmo_out) hmo_out += gi * (size_t)N * M;
     }
 
-    const double* Usrc = U + (size_t)n * N * M2;
-    for (int idx = tid; idx < N * M2; idx += COL_THREADS) Un[idx] = Usrc[idx];
+    if (Gm_in) {
+        for (int idx = tid; idx < M3; idx += COL_THREADS) Gn[idx] = Gm_in[(size_t)n * M3 + idx];
+    } else {
+        const double* Usrc = U + (size_t)n * N * M2;
+        for (int idx = tid; idx < N * M2; idx += COL_THREADS) Un[idx] = Usrc[idx];
+    }
     for (int idx = tid; idx < N * M; idx += COL_THREADS) {
         const int q = idx / M, x = idx - q * M;
         Cl[idx] = C[(size_t)q * N + x];
@@ -504,7 +860,7 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
     }
     // Gn[x,yz] = sum_q C[q,x] U[n,q,yz]: four outputs per thread share one q loop (independent
     // LDS reads in flight instead of one dependent chain per output)
-    for (int base = 0; base < M3; base += 4 * COL_THREADS) {
+    for (int base = 0; base < (Gm_in ? 0 : M3); base += 4 * COL_THREADS) {
         int xo[4], yo[4];
         bool ok[4];
 #pragma unroll
@@ -536,7 +892,7 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
         for (int i = 0; i < no; ++i) fi += 2.0 * Gn[tid * M2 + i * M + i] - Gn[i * M2 + i * M + tid];
         FIn[tid] = fi;
     }
-    if (Gm_out)
+    if (Gm_out && Gm_out != Gm_in)
         for (int idx = tid; idx < M3; idx += COL_THREADS) Gm_out[(size_t)n * M3 + idx] = Gn[idx];
     __syncthreads();
     if (hmo_out && tid < M) hmo_out[(size_t)n * M + tid] = hn[tid];
@@ -744,6 +1100,102 @@ static int half_transform_batched(const double* g_ao, const double* C, int N, in
     return 0;
 }
 
+// Plan of the fused stage-1 + q->x kernel for `batch` geometries: number of q chunks, slots per
+// chunk, LDS ring.  Returns false when the shape is outside the kernel (M > 16, N > 48, no room
+// for two ring blocks, workspace) -- the caller then takes the T2 path.
+struct FusedPlan {
+    int nchunk, qc, nbuf, ldb, wpg;
+    size_t lds_bytes;
+};
+
+static int device_cu_count()
+{
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    return n_cu;
+}
+
+static bool fused_plan(int N, int M, int batch, FusedPlan* fp)
+{
+    if (M > 16 || N > 48 || N < 1) return false;
+    static const long chunks_env = getenv("OOVQE_FUSED_CHUNKS") ? atol(getenv("OOVQE_FUSED_CHUNKS")) : 0;
+    const long m2 = (long)M * M, m3 = m2 * M;
+    const int n_cu = device_cu_count();
+    // tasks (chunk, p) per geometry: about one workgroup's worth per CU when geometries are few
+    long target = n_cu / batch;
+    long nchunk0 = chunks_env > 0 ? chunks_env : target / N;
+    if (nchunk0 < 1) nchunk0 = 1;
+    // T3 [nchunk][N][M^3] + Gm [N][M^3] + Cdup [nchunk][N][N] share the 2 N^2 M^2 workspace
+    const long cap = (2L * N * m2 - m3) / (m3 + N);
+    if (cap < 1) return false;
+    if (nchunk0 > cap) nchunk0 = cap;
+    int qc = N, nchunk = 1;
+    if (nchunk0 > 1) {
+        qc = 4 * (int)((N + 4 * nchunk0 - 1) / (4 * nchunk0));
+        nchunk = (N + qc - 1) / qc;
+    }
+    const int QR = (qc + 3) & ~3, CR = (nchunk - 1) * qc + QR;
+    int ldb = (int)((m2 + 15) / 16 * 16);
+    if (ldb % 32 == 0) ldb += 16;                  // rows lq, lq+1 of a B fragment in different bank halves
+    const size_t fixed = ((size_t)CR * 16 + 64) * sizeof(double) + 64;   // + 5 counters per ring block
+    const size_t block = (size_t)QR * ldb * sizeof(double);
+    long nbuf = (long)((160 * 1024 - fixed) / block);
+    if (nbuf < 2) return false;
+    if (nbuf > 3) nbuf = 3;
+    long wpg = target < 1 ? 1 : target;
+    if (wpg > (long)nchunk * N) wpg = (long)nchunk * N;
+    fp->nchunk = nchunk;
+    fp->qc = qc;
+    fp->nbuf = (int)nbuf;
+    fp->ldb = ldb;
+    fp->wpg = (int)wpg;
+    fp->lds_bytes = fixed + (size_t)nbuf * block;
+    return true;
+}
+
+static int half_transform_fused_batched(const double* g_ao, const double* C, int N, int M, double* T3,
+                                        double* Cdup, const FusedPlan& fp, int batch, hipStream_t st)
+{
+    const int ksteps = (N + 3) / 4, nrb = (N + 15) / 16;
+    const int kch = ksteps <= 4 ? 4 : ksteps <= 8 ? 8 : ksteps <= 11 ? 11 : 12;
+#define OOVQE_LAUNCH_FUSED(KC_, NS_)                                                              \
+    do {                                                                                          \
+        static bool attr_done = false;                                                            \
+        if (!attr_done) {                                                                         \
+            hipError_t e = hipFuncSetAttribute((const void*)half_transform_fused_kernel<KC_, NS_>, \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                               160 * 1024);                                       \
+            if (e != hipSuccess) {                                                                \
+                oovqe_set_error("cas_eval: hipFuncSetAttribute: %s", hipGetErrorString(e));       \
+                return OOVQE_ERR_HIP;                                                             \
+            }                                                                                     \
+            attr_done = true;                                                                     \
+        }                                                                                         \
+        hipLaunchKernelGGL((half_transform_fused_kernel<KC_, NS_>), dim3(fp.wpg, batch),          \
+                           dim3(HALF_WAVES * 64), fp.lds_bytes, st, g_ao, C, T3, Cdup, N, M,      \
+                           fp.nchunk, fp.qc, fp.nbuf, fp.ldb);                                    \
+    } while (0)
+    oovqe_profile_mark_start(st);
+    if (kch == 4 && nrb == 1) OOVQE_LAUNCH_FUSED(4, 1);
+    else if (kch == 8 && nrb == 2) OOVQE_LAUNCH_FUSED(8, 2);
+    else if (kch == 11 && nrb == 3) OOVQE_LAUNCH_FUSED(11, 3);
+    else if (kch == 12 && nrb == 3) OOVQE_LAUNCH_FUSED(12, 3);
+    else {
+        oovqe_set_error("cas_eval: no fused half-transform variant for N=%d", N);
+        return OOVQE_ERR_ARG;
+    }
+    oovqe_profile_mark_stop(st);
+#undef OOVQE_LAUNCH_FUSED
+    OOVQE_CHECK_LAUNCH("cas_eval/half_transform_fused");
+    return 0;
+}
+
 extern "C" int oovqe_cas_finish_transform(const double* T2, const double* h_ao, const double* C,
                                           int N, int M, double* Gm, double* hmo, double* work,
                                           oovqe_stream_t stream)
@@ -826,16 +1278,38 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
     double* Epart = Fcol + nb * nrdm * M * N;            // [G][nrdm][N]
     double* Cpart = Epart + nb * nrdm * N;               // [G][N]
     int rc;
-    if ((rc = half_transform_batched(g_ao, C, N, M, T2, batch, stream))) return rc;
-    // U[n,(q y z)] = sum_p C[p,n] T2[p,(q y z)]
-    oovqe_profile_mark_start_l(st, 2);
-    if ((rc = oovqe_mode_contract_batched(T2, C, U, 1, N, N, (long)N * m2, N, 0, batch,
-                                          (long)N * N * m2, (long)N * N, (long)N * N * m2, st)))
-        return rc;
-    oovqe_profile_mark_stop(st);
+    // fused path: T3 = stage 1 + q -> x in one kernel, then the small p -> n contraction gives
+    // g_mo[n,x,y,z] directly; T2 path (M > 16 or N > 48): T2, U = C^T T2, q -> x in the column kernel
+    static const bool unfused_env = getenv("OOVQE_CAS_UNFUSED") != nullptr;
+    FusedPlan fp;
+    const bool fused = !unfused_env && fused_plan(N, M, batch, &fp);
+    const double* Gm_in = nullptr;
+    if (fused) {
+        double* T3 = work;                                       // [G][nchunk][N][M^3]
+        double* Gmw = T3 + nb * fp.nchunk * N * m3;              // [G][N][M^3]
+        double* Cdup = Gmw + nb * N * m3;                        // [G][nchunk][N][N]  (nchunk > 1)
+        if ((rc = half_transform_fused_batched(g_ao, C, N, M, T3, Cdup, fp, batch, st))) return rc;
+        // Gm[n,(x y z)] = sum_{c,p} C[p,n] T3[c,p,(x y z)]
+        oovqe_profile_mark_start_l(st, 2);
+        const long K = (long)fp.nchunk * N;
+        if ((rc = oovqe_mode_contract_batched(T3, fp.nchunk > 1 ? Cdup : C, Gmw, 1, (int)K, N, m3, N, 0,
+                                              batch, K * m3, fp.nchunk > 1 ? K * N : (long)N * N,
+                                              (long)N * m3, st)))
+            return rc;
+        oovqe_profile_mark_stop(st);
+        Gm_in = Gmw;
+    } else {
+        if ((rc = half_transform_batched(g_ao, C, N, M, T2, batch, stream))) return rc;
+        // U[n,(q y z)] = sum_p C[p,n] T2[p,(q y z)]
+        oovqe_profile_mark_start_l(st, 2);
+        if ((rc = oovqe_mode_contract_batched(T2, C, U, 1, N, N, (long)N * m2, N, 0, batch,
+                                              (long)N * N * m2, (long)N * N, (long)N * N * m2, st)))
+            return rc;
+        oovqe_profile_mark_stop(st);
+    }
     const size_t na2 = (size_t)ncas * ncas;
-    const size_t base_bytes = ((size_t)N * m2 + (size_t)N * M + m3 + N + M + M + N + (size_t)4 * N) *
-                              sizeof(double);
+    const size_t base_bytes = ((fused ? 0 : (size_t)N * m2) + (size_t)N * M + m3 + N + M + M + N +
+                               (size_t)4 * N) * sizeof(double);
     const size_t set_bytes = (na2 + na2 * na2) * sizeof(double);
     OOVQE_REQUIRE(base_bytes + set_bytes <= 160 * 1024, "cas_eval: N=%d M=%d needs %zu B of LDS", N, M,
                   base_bytes + set_bytes);
@@ -853,7 +1327,7 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
         attr_done = true;
     }
     oovqe_profile_mark_start_l(st, 3);
-    hipLaunchKernelGGL(cas_column_kernel, dim3(N, batch), dim3(COL_THREADS), lds_bytes, st, U, h_ao, C,
+    hipLaunchKernelGGL(cas_column_kernel, dim3(N, batch), dim3(COL_THREADS), lds_bytes, st, U, Gm_in, h_ao, C,
                        gamma, Gamma, nrdm, N, n_occ, ncas, Fcol, Epart, Cpart, c1, c2, Gm, hmo,
                        out_stride, rdm_chunk);
     oovqe_profile_mark_stop(st);

@@ -331,3 +331,17 @@ def test_sector_engine_state_rdms_adjoint(ncas, nelecas, kind, k):
             return (c1.cpu() * a).sum() + (c2.cpu() * b).sum()
         ref = torch.autograd.functional.jacobian(f, th[0].cpu())
         assert (dth[0] - ref).abs().max() < 1e-10
+
+
+@pytest.mark.parametrize("N,M", [(5, 3), (16, 16), (17, 4), (31, 9), (32, 12), (33, 7), (43, 9),
+                                 (44, 16), (47, 5), (48, 10)])
+def test_half_transform_sizes(N, M):
+    """T2[p,q,y,z] = sum_rs C[r,y] g[p,q,r,s] C[s,z] for every register-chunk variant of the
+    persistent slab kernel (N <= 48, M <= 16), odd and even slab counts per wave included."""
+    rng = np.random.default_rng(1000 * N + M)
+    g = torch.tensor(rng.standard_normal((N, N, N, N)))
+    C = torch.tensor(rng.standard_normal((N, N)))
+    T2 = ops.cas_half_transform(g.to(DEV), C.to(DEV), M).cpu()
+    ref = torch.einsum("ry,pqrs,sz->pqyz", C[:, :M], g, C[:, :M])
+    assert T2.shape == ref.shape
+    assert (T2 - ref).abs().max() < 1e-11 * max(1.0, float(ref.abs().max()))
