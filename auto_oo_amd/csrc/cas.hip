@@ -11,6 +11,7 @@
 //   stage 2  Gm = contract q->x, p->n; hmo = C^T h C[:, :M]           (contract.hip kernels)
 //   stage 3  c0,c1,c2,E, Fock matrices, orbital gradient              (this file, fock kernel)
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 int oovqe_mode_contract_impl(const double* T, const double* Cm, double* out, long A, int K, int J,
@@ -282,12 +283,15 @@ void half_transform_kernel(const double* __restrict__ g, const double* __restric
 // Stages 1 + 2a fused, persistent and software-pipelined (M <= 16, N <= 48: a slab is one register
 // chunk):   T3[c][p][x][y][z] = sum_{q in chunk c} C[q,x] * ( sum_rs C[r,y] g[p,q,r,s] C[s,z] )
 //
-// Why fused: written per slab, T2[p,q,:,:] (8 M^2 bytes every 8 N^2 bytes read) costs ~25 % of the
-// kernel although it is 4 % of the bytes -- a store burst per slab from every wave keeps turning the
-// HBM channels around inside the read stream (measured: identical kernel without the stores
-// 305 us, with them 385 us; store flavour, coalescing and destination make no difference, fewer
-// bursts do).  Contracting q -> x inside the workgroup shrinks the output M/N-fold (T3 is 8 N M^3
-// bytes) and leaves ONE contiguous 8 M^3-byte burst per N slabs.
+// Why fused, and why nothing is stored inside the loop: ANY store traffic interleaved with the read
+// stream costs far more than its bytes.  Measured on this kernel (64 geometries, N = 43, M = 9,
+// 1.75 GB read): no stores 305-313 us; T2 written per slab (77 MB, 4 % of the bytes) 385 us; T3
+// written per task (16 MB, 1 %) 345 us -- the same whether the stores are coalesced, line-aligned,
+// non-temporal, aimed at an L2-resident region, issued by a dedicated wave, or kept out of the
+// s_waitcnt chain; only dropping them (or thinning them) helps.  That is the signature of
+// write bursts turning the HBM channels around inside the read stream, so the kernel contracts
+// q -> x in the workgroup (T3 is 8 N M^3 bytes, M/N of T2), keeps its T3 rows in LDS and writes
+// them in one burst after its last slab.
 //
 // Work split: a task is (chunk c of the q range, p); a workgroup owns the tasks bx, bx+W, ... of
 // its geometry and its 8 waves take the slab positions of that task list round-robin (position j
@@ -296,11 +300,11 @@ void half_transform_kernel(const double* __restrict__ g, const double* __restric
 // two, straight-line body); C fragments are loaded once.  Per slab the 16x16 result tile goes to
 // an LDS block [slot][y*M+z] of the task (ring of nbuf blocks).  The arrival that completes a block
 // (LDS counter) opens its tile jobs: one job contracts the block with C[q,x] for 16 (y,z) on the
-// MFMA (A = C rows from LDS, B = block) and writes that part of T3.  Every wave takes at most one
-// open job per slab, so the contraction is spread over the waves (done by the completing wave
-// alone it made that wave the straggler of every following task: +9 % kernel time).  No
-// workgroup barrier after the prologue; a block is reused only after its generation counter says
-// the previous task in it has been consumed.
+// MFMA (A = C rows from LDS, B = block) into the LDS stage.  Every wave takes at most one open job
+// per slab, so the contraction is spread over the waves (done by the completing wave alone it
+// made that wave the straggler of every following task: +9 % kernel time).  A block is reused
+// only after its generation counter says the previous task in it has been consumed.  One
+// workgroup barrier after the prologue, one before the final T3 burst.
 // LDS ordering relies on one wave's LDS instructions executing in issue order (ds_write of the
 // tile, then ds_add of the arrival).  Rows/columns beyond N are dropped loads (descriptor range
 // check) and zeroed C fragments, so g_ao needs no masks (it must be finite).
@@ -334,6 +338,7 @@ void half_transform_fused_kernel(const double* __restrict__ g, const double* __r
     int* job = gen + nbuf;                          // [nbuf] next tile job of block b (>= nty: closed)
     int* done = job + nbuf;                         // [nbuf] tile jobs finished
     int* tsk = done + nbuf;                         // [nbuf] task held by block b
+    double* stg = dump + 64 + 8;                    // [ntask][M][M2] T3 of this workgroup's tasks
     g += (size_t)blockIdx.y * nslabs * slab_elems;
     C += (size_t)blockIdx.y * N * N;
     T3 += (size_t)blockIdx.y * nchunk * N * M2 * M;
@@ -419,8 +424,7 @@ void half_transform_fused_kernel(const double* __restrict__ g, const double* __r
             const int t = bx + k * W, p = t % N;
             for (int n = tid; n < N; n += HALF_WAVES * 64) Cdup[(size_t)t * N + n] = C[(size_t)p * N + n];
         }
-    if (wave >= npos) return;
-    const int n_mine = (npos - wave + HALF_WAVES - 1) / HALF_WAVES;
+    const int n_mine = wave < npos ? (npos - wave + HALF_WAVES - 1) / HALF_WAVES : 0;
     struct Pos { int k, qi; };
     auto advance = [&](Pos a) -> Pos {
         a.qi += HALF_WAVES;
@@ -462,37 +466,14 @@ void half_transform_fused_kernel(const double* __restrict__ g, const double* __r
         const int zz = lq + 4 * i;
         tile_off[i] = (lr < M && zz < M) ? lr * M + zz : -1;
     }
-    // T3 goes out through a descriptor with a FIXED number of store instructions per slab: lanes
-    // outside the tile, and slabs without a job, get an out-of-range offset (dropped).  A
-    // conditional store would leave the compiler unsure how many VMEM operations are younger than
-    // the prefetched loads, and its conservative s_waitcnt then waits for the stores' acknowledgement
-    // before every MFMA phase.
-    const unsigned t3_bytes = (unsigned)((size_t)nchunk * N * M * M2 * sizeof(double));
-    const __amdgpu_buffer_rsrc_t rsrc_t3 = __builtin_amdgcn_make_buffer_rsrc(T3, 0, (int)t3_bytes, 0x00020000);
-    unsigned t3_off[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) t3_off[j] = (unsigned)(((lq + 4 * j) * M2 + lr) * sizeof(double));
-    auto store_tile = [&](d4 acc, unsigned obase, int ty) {
-        // obase = byte offset of T3[c][p][0][16 ty] (ty < 0: no job); valid lanes: x = lq + 4j < M,
-        // 16 ty + lr < M2
-        const unsigned sb = __builtin_amdgcn_readfirstlane(obase);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const double v = acc[j];
-            // (ty = -1 makes the unsigned comparison fail: no short-circuit branches here)
-            const bool ok = ((unsigned)(16 * ty + lr) < (unsigned)M2) & ((lq + 4 * j) < M);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), rsrc_t3,
-                                                  ok ? t3_off[j] : t3_bytes, sb, 0);
-        }
-    };
-    // One tile job of a complete block: T3[c][p][x][yz] = sum_slot C[q0+slot][x] blk[slot][yz] for
-    // the 16 yz of tile ty (A = C rows: m = x, k = slot; B = block rows: k = slot, n = yz).  All
+    // One tile job of a complete block: stg[k][x][yz] = sum_slot C[q0+slot][x] blk[slot][yz] for the
+    // 16 yz of tile ty (A = C rows: m = x, k = slot; B = block rows: k = slot, n = yz).  All
     // fragments are read before the MFMA chain (QR/4 <= NCF k-steps; the ones past QR/4 re-read
     // k-step 0 against a zero A operand).
     const int nty = (M2 + 15) / 16, kf = QR / 4;
-    auto do_tile = [&](int k, int b, int ty, unsigned* obase, int* ty_out) -> d4 {
+    auto do_tile = [&](int k, int b, int ty) {
         const int t = bx + k * W;
-        const int c = t / N, p = t - c * N;
+        const int c = t / N;
         const double* arow = CxL + (size_t)(c * qc + lq) * 16 + lr;
         const double* brow = blk + ((size_t)b * QR + lq) * ldb + lr + 16 * ty;
         double af[NCF], bf[NCF];
@@ -505,13 +486,18 @@ void half_transform_fused_kernel(const double* __restrict__ g, const double* __r
         d4 acc = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int i = 0; i < NCF; ++i) acc = mfma_f64(i < kf ? af[i] : 0.0, bf[i], acc);
-        *obase = (unsigned)((c * N + p) * M * M2 + 16 * ty) * (unsigned)sizeof(double);
-        *ty_out = ty;
-        return acc;
+        double* out = stg + (size_t)k * M * M2;
+        const int yz = 16 * ty + lr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = lq + 4 * j;
+            double* dst = (x < M && yz < M2) ? out + (size_t)x * M2 + yz : dump + lane;
+            *dst = acc[j];
+        }
     };
     // Take at most one tile job from the blocks that are open (complete, not yet consumed).  The
     // wave that finishes the last job of a block releases it (gen).  Returns whether a job was done.
-    auto take_job = [&](d4* acc, unsigned* obase, int* ty_out) -> bool {
+    auto take_job = [&]() -> bool {
         for (int b = 0; b < nbuf; ++b) {
             if (__hip_atomic_load(&job[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= nty)
                 continue;
@@ -523,7 +509,7 @@ void half_transform_fused_kernel(const double* __restrict__ g, const double* __r
             asm volatile("" ::: "memory");
             const int k = __builtin_amdgcn_readfirstlane(
                 __hip_atomic_load(&tsk[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            *acc = do_tile(k, b, j, obase, ty_out);
+            do_tile(k, b, j);
             asm volatile("" ::: "memory");
             int d = 0;
             if (lane == 0)
@@ -559,67 +545,67 @@ void half_transform_fused_kernel(const double* __restrict__ g, const double* __r
 #pragma unroll
             for (int i = 0; i < 4; ++i) jt = mfma_f64(cfr[NP * 8 + i], xt[i], jt);
         }
-        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-        unsigned obase = t3_bytes;
-        int ty = -1;
-        if (a.k < ntask) {                            // (else: padding position of the unrolled loop)
-            const int b = a.k % nbuf, need = a.k / nbuf;
-            // the block is free once the previous task in it has been consumed
-            while (__hip_atomic_load(&gen[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
-                __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");
-            double* row = blk + ((size_t)b * QR + a.qi) * ldb;
+        if (a.k >= ntask) return;                     // padding position of the unrolled loop
+        const int b = a.k % nbuf, need = a.k / nbuf;
+        // The block is free once the previous task in it has been consumed.  If it is not (this wave
+        // ran a whole ring ahead), help consuming: that rules out a deadlock (the oldest unconsumed
+        // task can always complete: its arrivals are never blocked, and every waiting wave takes
+        // its jobs).
+        while (__hip_atomic_load(&gen[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+            if (!take_job()) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        double* row = blk + ((size_t)b * QR + a.qi) * ldb;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                double* dst = tile_off[i] >= 0 ? row + tile_off[i] : dump + lane;
-                *dst = jt[i];
-            }
-            asm volatile("" ::: "memory");
-            int old = 0;
-            if (lane == 0)
-                old = __hip_atomic_fetch_add(&cnt[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            old = __builtin_amdgcn_readfirstlane(old);
-            asm volatile("" ::: "memory");
-            if (old == qc - 1 && lane == 0) {         // block complete: open its tile jobs
-                __hip_atomic_store(&cnt[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(&tsk[b], a.k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(&done[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                asm volatile("" ::: "memory");
-                __hip_atomic_store(&job[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            asm volatile("" ::: "memory");
-            take_job(&acc, &obase, &ty);
+        for (int i = 0; i < 4; ++i) {
+            double* dst = tile_off[i] >= 0 ? row + tile_off[i] : dump + lane;
+            *dst = jt[i];
         }
-        store_tile(acc, obase, ty);                   // always 4 store instructions
+        asm volatile("" ::: "memory");
+        int old = 0;
+        if (lane == 0)
+            old = __hip_atomic_fetch_add(&cnt[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        old = __builtin_amdgcn_readfirstlane(old);
+        asm volatile("" ::: "memory");
+        if (old == qc - 1 && lane == 0) {             // block complete: open its tile jobs
+            __hip_atomic_store(&cnt[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&tsk[b], a.k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&done[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
+            __hip_atomic_store(&job[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        asm volatile("" ::: "memory");
+        take_job();
     };
 
-    d2u ap0[NPA][KCH], ap1[NPA][KCH];
-    double as0[KCH], as1[KCH];
-    // Straight-line loop body (no exit test between an issue and its use: the optimiser sinks
-    // loads below such a test, which serialises them with the MFMAs).  An odd position count
-    // costs one idle MFMA pass on dropped loads.
-    Pos p0{wave / qc, wave % qc};
-    issue(p0, ap0, as0);
-    store_tile(d4{0.0, 0.0, 0.0, 0.0}, t3_bytes, -1);   // same VMEM sequence as a loop iteration leaves
-    for (int it = 0; it < n_mine; it += 2) {
-        const Pos p1 = advance(p0);
-        issue(p1, ap1, as1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(p0, ap0, as0);
-        __builtin_amdgcn_sched_barrier(0);
-        const Pos p2 = advance(p1);
-        issue(p2, ap0, as0);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(p1, ap1, as1);
-        __builtin_amdgcn_sched_barrier(0);
-        p0 = p2;
+    if (n_mine > 0) {
+        d2u ap0[NPA][KCH], ap1[NPA][KCH];
+        double as0[KCH], as1[KCH];
+        // Straight-line loop body (no exit test between an issue and its use: the optimiser sinks
+        // loads below such a test, which serialises them with the MFMAs), and no VMEM store in it
+        // (T3 is staged in LDS): the only VMEM traffic of the loop is the g_ao stream.  An odd
+        // position count costs one idle MFMA pass on dropped loads.
+        Pos p0{wave / qc, wave % qc};
+        issue(p0, ap0, as0);
+        for (int it = 0; it < n_mine; it += 2) {
+            const Pos p1 = advance(p0);
+            issue(p1, ap1, as1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(p0, ap0, as0);
+            __builtin_amdgcn_sched_barrier(0);
+            const Pos p2 = advance(p1);
+            issue(p2, ap0, as0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(p1, ap1, as1);
+            __builtin_amdgcn_sched_barrier(0);
+            p0 = p2;
+        }
+        while (take_job()) {}   // blocks opened by this wave's last arrivals
     }
-    for (;;) {   // blocks opened by this wave's last arrivals
-        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-        unsigned obase = t3_bytes;
-        int ty = -1;
-        if (!take_job(&acc, &obase, &ty)) break;
-        store_tile(acc, obase, ty);
+    // every job has been run by a wave that is now past this point: the staged T3 is complete
+    __syncthreads();
+    for (int e = tid; e < ntask * M * M2; e += HALF_WAVES * 64) {
+        const int k = e / (M * M2), idx = e - k * (M * M2);
+        T3[(size_t)(bx + k * W) * M * M2 + idx] = stg[e];
     }
 }
 
@@ -1143,19 +1129,27 @@ static bool fused_plan(int N, int M, int batch, FusedPlan* fp)
     const int QR = (qc + 3) & ~3, CR = (nchunk - 1) * qc + QR;
     int ldb = (int)((m2 + 15) / 16 * 16);
     if (ldb % 32 == 0) ldb += 16;                  // rows lq, lq+1 of a B fragment in different bank halves
-    const size_t fixed = ((size_t)CR * 16 + 64) * sizeof(double) + 64;   // + 5 counters per ring block
+    const size_t fixed = ((size_t)CR * 16 + 64 + 8) * sizeof(double);   // C copy, sink, 5 counters per block
     const size_t block = (size_t)QR * ldb * sizeof(double);
-    long nbuf = (long)((160 * 1024 - fixed) / block);
-    if (nbuf < 2) return false;
-    if (nbuf > 3) nbuf = 3;
+    const size_t task_stage = (size_t)m3 * sizeof(double);            // T3 rows of one task
+    const long Tg = (long)nchunk * N;
     long wpg = target < 1 ? 1 : target;
-    if (wpg > (long)nchunk * N) wpg = (long)nchunk * N;
+    if (wpg > Tg) wpg = Tg;
+    // ring of 2-3 blocks + the T3 stage of the workgroup's ceil(Tg/wpg) tasks must fit in LDS;
+    // more workgroups per geometry (fewer tasks each) if they do not
+    const size_t lds_cap = 160 * 1024;
+    if (fixed + 2 * block + task_stage > lds_cap) return false;
+    const long max_tasks = (long)((lds_cap - fixed - 2 * block) / task_stage);
+    if ((Tg + wpg - 1) / wpg > max_tasks) wpg = (Tg + max_tasks - 1) / max_tasks;
+    const long ntask = (Tg + wpg - 1) / wpg;
+    long nbuf = (long)((lds_cap - fixed - (size_t)ntask * task_stage) / block);
+    if (nbuf > 3) nbuf = 3;
     fp->nchunk = nchunk;
     fp->qc = qc;
     fp->nbuf = (int)nbuf;
     fp->ldb = ldb;
     fp->wpg = (int)wpg;
-    fp->lds_bytes = fixed + (size_t)nbuf * block;
+    fp->lds_bytes = fixed + (size_t)nbuf * block + (size_t)ntask * task_stage;
     return true;
 }
 

@@ -271,7 +271,7 @@ def main():
     kern_by = ops.profile_end()[2]
     kern_s = kern_total_ms * 1e-3 / kern_count if kern_count else float("nan")
     M = batch._n_occ + NCAS
-    bytes_per_eval = 8.0 * NAO ** 4 + 8.0 * NAO ** 2 * M ** 2       # g_ao read once + T2 written
+    bytes_per_eval = 8.0 * NAO ** 4 + 8.0 * NAO * M ** 3            # g_ao read once + T3 written
     alg_bytes = bytes_per_eval * args.steps / max(kern_count, 1)   # per launch (batched)
     achieved = alg_bytes / kern_s / 1e9
     # HBM traffic of that kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 [gfx950 correction] +
@@ -310,7 +310,8 @@ def main():
             "parallelism": f"geometry-sharded x{world}, one all_gather at the end",
         },
         "roofline": {
-            "kernel": "half_transform_kernel<1,11> (T2[p,q,y,z] = sum_rs C[r,y] g[p,q,r,s] C[s,z])",
+            "kernel": ("half_transform_fused_kernel<11,3> (T3[p,x,y,z] = sum_q C[q,x] "
+                       "sum_rs C[r,y] g[p,q,r,s] C[s,z])"),
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
