@@ -1110,9 +1110,15 @@ static int device_cu_count()
 static bool fused_plan(int N, int M, int batch, FusedPlan* fp)
 {
     if (M > 16 || N > 48 || N < 1) return false;
-    static const long chunks_env = getenv("OOVQE_FUSED_CHUNKS") ? atol(getenv("OOVQE_FUSED_CHUNKS")) : 0;
+    // test hooks: OOVQE_FUSED_CHUNKS=n forces n chunks of the q range (and the fused path)
+    const char* ce = getenv("OOVQE_FUSED_CHUNKS");   // read per call so that tests can switch it
+    const long chunks_env = ce ? atol(ce) : 0;
     const long m2 = (long)M * M, m3 = m2 * M;
     const int n_cu = device_cu_count();
+    // The persistent kernel pays off once the sweep is bandwidth-bound (>= ~6 slabs per wave on
+    // every CU); below that the one-slab-per-wave T2 kernels have the shorter latency
+    // (measured crossover at N = 43: 7-8 geometries).
+    if (chunks_env <= 0 && (long)batch * N * N < 48L * n_cu) return false;
     // tasks (chunk, p) per geometry: about one workgroup's worth per CU when geometries are few
     long target = n_cu / batch;
     long nchunk0 = chunks_env > 0 ? chunks_env : target / N;
@@ -1274,7 +1280,7 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
     int rc;
     // fused path: T3 = stage 1 + q -> x in one kernel, then the small p -> n contraction gives
     // g_mo[n,x,y,z] directly; T2 path (M > 16 or N > 48): T2, U = C^T T2, q -> x in the column kernel
-    static const bool unfused_env = getenv("OOVQE_CAS_UNFUSED") != nullptr;
+    const bool unfused_env = getenv("OOVQE_CAS_UNFUSED") != nullptr;   // test hook, read per call
     FusedPlan fp;
     const bool fused = !unfused_env && fused_plan(N, M, batch, &fp);
     const double* Gm_in = nullptr;

@@ -16,11 +16,16 @@ constexpr int LDS_STATE_MAX = 8192;   // amplitudes kept in LDS (64 KiB); larger
 __device__ __forceinline__ uint32_t deposit(uint32_t t, const oovqe_gate_t& g)
 {
     // insert zero bits at the (ascending) positions g.pos[0..nfix)
+    // (fixed trip count with constant indices: a runtime index into g.pos would put the gate in
+    // scratch memory)
     uint32_t x = t;
-    for (int i = 0; i < g.nfix; ++i) {
-        const uint32_t p = (uint32_t)g.pos[i];
-        const uint32_t low = x & ((1u << p) - 1u);
-        x = ((x >> p) << (p + 1)) | low;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < g.nfix) {
+            const uint32_t p = (uint32_t)g.pos[i];
+            const uint32_t low = x & ((1u << p) - 1u);
+            x = ((x >> p) << (p + 1)) | low;
+        }
     }
     return x;
 }

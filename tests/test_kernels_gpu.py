@@ -226,11 +226,18 @@ def test_cas_pipeline_vs_oracle(N, seed):
     assert (res["gvec"].cpu()[0] - gv_ref).abs().max() < 1e-10
 
 
+@pytest.mark.parametrize("path", ["auto", "t3x1", "t3x3", "t3x6", "t2"])
 @pytest.mark.parametrize("N,seed,nelec,ncas,nelecas", [(13, 20261, 16, 3, 4), (43, 20262, 16, 3, 4),
-                                                     (20, 7, 8, 2, 2), (16, 9, 4, 4, 4)])
-def test_cas_eval_fused_matches_staged_and_oracle(N, seed, nelec, ncas, nelecas):
+                                                     (20, 7, 8, 2, 2), (16, 9, 4, 4, 4),
+                                                     (27, 11, 8, 3, 2), (47, 12, 10, 3, 4)])
+def test_cas_eval_fused_matches_staged_and_oracle(N, seed, nelec, ncas, nelecas, path, monkeypatch):
     """oovqe_cas_eval (4 launches, column kernel) against the staged kernels and the oracle, with
-    a stack of RDM sets (set 0 = RDMs, sets >= 1 = arbitrary 'derivative' RDMs)."""
+    a stack of RDM sets (set 0 = RDMs, sets >= 1 = arbitrary 'derivative' RDMs).  `path` forces the
+    persistent T3 kernel with 1/3/6 chunks of the q range, or the T2 kernels (library test hooks)."""
+    if path.startswith("t3x"):
+        monkeypatch.setenv("OOVQE_FUSED_CHUNKS", path[3:])
+    elif path == "t2":
+        monkeypatch.setenv("OOVQE_CAS_UNFUSED", "1")
     P = R.synthetic_problem(N, seed)
     mol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec)
     pqc = R.OraclePQC(ncas, nelecas, "ucc")
