@@ -62,3 +62,57 @@ class Moldata:
                     "Moldata has no RHF engine: pass mo_coeff=... to Moldata, or oao_mo_coeff=... "
                     "to OO_energy / OO_pqc")
             self.hf = SimpleNamespace(mo_coeff=self._mo_coeff0)
+
+    # ---- real-molecule inputs -----------------------------------
+    NPZ_KEYS = ("int1e_ao", "int2e_ao", "overlap", "nuc", "nelectron")
+
+    def save_npz(self, path):
+        """Write the arrays this container holds to ``path`` (numpy .npz, fp64)."""
+        extra = {} if self._mo_coeff0 is None else {"mo_coeff": self._mo_coeff0}
+        np.savez(path, int1e_ao=self.int1e_ao, int2e_ao=self.int2e_ao, overlap=self.overlap,
+                 nuc=np.float64(self.nuc), nelectron=np.int64(self.nelectron), **extra)
+
+    @classmethod
+    def from_npz(cls, path):
+        """Molecule from integrals produced elsewhere, e.g. with PySCF on a machine that has it
+        (the quantities of moldata_pyscf.py:28-35, see ``tools/export_pyscf_npz.py``):
+        ``int1e_ao`` = int1e_kin + int1e_nuc, ``int2e_ao`` = int2e (full [N,N,N,N], chemist order),
+        ``overlap`` = int1e_ovlp, ``nuc`` = energy_nuc(), ``nelectron``; optional ``mo_coeff``
+        (RHF orbitals).  An 8-fold packed ``int2e_ao`` of length npair*(npair+1)/2 is unpacked."""
+        with np.load(path) as data:
+            missing = [k for k in cls.NPZ_KEYS if k not in data]
+            if missing:
+                raise KeyError(f"{path}: missing arrays {missing}; expected {cls.NPZ_KEYS}")
+            overlap = np.asarray(data["overlap"], dtype=np.float64)
+            n = overlap.shape[0]
+            g = np.asarray(data["int2e_ao"], dtype=np.float64)
+            if g.ndim == 1:
+                g = unpack_eri_s8(g, n)
+            elif g.shape != (n, n, n, n):
+                raise ValueError(f"{path}: int2e_ao has shape {g.shape}, expected {(n, n, n, n)} or "
+                                 "the 8-fold packed vector")
+            mo = np.asarray(data["mo_coeff"], dtype=np.float64) if "mo_coeff" in data else None
+            return cls(data["int1e_ao"], g, overlap, float(data["nuc"]), int(data["nelectron"]),
+                       mo_coeff=mo)
+
+
+def unpack_eri_s8(packed, n):
+    """8-fold symmetric two-electron integrals (lower-triangular pairs of lower-triangular pairs,
+    the layout of PySCF's ``aosym='s8'``) -> full [n,n,n,n] chemist-order tensor."""
+    npair = n * (n + 1) // 2
+    packed = np.asarray(packed, dtype=np.float64)
+    if packed.shape != (npair * (npair + 1) // 2,):
+        raise ValueError(f"packed ERI has {packed.shape[0]} elements, expected "
+                         f"{npair * (npair + 1) // 2} for n = {n}")
+    tri = np.zeros((npair, npair))
+    ij = np.tril_indices(npair)
+    tri[ij] = packed
+    tri = tri + tri.T - np.diag(np.diag(tri))
+    pq = np.tril_indices(n)
+    full = np.zeros((n, n, npair))
+    full[pq[0], pq[1], :] = tri
+    full[pq[1], pq[0], :] = tri
+    out = np.zeros((n, n, n, n))
+    out[:, :, pq[0], pq[1]] = full
+    out[:, :, pq[1], pq[0]] = full
+    return out

@@ -48,7 +48,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=25600)
     ap.add_argument("--warmup", type=int, default=640)
-    ap.add_argument("--geoms", type=int, default=N_GEOM)
+    ap.add_argument("--geoms", type=int, default=N_GEOM,
+                    help="molecular geometries PER GPU (weak scaling: the job holds geoms x n_gpus)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-transform", action="store_true")
     ap.add_argument("--no-berry", action="store_true",
@@ -217,7 +218,9 @@ def main():
     from auto_oo_amd import ops
     from auto_oo_amd.parallel import shard_geometries, gather_results
 
-    my_geoms = shard_geometries(args.geoms, rank, world)
+    # weak scaling: every GPU owns args.geoms geometries; geometry g of the job lives on rank g mod world
+    n_geom_total = args.geoms * world
+    my_geoms = shard_geometries(n_geom_total, rank, world)
     pqc, batch, single, thetas = build_geometries(my_geoms)
     G = batch.G
     n_out = 1 + batch.n_theta + batch.n_kappa
@@ -240,7 +243,7 @@ def main():
     while time.perf_counter() - t_prime < args.prime_seconds:
         run(8 * G)
         torch.cuda.synchronize()
-    gather_results(results, my_geoms, args.geoms, dist)
+    gather_results(results, my_geoms, n_geom_total, dist)
     run(args.warmup)
     torch.cuda.synchronize()
     if dist is not None:
@@ -250,7 +253,7 @@ def main():
     t0 = time.perf_counter()
     n_calls = run(args.steps)
     t_submit = time.perf_counter() - t0                              # host time to enqueue everything
-    gathered = gather_results(results, my_geoms, args.geoms, dist)   # the one exchange step
+    gathered = gather_results(results, my_geoms, n_geom_total, dist)   # the one exchange step
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -302,8 +305,8 @@ def main():
         "config": {
             "workload": (f"configs[1] shape: N={NAO} AOs, n_occ=6, CAS(4e,3o), UCCD n_theta=4, "
                          f"n_kappa={batch.n_kappa}; one energy + full-gradient evaluation per "
-                         f"step; {args.geoms} synthetic geometries sharded g mod n_gpus, evaluated "
-                         f"in batched calls of up to {G} geometries"),
+                         f"step; {n_geom_total} synthetic geometries ({args.geoms} per GPU, geometry g "
+                         f"on rank g mod n_gpus), evaluated in batched calls of up to {G} geometries"),
             "geometries_per_rank": G,
             "batched_calls": n_calls,
             "host_submit_us_per_call": t_submit / max(n_calls, 1) * 1e6,
@@ -338,7 +341,7 @@ def main():
         torch.cuda.synchronize()
         out["single_eval_us"] = (time.perf_counter() - t1) / 500 * 1e6
     if not args.no_berry:
-        berry = berry_loop_extra(my_geoms, args.geoms, dist, world, args.backend)
+        berry = berry_loop_extra(my_geoms, n_geom_total, dist, world, args.backend)
         if rank == 0:
             out["berry_loop"] = berry
     if rank == 0:

@@ -119,3 +119,31 @@ def test_gatefabric_table_reproduces_reference_states(case):
 def test_gatefabric_redundant_idx_matches_oracle():
     for ncas, ne in [(2, 2), (3, 4), (3, 2), (4, 4), (5, 6), (6, 6)]:
         assert X.gatefabric_redundant_idx(ncas, ne) == R.gatefabric_redundant_idx(ncas, ne)
+
+
+def test_moldata_npz_roundtrip_and_packed_eri(tmp_path):
+    """Moldata.from_npz: full and 8-fold packed two-electron tensors."""
+    from auto_oo_amd.moldata import Moldata, unpack_eri_s8
+    P = R.synthetic_problem(6, 77)
+    n = 6
+    mol = Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], 4,
+                  mo_coeff=np.asarray(P["oao_mo_coeff"]))
+    mol.save_npz(tmp_path / "m.npz")
+    back = Moldata.from_npz(tmp_path / "m.npz")
+    for key in ("int1e_ao", "int2e_ao", "overlap", "oao_coeff"):
+        assert np.array_equal(getattr(back, key), getattr(mol, key)), key
+    assert back.nuc == mol.nuc and back.nelectron == 4 and back.nao == n
+    back.run_rhf()
+    assert np.array_equal(back.hf.mo_coeff, np.asarray(P["oao_mo_coeff"]))
+    # 8-fold packing: pairs (p>=q), then pairs of pairs (pq >= rs)
+    g = np.asarray(P["int2e_ao"])
+    pq = np.tril_indices(n)
+    sq = g[pq[0], pq[1]][:, pq[0], pq[1]]
+    packed = sq[np.tril_indices(sq.shape[0])]
+    assert np.abs(unpack_eri_s8(packed, n) - g).max() < 1e-15   # g is symmetric to rounding only
+    np.savez(tmp_path / "p.npz", int1e_ao=mol.int1e_ao, int2e_ao=packed, overlap=mol.overlap,
+             nuc=mol.nuc, nelectron=4)
+    assert np.abs(Moldata.from_npz(tmp_path / "p.npz").int2e_ao - g).max() < 1e-15
+    with pytest.raises(KeyError):
+        np.savez(tmp_path / "bad.npz", overlap=mol.overlap)
+        Moldata.from_npz(tmp_path / "bad.npz")
