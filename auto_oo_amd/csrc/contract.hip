@@ -17,6 +17,9 @@
 //     in K-chunks of 20 rows, double buffered (global->VGPR prefetch during the MFMAs of the
 //     previous chunk), row pitch 16*(NT|1) doubles so that the ds_read_b64 fragment reads of
 //     the two 32-lane halves land on disjoint banks;
+//   * every global load goes through a buffer descriptor (32-bit lane offset + SGPR base, range
+//     check instead of clamps and masks): measured on the N = 200 transform, the address
+//     arithmetic, clamps and masks of flat loads cost 8 % of the run time (52 -> 56 TFLOP/s);
 //   * f64 MFMA issues one 16x16x4 every 64 cycles per SIMD, so per 13 MFMAs (832 cycles) a wave
 //     needs 1 global load + 13 LDS reads: the kernel is MFMA-bound by construction.
 #include "common.h"
@@ -58,37 +61,44 @@ void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm
     // items: while the last K-chunk of item i is in the MFMA pipe, chunk 0 of item i+1 is already
     // being fetched, so neither the workgroup launch nor the first HBM round trip of an item is
     // ever exposed.
+    // T and Cm are read through buffer descriptors: a 32-bit per-lane byte offset (constant for
+    // the whole item) plus a wave-uniform base kept in SGPRs, instead of one 64-bit VGPR address
+    // per load (the address arithmetic of the flat loads, ~170 VALU instructions per chunk, and
+    // their clamps / masks cost a quarter of the MFMA issue slots).  Anything outside the tensor
+    // gets an out-of-range offset: the range check drops the load and returns 0.
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    const long t_elems = LAST ? A * (long)K : A * (long)K * B;
     struct Strip {
-        const double* tp;   // base of this lane's T column / row (clamped to a valid address)
+        long tb;        // element index of T[a, 0, 16 bt] (INNER) / T[a, 0] (LAST): wave-uniform
         long a, bcol;
+        unsigned tvo;   // this lane's byte offset inside a k-step block, or OOB
         bool active;
     };
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto decode = [&](long group) -> Strip {
         Strip st;
-        const long item = group * NWAVES + wave;
+        const long item = group * NWAVES + wave_u;
         st.active = group < n_groups && item < n_items;
         st.a = 0;
         st.bcol = 0;
-        long tbase = 0;
+        st.tb = 0;
         bool tvalid = false;
         if (LAST) {
             st.a = item * 16;
-            const long row = st.a + lr;
-            tvalid = st.active && row < A;
-            tbase = row * (long)K;
+            tvalid = st.active && st.a + lr < A;
+            st.tb = st.a * (long)K;
+            st.tvo = tvalid ? (unsigned)((lr * (long)K + lq) * sizeof(double)) : OOB;
         } else {
-            // 32-bit division (n_items < 2^31 is checked on the host): the 64-bit one costs ~40
-            // live VGPRs at this point and pushes the NT = 13 instantiation into scratch
+            // 32-bit division (n_items < 2^31 is checked on the host)
             const unsigned ai = (unsigned)item / (unsigned)nbt;
             st.a = ai;
             const long bt = (long)((unsigned)item - ai * (unsigned)nbt);
             st.bcol = bt * 16 + lr;
             tvalid = st.active && st.bcol < B;
-            tbase = st.a * (long)K * B + st.bcol;
+            st.tb = st.a * (long)K * B + bt * 16;
+            st.tvo = tvalid ? (unsigned)((lq * B + lr) * sizeof(double)) : OOB;
         }
-        // T needs no mask: a lane outside the tensor only feeds output columns / rows that are
-        // never stored, and rows k >= K meet zero rows of Cm; its address is clamped to T[0].
-        st.tp = T + (tvalid ? tbase : 0);
+        if (!st.active) st.tb = 0;
         return st;
     };
     const long tstride = LAST ? 1 : B;
@@ -100,55 +110,42 @@ void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm
     double creg[CREG];
     double tcur[KSTEPS], tnext[KSTEPS];
 
-    // Every global load is unconditional on a clamped (always in-bounds) address and lives in the
-    // same basic block as its use: nothing for the compiler to sink behind a branch, so the loads
-    // of a chunk stay in flight together and vmcnt is counted, not drained.  Masks are
-    // multiplicative (a select on a loaded value is turned back into a branch around the load).
-    //
-    // Address arithmetic is kept out of the MFMA stream as far as possible (measured: ~170 VALU
-    // instructions per chunk, issued in one burst next to the 13 MFMAs of k-step 0, cost ~12 % of
-    // the matrix pipe): the per-thread staging geometry (row kk, clamped column) is computed once
-    // per workgroup and packed into one register per element; full chunks (kbase + KC <= K) take
-    // a clamp-free path that only adds the chunk offset.
-    int cgeo[CREG];          // kk | (clamped column offset << 8) | (column valid << 31)
+    // Staging geometry of Cm, once per workgroup: byte offset of this thread's i-th element inside
+    // a chunk (row kk, column j0 + jj), OOB for padding columns / rows; the chunk's first row is
+    // added as a scalar offset and rows k >= K fall outside the descriptor (-> 0, the zero padding
+    // the MFMAs rely on).
+    unsigned cvo[CREG];
 #pragma unroll
     for (int i = 0; i < CREG; ++i) {
         const int idx = tid + i * NTHREADS;
         const int kk = idx / LDJ, jj = idx - kk * LDJ;
         const int j = j0 + jj;
         const bool jok = kk < KC && jj < NT * 16 && j < J;
-        cgeo[i] = (kk < KC ? kk : KC - 1) | ((j < J ? j : J - 1) << 8) | (jok ? (1 << 31) : 0);
+        cvo[i] = jok ? (unsigned)((kk * (long)ldc + j) * sizeof(double)) : OOB;
     }
+    const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double*>(Cm), 0, (int)((long)K * ldc * sizeof(double)), 0x00020000);
     auto stage_load = [&](int kbase) {
-        const bool full = kbase + KC <= K;
+        const unsigned so = (unsigned)((long)kbase * ldc * sizeof(double));
 #pragma unroll
-        for (int i = 0; i < CREG; ++i) {
-            const int kk = cgeo[i] & 0xff, jc = (cgeo[i] >> 8) & 0x7fffff;
-            int k = kbase + kk;
-            if (!full) k = k < K ? k : K - 1;
-            creg[i] = Cm[(long)k * ldc + jc];
-        }
+        for (int i = 0; i < CREG; ++i)
+            creg[i] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc_c, cvo[i], so, 0));
     };
-    auto stage_store = [&](int kbase, double* buf) {
+    auto stage_store = [&](double* buf) {
 #pragma unroll
-        for (int i = 0; i < CREG; ++i) {
-            const int idx = tid + i * NTHREADS;
-            const bool ok = cgeo[i] < 0 && (kbase + (cgeo[i] & 0xff)) < K;
-            buf[idx] = creg[i] * (ok ? 1.0 : 0.0);
-        }
+        for (int i = 0; i < CREG; ++i) buf[tid + i * NTHREADS] = creg[i];
     };
-    const long ts4 = 4 * tstride;
-    auto load_t = [&](const double* tp, int kbase, double* dst) {
-        if (kbase + KC <= K) {
-            const double* q = tp + (long)(kbase + lq) * tstride;
+    // k-step s of a chunk: lane (lq, lr) reads T[.., kbase + 4s + lq, ..]; the descriptor is rebased
+    // per k-step (T can be larger than the 4 GB a descriptor spans) and ends where T ends
+    auto load_t = [&](const Strip& st, int kbase, double* dst) {
 #pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) dst[s] = q[(long)s * ts4];
-        } else {
-#pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) {
-                const int k = kbase + s * 4 + lq;
-                dst[s] = tp[(long)(k < K ? k : K - 1) * tstride];
-            }
+        for (int s2 = 0; s2 < KSTEPS; ++s2) {
+            const long e0 = st.tb + (long)(kbase + 4 * s2) * tstride;   // wave-uniform
+            long rem = (t_elems - e0) * (long)sizeof(double);
+            rem = rem < 0 ? 0 : (rem > 0xFFFFFFFFL ? 0xFFFFFFFFL : rem);
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<double*>(T) + e0, 0, (int)(unsigned)rem, 0x00020000);
+            dst[s2] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, st.tvo, 0, 0));
         }
     };
 
@@ -156,8 +153,8 @@ void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm
     long group = blockIdx.x;
     Strip cur = decode(group);
     stage_load(0);
-    load_t(cur.tp, 0, tcur);
-    stage_store(0, lds);
+    load_t(cur, 0, tcur);
+    stage_store(lds);
     __syncthreads();
     int par = 0;   // LDS buffer holding the chunk being consumed
 
@@ -168,7 +165,7 @@ void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm
             const bool last = (c + 1 == nchunks);
             // next chunk in the pipeline: chunk c+1 of this item, or chunk 0 of the next item
             const int knext = last ? 0 : kbase + KC;
-            const double* tpn = last ? nxt.tp : cur.tp;
+            const Strip& stn = last ? nxt : cur;
             // One straight-line code path for every chunk (rows k >= K of the staged Cm are zero,
             // so the padded k-steps of the last chunk add nothing).  The Cm fragments of k-step
             // s+1 are read from LDS while the MFMAs of k-step s issue (two-stage pipeline).  The
@@ -193,9 +190,9 @@ void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm
                                   : mfma_f64(cv[s & 1][t], tcur[s], acc[t]);
                 if (s == 0) {
                     stage_load(knext);
-                    load_t(tpn, knext, tnext);
+                    load_t(stn, knext, tnext);
                 }
-                if (s == KSTEPS - 1) stage_store(knext, lds + (par ^ 1) * BUF);
+                if (s == KSTEPS - 1) stage_store(lds + (par ^ 1) * BUF);
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();

@@ -1,0 +1,40 @@
+// Standalone timing of the K1 contraction kernel on the N=200 quarter transforms (tools only).
+#include "../auto_oo_amd/csrc/contract.hip"
+#include <vector>
+int main(int argc, char** argv)
+{
+    const int N = argc > 1 ? atoi(argv[1]) : 200;
+    const long n = N, n2 = n * n, n3 = n2 * n, n4 = n3 * n;
+    double *g, *w, *C;
+    (void)hipMalloc(&g, n4 * 8);
+    (void)hipMalloc(&w, n4 * 8);
+    (void)hipMalloc(&C, n2 * 8);
+    std::vector<double> h(1 << 20);
+    for (auto& x : h) x = rand() / (double)RAND_MAX - 0.5;
+    for (long off = 0; off + (long)h.size() <= n4; off += h.size())
+        (void)hipMemcpy(g + off, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+    (void)hipMemcpy(C, h.data(), n2 * 8, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    const char* names[4] = {"pi,pqrs->iqrs", "qj,iqrs->ijrs", "rk,ijrs->ijks", "sl,ijks->ijkl"};
+    for (int step = 0; step < 4; ++step) {
+        float best = 1e30f;
+        for (int r = 0; r < 4; ++r) {
+            (void)hipEventRecord(e0, 0);
+            int rc = 0;
+            if (step == 0) rc = oovqe_mode_contract_impl(g, C, w, 1, N, N, n3, N, 0, nullptr);
+            if (step == 1) rc = oovqe_mode_contract_impl(g, C, w, n, N, N, n2, N, 0, nullptr);
+            if (step == 2) rc = oovqe_mode_contract_impl(g, C, w, n2, N, N, n, N, 0, nullptr);
+            if (step == 3) rc = oovqe_mode_contract_impl(g, C, w, n3, N, N, 1, N, 1, nullptr);
+            (void)hipEventRecord(e1, 0);
+            (void)hipEventSynchronize(e1);
+            if (rc) { printf("error: %s\n", oovqe_last_error()); return 1; }
+            float ms;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best) best = ms;
+        }
+        printf("%s: %.2f ms = %.1f TFLOP/s\n", names[step], best, 2.0 * n4 * N / best / 1e9);
+    }
+    return 0;
+}
