@@ -147,3 +147,26 @@ def test_moldata_npz_roundtrip_and_packed_eri(tmp_path):
     with pytest.raises(KeyError):
         np.savez(tmp_path / "bad.npz", overlap=mol.overlap)
         Moldata.from_npz(tmp_path / "bad.npz")
+
+
+def test_newton_step_augmentation_matches_rediagonalisation():
+    """NewtonStep.newton_step shifts the eigenvalues of an indefinite Hessian instead of
+    diagonalising H + c*1 again (newton_raphson.py:107-128): same step to rounding."""
+    from auto_oo_amd.newton_raphson import NewtonStep
+    rng = np.random.default_rng(3)
+    n = 40
+    A = rng.standard_normal((n, n))
+    H = torch.tensor(A + A.T)                      # indefinite
+    g = torch.tensor(rng.standard_normal(n))
+    opt = NewtonStep(verbose=0)
+    dp, low = opt.newton_step(g, H)
+    v = torch.linalg.eigvalsh(H)
+    assert abs(low - v[0].item()) < 1e-12 and low < 0
+    c = opt.mu + opt.rho * abs(low)
+    v2, w2 = torch.linalg.eigh(H + c * torch.eye(n, dtype=torch.float64))
+    ref = -(w2 @ torch.diag(1 / v2) @ w2.T @ g)
+    assert (dp - ref).abs().max() < 1e-9 * ref.abs().max()
+    # positive definite: plain Newton step
+    Hp = H @ H + torch.eye(n, dtype=torch.float64)
+    dp2, low2 = opt.newton_step(g, Hp)
+    assert low2 > 0 and (Hp @ dp2 + g).abs().max() < 1e-9
