@@ -352,3 +352,41 @@ def test_half_transform_sizes(N, M):
     ref = torch.einsum("ry,pqrs,sz->pqyz", C[:, :M], g, C[:, :M])
     assert T2.shape == ref.shape
     assert (T2 - ref).abs().max() < 1e-11 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("path", ["t3x1", "t3x2", "t2"])
+@pytest.mark.parametrize("N,nelec,ncas,nelecas", [(43, 16, 8, 8), (30, 14, 10, 8), (24, 12, 6, 6)])
+def test_cas_eval_large_active_space_random_rdms(N, nelec, ncas, nelecas, path, monkeypatch):
+    """CAS path with M = n_occ + ncas up to 13 (config-5-like active spaces) on every transform
+    path; the kernels are linear in the RDMs, so random (unphysical) RDM sets exercise them fully.
+    Checked against the oracle's energy, CAS coefficients and analytic orbital gradient."""
+    if path.startswith("t3x"):
+        monkeypatch.setenv("OOVQE_FUSED_CHUNKS", path[3:])
+    else:
+        monkeypatch.setenv("OOVQE_CAS_UNFUSED", "1")
+    P = R.synthetic_problem(N, 500 + N)
+    mol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec)
+    oo = R.OracleOOEnergy(mol, ncas, nelecas, P["oao_mo_coeff"])
+    no = len(oo.occ_idx)
+    C = oo.mo_coeff
+    rng = np.random.default_rng(N)
+    nrdm = 2
+    gam = torch.stack([_rand(rng, ncas, ncas) for _ in range(nrdm)])
+    Gam = torch.stack([_rand(rng, ncas, ncas, ncas, ncas) for _ in range(nrdm)])
+    rows, cols = X.tril_tables(N, oo.params_idx)
+    res = ops.cas_eval(oo.int2e_ao.to(DEV).contiguous(), oo.int1e_ao.to(DEV).contiguous(),
+                       C.to(DEV).contiguous(), gam.to(DEV).contiguous(), Gam.to(DEV).contiguous(),
+                       oo.nuc, no, ncas, torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV),
+                       want_matrices=True, want_integrals=True)
+    c0r, c1r, c2r = oo.get_active_integrals(C)
+    g_mo = R.int2e_transform(oo.int2e_ao, C)
+    M = no + ncas
+    scale = float(g_mo.abs().max())
+    assert (res["Gm"].cpu() - g_mo[:, :M, :M, :M]).abs().max() < 1e-11 * max(1.0, scale)
+    assert abs(res["c0"].item() - float(c0r)) < 1e-9
+    assert (res["c1"].cpu() - c1r).abs().max() < 1e-10
+    assert (res["c2"].cpu() - c2r).abs().max() < 1e-10
+    E_ref = oo.energy_from_mo_coeff(C, gam[0], Gam[0])
+    assert abs(res["E"].item() - E_ref.item()) < 1e-8 * max(1.0, abs(E_ref.item()))
+    gv_ref = oo.kappa_matrix_to_vector(oo.analytic_gradient(gam[0], Gam[0]))
+    assert (res["gvec"].cpu()[0] - gv_ref).abs().max() < 1e-8 * max(1.0, float(gv_ref.abs().max()))
