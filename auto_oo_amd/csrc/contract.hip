@@ -287,6 +287,26 @@ int launch_group(int nt, const double* T, const double* Cm, double* out, long A,
     return OOVQE_ERR_ARG;
 }
 
+// Short contractions (K <= 48) with few tiles: the whole small matrix is ONE staged chunk
+// (KSTEPS = 12), so an item costs one barrier instead of four chunk rounds -- these launches are
+// latency-bound (p -> n step of an evaluation: 43 x 43 x 729 per geometry).
+template <bool LAST>
+int launch_short(int nt, const double* T, const double* Cm, double* out, long A, int K, int J, long B,
+                 int ldc, int ngroups, long n_items, int nbt, int batch, long t_bs, long c_bs, long o_bs,
+                 hipStream_t st)
+{
+    switch (nt) {
+#define OOVQE_CASE(n) \
+    case n:                                                                                    \
+        return launch_nt<n, LAST, 12>(T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, batch, t_bs, \
+                                      c_bs, o_bs, st);
+        OOVQE_CASE(1) OOVQE_CASE(2) OOVQE_CASE(3) OOVQE_CASE(4)
+#undef OOVQE_CASE
+    }
+    oovqe_set_error("mode_contract: bad tile count %d", nt);
+    return OOVQE_ERR_ARG;
+}
+
 }  // namespace
 
 int oovqe_mode_contract_batched(const double* T, const double* Cm, double* out, long A, int K, int J,
@@ -324,7 +344,13 @@ int oovqe_mode_contract_batched(const double* T, const double* Cm, double* out, 
     // small to fill 256 CUs with 8-wave workgroups.  The j-groups are grid.y of ONE launch.
     int nt = JT < 13 ? JT : 13;
     const long wgs = (n_items + NWAVES - 1) / NWAVES;
-    while (nt > 1 && wgs * ((JT + nt - 1) / nt) * batch < 512) nt = (nt + 1) / 2;
+    // (never past one resident round of workgroups, ~2 per CU: a second round doubles the latency of
+    // these short launches -- 17 -> 9 us for the p -> n step of a 64-geometry evaluation)
+    while (nt > 1 && wgs * ((JT + nt - 1) / nt) * batch < 512) {
+        const int nt2 = (nt + 1) / 2;
+        if (wgs * ((JT + nt2 - 1) / nt2) * batch > 512) break;
+        nt = nt2;
+    }
     const int ngroups = (JT + nt - 1) / nt;
     nt = (JT + ngroups - 1) / ngroups;   // even split
     OOVQE_REQUIRE(ngroups <= 65535, "mode_contract: J too large");
@@ -332,7 +358,12 @@ int oovqe_mode_contract_batched(const double* T, const double* Cm, double* out, 
     const int pad20 = ((K + 19) / 20) * 20, pad12 = ((K + 11) / 12) * 12;
     const bool deep = pad20 <= pad12 || pad20 * 100 <= K * 105;
     int rc;
-    if (deep)
+    if (K <= 48 && nt <= 4)
+        rc = last ? launch_short<true>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, batch, t_bs,
+                                       c_bs, o_bs, st)
+                  : launch_short<false>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, batch, t_bs,
+                                        c_bs, o_bs, st);
+    else if (deep)
         rc = last ? launch_group<true, 5>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, batch,
                                      t_bs, c_bs, o_bs, st)
                   : launch_group<false, 5>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, batch,

@@ -154,7 +154,7 @@ def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl"):
         el = float(tmax.item())
     return {"geometries": n_geom, "seconds": el, "geometries_per_s": n_geom / el,
             "per_geometry_ms": el / max(len(objs), 1) * 1e3, "hessian_dim": objs[0].n_kappa + pqc.theta_shape,
-            "scaling": "strong (fixed 64 geometries, sharded g mod n_gpus)",
+            "scaling": f"weak ({len(objs)} geometries per GPU, geometry g on rank g mod n_gpus)",
             "mean_energy_after_step": float(full.mean().item())}
 
 
