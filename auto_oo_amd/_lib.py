@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liboovqe_hip.so")
+LIB_PATH = os.environ.get("OOVQE_LIB_PATH") or os.path.join(_HERE, "lib", "liboovqe_hip.so")
 
 c_double_p = ctypes.c_void_p
 c_int32_p = ctypes.c_void_p

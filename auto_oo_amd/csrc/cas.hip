@@ -759,9 +759,8 @@ void fock_kernel(const double* __restrict__ Gm, const double* __restrict__ hmo,
 
 // ------------------------------------------------------------------------------------------
 // Fused stage 2b + 3 ("column" kernel): one workgroup per general index n.
-//   in : Gm_in[n,x,y,z] = g_mo[n,x,y,z] (fused path: T3 contracted p -> n), or
-//        U[n,q,y,z] = sum_p C[p,n] T2[p,q,y,z] (T2 path), then
-//        Gn[x,y,z] = sum_q C[q,x] U[n,q,y,z]     (= g_mo[n,x,y,z], kept in LDS, 8 M^3 bytes)
+//   in : U[n,q,y,z] = sum_p C[p,n] T2[p,q,y,z]   (from the K1 contraction kernel, T2 path)
+//   Gn[x,y,z] = sum_q C[q,x] U[n,q,y,z]          (= g_mo[n,x,y,z], kept in LDS, 8 M^3 bytes)
 //   hn[x]     = sum_q (sum_p C[p,n] h[p,q]) C[q,x]
 //   FI[n,x], and for every RDM set k the n-th COLUMN of the generalized Fock matrix
 //   (rows m < M only; virtual rows are zero), the per-n pieces of c0 / c1 / c2 and of the energy.
@@ -771,8 +770,7 @@ void fock_kernel(const double* __restrict__ Gm, const double* __restrict__ hmo,
 constexpr int COL_THREADS = 256;
 
 __global__ __launch_bounds__(COL_THREADS)
-void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ Gm_in,
-                       const double* __restrict__ h_ao,
+void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ h_ao,
                        const double* __restrict__ C, const double* __restrict__ gamma,
                        const double* __restrict__ Gamma, int nrdm, int N, int no, int na,
                        double* __restrict__ Fcol, double* __restrict__ Epart,
@@ -783,8 +781,8 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
     extern __shared__ double lds[];
     const int M = no + na, M2 = M * M, M3 = M2 * M;
     const int na2 = na * na, na3 = na2 * na, na4 = na2 * na2;
-    double* Un = lds;                    // [N][M2]  (absent when Gm_in supplies g_mo[n,x,y,z])
-    double* Cl = Un + (Gm_in ? 0 : (size_t)N * M2);   // [N][M]   C[:, :M]
+    double* Un = lds;                    // [N][M2]
+    double* Cl = Un + (size_t)N * M2;    // [N][M]   C[:, :M]
     double* Gn = Cl + (size_t)N * M;     // [M3]
     double* Wn = Gn + M3;                // [N]      (C^T h)[n, :]
     double* hn = Wn + N;                 // [M]
@@ -797,8 +795,7 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
     const int n = blockIdx.x;
     {   // blockIdx.y = geometry of a batch: every per-geometry array is stacked
         const size_t gi = blockIdx.y;
-        if (Gm_in) Gm_in += gi * (size_t)N * M3;
-        else U += gi * (size_t)N * N * M2;
+        U += gi * (size_t)N * N * M2;
         h_ao += gi * (size_t)N * N;
         C += gi * (size_t)N * N;
         gamma += gi * (size_t)nrdm * na2;
@@ -812,12 +809,8 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
         if (hmo_out) hmo_out += gi * (size_t)N * M;
     }
 
-    if (Gm_in) {
-        for (int idx = tid; idx < M3; idx += COL_THREADS) Gn[idx] = Gm_in[(size_t)n * M3 + idx];
-    } else {
-        const double* Usrc = U + (size_t)n * N * M2;
-        for (int idx = tid; idx < N * M2; idx += COL_THREADS) Un[idx] = Usrc[idx];
-    }
+    const double* Usrc = U + (size_t)n * N * M2;
+    for (int idx = tid; idx < N * M2; idx += COL_THREADS) Un[idx] = Usrc[idx];
     for (int idx = tid; idx < N * M; idx += COL_THREADS) {
         const int q = idx / M, x = idx - q * M;
         Cl[idx] = C[(size_t)q * N + x];
@@ -846,7 +839,7 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
     }
     // Gn[x,yz] = sum_q C[q,x] U[n,q,yz]: four outputs per thread share one q loop (independent
     // LDS reads in flight instead of one dependent chain per output)
-    for (int base = 0; base < (Gm_in ? 0 : M3); base += 4 * COL_THREADS) {
+    for (int base = 0; base < M3; base += 4 * COL_THREADS) {
         int xo[4], yo[4];
         bool ok[4];
 #pragma unroll
@@ -878,7 +871,7 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
         for (int i = 0; i < no; ++i) fi += 2.0 * Gn[tid * M2 + i * M + i] - Gn[i * M2 + i * M + tid];
         FIn[tid] = fi;
     }
-    if (Gm_out && Gm_out != Gm_in)
+    if (Gm_out)
         for (int idx = tid; idx < M3; idx += COL_THREADS) Gm_out[(size_t)n * M3 + idx] = Gn[idx];
     __syncthreads();
     if (hmo_out && tid < M) hmo_out[(size_t)n * M + tid] = hn[tid];
@@ -947,6 +940,205 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
                         for (int s2 = 0; s2 < na; ++s2)
                             acc += 0.5 * Gn[(no + q) * M2 + (no + r) * M + no + s2]
                                    * Gp[(q * na + r) * na + s2];
+            }
+            Epart[(size_t)(k0 + kl) * N + n] = acc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage 3 on panels ("panel" kernel, T3 path): one workgroup per npan consecutive general indices
+// n of one geometry, g_mo[n,x,y,z] supplied by the p -> n contraction (K1).  Same arithmetic, in
+// the same order per n, as cas_column_kernel; npan is chosen so that a batched call fills the chip
+// with one round of workgroups (a workgroup per n is 2752 small workgroups in ~1.5 rounds at 64
+// geometries) and C[:, :M], h_ao and the RDM sets are staged once per panel instead of once per n.
+// ------------------------------------------------------------------------------------------
+constexpr int PAN_THREADS = 512;
+
+__global__ __launch_bounds__(PAN_THREADS)
+void cas_panel_kernel(const double* __restrict__ Gm_in, const double* __restrict__ h_ao,
+                      const double* __restrict__ C, const double* __restrict__ gamma,
+                      const double* __restrict__ Gamma, int nrdm, int N, int no, int na, int npan,
+                      double* __restrict__ Fcol, double* __restrict__ Epart,
+                      double* __restrict__ Cpart, double* __restrict__ c1, double* __restrict__ c2,
+                      double* __restrict__ Gm_out, double* __restrict__ hmo_out, size_t out_stride,
+                      int rdm_chunk)
+{
+    extern __shared__ double lds[];
+    const int M = no + na, M2 = M * M, M3 = M2 * M;
+    const int na2 = na * na, na3 = na2 * na, na4 = na2 * na2;
+    double* Gp = lds;                          // [npan][M3]   g_mo[n0+nl, x, y, z]
+    double* Cl = Gp + (size_t)npan * M3;       // [N][M]       C[:, :M]
+    double* hl = Cl + (size_t)N * M;           // [N][N]       h_ao
+    double* cn = hl + (size_t)N * N;           // [npan][N]    C[:, n]
+    double* Wn = cn + (size_t)npan * N;        // [npan][N]    (C^T h)[n, :]
+    double* hn = Wn + (size_t)npan * N;        // [npan][M]
+    double* FIn = hn + (size_t)npan * M;       // [npan][M]
+    double* gml = FIn + (size_t)npan * M;      // [rdm_chunk][na2]
+    double* Gml = gml + (size_t)rdm_chunk * na2;   // [rdm_chunk][na4]
+    const int tid = threadIdx.x;
+    const int n0 = blockIdx.x * npan;
+    const int nn = (N - n0) < npan ? (N - n0) : npan;   // valid n in this panel
+    {   // blockIdx.y = geometry of a batch: every per-geometry array is stacked
+        const size_t gi = blockIdx.y;
+        Gm_in += gi * (size_t)N * M3;
+        h_ao += gi * (size_t)N * N;
+        C += gi * (size_t)N * N;
+        gamma += gi * (size_t)nrdm * na2;
+        Gamma += gi * (size_t)nrdm * na4;
+        Fcol += gi * (size_t)nrdm * M * N;
+        Epart += gi * (size_t)nrdm * N;
+        Cpart += gi * (size_t)N;
+        c1 += gi * out_stride;
+        c2 += gi * out_stride;
+        if (Gm_out) Gm_out += gi * (size_t)N * M3;
+        if (hmo_out) hmo_out += gi * (size_t)N * M;
+    }
+
+    // every global load first (straight-line, into registers), then every LDS store: a load/store
+    // loop per array would put one full memory latency per array in front of the barrier
+    // (N <= 48, M <= 16, npan <= 16 bound the trip counts of the small arrays)
+    {
+        constexpr int IT_C = 2, IT_H = 5, IT_N = 2;
+        double rc[IT_C], rh[IT_H], rn[IT_N];
+#pragma unroll
+        for (int it = 0; it < IT_C; ++it) {
+            const int idx = tid + it * PAN_THREADS, q = idx / M, x = idx - q * M;
+            rc[it] = idx < N * M ? C[(size_t)q * N + x] : 0.0;
+        }
+#pragma unroll
+        for (int it = 0; it < IT_H; ++it) {
+            const int idx = tid + it * PAN_THREADS;
+            rh[it] = idx < N * N ? h_ao[idx] : 0.0;
+        }
+#pragma unroll
+        for (int it = 0; it < IT_N; ++it) {
+            const int idx = tid + it * PAN_THREADS, nl = idx / N, p = idx - nl * N;
+            rn[it] = idx < nn * N ? C[(size_t)p * N + n0 + nl] : 0.0;
+        }
+        for (int idx = tid; idx < nn * M3; idx += PAN_THREADS) Gp[idx] = Gm_in[(size_t)n0 * M3 + idx];
+#pragma unroll
+        for (int it = 0; it < IT_C; ++it) {
+            const int idx = tid + it * PAN_THREADS;
+            if (idx < N * M) Cl[idx] = rc[it];
+        }
+#pragma unroll
+        for (int it = 0; it < IT_H; ++it) {
+            const int idx = tid + it * PAN_THREADS;
+            if (idx < N * N) hl[idx] = rh[it];
+        }
+#pragma unroll
+        for (int it = 0; it < IT_N; ++it) {
+            const int idx = tid + it * PAN_THREADS;
+            if (idx < nn * N) cn[idx] = rn[it];
+        }
+    }
+    __syncthreads();
+    // W[n,q] = sum_p C[p,n] h[p,q]
+    for (int idx = tid; idx < nn * N; idx += PAN_THREADS) {
+        const int nl = idx / N, q = idx - nl * N;
+        const double* cv = cn + (size_t)nl * N;
+        double a0 = 0.0, a1 = 0.0;
+        int p = 0;
+        for (; p + 1 < N; p += 2) {
+            a0 += cv[p] * hl[(size_t)p * N + q];
+            a1 += cv[p + 1] * hl[(size_t)(p + 1) * N + q];
+        }
+        if (p < N) a0 += cv[p] * hl[(size_t)p * N + q];
+        Wn[idx] = a0 + a1;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nn * M; idx += PAN_THREADS) {
+        const int nl = idx / M, x = idx - nl * M;
+        const double* Gn = Gp + (size_t)nl * M3;
+        double acc = 0.0;
+        for (int q = 0; q < N; ++q) acc += Wn[(size_t)nl * N + q] * Cl[q * M + x];
+        hn[idx] = acc;
+        double fi = acc;
+        for (int i = 0; i < no; ++i) fi += 2.0 * Gn[x * M2 + i * M + i] - Gn[i * M2 + i * M + x];
+        FIn[idx] = fi;
+    }
+    if (Gm_out && Gm_out != Gm_in)
+        for (int idx = tid; idx < nn * M3; idx += PAN_THREADS) Gm_out[(size_t)n0 * M3 + idx] = Gp[idx];
+    __syncthreads();
+    if (hmo_out)
+        for (int idx = tid; idx < nn * M; idx += PAN_THREADS) hmo_out[(size_t)n0 * M + idx] = hn[idx];
+
+    // per-n pieces of the CAS coefficients (independent of the RDM sets)
+    for (int nl = tid; nl < nn; nl += PAN_THREADS) {
+        const int n = n0 + nl;
+        Cpart[n] = n < no ? hn[nl * M + n] + FIn[nl * M + n] : 0.0;
+    }
+    for (int idx = tid; idx < nn * (na + na3); idx += PAN_THREADS) {
+        const int nl = idx / (na + na3), r0 = idx - nl * (na + na3);
+        const int n = n0 + nl;
+        if (n < no || n >= M) continue;
+        const int p = n - no;
+        if (r0 < na) {
+            c1[p * na + r0] = FIn[nl * M + no + r0];
+        } else {
+            int t = r0 - na;
+            const int i3 = t;
+            const int s = t % na; t /= na;
+            const int r = t % na; t /= na;
+            const int q = t;
+            c2[(size_t)p * na3 + i3] = 0.5 * Gp[(size_t)nl * M3 + (no + q) * M2 + (no + r) * M + no + s];
+        }
+    }
+
+    // RDM sets, rdm_chunk at a time through LDS
+    for (int k0 = 0; k0 < nrdm; k0 += rdm_chunk) {
+        const int kc = (nrdm - k0) < rdm_chunk ? (nrdm - k0) : rdm_chunk;
+        __syncthreads();
+        for (int idx = tid; idx < kc * na2; idx += PAN_THREADS) gml[idx] = gamma[(size_t)k0 * na2 + idx];
+        for (int idx = tid; idx < kc * na4; idx += PAN_THREADS) Gml[idx] = Gamma[(size_t)k0 * na4 + idx];
+        __syncthreads();
+        // Fock columns: one thread per (n, set k, row m)
+        for (int idx = tid; idx < nn * kc * M; idx += PAN_THREADS) {
+            const int nl = idx / (kc * M), r0 = idx - nl * (kc * M);
+            const int kl = r0 / M, m = r0 - kl * M, k = k0 + kl;
+            const double* Gn = Gp + (size_t)nl * M3;
+            const double* FIv = FIn + (size_t)nl * M;
+            const double* gam = gml + (size_t)kl * na2;
+            double val;
+            if (m < no) {
+                double fa = 0.0;
+                for (int v = 0; v < na; ++v)
+                    for (int w = 0; w < na; ++w) {
+                        const int V = no + v, W = no + w;
+                        fa += gam[v * na + w] * (Gn[m * M2 + V * M + W] - 0.5 * Gn[W * M2 + V * M + m]);
+                    }
+                val = 2.0 * ((k == 0 ? FIv[m] : 0.0) + fa);
+            } else {
+                const int v = m - no;
+                const double* Gv = Gml + (size_t)kl * na4 + (size_t)v * na3;
+                double acc = 0.0;
+                for (int w = 0; w < na; ++w) acc += FIv[no + w] * gam[v * na + w];
+                for (int w = 0; w < na; ++w)
+                    for (int x = 0; x < na; ++x)
+                        for (int y = 0; y < na; ++y)
+                            acc += Gv[(w * na + x) * na + y] * Gn[(no + w) * M2 + (no + x) * M + no + y];
+                val = acc;
+            }
+            Fcol[((size_t)k * M + m) * N + n0 + nl] = val;
+        }
+        // E_k contribution of row p = n - no (active n only), serial per (n, set): deterministic
+        for (int idx = tid; idx < nn * kc; idx += PAN_THREADS) {
+            const int nl = idx / kc, kl = idx - nl * kc;
+            const int n = n0 + nl;
+            double acc = 0.0;
+            if (n >= no && n < M) {
+                const int p = n - no;
+                const double* Gn = Gp + (size_t)nl * M3;
+                const double* FIv = FIn + (size_t)nl * M;
+                const double* gam = gml + (size_t)kl * na2 + (size_t)p * na;
+                const double* Gpq = Gml + (size_t)kl * na4 + (size_t)p * na3;
+                for (int q = 0; q < na; ++q) acc += FIv[no + q] * gam[q];
+                for (int q = 0; q < na; ++q)
+                    for (int r = 0; r < na; ++r)
+                        for (int s2 = 0; s2 < na; ++s2)
+                            acc += 0.5 * Gn[(no + q) * M2 + (no + r) * M + no + s2]
+                                   * Gpq[(q * na + r) * na + s2];
             }
             Epart[(size_t)(k0 + kl) * N + n] = acc;
         }
@@ -1308,30 +1500,63 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
         oovqe_profile_mark_stop(st);
     }
     const size_t na2 = (size_t)ncas * ncas;
-    const size_t base_bytes = ((fused ? 0 : (size_t)N * m2) + (size_t)N * M + m3 + N + M + M + N +
-                               (size_t)4 * N) * sizeof(double);
     const size_t set_bytes = (na2 + na2 * na2) * sizeof(double);
-    OOVQE_REQUIRE(base_bytes + set_bytes <= 160 * 1024, "cas_eval: N=%d M=%d needs %zu B of LDS", N, M,
-                  base_bytes + set_bytes);
-    int rdm_chunk = (int)((160 * 1024 - base_bytes) / set_bytes);
-    if (rdm_chunk > nrdm) rdm_chunk = nrdm;
-    const size_t lds_bytes = base_bytes + (size_t)rdm_chunk * set_bytes;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)cas_column_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            oovqe_set_error("cas_eval: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return OOVQE_ERR_HIP;
+    const size_t lds_cap = 160 * 1024;
+    if (fused) {
+        // panel kernel: npan general indices per workgroup, about one resident round of workgroups
+        const size_t fixed_bytes = ((size_t)N * M + (size_t)N * N) * sizeof(double);
+        const size_t per_n = ((size_t)m3 + 2 * (size_t)N + 2 * (size_t)M) * sizeof(double);
+        OOVQE_REQUIRE(fixed_bytes + per_n + set_bytes <= lds_cap, "cas_eval: N=%d M=%d needs %zu B of LDS",
+                      N, M, fixed_bytes + per_n + set_bytes);
+        long npan = ((long)N * batch + 383) / 384;
+        const long npan_max = (long)((lds_cap - fixed_bytes - set_bytes) / per_n);
+        if (npan > npan_max) npan = npan_max;
+        if (npan > 16) npan = 16;
+        if (npan < 1) npan = 1;
+        int rdm_chunk = (int)((lds_cap - fixed_bytes - (size_t)npan * per_n) / set_bytes);
+        if (rdm_chunk > nrdm) rdm_chunk = nrdm;
+        const size_t lds_bytes = fixed_bytes + (size_t)npan * per_n + (size_t)rdm_chunk * set_bytes;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute((const void*)cas_panel_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
+            if (e != hipSuccess) {
+                oovqe_set_error("cas_eval: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                return OOVQE_ERR_HIP;
+            }
+            attr_done = true;
         }
-        attr_done = true;
+        oovqe_profile_mark_start_l(st, 3);
+        hipLaunchKernelGGL(cas_panel_kernel, dim3((unsigned)((N + npan - 1) / npan), batch),
+                           dim3(PAN_THREADS), lds_bytes, st, Gm_in, h_ao, C, gamma, Gamma, nrdm, N, n_occ,
+                           ncas, (int)npan, Fcol, Epart, Cpart, c1, c2, Gm, hmo, out_stride, rdm_chunk);
+        oovqe_profile_mark_stop(st);
+        OOVQE_CHECK_LAUNCH("cas_eval/panel");
+    } else {
+        const size_t base_bytes = ((size_t)N * m2 + (size_t)N * M + m3 + N + M + M + N + (size_t)4 * N) *
+                                  sizeof(double);
+        OOVQE_REQUIRE(base_bytes + set_bytes <= lds_cap, "cas_eval: N=%d M=%d needs %zu B of LDS", N, M,
+                      base_bytes + set_bytes);
+        int rdm_chunk = (int)((lds_cap - base_bytes) / set_bytes);
+        if (rdm_chunk > nrdm) rdm_chunk = nrdm;
+        const size_t lds_bytes = base_bytes + (size_t)rdm_chunk * set_bytes;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute((const void*)cas_column_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap);
+            if (e != hipSuccess) {
+                oovqe_set_error("cas_eval: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                return OOVQE_ERR_HIP;
+            }
+            attr_done = true;
+        }
+        oovqe_profile_mark_start_l(st, 3);
+        hipLaunchKernelGGL(cas_column_kernel, dim3(N, batch), dim3(COL_THREADS), lds_bytes, st, U, h_ao, C,
+                           gamma, Gamma, nrdm, N, n_occ, ncas, Fcol, Epart, Cpart, c1, c2, Gm, hmo,
+                           out_stride, rdm_chunk);
+        oovqe_profile_mark_stop(st);
+        OOVQE_CHECK_LAUNCH("cas_eval/column");
     }
-    oovqe_profile_mark_start_l(st, 3);
-    hipLaunchKernelGGL(cas_column_kernel, dim3(N, batch), dim3(COL_THREADS), lds_bytes, st, U, Gm_in, h_ao, C,
-                       gamma, Gamma, nrdm, N, n_occ, ncas, Fcol, Epart, Cpart, c1, c2, Gm, hmo,
-                       out_stride, rdm_chunk);
-    oovqe_profile_mark_stop(st);
-    OOVQE_CHECK_LAUNCH("cas_eval/column");
     oovqe_profile_mark_start_l(st, 4);
     hipLaunchKernelGGL(cas_final_kernel, dim3(batch), dim3(512), 0, st, Fcol, Epart, Cpart, nuc, nrdm,
                        N, M, kap_row, kap_col, n_kappa, c0, E, gvec, dE, fock, gmat, nuc_arr,
