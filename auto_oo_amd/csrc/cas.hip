@@ -809,13 +809,43 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
         if (hmo_out) hmo_out += gi * (size_t)N * M;
     }
 
+    // Staging with the loads of up to 8 iterations in flight together (a plain load/store loop
+    // pays one memory latency per iteration: 14 of them for U[n] at N = 43, M = 9)
     const double* Usrc = U + (size_t)n * N * M2;
-    for (int idx = tid; idx < N * M2; idx += COL_THREADS) Un[idx] = Usrc[idx];
-    for (int idx = tid; idx < N * M; idx += COL_THREADS) {
-        const int q = idx / M, x = idx - q * M;
-        Cl[idx] = C[(size_t)q * N + x];
+    {
+        const int total = N * M2;
+        for (int base = 0; base < total; base += 8 * COL_THREADS) {
+            double r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * COL_THREADS + tid;
+                r[u] = idx < total ? Usrc[idx] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * COL_THREADS + tid;
+                if (idx < total) Un[idx] = r[u];
+            }
+        }
+        double rc[4], rn = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = u * COL_THREADS + tid, q = idx / M, x = idx - q * M;
+            rc[u] = idx < N * M ? C[(size_t)q * N + x] : 0.0;
+        }
+        if (tid < N) rn = C[(size_t)tid * N + n];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = u * COL_THREADS + tid;
+            if (idx < N * M) Cl[idx] = rc[u];
+        }
+        if (tid < N) cn[tid] = rn;
+        for (int idx = 4 * COL_THREADS + tid; idx < N * M; idx += COL_THREADS) {
+            const int q = idx / M, x = idx - q * M;
+            Cl[idx] = C[(size_t)q * N + x];
+        }
+        for (int p = COL_THREADS + tid; p < N; p += COL_THREADS) cn[p] = C[(size_t)p * N + n];
     }
-    for (int p = tid; p < N; p += COL_THREADS) cn[p] = C[(size_t)p * N + n];
     __syncthreads();
     // W[n,q] = sum_p C[p,n] h[p,q]: 4 thread groups split the p range (coalesced rows of h),
     // partial sums combined in fixed order
