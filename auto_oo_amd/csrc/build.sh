@@ -19,5 +19,6 @@ for p in "${pids[@]:-}"; do
     if [ -n "$p" ]; then wait "$p" || rc=1; fi
 done
 [ $rc -eq 0 ] || { echo "compile failed" >&2; exit 1; }
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/liboovqe_hip.so" "$HERE"/obj/*.o
+# -z defs: an undefined symbol (e.g. a kernel stub the host pass silently dropped) fails the build
+$HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,-z,defs -o "$OUT/liboovqe_hip.so" "$HERE"/obj/*.o
 echo "built $OUT/liboovqe_hip.so"
