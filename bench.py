@@ -52,6 +52,7 @@ def parse():
                     help="molecular geometries PER GPU (weak scaling: the job holds geoms x n_gpus)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-transform", action="store_true")
+    ap.add_argument("--no-kupccd", action="store_true", help="skip the configs[4] kUpCCD CAS(8e,8o) extra")
     ap.add_argument("--no-berry", action="store_true",
                     help="skip the configs[3] extra (energy+gradient+Hessian+Newton step per geometry)")
     ap.add_argument("--transform-n", type=int, default=200)
@@ -186,6 +187,54 @@ def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl"):
                          "note": "independent geometries stepped together: batched eigh, one host "
                                  "sync per line-search trial (BatchedNewtonStep)"},
             "mean_energy_after_step": float(full.mean().item())}
+
+
+def kupccd_extra():
+    """BASELINE.json configs[4]: kUpCCD CAS(8e,8o), 16-qubit register simulated in its 4900-determinant
+    (N_alpha, N_beta) sector: gate-apply rate, state + RDMs + reverse-mode theta-gradient per second,
+    and one full OO evaluation (E + full gradient) on a synthetic N=43 geometry."""
+    import auto_oo_amd as aoo
+    from auto_oo_amd.synthetic import synthetic_problem
+    ncas, nelecas, D = 8, 8, 1 << 16
+    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="kupccd", k=1)
+    eng = pqc._sector
+    n_theta = int(pqc.theta_shape)
+    rng = np.random.default_rng(6)
+    c1 = torch.tensor(rng.standard_normal((ncas, ncas)), device="cuda")
+    c2 = torch.tensor(rng.standard_normal((ncas,) * 4), device="cuda")
+
+    def timed(fn, warm=3, reps=10):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    out = {"n_theta": n_theta, "n_gates": pqc._n_gates, "sector_dim": eng.Dc, "batches": []}
+    for batch in (1, 256):
+        th = torch.tensor(rng.uniform(0, 2 * np.pi, (batch, n_theta)), device="cuda")
+        t_state = timed(lambda: eng.state(th))
+
+        def full():
+            psi_c = eng.state(th)
+            eng.rdms(psi_c)
+            return eng.adjoint(th, psi_c, c1, c2)
+        t_full = timed(full, warm=2, reps=5)
+        out["batches"].append({
+            "batch": batch, "state_us": t_state * 1e6,
+            "gate_apply_GBs_dense_complex128_equivalent": batch * pqc._n_gates * 2.0 * D * 16 / t_state / 1e9,
+            "gate_apply_GBs_sector_in_lds": batch * pqc._n_gates * 2.0 * eng.Dc * 8 / t_state / 1e9,
+            "state_rdm_grad_evals_per_s": batch / t_full})
+    P = synthetic_problem(NAO, 20265)
+    mol = aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], NELEC)
+    oo = aoo.OO_pqc(pqc, mol, ncas, nelecas, oao_mo_coeff=P["oao_mo_coeff"])
+    th1 = torch.tensor(rng.uniform(0, 2 * np.pi, n_theta), device="cuda")
+    out["oo_eval_us"] = timed(lambda: oo.energy_and_gradient(th1), warm=3, reps=20) * 1e6
+    out["n_kappa"] = oo.n_kappa
+    return out
 
 
 def transform_microbench(N):
@@ -385,6 +434,8 @@ def main():
                                  float((gathered[0, 1:].cpu() - g_ref).abs().max())}
         if world == 1 and not args.no_transform:
             out["transform"] = transform_microbench(args.transform_n)
+        if world == 1 and not args.no_kupccd:
+            out["kupccd_cas88"] = kupccd_extra()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
