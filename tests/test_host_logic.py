@@ -201,3 +201,54 @@ def test_batched_newton_step_matches_per_problem_steps():
         assert abs(low_b[g].item() - low_s) < 1e-10
         for a, b in zip(new_b[g], new_s):
             assert a.shape == b.shape and (a - b).abs().max() < 1e-9 * max(1.0, float(b.abs().max()))
+
+
+def _newton_optimize(cost, x0, max_iterations, conv_tol, **kw):
+    """Driver of the reference's Newton property tests (test/utils/test_newton_raphson.py:44-96):
+    autodiff gradient/Hessian of `cost`, damped Newton steps until the energy stalls."""
+    from torch.autograd.functional import jacobian, hessian
+    from auto_oo_amd.newton_raphson import NewtonStep
+    opt = NewtonStep(verbose=0, **kw)
+    theta = x0
+    energies = [cost(theta).item()]
+    for n in range(max_iterations):
+        grad = jacobian(cost, theta)
+        hess = hessian(cost, theta)
+        theta, _ = opt.damped_newton_step(cost, (theta,), grad, hess)
+        energies.append(cost(theta).item())
+        if n > 1 and abs(energies[-1] - energies[-2]) < conv_tol:
+            break
+    return energies, theta
+
+
+@pytest.mark.parametrize("dim,max_iterations,conv_tol,lambda_min,rho,mu",
+                         [(2, 20, 1e-12, 1e-6, 2, 1e-4), (4, 20, 1e-12, 1e-6, 2, 1e-4),
+                          (8, 50, 1e-10, 1e-6, 3, 1e-4)])
+def test_newton_diagonalises_symmetric_matrix(dim, max_iterations, conv_tol, lambda_min, rho, mu):
+    """test_newton_raphson.py:99-116 ('type a'): minimise || U^T A U - diag(eig A) ||^2 over
+    U = expm(-skew(x)); the augmented-Hessian Newton iteration must reach 0."""
+    gen = torch.Generator().manual_seed(dim)
+    a = torch.rand(dim, dim, generator=gen, dtype=torch.float64) - 0.5
+    a = a.T + a
+    va = torch.linalg.eigvalsh(a)
+
+    def cost(x):
+        u = torch.linalg.matrix_exp(-R.vector_to_skew_symmetric(x))
+        return ((u.T @ a @ u - torch.diag(va)) ** 2).sum()
+    x0 = 1e-5 * (torch.rand(dim * (dim - 1) // 2, generator=gen, dtype=torch.float64) - 0.5)
+    energies, x = _newton_optimize(cost, x0, max_iterations, conv_tol, aug=True,
+                                   lambda_min=lambda_min, rho=rho, mu=mu)
+    assert abs(energies[-1]) < 1e-8
+    u = torch.linalg.matrix_exp(-R.vector_to_skew_symmetric(x))
+    assert torch.allclose(u.T @ a @ u, torch.diag(va), atol=1e-6)
+
+
+@pytest.mark.parametrize("t,max_iterations", [(4.0, 10), (3.0, 10), (0.00004, 100)])
+def test_newton_log_barrier_scalar(t, max_iterations):
+    """test_newton_raphson.py:119-130 ('type b'): -t log|x| + |x| - t + t log t has its minimum 0
+    at x = t; plain (non-augmented) damped Newton with backtracking from x = 10."""
+    def cost(x):
+        return (-t * torch.log(torch.abs(x)) + torch.abs(x) - t + t * np.log(t)).sum()
+    energies, x = _newton_optimize(cost, torch.tensor([10.0], dtype=torch.float64), max_iterations,
+                                   1e-12, aug=False)
+    assert abs(energies[-1]) < 1e-8
