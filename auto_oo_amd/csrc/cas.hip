@@ -7,9 +7,17 @@
 // range starting at 0, moldata_pyscf.py:50-54).  So the engine forms only
 //     Gm[n,x,y,z] = sum_pqrs C[p,n] C[q,x] C[r,y] C[s,z] g_ao[p,q,r,s]
 // in three stages; stage 1 is the only pass over N^4 data and is HBM-bound:
-//   stage 1  T2[p,q,y,z] = sum_rs C[r,y] g_ao[p,q,r,s] C[s,z]        (this file, slab kernel)
-//   stage 2  Gm = contract q->x, p->n; hmo = C^T h C[:, :M]           (contract.hip kernels)
-//   stage 3  c0,c1,c2,E, Fock matrices, orbital gradient              (this file, fock kernel)
+//   stage 1  T2[p,q,y,z] = sum_rs C[r,y] g_ao[p,q,r,s] C[s,z]        (this file, slab kernels)
+//   stage 2  Gm = contract q->x, p->n; hmo = C^T h C[:, :M]
+//   stage 3  c0,c1,c2,E, Fock matrices, orbital gradient
+// Two realisations, chosen per call by oovqe_cas_eval (cas_eval_batched):
+//   T3 path (bandwidth-bound sweeps, M <= 16, N <= 48): half_transform_fused_kernel does stage 1 and
+//     the q->x half of stage 2 in one persistent kernel (T2 never leaves the chip), K1 contracts
+//     p->n, cas_panel_kernel does stage 3 on panels of general indices, cas_final_kernel assembles;
+//   T2 path (few geometries, or larger M / N): half_transform_kernel writes T2, K1 contracts p->n,
+//     cas_column_kernel contracts q->x and does stage 3 per general index, cas_final_kernel.
+// The staged entry points (oovqe_cas_half_transform / _finish_transform / _energy_gradient) keep
+// the three stages separate for callers that want the intermediates.
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>

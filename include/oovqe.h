@@ -163,8 +163,9 @@ int oovqe_cas_energy_gradient(const double* Gm, const double* hmo, const double*
                               double* fock, double* gmat, double* gvec, double* dE,
                               oovqe_stream_t stream);
 
-/* The whole CAS path in one call (stage 1, contraction p->n, fused per-n column kernel, final
- * assembly: 4 launches, no N M^3 MO tensor round trip unless Gm/hmo are requested).
+/* The whole CAS path in one call: 4 launches (stage 1 [+ q->x inside the same persistent kernel
+ * when the sweep is bandwidth-bound], contraction p->n, Fock-column kernel, final assembly); the
+ * N^2 M^2 half-transformed tensor stays on chip on the batched path.
  * Same inputs/outputs as the three stages above; work: oovqe_cas_eval_work_size() doubles;
  * fock, gmat, Gm [N,M,M,M], hmo [N,M], dE may be NULL (dE only when nrdm == 1).
  * This is what OO_pqc.energy_from_parameters / full_gradient / orbital_circuit_hessian run on
