@@ -342,6 +342,21 @@ def orbital_hessian(g_ao, h_ao, C, gamma, Gamma, fock, n_occ, ncas, kap_row, kap
     return Hm, Hf
 
 
+_PAIR_TABLES = {}
+
+
+def _hessian_pair_tables(n_theta, dev):
+    """(pairs [n_pairs, 2] int32, j [n_pairs], k [n_pairs]) for j <= k, on `dev`, built once."""
+    key = (n_theta, str(dev))
+    tabs = _PAIR_TABLES.get(key)
+    if tabs is None:
+        pairs = [(j, k) for j in range(n_theta) for k in range(j, n_theta)]
+        pairs_dev = torch.tensor(pairs, dtype=torch.int32, device=dev).contiguous()
+        tabs = (pairs_dev, pairs_dev[:, 0].long().contiguous(), pairs_dev[:, 1].long().contiguous())
+        _PAIR_TABLES[key] = tabs
+    return tabs
+
+
 def circuit_hessian(theta, gates_dev, n_gates, n_qubits, ncas, init_index, c1, c2):
     """d^2E/dtheta^2 for E = c0 + c1.gamma(theta) + c2.Gamma(theta)  (oo_pqc.py:103-111):
     second tangents + transition RDMs + contraction; theta [n_theta]."""
@@ -352,9 +367,8 @@ def circuit_hessian(theta, gates_dev, n_gates, n_qubits, ncas, init_index, c1, c
     th2 = theta.reshape(1, n_theta).contiguous()
     psi, dpsi = circuit_state(th2, gates_dev, n_gates, n_qubits, init_index, tangents=True)
     psi, dpsi = psi[0], dpsi[0]
-    pairs = [(j, k) for j in range(n_theta) for k in range(j, n_theta)]
-    n_pairs = len(pairs)
-    pairs_dev = torch.tensor(pairs, dtype=torch.int32, device=dev).contiguous()
+    pairs_dev, jj, kk = _hessian_pair_tables(n_theta, dev)   # cached: no host->device copy per call
+    n_pairs = pairs_dev.shape[0]
     psi2 = torch.empty((n_pairs, D), dtype=F64, device=dev)
     scratch = torch.empty((n_pairs, D), dtype=F64, device=dev)
     check(lib.oovqe_circuit_second_tangents(dptr(th2), n_theta, dptr(gates_dev, torch.uint8), n_gates,
@@ -363,8 +377,6 @@ def circuit_hessian(theta, gates_dev, n_gates, n_qubits, ncas, init_index, c1, c
                                             dptr(scratch), stream_ptr()),
           "oovqe_circuit_second_tangents")
     # transition-RDM operand lists (pure data movement): per pair the four (bra, ket) combinations
-    jj = torch.tensor([p[0] for p in pairs], device=dev)
-    kk = torch.tensor([p[1] for p in pairs], device=dev)
     psi_rep = psi.unsqueeze(0).expand(n_pairs, D)
     bra = torch.stack((psi2, dpsi[jj], dpsi[kk], psi_rep), dim=1).reshape(4 * n_pairs, D).contiguous()
     ket = torch.stack((psi_rep, dpsi[kk], dpsi[jj], psi2), dim=1).reshape(4 * n_pairs, D).contiguous()
