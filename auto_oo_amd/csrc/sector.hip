@@ -379,9 +379,8 @@ void sector_adjoint_kernel(const double* __restrict__ theta, int n_theta,
     double* ps = lds;                                   // [Dc]
     double* lm = ps + Dc;                               // [Dc]
     double* cs = lm + Dc;                               // [n_gates][2]
-    double* part = cs + 2 * n_gates;                    // [16 waves]
-    double* gth = part + SEC_THREADS / 64;              // [n_theta]
-    oovqe_gate_t* gl = reinterpret_cast<oovqe_gate_t*>(gth + n_theta);
+    double* part = cs + 2 * n_gates;                    // [n_gates][16 waves]
+    oovqe_gate_t* gl = reinterpret_cast<oovqe_gate_t*>(part + (size_t)n_gates * (SEC_THREADS / 64) + n_theta);
     uint32_t* xfull;
     s = sec_stage_lds(s, reinterpret_cast<uint32_t*>(gl + n_gates), &xfull, SEC_THREADS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
@@ -397,7 +396,6 @@ void sector_adjoint_kernel(const double* __restrict__ theta, int n_theta,
             cs[2 * g] = c;
             cs[2 * g + 1] = sn;
         }
-        for (int k = tid; k < n_theta; k += SEC_THREADS) gth[k] = 0.0;
         for (int d = tid; d < Dc; d += SEC_THREADS) {
             ps[d] = psi_c[(size_t)b * Dc + d];
             lm[d] = lam[(size_t)b * Dc + d];
@@ -437,18 +435,24 @@ void sector_adjoint_kernel(const double* __restrict__ theta, int n_theta,
                 lm[ee] = c * ly + ps_ * lx;
             }
         }
-        // deterministic reduction: wave shuffle tree, then the 16 wave partials in fixed order
+        // deterministic reduction: wave shuffle tree now, the 16 wave partials of every gate are
+        // summed in fixed order after the sweep (one barrier per gate instead of two and no
+        // single-thread section inside the sweep)
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-        if (lane == 0) part[wave] = acc;
-        __syncthreads();
-        if (tid == 0) {
-            double tot = 0.0;
-            for (int w = 0; w < SEC_THREADS / 64; ++w) tot += part[w];
-            gth[gt.theta_idx] += 0.5 * (double)gt.sign * tot;
-        }
+        if (lane == 0) part[(size_t)g * (SEC_THREADS / 64) + wave] = acc;
         __syncthreads();
     }
-    for (int k = tid; k < n_theta; k += SEC_THREADS) dtheta[(size_t)b * n_theta + k] = gth[k];
+    // gth[k] = sum over the gates driven by theta_k, in the order of the sweep (last gate first)
+    for (int k = tid; k < n_theta; k += SEC_THREADS) {
+        double acc = 0.0;
+        for (int g = n_gates - 1; g >= 0; --g) {
+            if (gl[g].theta_idx != k) continue;
+            double tot = 0.0;
+            for (int w = 0; w < SEC_THREADS / 64; ++w) tot += part[(size_t)g * (SEC_THREADS / 64) + w];
+            acc += 0.5 * (double)gl[g].sign * tot;
+        }
+        dtheta[(size_t)b * n_theta + k] = acc;
+    }
 }
 
 Sector make_sector(const uint32_t* ua, const uint32_t* ub, const int32_t* ra, const int32_t* rb, int na,
@@ -468,7 +472,8 @@ size_t circuit_lds(int na, int nb, int ncas, int n_gates)
 
 size_t adjoint_lds(int na, int nb, int ncas, int n_gates, int n_theta)
 {
-    return ((size_t)2 * na * nb + 2 * n_gates + SEC_THREADS / 64 + n_theta) * sizeof(double) +
+    return ((size_t)2 * na * nb + 2 * n_gates + (size_t)n_gates * (SEC_THREADS / 64) + n_theta) *
+               sizeof(double) +
            (size_t)n_gates * sizeof(oovqe_gate_t) + sec_lds_words(na, nb, ncas) * 4;
 }
 
