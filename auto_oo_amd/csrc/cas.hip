@@ -352,43 +352,6 @@ void half_transform_fused_kernel(const double* __restrict__ g, const double* __r
     T3 += (size_t)blockIdx.y * nchunk * N * M2 * M;
     if (nchunk > 1) Cdup += (size_t)blockIdx.y * nchunk * N * N;
 
-    for (int idx = tid; idx < CR * 16; idx += HALF_WAVES * 64) {
-        const int r = idx >> 4, x = idx & 15;
-        CxL[idx] = (r < N && x < M) ? C[(size_t)r * N + x] : 0.0;
-    }
-    for (int idx = tid; idx < nbuf * QR * ldb + 64; idx += HALF_WAVES * 64) blk[idx] = 0.0;
-    if (tid < 5 * nbuf) cnt[tid] = (tid >= 2 * nbuf && tid < 3 * nbuf) ? (1 << 30) : 0;
-
-    // stage-1 B fragments cfr[j] = C[4j + lq][lr]; stage-2 A fragments in MFMA row order:
-    //   even/odd tile of pair pp: row m = lq + 4i <-> column pp*32 + 2(lq+4i) (+1)
-    //   single tile             : column NP*32 + lq + 4i = row (NP*8 + i)*4 + lq  (= cfr[NP*8 + i])
-    double cfr[NCF];
-#pragma unroll
-    for (int j = 0; j < NCF; ++j) {
-        const int r = 4 * j + lq;
-        cfr[j] = C[(size_t)(r < N ? r : N - 1) * N + (lr < M ? lr : M - 1)];
-    }
-    double cpr[NPA][2][4];
-#pragma unroll
-    for (int pp = 0; pp < NP; ++pp)
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int col = pp * 32 + 2 * (lq + 4 * i) + half;
-                cpr[pp][half][i] = C[(size_t)(col < N ? col : N - 1) * N + (lr < M ? lr : M - 1)];
-            }
-#pragma unroll
-    for (int j = 0; j < NCF; ++j) cfr[j] *= ((4 * j + lq) < N && lr < M) ? 1.0 : 0.0;
-#pragma unroll
-    for (int pp = 0; pp < NP; ++pp)
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                cpr[pp][half][i] *= ((pp * 32 + 2 * (lq + 4 * i) + half) < N && lr < M) ? 1.0 : 0.0;
-    __syncthreads();   // the only workgroup barrier
-
     // lane-invariant byte offsets inside a slab, relative to the (wave-uniform) start of the row
     // block 4i.  Only the k-step i_last = (N-1)/4 can straddle the end of the slab: its lanes with
     // row >= N get an out-of-range offset (the load is dropped and returns 0), and whole k-steps
@@ -467,6 +430,50 @@ void half_transform_fused_kernel(const double* __restrict__ g, const double* __r
             }
         }
     };
+    // The loads of this wave's first slab go out before anything else: the LDS set-up and the C
+    // fragment loads below (one L2 round trip and a barrier) then overlap the first HBM round trip.
+    d2u ap0[NPA][KCH], ap1[NPA][KCH];
+    double as0[KCH], as1[KCH];
+    Pos p0{wave / qc, wave % qc};
+    if (n_mine > 0) issue(p0, ap0, as0);
+
+    for (int idx = tid; idx < CR * 16; idx += HALF_WAVES * 64) {
+        const int r = idx >> 4, x = idx & 15;
+        CxL[idx] = (r < N && x < M) ? C[(size_t)r * N + x] : 0.0;
+    }
+    for (int idx = tid; idx < nbuf * QR * ldb + 64; idx += HALF_WAVES * 64) blk[idx] = 0.0;
+    if (tid < 5 * nbuf) cnt[tid] = (tid >= 2 * nbuf && tid < 3 * nbuf) ? (1 << 30) : 0;
+
+    // stage-1 B fragments cfr[j] = C[4j + lq][lr]; stage-2 A fragments in MFMA row order:
+    //   even/odd tile of pair pp: row m = lq + 4i <-> column pp*32 + 2(lq+4i) (+1)
+    //   single tile             : column NP*32 + lq + 4i = row (NP*8 + i)*4 + lq  (= cfr[NP*8 + i])
+    double cfr[NCF];
+#pragma unroll
+    for (int j = 0; j < NCF; ++j) {
+        const int r = 4 * j + lq;
+        cfr[j] = C[(size_t)(r < N ? r : N - 1) * N + (lr < M ? lr : M - 1)];
+    }
+    double cpr[NPA][2][4];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = pp * 32 + 2 * (lq + 4 * i) + half;
+                cpr[pp][half][i] = C[(size_t)(col < N ? col : N - 1) * N + (lr < M ? lr : M - 1)];
+            }
+#pragma unroll
+    for (int j = 0; j < NCF; ++j) cfr[j] *= ((4 * j + lq) < N && lr < M) ? 1.0 : 0.0;
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                cpr[pp][half][i] *= ((pp * 32 + 2 * (lq + 4 * i) + half) < N && lr < M) ? 1.0 : 0.0;
+    __syncthreads();   // the only workgroup barrier
+
     // LDS destination of jt[i] = Jt[z = lq + 4i][y = lr] inside a block row: [y*M + z]
     int tile_off[4];
 #pragma unroll
@@ -586,14 +593,10 @@ void half_transform_fused_kernel(const double* __restrict__ g, const double* __r
     };
 
     if (n_mine > 0) {
-        d2u ap0[NPA][KCH], ap1[NPA][KCH];
-        double as0[KCH], as1[KCH];
         // Straight-line loop body (no exit test between an issue and its use: the optimiser sinks
         // loads below such a test, which serialises them with the MFMAs), and no VMEM store in it
         // (T3 is staged in LDS): the only VMEM traffic of the loop is the g_ao stream.  An odd
         // position count costs one idle MFMA pass on dropped loads.
-        Pos p0{wave / qc, wave % qc};
-        issue(p0, ap0, as0);
         for (int it = 0; it < n_mine; it += 2) {
             const Pos p1 = advance(p0);
             issue(p1, ap1, as1);
