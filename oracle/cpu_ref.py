@@ -756,3 +756,21 @@ def synthetic_problem(nao, seed, n_aux=None, enuc=31.0):
     g = np.einsum('Lpq,Lrs->pqrs', B, B, optimize=True) / n_aux
     Qc, _ = np.linalg.qr(rng.standard_normal((n, n)))
     return dict(int1e_ao=h, int2e_ao=g, overlap=S, oao_mo_coeff=Qc, nuc=float(enuc))
+
+
+def bogoliubov_unitary(U_act):
+    """Tutorial_Berry_phase.ipynb cell 27: G = exp{ sum_pq [log U]_pq c+_p c_q } over both spins of
+    the active orbitals, as a dense 2^n x 2^n matrix built from the Jordan-Wigner E_pq operators
+    (the notebook obtains it from openfermion.bogoliubov_transform + cirq, normalised to
+    G[0, 0] = 1, which this exponential satisfies by construction).  U_act must be a proper
+    rotation (orthogonal, det +1) so that log U is real antisymmetric."""
+    import scipy.linalg
+    U_act = np.asarray(U_act, dtype=np.float64)
+    ncas = U_act.shape[0]
+    logU = scipy.linalg.logm(U_act)
+    if np.abs(np.imag(logU)).max() > 1e-10:
+        raise ValueError("log U is not real: U must be a proper rotation")
+    logU = np.real(logU)
+    ops = RdmOperators(ncas)
+    K = sum(logU[p, q] * ops.E[p][q].toarray() for p in range(ncas) for q in range(ncas))
+    return scipy.linalg.expm(K)

@@ -1,0 +1,69 @@
+"""Berry-phase post-processing: the active-space Bogoliubov
+transformation of the reference notebook, applied through sector minors instead of a dense
+2^n x 2^n unitary.  The reference builds it with openfermion + cirq (absent here): parity is pinned
+against the operator definition of the notebook (oracle.cpu_ref.bogoliubov_unitary)."""
+import numpy as np
+import pytest
+import scipy.linalg
+import torch
+
+from oracle import cpu_ref as R
+
+
+def _rotation(ncas, seed, scale=0.4):
+    rng = np.random.default_rng(seed)
+    k = rng.standard_normal((ncas, ncas)) * scale
+    return scipy.linalg.expm(k - k.T)
+
+
+@pytest.mark.parametrize("ncas,nelecas", [(2, 2), (3, 4), (3, 2), (4, 4)])
+def test_sector_minors_equal_operator_exponential(ncas, nelecas):
+    from auto_oo_amd.berry import ActiveSpaceRotation
+    from auto_oo_amd.sector import sector_of
+    U = _rotation(ncas, 10 * ncas + nelecas)
+    occ = [1 if i < nelecas else 0 for i in range(2 * ncas)]
+    na, nb = sector_of(occ, ncas)
+    rot = ActiveSpaceRotation(U, ncas, na, nb, orthogonalize=False)
+    G_ref = R.bogoliubov_unitary(U)
+    idx = rot.index.reshape(-1)
+    # the exponential conserves N_alpha and N_beta: its sector block must equal the minor form
+    assert np.abs(G_ref[np.ix_(idx, idx)] - rot.dense()[np.ix_(idx, idx)]).max() < 1e-12
+    outside = np.setdiff1d(np.arange(G_ref.shape[0]), idx)
+    assert np.abs(G_ref[np.ix_(outside, idx)]).max() < 1e-12
+    assert abs(G_ref[0, 0] - 1.0) < 1e-12             # the notebook's gauge: vacuum phase 1
+
+
+def test_polar_factor_and_identity():
+    from auto_oo_amd.berry import ActiveSpaceRotation, polar_orthogonal
+    U = _rotation(3, 5)
+    noisy = U + 1e-3 * np.random.default_rng(1).standard_normal((3, 3))
+    Q = polar_orthogonal(noisy)
+    assert np.abs(Q.T @ Q - np.eye(3)).max() < 1e-13 and np.abs(Q - U).max() < 5e-3
+    eye = ActiveSpaceRotation(np.eye(3), 3, 2, 2)
+    assert np.abs(eye.M_alpha - np.eye(eye.M_alpha.shape[0])).max() == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ncas,nelecas", [(3, 4), (4, 4)])
+def test_apply_and_overlap_on_device(ncas, nelecas):
+    import auto_oo_amd as aoo
+    from auto_oo_amd.berry import bogoliubov_atob_cas, state_overlap
+    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="ucc")
+    rng = np.random.default_rng(3)
+    th_a = torch.tensor(rng.uniform(0, 2 * np.pi, pqc.theta_shape))
+    th_b = torch.tensor(rng.uniform(0, 2 * np.pi, pqc.theta_shape))
+    psi_a, psi_b = pqc.qnode(th_a), pqc.qnode(th_b)
+    n_occ = 2
+    N = n_occ + ncas + 3
+    mo_atob = np.eye(N)
+    act = list(range(n_occ, n_occ + ncas))
+    mo_atob[np.ix_(act, act)] = _rotation(ncas, 7)
+    rot = bogoliubov_atob_cas(torch.tensor(mo_atob), act, nelecas)
+    G_ref = R.bogoliubov_unitary(mo_atob[np.ix_(act, act)])
+    ref = G_ref @ psi_a.cpu().numpy()
+    got = rot.apply(psi_a).cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-12
+    ov = state_overlap(psi_b, rot, psi_a)
+    assert abs(complex(ov.item()) - np.vdot(psi_b.cpu().numpy(), ref)) < 1e-12
+    # the transformation is unitary on the sector: norms are preserved
+    assert abs(np.linalg.norm(got) - 1.0) < 1e-12
