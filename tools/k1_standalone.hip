@@ -1,8 +1,37 @@
 // Standalone timing of the K1 contraction kernel on the N=200 quarter transforms (tools only).
 #include "../auto_oo_amd/csrc/contract.hip"
 #include <vector>
+#include <string.h>
 int main(int argc, char** argv)
 {
+    if (argc > 1 && !strcmp(argv[1], "small")) {
+        // p -> n step of a batched evaluation: out[g][n][xyz] = sum_p C[g][p][n] T3[g][p][xyz]
+        const int N = 43, M3 = 729, G = 64;
+        double *T, *C, *O;
+        (void)hipMalloc(&T, (size_t)G * N * M3 * 8);
+        (void)hipMalloc(&C, (size_t)G * N * N * 8);
+        (void)hipMalloc(&O, (size_t)G * N * M3 * 8);
+        (void)hipMemset(T, 0, (size_t)G * N * M3 * 8);
+        (void)hipMemset(C, 0, (size_t)G * N * N * 8);
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        float tot = 0;
+        const int reps = 300;
+        for (int r = 0; r < reps + 20; ++r) {
+            (void)hipEventRecord(e0, 0);
+            int rc = oovqe_mode_contract_batched(T, C, O, 1, N, N, M3, N, 0, G, (long)N * M3, (long)N * N,
+                                                 (long)N * M3, nullptr);
+            (void)hipEventRecord(e1, 0);
+            (void)hipEventSynchronize(e1);
+            if (rc) { printf("error: %s\n", oovqe_last_error()); return 1; }
+            float ms;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (r >= 20) tot += ms;
+        }
+        printf("p->n step, 64 geometries: %.2f us per launch\n", tot / reps * 1e3);
+        return 0;
+    }
     const int N = argc > 1 ? atoi(argv[1]) : 200;
     const long n = N, n2 = n * n, n3 = n2 * n, n4 = n3 * n;
     double *g, *w, *C;
