@@ -9,7 +9,7 @@ FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function"
 pids=()
 for src in "$HERE"/*.hip; do
     obj="$HERE/obj/$(basename "${src%.hip}").o"
-    if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/common.h" -nt "$obj" ] || [ "$HERE/../../include/oovqe.h" -nt "$obj" ]; then
+    if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/common.h" -nt "$obj" ] || [ "$HERE/circuit_small.h" -nt "$obj" ] || [ "$HERE/../../include/oovqe.h" -nt "$obj" ]; then
         $HIPCC $FLAGS -c "$src" -o "$obj" &
         pids+=($!)
     fi

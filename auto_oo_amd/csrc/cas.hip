@@ -19,6 +19,7 @@
 // The staged entry points (oovqe_cas_half_transform / _finish_transform / _energy_gradient) keep
 // the three stages separate for callers that want the intermediates.
 #include "common.h"
+#include "circuit_small.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -27,6 +28,10 @@ int oovqe_mode_contract_impl(const double* T, const double* Cm, double* out, lon
 int oovqe_mode_contract_batched(const double* T, const double* Cm, double* out, long A, int K, int J,
                                 long B, int ldc, int last, int batch, long t_bs, long c_bs, long o_bs,
                                 hipStream_t st);
+int oovqe_mode_contract_batched_circ(const double* T, const double* Cm, double* out, long A, int K, int J,
+                                     long B, int ldc, int last, int batch, long t_bs, long c_bs,
+                                     long o_bs, hipStream_t st, const oovqe_circuit_job_t* cj);
+int oovqe_contract_hosts_circuit(long A, int K, int J, long B, int last, int batch);
 extern "C" int oovqe_circuit_rdms_is_small(int n_qubits, int ncas, int nvec, int n_gates);
 
 namespace {
@@ -1491,8 +1496,10 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
                             const int32_t* kap_col, int n_kappa, double* work, double* c0, double* c1,
                             double* c2, double* E, double* gvec, double* dE, double* fock,
                             double* gmat, double* Gm, double* hmo, int batch, size_t out_stride,
-                            oovqe_stream_t stream)
+                            oovqe_stream_t stream, const oovqe_circuit_job_t* cj = nullptr)
 {
+    // cj: circuit + RDM evaluations that produce gamma / Gamma; they ride along the p -> n
+    // contraction launch (the caller has checked oovqe_contract_hosts_circuit for this shape)
     OOVQE_REQUIRE(g_ao && h_ao && C && gamma && Gamma && work && c0 && c1 && c2 && E && gvec,
                   "cas_eval: null pointer");
     OOVQE_REQUIRE(nrdm >= 1 && N >= 1 && n_occ >= 0 && ncas >= 1 && n_occ + ncas <= N,
@@ -1525,9 +1532,9 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
         // Gm[n,(x y z)] = sum_{c,p} C[p,n] T3[c,p,(x y z)]
         oovqe_profile_mark_start_l(st, 2);
         const long K = (long)fp.nchunk * N;
-        if ((rc = oovqe_mode_contract_batched(T3, fp.nchunk > 1 ? Cdup : C, Gmw, 1, (int)K, N, m3, N, 0,
-                                              batch, K * m3, fp.nchunk > 1 ? K * N : (long)N * N,
-                                              (long)N * m3, st)))
+        if ((rc = oovqe_mode_contract_batched_circ(T3, fp.nchunk > 1 ? Cdup : C, Gmw, 1, (int)K, N, m3, N, 0,
+                                                   batch, K * m3, fp.nchunk > 1 ? K * N : (long)N * N,
+                                                   (long)N * m3, st, cj)))
             return rc;
         oovqe_profile_mark_stop(st);
         Gm_in = Gmw;
@@ -1535,8 +1542,9 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
         if ((rc = half_transform_batched(g_ao, C, N, M, T2, batch, stream))) return rc;
         // U[n,(q y z)] = sum_p C[p,n] T2[p,(q y z)]
         oovqe_profile_mark_start_l(st, 2);
-        if ((rc = oovqe_mode_contract_batched(T2, C, U, 1, N, N, (long)N * m2, N, 0, batch,
-                                              (long)N * N * m2, (long)N * N, (long)N * N * m2, st)))
+        if ((rc = oovqe_mode_contract_batched_circ(T2, C, U, 1, N, N, (long)N * m2, N, 0, batch,
+                                                   (long)N * N * m2, (long)N * N, (long)N * N * m2, st,
+                                                   cj)))
             return rc;
         oovqe_profile_mark_stop(st);
     }
@@ -1674,12 +1682,41 @@ static int oo_eval_batched(const double* theta, int n_theta, const oovqe_gate_t*
         dpsi = psi + nb * D;                               // [G][n_theta][D]
         rwork = psi + nb * nvec * D;
     }
-    oovqe_profile_mark_start_l((hipStream_t)stream, 1);
-    int rc = oovqe_circuit_rdms(theta, n_theta, gates, n_gates, n_qubits, ncas, init_index,
-                                derivatives, batch, psi, derivatives ? dpsi : nullptr, gamma, Gamma,
-                                rwork, stream);
-    if (rc) return rc;
-    oovqe_profile_mark_stop((hipStream_t)stream);
+    // The circuit + RDM step is independent of the integral transform until the Fock stage.  When
+    // it is the one-workgroup kind and the p -> n contraction of this shape is a single-chunk K1
+    // launch, its workgroups ride along that launch (one launch and ~12 us of latency less per
+    // evaluation); otherwise it is launched here.  OOVQE_NO_RIDE=1 forces the separate launch.
+    oovqe_circuit_job_t cj;
+    bool ride = false;
+    if (oovqe_circuit_rdms_is_small(n_qubits, ncas, nvec, n_gates) && getenv("OOVQE_NO_RIDE") == nullptr) {
+        const int M = n_occ + ncas;
+        const long m2 = (long)M * M, m3 = m2 * M;
+        cj.theta = theta;
+        cj.gates = gates;
+        cj.gamma = gamma;
+        cj.Gamma = Gamma;
+        cj.n_theta = n_theta;
+        cj.n_gates = n_gates;
+        cj.n_qubits = n_qubits;
+        cj.ncas = ncas;
+        cj.n_tan = nvec - 1;
+        cj.count = batch;
+        cj.init_index = init_index;
+        cj.lds_bytes = oovqe_small_circuit_lds_bytes(n_qubits, ncas, nvec, n_gates);
+        FusedPlan fp;
+        const bool fused = getenv("OOVQE_CAS_UNFUSED") == nullptr && fused_plan(N, M, batch, &fp);
+        const long K = fused ? (long)fp.nchunk * N : N, B = fused ? m3 : (long)N * m2;
+        ride = cj.lds_bytes <= 64 * 1024 && K <= 0x7fffffffL &&
+               oovqe_contract_hosts_circuit(1, (int)K, N, B, 0, batch);
+    }
+    if (!ride) {
+        oovqe_profile_mark_start_l((hipStream_t)stream, 1);
+        int rc = oovqe_circuit_rdms(theta, n_theta, gates, n_gates, n_qubits, ncas, init_index,
+                                    derivatives, batch, psi, derivatives ? dpsi : nullptr, gamma, Gamma,
+                                    rwork, stream);
+        if (rc) return rc;
+        oovqe_profile_mark_stop((hipStream_t)stream);
+    }
     // packed output per geometry: [c0 | E | dE (max(nvec-1,1)) | gvec (nvec x n_kappa) | c1 | c2]
     const size_t out_stride = (size_t)oovqe_oo_eval_out_size(n_theta, n_kappa, ncas, derivatives);
     const int n_t = nvec > 1 ? nvec - 1 : 1;
@@ -1691,7 +1728,7 @@ static int oo_eval_batched(const double* theta, int n_theta, const oovqe_gate_t*
     double* c2 = c1 + na2;
     return cas_eval_batched(g_ao, h_ao, C, gamma, Gamma, nvec, nuc, nuc_arr, N, n_occ, ncas, kap_row,
                             kap_col, n_kappa, cas_work, c0, c1, c2, E, gvec, dE, nullptr, nullptr,
-                            nullptr, nullptr, batch, out_stride, stream);
+                            nullptr, nullptr, batch, out_stride, stream, ride ? &cj : nullptr);
 }
 
 extern "C" int oovqe_oo_eval(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,

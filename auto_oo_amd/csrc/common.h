@@ -38,6 +38,18 @@ void oovqe_profile_mark_stop(hipStream_t st);
         }                                                                                 \
     } while (0)
 
+// Small-circuit evaluations riding along a K1 launch (contract.hip: contract_circuit_kernel):
+// `count` independent instances (one per geometry of a batch), see circuit_small.h.
+struct oovqe_circuit_job_t {
+    const double* theta;         // [count][n_theta]
+    const oovqe_gate_t* gates;
+    double* gamma;               // [count][1 + n_tan][a^2]
+    double* Gamma;               // [count][1 + n_tan][a^4]
+    int n_theta, n_gates, n_qubits, ncas, n_tan, count;
+    uint32_t init_index;
+    size_t lds_bytes;            // oovqe_small_circuit_lds_bytes(...)
+};
+
 // v_mfma_f64_16x16x4_f64: D[16x16] += A[16x4] B[4x16].
 // lane l supplies A[m = l&15][k = l>>4] and B[k = l>>4][n = l&15]; receives
 // D[m = (l>>4) + 4*i][n = l&15] in element i of the accumulator (cdna_hip_programming.md:161).

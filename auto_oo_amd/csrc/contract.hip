@@ -23,6 +23,7 @@
 //   * f64 MFMA issues one 16x16x4 every 64 cycles per SIMD, so per 13 MFMAs (832 cycles) a wave
 //     needs 1 global load + 13 LDS reads: the kernel is MFMA-bound by construction.
 #include "common.h"
+#include "circuit_small.h"
 
 namespace {
 
@@ -33,10 +34,11 @@ constexpr int NWAVES = 8;
 constexpr int NTHREADS = NWAVES * 64;
 
 template <int NT, bool LAST, int KSTEPS>
-__global__ __launch_bounds__(NTHREADS, 2)
-void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm,
-                     double* __restrict__ out, long A, int K, int J, long B, int ldc,
-                     long n_items, int nbt, long t_bs, long c_bs, long o_bs)
+__device__ __forceinline__
+void contract_body(const double* __restrict__ T, const double* __restrict__ Cm,
+                   double* __restrict__ out, long A, int K, int J, long B, int ldc,
+                   long n_items, int nbt, long t_bs, long c_bs, long o_bs, double* lds,
+                   const unsigned grid_x)
 {
     // blockIdx.z = batch element (independent problems of identical shape)
     T += (long)blockIdx.z * t_bs;
@@ -48,7 +50,7 @@ void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm
     constexpr int CHUNK = KC * LDJ;
     constexpr int CREG = (CHUNK + NTHREADS - 1) / NTHREADS;
     constexpr int BUF = CREG * NTHREADS;      // chunk buffer, padded so staging stores need no guard
-    extern __shared__ double lds[];           // [2][BUF]
+    // lds: [2][BUF]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -57,7 +59,7 @@ void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm
     const long n_groups = (n_items + NWAVES - 1) / NWAVES;
 
     // One wave = one 16-wide strip of T ("item"); a workgroup walks the item groups
-    // blockIdx.x, blockIdx.x + gridDim.x, ... (persistent), and the chunk pipeline runs ACROSS
+    // blockIdx.x, blockIdx.x + grid_x, ... (persistent), and the chunk pipeline runs ACROSS
     // items: while the last K-chunk of item i is in the MFMA pipe, chunk 0 of item i+1 is already
     // being fetched, so neither the workgroup launch nor the first HBM round trip of an item is
     // ever exposed.
@@ -159,7 +161,7 @@ void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm
     int par = 0;   // LDS buffer holding the chunk being consumed
 
     while (group < n_groups) {
-        const Strip nxt = decode(group + gridDim.x);
+        const Strip nxt = decode(group + grid_x);
         for (int c = 0; c < nchunks; ++c) {
             const int kbase = c * KC;
             const bool last = (c + 1 == nchunks);
@@ -232,19 +234,83 @@ void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
         cur = nxt;
-        group += gridDim.x;
+        group += grid_x;
     }
+}
+
+template <int NT, bool LAST, int KSTEPS>
+__global__ __launch_bounds__(NTHREADS, 2)
+void contract_kernel(const double* __restrict__ T, const double* __restrict__ Cm,
+                     double* __restrict__ out, long A, int K, int J, long B, int ldc,
+                     long n_items, int nbt, long t_bs, long c_bs, long o_bs)
+{
+    extern __shared__ double lds[];
+    contract_body<NT, LAST, KSTEPS>(T, Cm, out, A, K, J, B, ldc, n_items, nbt, t_bs, c_bs, o_bs, lds,
+                                    gridDim.x);
+}
+
+// The same contraction with one extra workgroup column (blockIdx.x == gridDim.x - 1) that runs
+// independent small-circuit evaluations (circuit_small.h) instead: instance b = blockIdx.z of the
+// batch, on the workgroups with blockIdx.y == 0.  Used by the OO evaluation, whose circuit + RDM
+// step and p -> n contraction are both short, mutually independent launches.
+template <int NT, bool LAST, int KSTEPS>
+__global__ __launch_bounds__(NTHREADS, 2)
+void contract_circuit_kernel(const double* __restrict__ T, const double* __restrict__ Cm,
+                             double* __restrict__ out, long A, int K, int J, long B, int ldc,
+                             long n_items, int nbt, long t_bs, long c_bs, long o_bs,
+                             oovqe_circuit_job_t cj)
+{
+    extern __shared__ double lds[];
+    static_assert(SMALL_THREADS == NTHREADS, "the circuit body needs the K1 workgroup size");
+    if (blockIdx.x == gridDim.x - 1) {
+        if (blockIdx.y == 0 && (int)blockIdx.z < cj.count)
+            circuit_rdm_small_body(cj.theta, cj.n_theta, cj.gates, cj.n_gates, cj.n_qubits, cj.ncas,
+                                   cj.init_index, cj.n_tan, nullptr, nullptr, cj.gamma, cj.Gamma,
+                                   (int)blockIdx.z, lds);
+        return;
+    }
+    contract_body<NT, LAST, KSTEPS>(T, Cm, out, A, K, J, B, ldc, n_items, nbt, t_bs, c_bs, o_bs, lds,
+                                    gridDim.x - 1);
 }
 
 template <int NT, bool LAST, int KS>
 int launch_nt(const double* T, const double* Cm, double* out, long A, int K, int J, long B,
               int ldc, int ngroups, long n_items, int nbt, int batch, long t_bs, long c_bs, long o_bs,
-              hipStream_t st)
+              hipStream_t st, const oovqe_circuit_job_t* cj = nullptr)
 {
     constexpr int LDJ = 16 * (NT | 1);
     constexpr int KC = 4 * KS;
     constexpr int CREG = (KC * LDJ + NTHREADS - 1) / NTHREADS;
-    const size_t lds_bytes = (size_t)2 * CREG * NTHREADS * sizeof(double);
+    size_t lds_bytes = (size_t)2 * CREG * NTHREADS * sizeof(double);
+    // persistent grid: at most ~2 workgroups per CU in total, each walks many item groups
+    const long ngroups_items = (n_items + NWAVES - 1) / NWAVES;
+    long per_slice = 512 / ((long)ngroups * batch);
+    if (per_slice < 1) per_slice = 1;
+    const long nblocks = ngroups_items < per_slice ? ngroups_items : per_slice;
+    if constexpr (KS == 12) {
+        if (cj) {
+            if (cj->lds_bytes > lds_bytes) lds_bytes = cj->lds_bytes;
+            static size_t attr_bytes = 0;   // per instantiation
+            if (lds_bytes > attr_bytes) {
+                hipError_t e = hipFuncSetAttribute((const void*)contract_circuit_kernel<NT, LAST, KS>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)lds_bytes);
+                if (e != hipSuccess) {
+                    oovqe_set_error("mode_contract: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                    return OOVQE_ERR_HIP;
+                }
+                attr_bytes = lds_bytes;
+            }
+            hipLaunchKernelGGL((contract_circuit_kernel<NT, LAST, KS>),
+                               dim3((unsigned)nblocks + 1, (unsigned)ngroups, (unsigned)batch),
+                               dim3(NTHREADS), lds_bytes, st, T, Cm, out, A, K, J, B, ldc, n_items, nbt,
+                               t_bs, c_bs, o_bs, *cj);
+            OOVQE_CHECK_LAUNCH("mode_contract+circuit");
+            return 0;
+        }
+    } else {
+        OOVQE_REQUIRE(!cj, "mode_contract: this shape cannot host circuit workgroups");
+    }
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)contract_kernel<NT, LAST, KS>,
@@ -256,11 +322,6 @@ int launch_nt(const double* T, const double* Cm, double* out, long A, int K, int
         }
         attr_done = true;
     }
-    // persistent grid: at most ~2 workgroups per CU in total, each walks many item groups
-    const long ngroups_items = (n_items + NWAVES - 1) / NWAVES;
-    long per_slice = 512 / ((long)ngroups * batch);
-    if (per_slice < 1) per_slice = 1;
-    const long nblocks = ngroups_items < per_slice ? ngroups_items : per_slice;
     hipLaunchKernelGGL((contract_kernel<NT, LAST, KS>),
                        dim3((unsigned)nblocks, (unsigned)ngroups, (unsigned)batch), dim3(NTHREADS),
                        lds_bytes, st, T, Cm, out, A, K, J, B, ldc, n_items, nbt, t_bs, c_bs, o_bs);
@@ -293,13 +354,13 @@ int launch_group(int nt, const double* T, const double* Cm, double* out, long A,
 template <bool LAST>
 int launch_short(int nt, const double* T, const double* Cm, double* out, long A, int K, int J, long B,
                  int ldc, int ngroups, long n_items, int nbt, int batch, long t_bs, long c_bs, long o_bs,
-                 hipStream_t st)
+                 hipStream_t st, const oovqe_circuit_job_t* cj)
 {
     switch (nt) {
 #define OOVQE_CASE(n) \
     case n:                                                                                    \
         return launch_nt<n, LAST, 12>(T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, batch, t_bs, \
-                                      c_bs, o_bs, st);
+                                      c_bs, o_bs, st, cj);
         OOVQE_CASE(1) OOVQE_CASE(2) OOVQE_CASE(3) OOVQE_CASE(4)
 #undef OOVQE_CASE
     }
@@ -319,16 +380,11 @@ int oovqe_mode_contract_impl(const double* T, const double* Cm, double* out, lon
     return oovqe_mode_contract_batched(T, Cm, out, A, K, J, B, ldc, last, 1, 0, 0, 0, st);
 }
 
-int oovqe_mode_contract_batched(const double* T, const double* Cm, double* out, long A, int K, int J,
-                                long B, int ldc, int last, int batch, long t_bs, long c_bs, long o_bs,
-                                hipStream_t st)
+// Can the launch for this shape host circuit workgroups (single-chunk kernels, K <= 48, <= 4 tiles)?
+// Mirrors the dispatch of oovqe_mode_contract_batched_circ below.
+static int contract_plan(long A, int K, int J, long B, int last, int batch, int* nt_out, int* ngroups_out,
+                         long* n_items_out, int* nbt_out)
 {
-    OOVQE_REQUIRE(batch >= 1 && batch <= 65535, "mode_contract: batch=%d", batch);
-    OOVQE_REQUIRE((double)A * (double)((B + 15) / 16) < 2.0e9, "mode_contract: too many strips");
-    OOVQE_REQUIRE(T && Cm && out, "mode_contract: null pointer");
-    OOVQE_REQUIRE(A >= 1 && K >= 1 && J >= 1 && B >= 1 && ldc >= J,
-                  "mode_contract: bad dims A=%ld K=%d J=%d B=%ld ldc=%d", A, K, J, B, ldc);
-    OOVQE_REQUIRE(!last || B == 1, "mode_contract: last-mode needs B == 1");
     const int JT = (J + 15) / 16;
     long n_items;
     int nbt = 1;
@@ -336,12 +392,9 @@ int oovqe_mode_contract_batched(const double* T, const double* Cm, double* out, 
         n_items = (A + 15) / 16;
     } else {
         const long nb = (B + 15) / 16;
-        OOVQE_REQUIRE(nb <= 0x7fffffffL, "mode_contract: B too large");
         nbt = (int)nb;
         n_items = A * nb;
     }
-    // tiles per wave: as many as fit (T is then streamed once), fewer when the problem is too
-    // small to fill 256 CUs with 8-wave workgroups.  The j-groups are grid.y of ONE launch.
     int nt = JT < 13 ? JT : 13;
     const long wgs = (n_items + NWAVES - 1) / NWAVES;
     // (never past one resident round of workgroups, ~2 per CU: a second round doubles the latency of
@@ -353,16 +406,60 @@ int oovqe_mode_contract_batched(const double* T, const double* Cm, double* out, 
     }
     const int ngroups = (JT + nt - 1) / nt;
     nt = (JT + ngroups - 1) / ngroups;   // even split
+    *nt_out = nt;
+    *ngroups_out = ngroups;
+    *n_items_out = n_items;
+    *nbt_out = nbt;
+    return 0;
+}
+
+int oovqe_contract_hosts_circuit(long A, int K, int J, long B, int last, int batch)
+{
+    int nt, ngroups, nbt;
+    long n_items;
+    contract_plan(A, K, J, B, last, batch, &nt, &ngroups, &n_items, &nbt);
+    return K <= 48 && nt <= 4;
+}
+
+int oovqe_mode_contract_batched_circ(const double* T, const double* Cm, double* out, long A, int K, int J,
+                                     long B, int ldc, int last, int batch, long t_bs, long c_bs,
+                                     long o_bs, hipStream_t st, const oovqe_circuit_job_t* cj);
+
+int oovqe_mode_contract_batched(const double* T, const double* Cm, double* out, long A, int K, int J,
+                                long B, int ldc, int last, int batch, long t_bs, long c_bs, long o_bs,
+                                hipStream_t st)
+{
+    return oovqe_mode_contract_batched_circ(T, Cm, out, A, K, J, B, ldc, last, batch, t_bs, c_bs, o_bs, st,
+                                            nullptr);
+}
+
+int oovqe_mode_contract_batched_circ(const double* T, const double* Cm, double* out, long A, int K, int J,
+                                     long B, int ldc, int last, int batch, long t_bs, long c_bs,
+                                     long o_bs, hipStream_t st, const oovqe_circuit_job_t* cj)
+{
+    OOVQE_REQUIRE(batch >= 1 && batch <= 65535, "mode_contract: batch=%d", batch);
+    OOVQE_REQUIRE((double)A * (double)((B + 15) / 16) < 2.0e9, "mode_contract: too many strips");
+    OOVQE_REQUIRE(T && Cm && out, "mode_contract: null pointer");
+    OOVQE_REQUIRE(A >= 1 && K >= 1 && J >= 1 && B >= 1 && ldc >= J,
+                  "mode_contract: bad dims A=%ld K=%d J=%d B=%ld ldc=%d", A, K, J, B, ldc);
+    OOVQE_REQUIRE(!last || B == 1, "mode_contract: last-mode needs B == 1");
+    OOVQE_REQUIRE(last || (B + 15) / 16 <= 0x7fffffffL, "mode_contract: B too large");
+    // tiles per wave: as many as fit (T is then streamed once), fewer when the problem is too
+    // small to fill 256 CUs with 8-wave workgroups.  The j-groups are grid.y of ONE launch.
+    int nt, ngroups, nbt;
+    long n_items;
+    contract_plan(A, K, J, B, last, batch, &nt, &ngroups, &n_items, &nbt);
     OOVQE_REQUIRE(ngroups <= 65535, "mode_contract: J too large");
     // chunk depth: 20 rows when that wastes <= 5 % of the MFMAs on zero padding, else 12 rows
     const int pad20 = ((K + 19) / 20) * 20, pad12 = ((K + 11) / 12) * 12;
     const bool deep = pad20 <= pad12 || pad20 * 100 <= K * 105;
     int rc;
+    OOVQE_REQUIRE(!cj || (K <= 48 && nt <= 4), "mode_contract: this shape cannot host circuit workgroups");
     if (K <= 48 && nt <= 4)
         rc = last ? launch_short<true>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, batch, t_bs,
-                                       c_bs, o_bs, st)
+                                       c_bs, o_bs, st, cj)
                   : launch_short<false>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, batch, t_bs,
-                                        c_bs, o_bs, st);
+                                        c_bs, o_bs, st, cj);
     else if (deep)
         rc = last ? launch_group<true, 5>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, batch,
                                      t_bs, c_bs, o_bs, st)

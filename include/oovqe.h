@@ -39,7 +39,8 @@ int         oovqe_profile_end(double* total_ms, int* count);
 /* bracket EVERY launch of an evaluation (costs ~8 us of dispatch gap per bracketed launch) */
 int         oovqe_profile_begin_detail(void);
 /* the same, broken down by launch of oovqe_oo_eval[_batch]: label 0 = half-transform,
- * 1 = circuit + RDMs, 2 = p->n contraction, 3 = column kernel, 4 = final assembly */
+ * 1 = circuit + RDMs (absent when they ride along launch 2), 2 = p->n contraction,
+ * 3 = Fock-column (panel) kernel, 4 = final assembly */
 int         oovqe_profile_end_labels(double* ms_by_label, int* count_by_label, int n_labels);
 
 /* ---- gate table for the statevector kernels ----------------------------------------------- *
