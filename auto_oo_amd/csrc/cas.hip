@@ -883,27 +883,29 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
             }
         }
     }
-    // Gn[x,yz] = sum_q C[q,x] U[n,q,yz]: four outputs per thread share one q loop (independent
-    // LDS reads in flight instead of one dependent chain per output)
-    for (int base = 0; base < M3; base += 4 * COL_THREADS) {
-        int xo[4], yo[4];
-        bool ok[4];
+    // Gn[x,yz] = sum_q C[q,x] U[n,q,yz] on the MFMA: A = C^T from LDS (m = x, k = q), B = U[n] rows
+    // from LDS (k = q, n = 16 consecutive yz); a wave owns the yz tiles wave, wave + 4, ...
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int lq = lane >> 4, lr = lane & 15;
+        const int nyz = (M2 + 15) / 16, nxt = (M + 15) / 16, ksteps = (N + 3) / 4;
+        for (int tile = wave; tile < nyz * nxt; tile += COL_THREADS / 64) {
+            const int ty = tile % nyz, tx = tile / nyz;
+            const int x = 16 * tx + lr, yz = 16 * ty + lr;
+            d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+            for (int i = 0; i < ksteps; ++i) {
+                const int q = 4 * i + lq;
+                const int qc = q < N ? q : N - 1;
+                const double av = Cl[qc * M + (x < M ? x : M - 1)] * ((q < N && x < M) ? 1.0 : 0.0);
+                const double bv = Un[qc * M2 + (yz < M2 ? yz : M2 - 1)] * ((q < N && yz < M2) ? 1.0 : 0.0);
+                acc = mfma_f64(av, bv, acc);
+            }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = base + u * COL_THREADS + tid;
-            ok[u] = idx < M3;
-            const int ii = ok[u] ? idx : 0;
-            xo[u] = ii / M2;
-            yo[u] = ii - xo[u] * M2;
+            for (int j = 0; j < 4; ++j) {
+                const int xo = 16 * tx + lq + 4 * j;
+                if (xo < M && yz < M2) Gn[xo * M2 + yz] = acc[j];
+            }
         }
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int q = 0; q < N; ++q) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] += Cl[q * M + xo[u]] * Un[q * M2 + yo[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (ok[u]) Gn[base + u * COL_THREADS + tid] = acc[u];
     }
     __syncthreads();
     for (int q = tid; q < N; q += COL_THREADS)
