@@ -1,0 +1,102 @@
+"""Properties at BASELINE.json's full sizes, where the oracle is too slow to run: the N = 200
+four-index transform (configs[2]) and the 64-geometry batched evaluation of the bench workload
+(configs[1] shape).  Size-independent properties only: round trips, linearity, invariants,
+permutation equivariance, derivative consistency."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _orthogonal(n, seed):
+    rng = np.random.default_rng(seed)
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    return torch.tensor(q, device=DEV)
+
+
+def test_transform_n200_round_trip_linearity_invariant():
+    from auto_oo_amd import ops
+    N = 200
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    g = torch.rand((N, N, N, N), dtype=torch.float64, device=DEV, generator=gen) - 0.5
+    Q = _orthogonal(N, 1)
+    QT = Q.T.contiguous()
+    out = torch.empty_like(g)
+    work = torch.empty_like(g)
+    back = torch.empty_like(g)
+    ops.general_4index_transform(g, Q, Q, Q, Q, out=out, work=work)
+    # invariant of an orthogonal transform: sum_pq g[p,p,q,q] (pair traces) and the Frobenius norm
+    tr_in = torch.einsum("ppqq->", g)
+    tr_out = torch.einsum("ppqq->", out)
+    assert abs((tr_out - tr_in).item()) < 1e-8 * max(1.0, abs(tr_in.item()))
+    n_in, n_out = torch.linalg.vector_norm(g), torch.linalg.vector_norm(out)
+    assert abs((n_out - n_in).item()) < 1e-11 * n_in.item()
+    # round trip: transforming back with Q^T restores the tensor
+    ops.general_4index_transform(out, QT, QT, QT, QT, out=back, work=work)
+    assert (back - g).abs().max().item() < 1e-11
+    # linearity in the tensor argument (independent coefficient matrices per index)
+    C = [_orthogonal(N, 10 + i) for i in range(4)]
+    g2 = torch.rand((N, N, N, N), dtype=torch.float64, device=DEV, generator=gen) - 0.5
+    ops.general_4index_transform(g, *C, out=out, work=work)       # T(g)
+    ops.general_4index_transform(g2, *C, out=back, work=work)     # T(g2)
+    out.mul_(0.75).add_(back)                                      # 0.75 T(g) + T(g2)
+    g.mul_(0.75).add_(g2)                                          # 0.75 g + g2 (in place: memory)
+    ops.general_4index_transform(g, *C, out=back, work=work)
+    scale = out.abs().max().item()
+    assert (back - out).abs().max().item() < 1e-12 * max(1.0, scale)
+
+
+def test_batched_evaluation_64_geometries_properties():
+    """configs[1] shape (N = 43, CAS(4e,3o), UCCD), 64 geometries in one call: permutation
+    equivariance (bitwise), energy-only == first column of energy+gradient, and dE/dtheta
+    against central differences of the energy for every geometry."""
+    import auto_oo_amd as aoo
+    from auto_oo_amd.synthetic import synthetic_problem
+    N, ncas, nelecas, nelec, G = 43, 3, 4, 16, 64
+    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="ucc")
+    mols, coeffs = [], []
+    for g in range(G):
+        P = synthetic_problem(N, 9000 + g)
+        mols.append(aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec))
+        coeffs.append(P["oao_mo_coeff"])
+    batch = aoo.OO_pqc_batch(pqc, mols, ncas, nelecas, oao_mo_coeffs=coeffs)
+    rng = np.random.default_rng(5)
+    thetas = torch.tensor(rng.uniform(0, 2 * np.pi, (G, pqc.theta_shape)), device=DEV)
+    eg = batch.energy_and_gradient(thetas).clone()
+    assert torch.isfinite(eg).all()
+    assert torch.equal(batch.energy(thetas), eg[:, 0])
+    # the same geometries in another order: same numbers, permuted (each geometry is evaluated
+    # by its own workgroups with a fixed summation order)
+    perm = torch.tensor(rng.permutation(G))
+    batch_p = aoo.OO_pqc_batch(pqc, [mols[i] for i in perm], ncas, nelecas,
+                               oao_mo_coeffs=[coeffs[i] for i in perm])
+    eg_p = batch_p.energy_and_gradient(thetas[perm.to(DEV)].contiguous())
+    assert torch.equal(eg_p, eg[perm.to(DEV)])
+    # dE/dtheta_k == central difference of E, all geometries at once
+    h = 1e-5
+    for k in range(pqc.theta_shape):
+        tp, tm = thetas.clone(), thetas.clone()
+        tp[:, k] += h
+        tm[:, k] -= h
+        fd = (batch.energy(tp) - batch.energy(tm)) / (2 * h)
+        assert (fd - eg[:, 1 + k]).abs().max().item() < 2e-7
+
+
+def test_expm_n200_orthogonality_and_inverse():
+    """configs[2]: expm(-K) of a 200 x 200 skew-symmetric K is orthogonal, expm(K) is its inverse,
+    and the exponential of a sum of commuting generators (K, 0.5 K) factorises."""
+    from auto_oo_amd import ops
+    N = 200
+    rng = np.random.default_rng(11)
+    a = rng.standard_normal((N, N)) * 0.05
+    K = torch.tensor(a - a.T, device=DEV)
+    U = ops.expm(K, sign=-1.0)
+    Ui = ops.expm(K, sign=1.0)
+    eye = torch.eye(N, dtype=torch.float64, device=DEV)
+    assert (U.T @ U - eye).abs().max().item() < 1e-12
+    assert (U @ Ui - eye).abs().max().item() < 1e-12
+    U15 = ops.expm((1.5 * K).contiguous(), sign=-1.0)
+    Uh = ops.expm((0.5 * K).contiguous(), sign=-1.0)
+    assert (U15 - U @ Uh).abs().max().item() < 1e-12
