@@ -100,3 +100,35 @@ def test_expm_n200_orthogonality_and_inverse():
     U15 = ops.expm((1.5 * K).contiguous(), sign=-1.0)
     Uh = ops.expm((0.5 * K).contiguous(), sign=-1.0)
     assert (U15 - U @ Uh).abs().max().item() < 1e-12
+
+
+def test_kupccd_cas88_state_rdm_gradient_properties():
+    """configs[4]: kUpCCD CAS(8e,8o) (16 qubits, 4900-determinant sector): normalisation, RDM sum
+    rules, and the reverse-mode theta-gradient against central differences of the energy."""
+    import auto_oo_amd as aoo
+    from auto_oo_amd.synthetic import synthetic_problem
+    ncas, nelecas, nelec, N = 8, 8, 16, 43
+    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="kupccd", k=1)
+    rng = np.random.default_rng(2)
+    th = torch.tensor(rng.uniform(0, 2 * np.pi, int(pqc.theta_shape)), device=DEV)
+    psi = pqc.qnode(th)
+    assert abs(torch.linalg.vector_norm(psi).item() - 1.0) < 1e-12
+    g1, g2 = pqc.get_rdms(th)
+    assert abs(torch.trace(g1).item() - nelecas) < 1e-10
+    assert (g1 - g1.T).abs().max().item() < 1e-12
+    assert abs(torch.einsum("ppqq->", g2).item() - nelecas * (nelecas - 1)) < 1e-9
+    # sum_q Gamma_pqqs-type partial trace: sum_rs delta_rs Gamma[p,q,r,s] = (N - 1) gamma[p,q]
+    assert (torch.einsum("pqrr->pq", g2) - (nelecas - 1) * g1).abs().max().item() < 1e-9
+    P = synthetic_problem(N, 20265)
+    mol = aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec)
+    oo = aoo.OO_pqc(pqc, mol, ncas, nelecas, oao_mo_coeff=P["oao_mo_coeff"])
+    E, grad = oo.energy_and_gradient(th)
+    assert abs(E.item() - oo.energy_from_parameters(th).item()) < 1e-10
+    h = 1e-5
+    order = torch.argsort(grad[:int(pqc.theta_shape)].abs(), descending=True)[:3]
+    for j in order.tolist():
+        tp, tm = th.clone(), th.clone()
+        tp[j] += h
+        tm[j] -= h
+        fd = (oo.energy_from_parameters(tp).item() - oo.energy_from_parameters(tm).item()) / (2 * h)
+        assert abs(fd - grad[j].item()) < 1e-6 * max(1.0, abs(fd))
