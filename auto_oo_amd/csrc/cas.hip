@@ -1064,7 +1064,32 @@ void cas_panel_kernel(const double* __restrict__ Gm_in, const double* __restrict
             const int idx = tid + it * PAN_THREADS, nl = idx / N, p = idx - nl * N;
             rn[it] = idx < nn * N ? C[(size_t)p * N + n0 + nl] : 0.0;
         }
-        for (int idx = tid; idx < nn * M3; idx += PAN_THREADS) Gp[idx] = Gm_in[(size_t)n0 * M3 + idx];
+        // first RDM chunk (one element of gamma and of Gamma per thread here, the rest in the loop)
+        const int kc0 = nrdm < rdm_chunk ? nrdm : rdm_chunk;
+        const double rg1 = tid < kc0 * na2 ? gamma[tid] : 0.0;
+        const double rg2 = tid < kc0 * na4 ? Gamma[tid] : 0.0;
+        // the panel of g_mo, eight loads in flight per thread
+        {
+            const double* src = Gm_in + (size_t)n0 * M3;
+            const int total = nn * M3;
+            for (int base = 0; base < total; base += 8 * PAN_THREADS) {
+                double r[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * PAN_THREADS + tid;
+                    r[u] = idx < total ? src[idx] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + u * PAN_THREADS + tid;
+                    if (idx < total) Gp[idx] = r[u];
+                }
+            }
+        }
+        if (tid < kc0 * na2) gml[tid] = rg1;
+        if (tid < kc0 * na4) Gml[tid] = rg2;
+        for (int idx = PAN_THREADS + tid; idx < kc0 * na2; idx += PAN_THREADS) gml[idx] = gamma[idx];
+        for (int idx = PAN_THREADS + tid; idx < kc0 * na4; idx += PAN_THREADS) Gml[idx] = Gamma[idx];
 #pragma unroll
         for (int it = 0; it < IT_C; ++it) {
             const int idx = tid + it * PAN_THREADS;
@@ -1138,9 +1163,11 @@ void cas_panel_kernel(const double* __restrict__ Gm_in, const double* __restrict
     for (int k0 = 0; k0 < nrdm; k0 += rdm_chunk) {
         const int kc = (nrdm - k0) < rdm_chunk ? (nrdm - k0) : rdm_chunk;
         __syncthreads();
-        for (int idx = tid; idx < kc * na2; idx += PAN_THREADS) gml[idx] = gamma[(size_t)k0 * na2 + idx];
-        for (int idx = tid; idx < kc * na4; idx += PAN_THREADS) Gml[idx] = Gamma[(size_t)k0 * na4 + idx];
-        __syncthreads();
+        if (k0 > 0) {   // (chunk 0 was staged with the other inputs)
+            for (int idx = tid; idx < kc * na2; idx += PAN_THREADS) gml[idx] = gamma[(size_t)k0 * na2 + idx];
+            for (int idx = tid; idx < kc * na4; idx += PAN_THREADS) Gml[idx] = Gamma[(size_t)k0 * na4 + idx];
+            __syncthreads();
+        }
         // Fock columns: one thread per (n, set k, row m)
         for (int idx = tid; idx < nn * kc * M; idx += PAN_THREADS) {
             const int nl = idx / (kc * M), r0 = idx - nl * (kc * M);
