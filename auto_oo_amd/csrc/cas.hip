@@ -850,12 +850,22 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
             rc[u] = idx < N * M ? C[(size_t)q * N + x] : 0.0;
         }
         if (tid < N) rn = C[(size_t)tid * N + n];
+        // first RDM chunk (two elements of Gamma per thread here, the rest in the loop)
+        const int kc0 = nrdm < rdm_chunk ? nrdm : rdm_chunk;
+        const double rg1 = tid < kc0 * na2 ? gamma[tid] : 0.0;
+        const double rg2 = tid < kc0 * na4 ? Gamma[tid] : 0.0;
+        const double rg3 = COL_THREADS + tid < kc0 * na4 ? Gamma[COL_THREADS + tid] : 0.0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int idx = u * COL_THREADS + tid;
             if (idx < N * M) Cl[idx] = rc[u];
         }
         if (tid < N) cn[tid] = rn;
+        if (tid < kc0 * na2) gml[tid] = rg1;
+        if (tid < kc0 * na4) Gml[tid] = rg2;
+        if (COL_THREADS + tid < kc0 * na4) Gml[COL_THREADS + tid] = rg3;
+        for (int idx = COL_THREADS + tid; idx < kc0 * na2; idx += COL_THREADS) gml[idx] = gamma[idx];
+        for (int idx = 2 * COL_THREADS + tid; idx < kc0 * na4; idx += COL_THREADS) Gml[idx] = Gamma[idx];
         for (int idx = 4 * COL_THREADS + tid; idx < N * M; idx += COL_THREADS) {
             const int q = idx / M, x = idx - q * M;
             Cl[idx] = C[(size_t)q * N + x];
@@ -946,9 +956,11 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
     for (int k0 = 0; k0 < nrdm; k0 += rdm_chunk) {
         const int kc = (nrdm - k0) < rdm_chunk ? (nrdm - k0) : rdm_chunk;
         __syncthreads();
-        for (int idx = tid; idx < kc * na2; idx += COL_THREADS) gml[idx] = gamma[(size_t)k0 * na2 + idx];
-        for (int idx = tid; idx < kc * na4; idx += COL_THREADS) Gml[idx] = Gamma[(size_t)k0 * na4 + idx];
-        __syncthreads();
+        if (k0 > 0) {   // (chunk 0 was staged with the other inputs)
+            for (int idx = tid; idx < kc * na2; idx += COL_THREADS) gml[idx] = gamma[(size_t)k0 * na2 + idx];
+            for (int idx = tid; idx < kc * na4; idx += COL_THREADS) Gml[idx] = Gamma[(size_t)k0 * na4 + idx];
+            __syncthreads();
+        }
         // Fock columns: one thread per (set k, row m)
         for (int idx = tid; idx < kc * M; idx += COL_THREADS) {
             const int kl = idx / M, m = idx - kl * M, k = k0 + kl;
