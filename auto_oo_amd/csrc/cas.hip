@@ -1256,13 +1256,33 @@ void cas_final_kernel(const double* __restrict__ Fcol, const double* __restrict_
         if (gmat) gmat += gi * (size_t)N * N;
         if (nuc_arr) nuc = nuc_arr[gi];
     }
-    for (long idx = tid; idx < (long)nrdm * n_kappa; idx += 512) {
-        const int k = (int)(idx / n_kappa), t = (int)(idx - (long)k * n_kappa);
-        const int r = kap_row[t], c = kap_col[t];
-        const double* F = Fcol + (size_t)k * M * N;
-        const double frc = r < M ? F[(size_t)r * N + c] : 0.0;
-        const double fcr = c < M ? F[(size_t)c * N + r] : 0.0;
-        gvec[idx] = 2.0 * (frc - fcr);
+    // four entries per thread at a time: index loads, then the dependent Fock loads, then the
+    // stores (a plain loop pays two memory latencies per entry)
+    for (long base = 0; base < (long)nrdm * n_kappa; base += 4 * 512) {
+        int rr[4], cc[4], kk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long idx = base + u * 512 + tid;
+            const bool ok = idx < (long)nrdm * n_kappa;
+            const long ii = ok ? idx : 0;
+            kk[u] = (int)(ii / n_kappa);
+            const int t = (int)(ii - (long)kk[u] * n_kappa);
+            rr[u] = kap_row[t];
+            cc[u] = kap_col[t];
+        }
+        double frc[4], fcr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double* F = Fcol + (size_t)kk[u] * M * N;
+            const int r = rr[u], c = cc[u];
+            frc[u] = F[(size_t)(r < M ? r : 0) * N + c] * (r < M ? 1.0 : 0.0);
+            fcr[u] = F[(size_t)(c < M ? c : 0) * N + r] * (c < M ? 1.0 : 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long idx = base + u * 512 + tid;
+            if (idx < (long)nrdm * n_kappa) gvec[idx] = 2.0 * (frc[u] - fcr[u]);
+        }
     }
     if (fock)
         for (int idx = tid; idx < N * N; idx += 512) {
