@@ -312,3 +312,29 @@ def test_orbital_optimization_fixed_rdms():
     newk, _ = opt.damped_newton_step(partial(ooo.energy_from_kappa, one_rdm=g1, two_rdm=g2),
                                      (kappa0,), grad, hess)
     assert abs(ooo.energy_from_kappa(newk, g1, g2).item() - energy_l[0]) < 1e-8
+
+
+@pytest.mark.parametrize("N,G", [(13, 100), (20, 37)])
+def test_batched_evaluation_many_small_geometries(N, G):
+    """Batch sizes that are no multiple of anything, on shapes where the library picks the
+    persistent T3 path by itself (G * N^2 slabs fill the chip): every geometry of the batch equals
+    its single evaluation."""
+    from auto_oo_amd.synthetic import synthetic_problem
+    ncas, nelecas, nelec = 2, 2, 6
+    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="ucc")
+    mols, coeffs = [], []
+    base = [synthetic_problem(N, 700 + g) for g in range(5)]
+    for g in range(G):
+        P = base[g % 5]
+        mols.append(aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"] + 0.01 * g, nelec))
+        coeffs.append(P["oao_mo_coeff"])
+    batch = aoo.OO_pqc_batch(pqc, mols, ncas, nelecas, oao_mo_coeffs=coeffs)
+    rng = np.random.default_rng(8)
+    thetas = torch.tensor(rng.uniform(0, 2 * np.pi, (G, pqc.theta_shape)))
+    eg = batch.energy_and_gradient(thetas).cpu()
+    assert torch.isfinite(eg).all()
+    for g in (0, 1, G // 2, G - 2, G - 1):
+        single = aoo.OO_pqc(pqc, mols[g], ncas, nelecas, oao_mo_coeff=coeffs[g])
+        E, grad = single.energy_and_gradient(thetas[g])
+        assert abs(eg[g, 0].item() - E.item()) < 1e-11
+        assert (eg[g, 1:] - grad.cpu()).abs().max() < 1e-11
