@@ -358,7 +358,10 @@ def main():
     kern_s = kern_total_ms * 1e-3 / kern_count if kern_count else float("nan")
     M = batch._n_occ + NCAS
     bytes_per_eval = 8.0 * NAO ** 4 + 8.0 * NAO * M ** 3            # g_ao read once + T3 written
-    alg_bytes = bytes_per_eval * args.steps / max(kern_count, 1)   # per launch (batched)
+    # evaluations per launch from the calls made (the event pool brackets at most 8192 launches of
+    # a long run: the average duration is then over those, the bytes are still per launch)
+    evals_per_launch = args.steps / max(n_calls, 1)
+    alg_bytes = bytes_per_eval * evals_per_launch                   # per launch (batched)
     achieved = alg_bytes / kern_s / 1e9
     # HBM traffic of that kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 [gfx950 correction] +
     # WRITE_SIZE, separate passes; profiles/pmc_half_transform.json), scaled to this launch size
@@ -368,7 +371,7 @@ def main():
         try:
             with open(pmc_path) as fh:
                 pmc = json.load(fh)
-            traffic = pmc["hbm_bytes_per_launch"] / 64.0 * args.steps / max(kern_count, 1)
+            traffic = pmc["hbm_bytes_per_launch"] / 64.0 * evals_per_launch
         except Exception:
             traffic = None
 
@@ -406,7 +409,7 @@ def main():
             "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes,
             "algorithmic_bytes_per_eval": bytes_per_eval,
-            "evals_per_launch": args.steps / max(kern_count, 1),
+            "evals_per_launch": evals_per_launch,
             "avg_launch_us": kern_s * 1e6,
             "all_launches_avg_us": {k: (v[0] / v[1] * 1e3 if v[1] else None) for k, v in kern_by.items()},
             "launches_timed": kern_count,
