@@ -357,7 +357,12 @@ def main():
     kern_by = ops.profile_end()[2]
     kern_s = kern_total_ms * 1e-3 / kern_count if kern_count else float("nan")
     M = batch._n_occ + NCAS
-    bytes_per_eval = 8.0 * NAO ** 4 + 8.0 * NAO * M ** 3            # g_ao read once + T3 written
+    # which stage-1 kernel the library picks (cas.hip: fused_plan): the persistent T3 kernel once a
+    # launch covers >= 48 slabs per CU, the one-slab-per-wave T2 kernel below that
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    t3_path = (args.steps / max(n_calls, 1)) * NAO ** 2 >= 48 * n_cu
+    # g_ao read once + T3 (8 N M^3) or T2 (8 N^2 M^2) written
+    bytes_per_eval = 8.0 * NAO ** 4 + (8.0 * NAO * M ** 3 if t3_path else 8.0 * NAO ** 2 * M ** 2)
     # evaluations per launch from the calls made (the event pool brackets at most 8192 launches of
     # a long run: the average duration is then over those, the bytes are still per launch)
     evals_per_launch = args.steps / max(n_calls, 1)
@@ -399,8 +404,9 @@ def main():
             "parallelism": f"geometry-sharded x{world}, one all_gather at the end",
         },
         "roofline": {
-            "kernel": ("half_transform_fused_kernel<11,3> (T3[p,x,y,z] = sum_q C[q,x] "
-                       "sum_rs C[r,y] g[p,q,r,s] C[s,z])"),
+            "kernel": (("half_transform_fused_kernel<11,3> (T3[p,x,y,z] = sum_q C[q,x] "
+                        "sum_rs C[r,y] g[p,q,r,s] C[s,z])") if t3_path else
+                       "half_transform_kernel<1,11,3> (T2[p,q,y,z] = sum_rs C[r,y] g[p,q,r,s] C[s,z])"),
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
