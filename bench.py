@@ -372,7 +372,7 @@ def main():
     # WRITE_SIZE, separate passes; profiles/pmc_half_transform.json), scaled to this launch size
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_half_transform.json")
-    if os.path.exists(pmc_path):
+    if os.path.exists(pmc_path) and t3_path:        # (the PMC passes were taken on the T3 kernel)
         try:
             with open(pmc_path) as fh:
                 pmc = json.load(fh)
