@@ -193,10 +193,19 @@ static __device__ void circuit_rdm_small_body(const double* __restrict__ theta, 
             }
             const int n = nt * 16 + lr;
             const double* brow = n < na2 ? V + ((size_t)vb * na2 + n) * LDV : nullptr;
-            for (uint32_t x0 = 0; x0 < D; x0 += 4) {
-                const double av = arow ? arow[x0 + lq] : 0.0;
-                const double bv = brow ? brow[x0 + lq] : 0.0;
-                acc = mfma_f64(av, bv, acc);
+            // 16 k-steps at a time: all fragment reads first, then the MFMA chain (one LDS latency
+            // per 16 MFMAs instead of one per MFMA); D is a power of two >= 4
+            for (uint32_t x0 = 0; x0 < D; x0 += 64) {
+                double af[16], bf[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t x = x0 + 4 * i + lq;
+                    const bool in = x0 + 4 * i < D;
+                    af[i] = (arow && in) ? arow[x] : 0.0;
+                    bf[i] = (brow && in) ? brow[x] : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc = mfma_f64(af[i], bf[i], acc);
             }
         }
 #pragma unroll
