@@ -32,6 +32,10 @@ int oovqe_mode_contract_batched_circ(const double* T, const double* Cm, double* 
                                      long B, int ldc, int last, int batch, long t_bs, long c_bs,
                                      long o_bs, hipStream_t st, const oovqe_circuit_job_t* cj);
 int oovqe_contract_hosts_circuit(long A, int K, int J, long B, int last, int batch);
+extern "C" int oovqe_circuit_rdms(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
+                                  int n_qubits, int ncas, uint32_t init_index, int want_tangents, int batch,
+                                  double* psi, double* dpsi, double* gamma, double* Gamma, double* work,
+                                  oovqe_stream_t stream);
 extern "C" int oovqe_circuit_rdms_is_small(int n_qubits, int ncas, int nvec, int n_gates);
 
 namespace {
@@ -658,9 +662,11 @@ void fock_kernel(const double* __restrict__ Gm, const double* __restrict__ hmo,
                  const double* __restrict__ gamma, const double* __restrict__ Gamma, double nuc,
                  int N, int no, int na, const int32_t* __restrict__ kap_row,
                  const int32_t* __restrict__ kap_col, int n_kappa, double* c0, double* c1,
-                 double* c2, double* E, double* fock, double* gmat, double* gvec, double* dE)
+                 double* c2, double* E, double* fock, double* gmat, double* gvec, double* dE,
+                 const double* __restrict__ nuc_dev)
 {
     extern __shared__ double lds[];
+    if (nuc_dev) nuc = *nuc_dev;         // batched callers keep the nuclear repulsion on the device
     const int M = no + na;
     const int M2 = M * M, M3 = M2 * M;
     const int na2 = na * na, na4 = na2 * na2;
@@ -1516,12 +1522,30 @@ extern "C" int oovqe_cas_finish_transform(const double* T2, const double* h_ao, 
     return 0;
 }
 
+static int cas_energy_gradient_impl(const double* Gm, const double* hmo, const double* gamma,
+                                    const double* Gamma, int nrdm, double nuc, const double* nuc_dev, int N,
+                                    int n_occ, int ncas, const int32_t* kap_row, const int32_t* kap_col,
+                                    int n_kappa, double* c0, double* c1, double* c2, double* E,
+                                    double* fock, double* gmat, double* gvec, double* dE,
+                                    oovqe_stream_t stream);
+
 extern "C" int oovqe_cas_energy_gradient(const double* Gm, const double* hmo, const double* gamma,
                                          const double* Gamma, int nrdm, double nuc, int N, int n_occ,
                                          int ncas, const int32_t* kap_row, const int32_t* kap_col,
                                          int n_kappa, double* c0, double* c1, double* c2, double* E,
                                          double* fock, double* gmat, double* gvec, double* dE,
                                          oovqe_stream_t stream)
+{
+    return cas_energy_gradient_impl(Gm, hmo, gamma, Gamma, nrdm, nuc, nullptr, N, n_occ, ncas, kap_row,
+                                    kap_col, n_kappa, c0, c1, c2, E, fock, gmat, gvec, dE, stream);
+}
+
+static int cas_energy_gradient_impl(const double* Gm, const double* hmo, const double* gamma,
+                                    const double* Gamma, int nrdm, double nuc, const double* nuc_dev, int N,
+                                    int n_occ, int ncas, const int32_t* kap_row, const int32_t* kap_col,
+                                    int n_kappa, double* c0, double* c1, double* c2, double* E,
+                                    double* fock, double* gmat, double* gvec, double* dE,
+                                    oovqe_stream_t stream)
 {
     OOVQE_REQUIRE(Gm && hmo && gamma && Gamma && c0 && c1 && c2 && E && gvec,
                   "cas_energy_gradient: null pointer");
@@ -1544,9 +1568,23 @@ extern "C" int oovqe_cas_energy_gradient(const double* Gm, const double* hmo, co
     }
     hipLaunchKernelGGL(fock_kernel, dim3(nrdm), dim3(FOCK_THREADS), lds_bytes, (hipStream_t)stream,
                        Gm, hmo, gamma, Gamma, nuc, N, n_occ, ncas, kap_row, kap_col, n_kappa, c0, c1,
-                       c2, E, fock, gmat, gvec, dE);
+                       c2, E, fock, gmat, gvec, dE, nuc_dev);
     OOVQE_CHECK_LAUNCH("cas_energy_gradient");
     return 0;
+}
+
+// LDS of cas_column_kernel without the RDM sets (U[n] and g_mo[n] resident): decides between the
+// column kernel and the staged kernels for large N * M^2
+static size_t column_base_bytes(int N, int M)
+{
+    const size_t m2 = (size_t)M * M, m3 = m2 * M;
+    return ((size_t)N * m2 + (size_t)N * M + m3 + N + M + M + N + (size_t)4 * N) * sizeof(double);
+}
+
+static bool column_fits(int N, int M, int ncas)
+{
+    const size_t na2 = (size_t)ncas * ncas;
+    return column_base_bytes(N, M) + (na2 + na2 * na2) * sizeof(double) <= 160 * 1024;
 }
 
 // Batched CAS path: `batch` geometries of identical shape, every per-geometry array stacked.
@@ -1599,6 +1637,43 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
             return rc;
         oovqe_profile_mark_stop(st);
         Gm_in = Gmw;
+    } else if (!column_fits(N, M, ncas)) {
+        // Large N * M^2 (many occupied orbitals): neither U[n] nor the panel fits LDS.  Staged path
+        // per geometry: T2 (batched) -> K1: q -> x, p -> n -> g_mo[n,x,y,z] and h_mo in memory ->
+        // fock_kernel (one workgroup per RDM set, streaming g_mo from L2).  Same outputs.
+        OOVQE_REQUIRE(M < N, "cas_eval: the staged path needs at least one virtual orbital (N=%d M=%d)", N, M);
+        if (cj) {   // the circuit workgroups cannot ride along here: own launch
+            if ((rc = oovqe_circuit_rdms(cj->theta, cj->n_theta, cj->gates, cj->n_gates, cj->n_qubits,
+                                         cj->ncas, cj->init_index, cj->n_tan > 0, batch, nullptr, nullptr,
+                                         cj->gamma, cj->Gamma, nullptr, stream)))
+                return rc;
+        }
+        if ((rc = half_transform_batched(g_ao, C, N, M, T2, batch, stream))) return rc;
+        const size_t na2s = (size_t)ncas * ncas, na4s = na2s * na2s;
+        for (int g = 0; g < batch; ++g) {
+            const size_t gi = (size_t)g;
+            double* T2g = T2 + gi * N * N * m2;
+            double* wk = U + gi * N * N * m2;                  // T3 [N][M^3] + Y [N][M]
+            double* Gmg = T2g;                                 // T2 of this geometry is dead after q -> x
+            double* hmog = Fcol + gi * nrdm * M * N;           // [N][M]
+            if ((rc = oovqe_cas_finish_transform(T2g, h_ao + gi * N * N, C + gi * N * N, N, M, Gmg, hmog,
+                                                 wk, stream)))
+                return rc;
+            if ((rc = cas_energy_gradient_impl(
+                     Gmg, hmog, gamma + gi * nrdm * na2s, Gamma + gi * nrdm * na4s, nrdm, nuc,
+                     nuc_arr ? nuc_arr + g : nullptr, N, n_occ, ncas, kap_row, kap_col, n_kappa,
+                     c0 + gi * out_stride, c1 + gi * out_stride, c2 + gi * out_stride, E + gi * out_stride,
+                     fock ? fock + gi * N * N : nullptr, gmat ? gmat + gi * N * N : nullptr,
+                     gvec + gi * out_stride, dE ? dE + gi * out_stride : nullptr, stream)))
+                return rc;
+            if (Gm)
+                OOVQE_CHECK_HIP(hipMemcpyAsync(Gm + gi * N * m3, Gmg, (size_t)N * m3 * sizeof(double),
+                                               hipMemcpyDeviceToDevice, st), "cas_eval: copy g_mo");
+            if (hmo)
+                OOVQE_CHECK_HIP(hipMemcpyAsync(hmo + gi * N * M, hmog, (size_t)N * M * sizeof(double),
+                                               hipMemcpyDeviceToDevice, st), "cas_eval: copy h_mo");
+        }
+        return 0;
     } else {
         if ((rc = half_transform_batched(g_ao, C, N, M, T2, batch, stream))) return rc;
         // U[n,(q y z)] = sum_p C[p,n] T2[p,(q y z)]

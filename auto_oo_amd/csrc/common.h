@@ -30,6 +30,15 @@ void oovqe_profile_mark_stop(hipStream_t st);
         }                                                                                 \
     } while (0)
 
+#define OOVQE_CHECK_HIP(call, name)                                                        \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            oovqe_set_error("%s: %s", name, hipGetErrorString(e__));                      \
+            return OOVQE_ERR_HIP;                                                         \
+        }                                                                                 \
+    } while (0)
+
 #define OOVQE_REQUIRE(cond, ...)                                                          \
     do {                                                                                  \
         if (!(cond)) {                                                                    \

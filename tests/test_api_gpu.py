@@ -338,3 +338,28 @@ def test_batched_evaluation_many_small_geometries(N, G):
         E, grad = single.energy_and_gradient(thetas[g])
         assert abs(eg[g, 0].item() - E.item()) < 1e-11
         assert (eg[g, 1:] - grad.cpu()).abs().max() < 1e-11
+
+
+def test_many_occupied_orbitals_use_the_staged_path():
+    """A molecule-like shape with many doubly occupied orbitals (N = 30, 20 occupied + CAS(4e,3o):
+    M = 23): U[n] / g_mo[n] no longer fit one workgroup's LDS, the library switches to the staged
+    kernels.  Energy, theta- and kappa-gradients against the oracle, batched call included."""
+    from auto_oo_amd.synthetic import synthetic_problem
+    N, ncas, nelecas, nelec = 30, 3, 4, 44
+    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="ucc")
+    P = synthetic_problem(N, 4242)
+    mol = aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec)
+    oo = aoo.OO_pqc(pqc, mol, ncas, nelecas, oao_mo_coeff=P["oao_mo_coeff"])
+    theta = torch.tensor(np.random.default_rng(1).uniform(0, 2 * np.pi, pqc.theta_shape))
+    E, grad = oo.energy_and_gradient(theta)
+    omol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec)
+    ooo = R.OracleOOPQC(R.OraclePQC(ncas, nelecas, "ucc"), omol, ncas, nelecas, P["oao_mo_coeff"])
+    E_ref = ooo.energy_from_parameters(theta)
+    assert abs(E.item() - E_ref.item()) < 1e-9 * max(1.0, abs(E_ref.item()))
+    g_ref = ooo.full_gradient(theta)
+    assert (grad.cpu() - g_ref).abs().max() < 1e-8 * max(1.0, float(g_ref.abs().max()))
+    batch = aoo.OO_pqc_batch(pqc, [mol, mol], ncas, nelecas,
+                             oao_mo_coeffs=[P["oao_mo_coeff"], P["oao_mo_coeff"]])
+    eg = batch.energy_and_gradient(torch.stack((theta, theta)))
+    assert abs(eg[1, 0].item() - E.item()) < 1e-11
+    assert (eg[1, 1:] - grad).abs().max().item() < 1e-11

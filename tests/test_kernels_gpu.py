@@ -390,3 +390,37 @@ def test_cas_eval_large_active_space_random_rdms(N, nelec, ncas, nelecas, path, 
     assert abs(res["E"].item() - E_ref.item()) < 1e-8 * max(1.0, abs(E_ref.item()))
     gv_ref = oo.kappa_matrix_to_vector(oo.analytic_gradient(gam[0], Gam[0]))
     assert (res["gvec"].cpu()[0] - gv_ref).abs().max() < 1e-8 * max(1.0, float(gv_ref.abs().max()))
+
+
+@pytest.mark.parametrize("N,M", [(52, 20), (64, 10), (70, 33), (96, 12)])
+def test_half_transform_streaming_sizes(N, M):
+    """Shapes beyond the one-chunk slab kernels (N > 48) and M > 16 (two / three 16-wide tiles of
+    occupied + active orbitals): the streaming half-transform against the einsum."""
+    rng = np.random.default_rng(7 * N + M)
+    g = torch.tensor(rng.standard_normal((N, N, N, N)))
+    C = torch.tensor(rng.standard_normal((N, N)))
+    T2 = ops.cas_half_transform(g.to(DEV), C.to(DEV), M).cpu()
+    ref = torch.einsum("ry,pqrs,sz->pqyz", C[:, :M], g, C[:, :M])
+    assert (T2 - ref).abs().max() < 1e-11 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("N,nelec,ncas,nelecas", [(56, 12, 4, 4), (50, 40, 4, 4), (64, 60, 3, 2)])
+def test_cas_eval_beyond_fused_shapes(N, nelec, ncas, nelecas):
+    """The whole CAS path on shapes that only the T2 path covers (N > 48), including N * M^2 too
+    large for the column kernel's LDS (M = 22, 32: staged kernels, g_mo streamed from memory)."""
+    P = R.synthetic_problem(N, 900 + N)
+    mol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec)
+    oo = R.OracleOOEnergy(mol, ncas, nelecas, P["oao_mo_coeff"])
+    no = len(oo.occ_idx)
+    C = oo.mo_coeff
+    rng = np.random.default_rng(N)
+    gam = torch.stack([_rand(rng, ncas, ncas)])
+    Gam = torch.stack([_rand(rng, ncas, ncas, ncas, ncas)])
+    rows, cols = X.tril_tables(N, oo.params_idx)
+    res = ops.cas_eval(oo.int2e_ao.to(DEV).contiguous(), oo.int1e_ao.to(DEV).contiguous(),
+                       C.to(DEV).contiguous(), gam.to(DEV).contiguous(), Gam.to(DEV).contiguous(),
+                       oo.nuc, no, ncas, torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV))
+    E_ref = oo.energy_from_mo_coeff(C, gam[0], Gam[0])
+    assert abs(res["E"].item() - E_ref.item()) < 1e-8 * max(1.0, abs(E_ref.item()))
+    gv_ref = oo.kappa_matrix_to_vector(oo.analytic_gradient(gam[0], Gam[0]))
+    assert (res["gvec"].cpu()[0] - gv_ref).abs().max() < 1e-8 * max(1.0, float(gv_ref.abs().max()))
