@@ -27,10 +27,11 @@ from .oo_energy import (                                    # noqa: E402
 from .newton_raphson import NewtonStep, BatchedNewtonStep   # noqa: E402
 from .berry import ActiveSpaceRotation, bogoliubov_atob_cas, state_overlap   # noqa: E402
 from .excitations import generalized_pair_doubles           # noqa: E402
+from .active_space import active_space_integrals, molecular_hamiltonian_coefficients   # noqa: E402
 
 __all__ = [
     "Parameterized_circuit", "Moldata", "ao_to_oao", "OO_pqc", "OO_pqc_batch", "OO_energy", "mo_ao_to_mo_oao",
     "int1e_transform", "int2e_transform", "general_4index_transform", "uniform_4index_transform",
     "vector_to_skew_symmetric", "skew_symmetric_to_vector", "non_redundant_indices", "NewtonStep", "BatchedNewtonStep", "ActiveSpaceRotation", "bogoliubov_atob_cas", "state_overlap",
-    "generalized_pair_doubles",
+    "generalized_pair_doubles", "active_space_integrals", "molecular_hamiltonian_coefficients",
 ]
