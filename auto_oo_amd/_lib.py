@@ -81,7 +81,9 @@ SIGNATURES = {
     "oovqe_cas_eval": (ctypes.c_int, [c_double_p] * 5 + [ctypes.c_int, ctypes.c_double, ctypes.c_int,
                                                         ctypes.c_int, ctypes.c_int, c_int32_p,
                                                         c_int32_p, ctypes.c_int]
-                       + [c_double_p] * 11 + [c_stream]),
+                       + [c_double_p] * 11 + [ctypes.c_uint, c_stream]),
+    "oovqe_eri_check_pq_symmetry": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.POINTER(ctypes.c_int), c_stream]),
     "oovqe_cas_eval_work_size": (ctypes.c_int64, [ctypes.c_int] * 4),
     "oovqe_fock_core_active": (ctypes.c_int, [c_double_p, c_double_p, c_double_p, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
@@ -114,7 +116,7 @@ SIGNATURES = {
                                      ctypes.c_int, ctypes.c_uint32, c_double_p, c_double_p, c_double_p,
                                      ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      c_int32_p, c_int32_p, ctypes.c_int, ctypes.c_int, c_double_p,
-                                     c_double_p, c_stream]),
+                                     c_double_p, ctypes.c_uint, c_stream]),
     "oovqe_oo_eval_work_size": (ctypes.c_int64, [ctypes.c_int] * 7),
     "oovqe_oo_eval_out_size": (ctypes.c_int64, [ctypes.c_int] * 4),
     "oovqe_oo_eval_batch": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
@@ -122,7 +124,7 @@ SIGNATURES = {
                                            c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, c_int32_p, c_int32_p, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
-                                           c_stream]),
+                                           ctypes.c_uint, c_stream]),
     "oovqe_circuit_rdms_is_small": (ctypes.c_int, [ctypes.c_int] * 4),
 }
 

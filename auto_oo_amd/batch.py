@@ -70,6 +70,9 @@ class OO_pqc_batch:
             self.set_oao_mo_coeff(g, c)
             nuc_host[g] = m.nuc
         self.nuc.copy_(torch.as_tensor(nuc_host))
+        # exact p<->q symmetry of every geometry's integrals (true for PySCF's int2e): the N^4 pass
+        # then reads only the slabs p <= q.  int2e_ao must not be modified in place afterwards.
+        self.eri_flags = ops.eri_flags(self.int2e_ao)
         self._plans = {}
 
     def set_oao_mo_coeff(self, g, oao_mo_coeff):
@@ -109,7 +112,8 @@ class OO_pqc_batch:
             pqc.n_qubits, ctypes.c_uint32(pqc._init_index), dptr(self.int2e_ao),
             dptr(self.int1e_ao), dptr(self.mo_coeff), dptr(self.nuc), self.nao, self._n_occ,
             self.ncas, dptr(self._kap_row, torch.int32), dptr(self._kap_col, torch.int32),
-            self.n_kappa, int(bool(derivatives)), G, dptr(work), dptr(out), stream_ptr()),
+            self.n_kappa, int(bool(derivatives)), G, dptr(work), dptr(out), int(self.eri_flags),
+            stream_ptr()),
             "oovqe_oo_eval_batch")
         return out
 

@@ -57,13 +57,29 @@ namespace {
 // ------------------------------------------------------------------------------------------
 constexpr int HALF_WAVES = 8;
 
+// Slab enumeration.  sym == 0: all N^2 slabs, t = p*N + q.  sym != 0 (the caller has verified
+// g[p,q,:,:] == g[q,p,:,:] exactly): only the N(N+1)/2 slabs p <= q are read, row-major over the
+// upper triangle, t = p(2N - p + 1)/2 + (q - p); the result goes to T2[p,q] AND T2[q,p] (sym == 1)
+// or to the packed triangle J[t] (sym == 2).
+constexpr int SYM_FULL = 0, SYM_MIRROR = 1, SYM_PACKED = 2;
+__device__ __forceinline__ void tri_decode(long t, int N, int& p, int& q)
+{
+    const double b = 2.0 * N + 1.0;
+    int pp = (int)((b - sqrt(b * b - 8.0 * (double)t)) * 0.5);
+    pp = pp < 0 ? 0 : (pp > N - 1 ? N - 1 : pp);
+    while (pp > 0 && (long)pp * (2 * N - pp + 1) / 2 > t) --pp;
+    while (pp < N - 1 && (long)(pp + 1) * (2 * N - pp) / 2 <= t) ++pp;
+    p = pp;
+    q = pp + (int)(t - (long)pp * (2 * N - pp + 1) / 2);
+}
+
 // NST > 0: the slab has exactly NST column tiles and nkc == 1; ALL its loads (NST*KCH per lane) are
 // issued at kernel entry, before the prologue barrier, so the HBM latency is paid once per wave.
 // NST == 0: streaming variant for large N (register double buffer, one chunk ahead).
 template <int ZT, int KCH, int NST>
 __global__ __launch_bounds__(HALF_WAVES * 64)
 void half_transform_kernel(const double* __restrict__ g, const double* __restrict__ C,
-                           double* __restrict__ T2, int N, int M, int nst, int nkc, long nslabs)
+                           double* __restrict__ T2, int N, int M, int nst, int nkc, long nslabs, int sym)
 {
     constexpr int LDM = 16 * (ZT | 1);
     extern __shared__ double lds[];
@@ -72,14 +88,27 @@ void half_transform_kernel(const double* __restrict__ g, const double* __restric
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane >> 4, lr = lane & 15;
-    // blockIdx.y = geometry of a batch (stacked g_ao [G][N^4], C [G][N^2], T2 [G][N^2 M^2])
-    g += (size_t)blockIdx.y * nslabs * N * N;
+    // blockIdx.y = geometry of a batch (stacked g_ao [G][N^4], C [G][N^2], T2 [G][N^2 M^2] or the
+    // packed triangle [G][N(N+1)/2][M^2]); nslabs = slabs to process per geometry
+    g += (size_t)blockIdx.y * N * N * N * N;
     C += (size_t)blockIdx.y * N * N;
-    T2 += (size_t)blockIdx.y * nslabs * M * M;
+    T2 += (size_t)blockIdx.y * (sym == SYM_PACKED ? (size_t)nslabs : (size_t)N * N) * M * M;
 
     const long slab = (long)blockIdx.x * HALF_WAVES + wave;
     const bool have = slab < nslabs;
-    const double* gs = g + (size_t)(have ? slab : 0) * N * N;
+    long src = have ? slab : 0, out1 = src, out2 = -1;   // slab read, slab(s) written
+    if (sym != SYM_FULL) {
+        int p, q;
+        tri_decode(src, N, p, q);
+        p = __builtin_amdgcn_readfirstlane(p);
+        q = __builtin_amdgcn_readfirstlane(q);
+        src = (long)p * N + q;
+        if (sym == SYM_MIRROR) {
+            out1 = src;
+            if (p != q) out2 = (long)q * N + p;
+        }
+    }
+    const double* gs = g + (size_t)src * N * N;
 
     d4 jt[ZT][ZT];   // [z tile][y tile]
 #pragma unroll
@@ -284,7 +313,8 @@ void half_transform_kernel(const double* __restrict__ g, const double* __restric
     }
 
     // jt[z tile][y tile][i] = Jt[z = zt*16 + lq + 4i][y = yt*16 + lr]  ->  T2[slab][y][z]
-    double* dst = T2 + (size_t)slab * M * M;
+    double* dst = T2 + (size_t)out1 * M * M;
+    double* dst2 = T2 + (size_t)(out2 >= 0 ? out2 : out1) * M * M;
 #pragma unroll
     for (int z = 0; z < ZT; ++z)
 #pragma unroll
@@ -292,8 +322,229 @@ void half_transform_kernel(const double* __restrict__ g, const double* __restric
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int zz = z * 16 + lq + 4 * i, yy = y * 16 + lr;
-                if (yy < M && zz < M) dst[yy * M + zz] = jt[z][y][i];
+                if (yy < M && zz < M) {
+                    dst[yy * M + zz] = jt[z][y][i];
+                    if (out2 >= 0) dst2[yy * M + zz] = jt[z][y][i];
+                }
             }
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage 1 for large N (N > 48), persistent: same per-wave algorithm as half_transform_kernel, but
+//   * one resident set of workgroups; wave w of the grid takes slabs w, w + S, w + 2S, ... and runs
+//     ONE continuous stream of (slab, column tile, k-chunk) chunks over them, DEPTH-1 chunks ahead
+//     of the MFMAs in registers: C is staged once per workgroup and the load pipeline never drains
+//     at a slab boundary;
+//   * loads go through a per-slab buffer descriptor (32-bit lane offset + SGPR row-block offset);
+//     rows r >= N, columns >= N and chunks past the wave's last slab are out of range for the
+//     descriptor and dropped by the hardware -- no clamps, no masks, no branch around a load, so
+//     the s_waitcnt counts in the loop stay exact;
+//   * KCH is chosen per N so that nkc * KCH wastes at most a few k-steps (half_stream_plan).
+// ------------------------------------------------------------------------------------------
+template <int ZT, int KCH, int DEPTH>
+__global__ __launch_bounds__(HALF_WAVES * 64)
+void half_stream_kernel(const double* __restrict__ g, const double* __restrict__ C,
+                        double* __restrict__ T2, int N, int M, int nst, int nkc, long nslabs, int sym)
+{
+    constexpr int LDM = 16 * (ZT | 1);
+    extern __shared__ double lds[];
+    const int RT16 = nst * 16;
+    double* Cl = lds;   // [RT16][LDM], zero padded
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane >> 4, lr = lane & 15;
+    g += (size_t)blockIdx.y * N * N * N * N;
+    C += (size_t)blockIdx.y * N * N;
+    T2 += (size_t)blockIdx.y * (sym == SYM_PACKED ? (size_t)nslabs : (size_t)N * N) * M * M;
+
+    const long stride = (long)gridDim.x * HALF_WAVES;
+    const long slab0 = (long)blockIdx.x * HALF_WAVES + wave;
+    const int n_mine = slab0 < nslabs ? (int)((nslabs - slab0 + stride - 1) / stride) : 0;
+    const int nchunks = nst * nkc;
+    const unsigned slab_bytes = (unsigned)((size_t)N * N * sizeof(double));
+    const unsigned rowblk_bytes = (unsigned)(4 * N * sizeof(double));
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+    d4 jt[ZT][ZT];   // [z tile][y tile]
+#pragma unroll
+    for (int z = 0; z < ZT; ++z)
+#pragma unroll
+        for (int y = 0; y < ZT; ++y) jt[z][y] = d4{0.0, 0.0, 0.0, 0.0};
+    d4 xt[ZT];       // [y tile]
+#pragma unroll
+    for (int y = 0; y < ZT; ++y) xt[y] = d4{0.0, 0.0, 0.0, 0.0};
+
+    // load side of the chunk stream
+    int lk = 0, lst = 0, lkc = 0;
+    auto issue = [&](double (&dst)[KCH]) {
+        long sl = lk < n_mine ? slab0 + (long)lk * stride : 0;
+        if (sym != SYM_FULL) {
+            int p, q;
+            tri_decode(sl, N, p, q);
+            sl = (long)__builtin_amdgcn_readfirstlane(p) * N + __builtin_amdgcn_readfirstlane(q);
+        }
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<double*>(g) + (size_t)sl * N * N, 0,
+            lk < n_mine ? (int)slab_bytes : 0, 0x00020000);
+        const int col = lst * 16 + lr;
+        const unsigned vo = col < N ? (unsigned)((lq * N + col) * sizeof(double)) : 0x7fffffffu;
+        const unsigned sb = (unsigned)lkc * KCH * rowblk_bytes;
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const v2u v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, vo, sb + i * rowblk_bytes, 0);
+            dst[i] = __builtin_bit_cast(double, v);
+        }
+        if (++lkc == nkc) {
+            lkc = 0;
+            if (++lst == nst) { lst = 0; ++lk; }
+        }
+    };
+    // compute side.  Rows of Cl beyond N are zero and dropped loads return zero, so every k-step
+    // runs unconditionally (straight-line MFMA stream, C fragments read ahead).
+    int ck = 0, cst = 0, ckc = 0;
+    auto compute = [&](const double (&a)[KCH]) {
+        const double* cb = Cl + (size_t)(ckc * KCH * 4 + lq) * LDM + lr;
+        double cf[KCH][ZT];
+#pragma unroll
+        for (int i = 0; i < KCH; ++i)
+#pragma unroll
+            for (int y = 0; y < ZT; ++y) cf[i][y] = cb[i * 4 * LDM + y * 16];
+#pragma unroll
+        for (int i = 0; i < KCH; ++i)
+#pragma unroll
+            for (int y = 0; y < ZT; ++y) xt[y] = mfma_f64(a[i], cf[i][y], xt[y]);
+        if (++ckc == nkc) {
+            ckc = 0;
+            const double* ca = Cl + (size_t)(cst * 16 + lq) * LDM + lr;
+            double af[4][ZT];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int z = 0; z < ZT; ++z) af[i][z] = ca[i * 4 * LDM + z * 16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int z = 0; z < ZT; ++z)
+#pragma unroll
+                    for (int y = 0; y < ZT; ++y) jt[z][y] = mfma_f64(af[i][z], xt[y][i], jt[z][y]);
+#pragma unroll
+            for (int y = 0; y < ZT; ++y) xt[y] = d4{0.0, 0.0, 0.0, 0.0};
+            if (++cst == nst) {
+                cst = 0;
+                // jt[z tile][y tile][i] = Jt[z = zt*16 + lq + 4i][y = yt*16 + lr] -> T2[slab][y][z]
+                if (ck < n_mine) {
+                    long out1 = slab0 + (long)ck * stride, out2 = -1;
+                    if (sym == SYM_MIRROR) {
+                        int p, q;
+                        tri_decode(out1, N, p, q);
+                        p = __builtin_amdgcn_readfirstlane(p);
+                        q = __builtin_amdgcn_readfirstlane(q);
+                        out1 = (long)p * N + q;
+                        if (p != q) out2 = (long)q * N + p;
+                    }
+                    double* dst = T2 + (size_t)out1 * M * M;
+                    double* dst2 = T2 + (size_t)(out2 >= 0 ? out2 : out1) * M * M;
+#pragma unroll
+                    for (int z = 0; z < ZT; ++z)
+#pragma unroll
+                        for (int y = 0; y < ZT; ++y)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int zz = z * 16 + lq + 4 * i, yy = y * 16 + lr;
+                                if (yy < M && zz < M) {
+                                    dst[yy * M + zz] = jt[z][y][i];
+                                    if (out2 >= 0) dst2[yy * M + zz] = jt[z][y][i];
+                                }
+                            }
+                }
+                ++ck;
+#pragma unroll
+                for (int z = 0; z < ZT; ++z)
+#pragma unroll
+                    for (int y = 0; y < ZT; ++y) jt[z][y] = d4{0.0, 0.0, 0.0, 0.0};
+            }
+        }
+    };
+
+    double ab[DEPTH][KCH];
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d) issue(ab[d]);
+    for (int idx = tid; idx < RT16 * LDM; idx += HALF_WAVES * 64) {
+        const int r = idx / LDM, z = idx - r * LDM;
+        Cl[idx] = (r < N && z < M) ? C[(size_t)r * N + z] : 0.0;
+    }
+    __syncthreads();
+    // the stream is padded to a multiple of DEPTH chunks: the padding chunks load nothing (their
+    // slab index is past the wave's list) and add zeros
+    const int rounds = (n_mine * nchunks + DEPTH - 1) / DEPTH;
+    for (int it = 0; it < rounds; ++it) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            issue(ab[(d + DEPTH - 1) % DEPTH]);
+            compute(ab[d]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// q -> x on the packed triangle (p <-> q symmetric integrals):
+//   T3[p,x,(y z)] = sum_q C[q,x] J[tri(min(p,q), max(p,q)), (y z)],   x < M
+// One workgroup per (p, geometry), one thread per (y z); the coefficients are wave-uniform (scalar
+// loads), every J element is read by two workgroups (rows p and q) and comes from L2 / MALL the
+// second time.  N M^3 outputs, 2 N^2 M^3 flops per geometry: noise next to the N^4 pass.
+// ------------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(1024)
+void sym_q_contract_kernel(const double* __restrict__ J, const double* __restrict__ C,
+                           double* __restrict__ T3, int N, int M)
+{
+    // one wave per 16-wide (y z) tile: D[x, yz] = sum_q A[x, q] B[q, yz] on the matrix cores,
+    // A = C^T (m = x, k = q), B = J rows (k = q, n = yz); all 2 KS loads of a lane are in flight
+    // together, so the kernel costs about one memory round trip
+    const int p = blockIdx.x;
+    const long tri = (long)N * (N + 1) / 2;
+    const int m2 = M * M;
+    J += (size_t)blockIdx.y * tri * m2;
+    C += (size_t)blockIdx.y * N * N;
+    T3 += (size_t)blockIdx.y * N * M * m2;
+    const int lane = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int lq = lane >> 4, lr = lane & 15;
+    const int yz = 16 * ty + lr;
+    const int yzc = yz < m2 ? yz : m2 - 1;
+    const int xc = lr < M ? lr : M - 1;
+    double af[KS], bf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int q = 4 * ks + lq;
+        const int qc = q < N ? q : N - 1;
+        const int lo = p < qc ? p : qc, hi = p < qc ? qc : p;
+        const long t = (long)lo * (2 * N - lo + 1) / 2 + (hi - lo);
+        bf[ks] = J[(size_t)t * m2 + yzc];
+        af[ks] = C[(size_t)qc * N + xc];
+    }
+    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = mfma_f64((4 * ks + lq) < N ? af[ks] : 0.0, bf[ks], acc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x = lq + 4 * i;
+        if (x < M && yz < m2) T3[((size_t)p * M + x) * m2 + yz] = acc[i];
+    }
+}
+
+// Exact (bitwise) test of g[p,q,:,:] == g[q,p,:,:]: one workgroup per (p < q, geometry).
+__global__ __launch_bounds__(256)
+void eri_pq_check_kernel(const unsigned long long* __restrict__ g, int N, int* __restrict__ mismatch)
+{
+    const int p = blockIdx.x, q = blockIdx.y;
+    if (p >= q) return;
+    const size_t n2 = (size_t)N * N;
+    const unsigned long long* a = g + (size_t)blockIdx.z * n2 * n2 + ((size_t)p * N + q) * n2;
+    const unsigned long long* b = g + (size_t)blockIdx.z * n2 * n2 + ((size_t)q * N + p) * n2;
+    bool bad = false;
+    for (size_t i = threadIdx.x; i < n2; i += 256) bad |= a[i] != b[i];
+    if (bad) atomicOr(mismatch, 1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -626,6 +877,190 @@ void half_transform_fused_kernel(const double* __restrict__ g, const double* __r
     for (int e = tid; e < ntask * M * M2; e += HALF_WAVES * 64) {
         const int k = e / (M * M2), idx = e - k * (M * M2);
         T3[(size_t)(bx + k * W) * M * M2 + idx] = stg[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage 1 over the upper triangle of slabs (p <-> q symmetric integrals; M <= 16, N <= 48),
+// persistent and software-pipelined like half_transform_fused_kernel, whose load path it shares:
+// wave gw of the W*8 waves of a geometry takes the slabs t = gw, gw + 8W, gw + 16W, ... of the
+// row-major triangle (all waves stream neighbouring slabs at any moment), two slabs in flight in
+// registers, buffer-descriptor loads with the range check as the only guard.  The 16x16 result
+// tiles J[t][y][z] are STAGED IN LDS and written in one burst per phase (a phase = as many rounds
+// as LDS holds; one phase for the batch shapes of the benchmark): a store stream interleaved with
+// the read stream costs far more than its bytes.
+// Algorithmic HBM bytes per geometry: 8 N^2 * N(N+1)/2 read + 8 M^2 * N(N+1)/2 written.
+// ------------------------------------------------------------------------------------------
+template <int KCH, int NST>
+__global__ __launch_bounds__(HALF_WAVES * 64)
+void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
+                     double* __restrict__ J, int N, int M, int phase_rounds)
+{
+    constexpr int NP = NST / 2, NS1 = NST % 2;
+    constexpr int NPA = NP > 0 ? NP : 1;
+    constexpr int NCF = NST * 4;
+    static_assert(KCH <= NCF, "C fragments must cover every k-step");
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane >> 4, lr = lane & 15;
+    const int M2 = M * M;
+    const long tri = (long)N * (N + 1) / 2;
+    const size_t slab_elems = (size_t)N * N;
+    double* dump = lds;             // [64] sink for lanes outside the M x M tile
+    double* stg = lds + 64;         // [phase_rounds][HALF_WAVES][M2]
+    g += (size_t)blockIdx.y * slab_elems * slab_elems;
+    C += (size_t)blockIdx.y * N * N;
+    J += (size_t)blockIdx.y * tri * M2;
+
+    // per-lane byte offsets inside a slab: see half_transform_fused_kernel
+    constexpr int MINK = KCH == 4 ? 1 : KCH == 8 ? 5 : KCH == 11 ? 9 : KCH;
+    const int i_last = (N - 1) / 4;
+    const unsigned slab_bytes = (unsigned)(slab_elems * sizeof(double));
+    const unsigned total_bytes = (unsigned)(slab_elems * slab_elems * sizeof(double));
+    const bool row_ok_last = 4 * i_last + lq < N;
+    unsigned offp[NPA], offp_last[NPA];
+    bool last_even[NPA];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+        const int col = pp * 32 + 2 * lr;
+        const int cc = col + 1 < N ? col : (N >= 2 ? N - 2 : 0);
+        offp[pp] = (unsigned)((lq * N + cc) * sizeof(double));
+        offp_last[pp] = row_ok_last ? offp[pp] : total_bytes;
+        last_even[pp] = col == N - 1;
+    }
+    const int col1 = NP * 32 + lr;
+    const unsigned offs = (unsigned)((lq * N + (col1 < N ? col1 : N - 1)) * sizeof(double));
+    const unsigned offs_last = row_ok_last ? offs : total_bytes;
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double*>(g), 0, (int)total_bytes, 0x00020000);
+    const unsigned rowblk_bytes = (unsigned)(4 * N * sizeof(double));
+    auto soff = [&](unsigned sb, int i) -> unsigned {
+        return (i < MINK || i <= i_last) ? sb + i * rowblk_bytes : total_bytes;
+    };
+
+    const int SW = gridDim.x * HALF_WAVES;                  // waves per geometry
+    const int gw = blockIdx.x * HALF_WAVES + wave;
+    const int n_rounds = (int)((tri + SW - 1) / SW);        // the same for every wave of the grid
+    // round r of this wave: slab t = r*SW + gw of the triangle; past the end -> dropped loads
+    auto slab_off = [&](int r) -> unsigned {
+        const long t = (long)r * SW + gw;
+        int p, q;
+        tri_decode(t < tri ? t : 0, N, p, q);
+        return __builtin_amdgcn_readfirstlane(t < tri ? (unsigned)(p * N + q) * slab_bytes : total_bytes);
+    };
+    auto issue = [&](int r, d2u (&ap)[NPA][KCH], double (&as)[KCH]) {
+        const unsigned sb = slab_off(r);
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) {
+                const v4u v = __builtin_amdgcn_raw_buffer_load_b128(
+                    rsrc, (i >= MINK - 1 && i == i_last) ? offp_last[pp] : offp[pp], soff(sb, i), 0);
+                ap[pp][i] = __builtin_bit_cast(d2u, v);
+            }
+        if constexpr (NS1) {
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) {
+                const v2u v = __builtin_amdgcn_raw_buffer_load_b64(
+                    rsrc, (i >= MINK - 1 && i == i_last) ? offs_last : offs, soff(sb, i), 0);
+                as[i] = __builtin_bit_cast(double, v);
+            }
+        }
+    };
+    d2u ap0[NPA][KCH], ap1[NPA][KCH];
+    double as0[KCH], as1[KCH];
+    issue(0, ap0, as0);
+
+    // C fragments: see half_transform_fused_kernel
+    double cfr[NCF];
+#pragma unroll
+    for (int j = 0; j < NCF; ++j) {
+        const int r = 4 * j + lq;
+        cfr[j] = C[(size_t)(r < N ? r : N - 1) * N + (lr < M ? lr : M - 1)];
+    }
+    double cpr[NPA][2][4];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = pp * 32 + 2 * (lq + 4 * i) + half;
+                cpr[pp][half][i] = C[(size_t)(col < N ? col : N - 1) * N + (lr < M ? lr : M - 1)];
+            }
+#pragma unroll
+    for (int j = 0; j < NCF; ++j) cfr[j] *= ((4 * j + lq) < N && lr < M) ? 1.0 : 0.0;
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                cpr[pp][half][i] *= ((pp * 32 + 2 * (lq + 4 * i) + half) < N && lr < M) ? 1.0 : 0.0;
+
+    // LDS destination of jt[i] = Jt[z = lq + 4i][y = lr] inside a staged tile: [y*M + z]
+    int tile_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int zz = lq + 4 * i;
+        tile_off[i] = (lr < M && zz < M) ? lr * M + zz : -1;
+    }
+    auto compute = [&](int r, int base, const d2u (&ap)[NPA][KCH], const double (&as)[KCH]) {
+        d4 jt = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                d4 xt = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int i = 0; i < KCH; ++i) {
+                    const double ev = last_even[pp] ? ap[pp][i].y : ap[pp][i].x;
+                    xt = mfma_f64(half == 0 ? ev : ap[pp][i].y, cfr[i], xt);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) jt = mfma_f64(cpr[pp][half][i], xt[i], jt);
+            }
+        if constexpr (NS1) {
+            d4 xt = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) xt = mfma_f64(as[i], cfr[i], xt);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) jt = mfma_f64(cfr[NP * 8 + i], xt[i], jt);
+        }
+        if ((long)r * SW + gw >= tri) return;          // padding round
+        double* row = stg + ((size_t)(r - base) * HALF_WAVES + wave) * M2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double* dst = tile_off[i] >= 0 ? row + tile_off[i] : dump + lane;
+            *dst = jt[i];
+        }
+    };
+
+    // phase_rounds is even: round `base` of every phase sits in register buffer 0.  Straight-line
+    // loop body, no VMEM store inside it (see half_transform_fused_kernel).
+    for (int base = 0; base < n_rounds; base += phase_rounds) {
+        const int end = base + phase_rounds < n_rounds ? base + phase_rounds : n_rounds;
+        for (int it = base; it < end; it += 2) {
+            issue(it + 1, ap1, as1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(it, base, ap0, as0);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(it + 2, ap0, as0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(it + 1, base, ap1, as1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        const int nslot = (end - base) * HALF_WAVES;
+        for (int e = tid; e < nslot * M2; e += HALF_WAVES * 64) {
+            const int slot = e / M2, idx = e - slot * M2;
+            const long t = (long)(base + slot / HALF_WAVES) * SW + blockIdx.x * HALF_WAVES + slot % HALF_WAVES;
+            if (t < tri) J[(size_t)t * M2 + idx] = stg[e];
+        }
+        __syncthreads();
     }
 }
 
@@ -1320,7 +1755,8 @@ void cas_final_kernel(const double* __restrict__ Fcol, const double* __restrict_
 }  // namespace
 
 static int half_transform_batched(const double* g_ao, const double* C, int N, int M, double* T2,
-                                  int batch, oovqe_stream_t stream);
+                                  int batch, oovqe_stream_t stream, int sym = SYM_FULL);
+static int device_cu_count();
 
 extern "C" int oovqe_cas_half_transform(const double* g_ao, const double* C, int N, int M, double* T2,
                                         oovqe_stream_t stream)
@@ -1329,7 +1765,7 @@ extern "C" int oovqe_cas_half_transform(const double* g_ao, const double* C, int
 }
 
 static int half_transform_batched(const double* g_ao, const double* C, int N, int M, double* T2,
-                                  int batch, oovqe_stream_t stream)
+                                  int batch, oovqe_stream_t stream, int sym)
 {
     OOVQE_REQUIRE(g_ao && C && T2, "cas_half_transform: null pointer");
     OOVQE_REQUIRE(batch >= 1 && batch <= 65535, "cas_half_transform: batch=%d", batch);
@@ -1344,7 +1780,7 @@ static int half_transform_batched(const double* g_ao, const double* C, int N, in
     OOVQE_REQUIRE(ZT <= 3, "cas_half_transform: n_occ+ncas = %d > 48 not supported", M);
     OOVQE_REQUIRE(lds_bytes <= 160 * 1024, "cas_half_transform: N=%d M=%d needs %zu B of LDS", N, M,
                   lds_bytes);
-    const long nslabs = (long)N * N;
+    const long nslabs = sym == SYM_FULL ? (long)N * N : (long)N * (N + 1) / 2;
     const unsigned grid = (unsigned)((nslabs + HALF_WAVES - 1) / HALF_WAVES);
     // k-steps per register chunk: the whole row when it fits (<= 16 k-steps), else chunks of 16
     int kch = ksteps <= 4 ? 4 : ksteps <= 8 ? 8 : ksteps <= 11 ? 11 : ksteps <= 12 ? 12 : 16;
@@ -1365,7 +1801,7 @@ static int half_transform_batched(const double* g_ao, const double* C, int N, in
         }                                                                                         \
         hipLaunchKernelGGL((half_transform_kernel<Z, KC_, NS_>), dim3(grid, batch),               \
                            dim3(HALF_WAVES * 64),                                                 \
-                           lds_bytes, st, g_ao, C, T2, N, M, nrb, nkc, nslabs);                   \
+                           lds_bytes, st, g_ao, C, T2, N, M, nrb, nkc, nslabs, sym);              \
     } while (0)
 #define OOVQE_DISPATCH_KCH(Z)                                                                     \
     do {                                                                                          \
@@ -1374,12 +1810,66 @@ static int half_transform_batched(const double* g_ao, const double* C, int N, in
         else if (kch == 8 && nrb == 2) OOVQE_LAUNCH_HALF(Z, 8, 2);                                \
         else if (kch == 11 && nrb == 3) OOVQE_LAUNCH_HALF(Z, 11, 3);                              \
         else if (kch == 12 && nrb == 3) OOVQE_LAUNCH_HALF(Z, 12, 3);                              \
-        else if (kch == 4) OOVQE_LAUNCH_HALF(Z, 4, 0);                                            \
-        else if (kch == 8) OOVQE_LAUNCH_HALF(Z, 8, 0);                                            \
-        else if (kch == 11) OOVQE_LAUNCH_HALF(Z, 11, 0);                                          \
-        else if (kch == 12) OOVQE_LAUNCH_HALF(Z, 12, 0);                                          \
-        else OOVQE_LAUNCH_HALF(Z, 16, 0);                                                         \
+        else OOVQE_LAUNCH_HALF(Z, 16, 0);   /* N > 48 (kch == 16 there) */                        \
     } while (0)
+    // N > 48: persistent streaming kernel.  k-chunk depth with the least padding (ties: deeper)
+    const bool stream_old = getenv("OOVQE_HALF_STREAM_OLD") != nullptr;   // A/B hook for tools/
+    if (nrb > 3 && !stream_old) {
+        int skch = 16, waste = 1 << 30;
+        for (int k = 16; k >= 10; --k) {
+            const int w = (ksteps + k - 1) / k * k - ksteps;
+            if (w < waste) { waste = w; skch = k; }
+        }
+        const int snkc = (ksteps + skch - 1) / skch;
+        const long want = (nslabs + HALF_WAVES - 1) / HALF_WAVES;
+#define OOVQE_LAUNCH_STREAM(Z, KC_, D_)                                                           \
+    do {                                                                                          \
+        static bool attr_done = false;                                                            \
+        static size_t occ_lds = 0;                                                                \
+        static int occ = 1;                                                                       \
+        const void* fn = (const void*)half_stream_kernel<Z, KC_, D_>;                             \
+        if (!attr_done) {                                                                         \
+            OOVQE_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                                160 * 1024), "cas_half_transform");               \
+            attr_done = true;                                                                     \
+        }                                                                                         \
+        if (occ_lds != lds_bytes) {                                                               \
+            int nb = 0;                                                                           \
+            OOVQE_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, HALF_WAVES * 64,\
+                                                                         lds_bytes),              \
+                            "cas_half_transform");                                                \
+            occ = nb < 1 ? 1 : nb;                                                                \
+            occ_lds = lds_bytes;                                                                  \
+        }                                                                                         \
+        long per = ((long)occ * device_cu_count()) / batch;                                       \
+        if (per < 1) per = 1;                                                                     \
+        if (per > want) per = want;                                                               \
+        hipLaunchKernelGGL((half_stream_kernel<Z, KC_, D_>), dim3((unsigned)per, batch),          \
+                           dim3(HALF_WAVES * 64), lds_bytes, st, g_ao, C, T2, N, M, nrb, snkc,    \
+                           nslabs, sym);                                                          \
+    } while (0)
+#define OOVQE_DISPATCH_STREAM(Z, D_)                                                              \
+    do {                                                                                          \
+        switch (skch) {                                                                           \
+        case 10: OOVQE_LAUNCH_STREAM(Z, 10, D_); break;                                           \
+        case 11: OOVQE_LAUNCH_STREAM(Z, 11, D_); break;                                           \
+        case 12: OOVQE_LAUNCH_STREAM(Z, 12, D_); break;                                           \
+        case 13: OOVQE_LAUNCH_STREAM(Z, 13, D_); break;                                           \
+        case 14: OOVQE_LAUNCH_STREAM(Z, 14, D_); break;                                           \
+        case 15: OOVQE_LAUNCH_STREAM(Z, 15, D_); break;                                           \
+        default: OOVQE_LAUNCH_STREAM(Z, 16, D_); break;                                           \
+        }                                                                                         \
+    } while (0)
+        oovqe_profile_mark_start(st);
+        if (ZT == 1) OOVQE_DISPATCH_STREAM(1, 3);
+        else if (ZT == 2) OOVQE_DISPATCH_STREAM(2, 3);
+        else OOVQE_DISPATCH_STREAM(3, 2);
+        oovqe_profile_mark_stop(st);
+#undef OOVQE_DISPATCH_STREAM
+#undef OOVQE_LAUNCH_STREAM
+        OOVQE_CHECK_LAUNCH("cas_half_transform");
+        return 0;
+    }
     oovqe_profile_mark_start(st);
     if (ZT == 1) OOVQE_DISPATCH_KCH(1);
     else if (ZT == 2) OOVQE_DISPATCH_KCH(2);
@@ -1388,6 +1878,48 @@ static int half_transform_batched(const double* g_ao, const double* C, int N, in
 #undef OOVQE_DISPATCH_KCH
 #undef OOVQE_LAUNCH_HALF
     OOVQE_CHECK_LAUNCH("cas_half_transform");
+    return 0;
+}
+
+extern "C" int oovqe_eri_check_pq_symmetry(const double* g_ao, int N, int batch, int* symmetric,
+                                           oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(g_ao && symmetric, "eri_check_pq_symmetry: null pointer");
+    OOVQE_REQUIRE(N >= 1 && N <= 65535 && batch >= 1 && batch <= 65535, "eri_check_pq_symmetry: N=%d batch=%d",
+                  N, batch);
+    hipStream_t st = (hipStream_t)stream;
+    int* flag = nullptr;
+    OOVQE_CHECK_HIP(hipMalloc(&flag, sizeof(int)), "eri_check_pq_symmetry");
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(eri_pq_check_kernel, dim3(N, N, batch), dim3(256), 0, st,
+                           reinterpret_cast<const unsigned long long*>(g_ao), N, flag);
+        e = hipGetLastError();
+    }
+    int bad = 1;
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(flag);
+    OOVQE_CHECK_HIP(e, "eri_check_pq_symmetry");
+    *symmetric = bad ? 0 : 1;
+    return 0;
+}
+
+static int sym_q_contract_batched(const double* J, const double* C, double* T3, int N, int M, int batch,
+                                  hipStream_t st)
+{
+    OOVQE_REQUIRE(M >= 1 && M <= 16 && N >= 1 && N <= 48, "sym_q_contract: N=%d M=%d", N, M);
+    const unsigned threads = (unsigned)((M * M + 15) / 16 * 64);
+    const int ksteps = (N + 3) / 4;
+    oovqe_profile_mark_start_l(st, 5);
+    if (ksteps <= 4)
+        hipLaunchKernelGGL(sym_q_contract_kernel<4>, dim3(N, batch), dim3(threads), 0, st, J, C, T3, N, M);
+    else if (ksteps <= 8)
+        hipLaunchKernelGGL(sym_q_contract_kernel<8>, dim3(N, batch), dim3(threads), 0, st, J, C, T3, N, M);
+    else
+        hipLaunchKernelGGL(sym_q_contract_kernel<12>, dim3(N, batch), dim3(threads), 0, st, J, C, T3, N, M);
+    oovqe_profile_mark_stop(st);
+    OOVQE_CHECK_LAUNCH("cas_eval/sym_q_contract");
     return 0;
 }
 
@@ -1501,6 +2033,50 @@ static int half_transform_fused_batched(const double* g_ao, const double* C, int
     return 0;
 }
 
+// Packed-triangle stage 1 (p <-> q symmetric integrals, M <= 16, N <= 48): J [G][N(N+1)/2][M^2].
+static int half_tri_batched(const double* g_ao, const double* C, int N, int M, double* J, int batch,
+                            hipStream_t st)
+{
+    OOVQE_REQUIRE(M >= 1 && M <= 16 && N >= M && N <= 48, "cas_eval: half_tri N=%d M=%d", N, M);
+    const int ksteps = (N + 3) / 4, nrb = (N + 15) / 16;
+    const int kch = ksteps <= 4 ? 4 : ksteps <= 8 ? 8 : ksteps <= 11 ? 11 : 12;
+    const long tri = (long)N * (N + 1) / 2;
+    long W = device_cu_count() / batch;                       // one 8-wave workgroup per CU
+    if (W < 1) W = 1;
+    if (W > (tri + HALF_WAVES - 1) / HALF_WAVES) W = (tri + HALF_WAVES - 1) / HALF_WAVES;
+    const long n_rounds = (tri + W * HALF_WAVES - 1) / (W * HALF_WAVES);
+    const size_t round_bytes = (size_t)HALF_WAVES * M * M * sizeof(double);
+    long phase = (long)((160 * 1024 - 64 * sizeof(double)) / round_bytes) & ~1L;   // even
+    OOVQE_REQUIRE(phase >= 2, "cas_eval: half_tri staging does not fit LDS (M=%d)", M);
+    if (phase > ((n_rounds + 1) & ~1L)) phase = (n_rounds + 1) & ~1L;
+    const size_t lds_bytes = 64 * sizeof(double) + (size_t)phase * round_bytes;
+#define OOVQE_LAUNCH_TRI(KC_, NS_)                                                                \
+    do {                                                                                          \
+        static bool attr_done = false;                                                            \
+        if (!attr_done) {                                                                         \
+            OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)half_tri_kernel<KC_, NS_>,           \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                                160 * 1024), "cas_eval/half_tri");                \
+            attr_done = true;                                                                     \
+        }                                                                                         \
+        hipLaunchKernelGGL((half_tri_kernel<KC_, NS_>), dim3((unsigned)W, batch),                 \
+                           dim3(HALF_WAVES * 64), lds_bytes, st, g_ao, C, J, N, M, (int)phase);   \
+    } while (0)
+    oovqe_profile_mark_start(st);
+    if (kch == 4 && nrb == 1) OOVQE_LAUNCH_TRI(4, 1);
+    else if (kch == 8 && nrb == 2) OOVQE_LAUNCH_TRI(8, 2);
+    else if (kch == 11 && nrb == 3) OOVQE_LAUNCH_TRI(11, 3);
+    else if (kch == 12 && nrb == 3) OOVQE_LAUNCH_TRI(12, 3);
+    else {
+        oovqe_set_error("cas_eval: no half_tri variant for N=%d", N);
+        return OOVQE_ERR_ARG;
+    }
+    oovqe_profile_mark_stop(st);
+#undef OOVQE_LAUNCH_TRI
+    OOVQE_CHECK_LAUNCH("cas_eval/half_tri");
+    return 0;
+}
+
 extern "C" int oovqe_cas_finish_transform(const double* T2, const double* h_ao, const double* C,
                                           int N, int M, double* Gm, double* hmo, double* work,
                                           oovqe_stream_t stream)
@@ -1595,7 +2171,8 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
                             const int32_t* kap_col, int n_kappa, double* work, double* c0, double* c1,
                             double* c2, double* E, double* gvec, double* dE, double* fock,
                             double* gmat, double* Gm, double* hmo, int batch, size_t out_stride,
-                            oovqe_stream_t stream, const oovqe_circuit_job_t* cj = nullptr)
+                            oovqe_stream_t stream, const oovqe_circuit_job_t* cj = nullptr,
+                            unsigned eri_flags = 0)
 {
     // cj: circuit + RDM evaluations that produce gamma / Gamma; they ride along the p -> n
     // contraction launch (the caller has checked oovqe_contract_hosts_circuit for this shape)
@@ -1623,7 +2200,32 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
     FusedPlan fp;
     const bool fused = !unfused_env && fused_plan(N, M, batch, &fp);
     const double* Gm_in = nullptr;
-    if (fused) {
+    // p <-> q symmetric integrals (verified by the caller): only the slabs p <= q are read
+    const bool pq_sym = (eri_flags & OOVQE_ERI_PQ_SYMMETRIC) != 0;
+    const int half_sym = pq_sym ? SYM_MIRROR : SYM_FULL;
+    const long tri = (long)N * (N + 1) / 2;
+    const bool sym_packed = fused && pq_sym && getenv("OOVQE_SYM_MIRROR") == nullptr &&
+                            tri * m2 + 2 * (long)N * m3 <= 2 * (long)N * N * m2;
+    if (sym_packed) {
+        // packed triangle J (instead of the fused kernel: its q -> x contraction needs whole rows
+        // of slabs), then the small q -> x kernel; from T3 on the same launches as the fused path
+        double* Jp = work;                                       // [G][tri][M^2]
+        double* T3 = Jp + nb * tri * m2;                         // [G][N][M^3]
+        double* Gmw = T3 + nb * N * m3;                          // [G][N][M^3]
+        // test hook OOVQE_SYM_SIMPLE: the one-slab-per-wave kernel (direct stores) instead
+        if (getenv("OOVQE_SYM_SIMPLE") != nullptr) {
+            if ((rc = half_transform_batched(g_ao, C, N, M, Jp, batch, stream, SYM_PACKED))) return rc;
+        } else if ((rc = half_tri_batched(g_ao, C, N, M, Jp, batch, st))) {
+            return rc;
+        }
+        if ((rc = sym_q_contract_batched(Jp, C, T3, N, M, batch, st))) return rc;
+        oovqe_profile_mark_start_l(st, 2);
+        if ((rc = oovqe_mode_contract_batched_circ(T3, C, Gmw, 1, N, N, m3, N, 0, batch, (long)N * m3,
+                                                   (long)N * N, (long)N * m3, st, cj)))
+            return rc;
+        oovqe_profile_mark_stop(st);
+        Gm_in = Gmw;
+    } else if (fused) {
         double* T3 = work;                                       // [G][nchunk][N][M^3]
         double* Gmw = T3 + nb * fp.nchunk * N * m3;              // [G][N][M^3]
         double* Cdup = Gmw + nb * N * m3;                        // [G][nchunk][N][N]  (nchunk > 1)
@@ -1648,7 +2250,7 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
                                          cj->gamma, cj->Gamma, nullptr, stream)))
                 return rc;
         }
-        if ((rc = half_transform_batched(g_ao, C, N, M, T2, batch, stream))) return rc;
+        if ((rc = half_transform_batched(g_ao, C, N, M, T2, batch, stream, half_sym))) return rc;
         const size_t na2s = (size_t)ncas * ncas, na4s = na2s * na2s;
         for (int g = 0; g < batch; ++g) {
             const size_t gi = (size_t)g;
@@ -1675,7 +2277,7 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
         }
         return 0;
     } else {
-        if ((rc = half_transform_batched(g_ao, C, N, M, T2, batch, stream))) return rc;
+        if ((rc = half_transform_batched(g_ao, C, N, M, T2, batch, stream, half_sym))) return rc;
         // U[n,(q y z)] = sum_p C[p,n] T2[p,(q y z)]
         oovqe_profile_mark_start_l(st, 2);
         if ((rc = oovqe_mode_contract_batched_circ(T2, C, U, 1, N, N, (long)N * m2, N, 0, batch,
@@ -1687,7 +2289,7 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
     const size_t na2 = (size_t)ncas * ncas;
     const size_t set_bytes = (na2 + na2 * na2) * sizeof(double);
     const size_t lds_cap = 160 * 1024;
-    if (fused) {
+    if (fused || sym_packed) {
         // panel kernel: npan general indices per workgroup, about one resident round of workgroups
         const size_t fixed_bytes = ((size_t)N * M + (size_t)N * N) * sizeof(double);
         const size_t per_n = ((size_t)m3 + 2 * (size_t)N + 2 * (size_t)M) * sizeof(double);
@@ -1756,11 +2358,11 @@ extern "C" int oovqe_cas_eval(const double* g_ao, const double* h_ao, const doub
                               int n_occ, int ncas, const int32_t* kap_row, const int32_t* kap_col,
                               int n_kappa, double* work, double* c0, double* c1, double* c2,
                               double* E, double* gvec, double* dE, double* fock, double* gmat,
-                              double* Gm, double* hmo, oovqe_stream_t stream)
+                              double* Gm, double* hmo, unsigned eri_flags, oovqe_stream_t stream)
 {
     return cas_eval_batched(g_ao, h_ao, C, gamma, Gamma, nrdm, nuc, nullptr, N, n_occ, ncas, kap_row,
                             kap_col, n_kappa, work, c0, c1, c2, E, gvec, dE, fock, gmat, Gm, hmo, 1, 0,
-                            stream);
+                            stream, nullptr, eri_flags);
 }
 
 extern "C" int64_t oovqe_cas_eval_work_size(int N, int n_occ, int ncas, int nrdm)
@@ -1799,7 +2401,7 @@ static int oo_eval_batched(const double* theta, int n_theta, const oovqe_gate_t*
                            const double* C, double nuc, const double* nuc_arr, int N, int n_occ,
                            int ncas, const int32_t* kap_row, const int32_t* kap_col, int n_kappa,
                            int derivatives, int batch, double* work, double* out,
-                           oovqe_stream_t stream)
+                           unsigned eri_flags, oovqe_stream_t stream)
 {
     OOVQE_REQUIRE(theta && gates && g_ao && h_ao && C && work && out, "oo_eval: null pointer");
     OOVQE_REQUIRE(n_qubits == 2 * ncas, "oo_eval: n_qubits != 2*ncas");
@@ -1864,18 +2466,19 @@ static int oo_eval_batched(const double* theta, int n_theta, const oovqe_gate_t*
     double* c2 = c1 + na2;
     return cas_eval_batched(g_ao, h_ao, C, gamma, Gamma, nvec, nuc, nuc_arr, N, n_occ, ncas, kap_row,
                             kap_col, n_kappa, cas_work, c0, c1, c2, E, gvec, dE, nullptr, nullptr,
-                            nullptr, nullptr, batch, out_stride, stream, ride ? &cj : nullptr);
+                            nullptr, nullptr, batch, out_stride, stream, ride ? &cj : nullptr, eri_flags);
 }
 
 extern "C" int oovqe_oo_eval(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
                              int n_qubits, uint32_t init_index, const double* g_ao,
                              const double* h_ao, const double* C, double nuc, int N, int n_occ,
                              int ncas, const int32_t* kap_row, const int32_t* kap_col, int n_kappa,
-                             int derivatives, double* work, double* out, oovqe_stream_t stream)
+                             int derivatives, double* work, double* out, unsigned eri_flags,
+                             oovqe_stream_t stream)
 {
     return oo_eval_batched(theta, n_theta, gates, n_gates, n_qubits, init_index, g_ao, h_ao, C, nuc,
                            nullptr, N, n_occ, ncas, kap_row, kap_col, n_kappa, derivatives, 1, work,
-                           out, stream);
+                           out, eri_flags, stream);
 }
 
 extern "C" int oovqe_oo_eval_batch(const double* theta, int n_theta, const oovqe_gate_t* gates,
@@ -1883,12 +2486,12 @@ extern "C" int oovqe_oo_eval_batch(const double* theta, int n_theta, const oovqe
                                    const double* h_ao, const double* C, const double* nuc, int N,
                                    int n_occ, int ncas, const int32_t* kap_row, const int32_t* kap_col,
                                    int n_kappa, int derivatives, int batch, double* work, double* out,
-                                   oovqe_stream_t stream)
+                                   unsigned eri_flags, oovqe_stream_t stream)
 {
     OOVQE_REQUIRE(nuc, "oo_eval_batch: null nuc");
     return oo_eval_batched(theta, n_theta, gates, n_gates, n_qubits, init_index, g_ao, h_ao, C, 0.0,
                            nuc, N, n_occ, ncas, kap_row, kap_col, n_kappa, derivatives, batch, work,
-                           out, stream);
+                           out, eri_flags, stream);
 }
 
 // ------------------------------------------------------------------------------------------

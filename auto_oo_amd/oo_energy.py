@@ -132,12 +132,26 @@ class OO_energy:
         T2 = ops.cas_half_transform(self.int2e_ao, C, self._M)
         return ops.cas_finish_transform(T2, self.int1e_ao, C, self._M)
 
+    def _eri_flags(self, g_ao=None):
+        """Symmetry flags of a resident two-electron tensor (ops.eri_flags), checked once per tensor
+        object: int2e_ao is set once and never modified in place, as in the reference
+        (moldata_pyscf.py:31, oo_energy.py:104).  PySCF integrals are exactly p<->q symmetric, so
+        the N^4 pass reads half of the tensor; anything else is treated as a general tensor."""
+        g_ao = self.int2e_ao if g_ao is None else g_ao
+        cache = self.__dict__.setdefault("_eri_flag_cache", {})
+        hit = cache.get(id(g_ao))
+        if hit is None or hit[0] is not g_ao:
+            hit = (g_ao, ops.eri_flags(g_ao))
+            cache.clear()
+            cache[id(g_ao)] = hit
+        return hit[1]
+
     def _cas_eval(self, mo_coeff, gamma_sets, Gamma_sets, want_matrices=False):
         """Fused energy / Fock / orbital gradient for a stack of RDM sets (set 0 = RDMs, sets k>=1
         = derivative RDMs)."""
         return ops.cas_eval(self.int2e_ao, self.int1e_ao, self._t(mo_coeff), gamma_sets, Gamma_sets,
                             self.nuc, self._n_occ, self.ncas, self._kap_row, self._kap_col,
-                            want_matrices=want_matrices)
+                            want_matrices=want_matrices, eri_flags=self._eri_flags())
 
     def _rdm_stack(self, one_rdm, two_rdm):
         g1 = self._t(one_rdm).reshape(1, self.ncas, self.ncas)
@@ -291,7 +305,8 @@ class OO_energy:
         C = self._t(mo_coeff)
         g1, g2 = self._rdm_stack(one_rdm, two_rdm)
         res = ops.cas_eval(g_ao, h_ao, C, g1, g2, self.nuc, self._n_occ, self.ncas, self._kap_row,
-                           self._kap_col, want_matrices=True)
+                           self._kap_col, want_matrices=True,
+                           eri_flags=self._eri_flags() if g_ao is self.int2e_ao else 0)
         return ops.orbital_hessian(g_ao, h_ao, C, g1[0].contiguous(), g2[0].contiguous(),
                                    res["fock"], self._n_occ, self.ncas, self._kap_row, self._kap_col,
                                    want_matrix=want_matrix, want_full=want_full)

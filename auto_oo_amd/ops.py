@@ -24,7 +24,7 @@ def profile_begin(detail=False):
         _lib.load().oovqe_profile_begin()
 
 
-PROFILE_LABELS = ("half_transform", "circuit_rdms", "contract_p_to_n", "column", "final")
+PROFILE_LABELS = ("half_transform", "circuit_rdms", "contract_p_to_n", "column", "final", "sym_q_contract")
 
 
 def profile_end():
@@ -244,9 +244,31 @@ def cas_energy_gradient(Gm, hmo, gamma, Gamma, nuc, n_occ, ncas, kap_row, kap_co
     return dict(c0=c0, c1=c1, c2=c2, E=E, fock=fock, gmat=gmat, gvec=gvec, dE=dE[:nrdm - 1])
 
 
+ERI_PQ_SYMMETRIC = 1   # include/oovqe.h: OOVQE_ERI_PQ_SYMMETRIC
+
+
+def eri_flags(g_ao):
+    """eri_flags for a resident g_ao ([N,N,N,N] or a stack [G,N,N,N,N]): ERI_PQ_SYMMETRIC when
+    g[p,q,:,:] == g[q,p,:,:] bit for bit (oovqe_eri_check_pq_symmetry; one pass over the tensor,
+    synchronises the stream).  The caller must not modify g_ao afterwards."""
+    lib = _lib.load()
+    _dev(g_ao)
+    if g_ao.dtype != F64 or not g_ao.is_contiguous() or g_ao.dim() not in (4, 5):
+        return 0
+    N = g_ao.shape[-1]
+    batch = g_ao.shape[0] if g_ao.dim() == 5 else 1
+    if tuple(g_ao.shape[-4:]) != (N, N, N, N) or batch > 65535 or N > 65535:
+        return 0
+    sym = ctypes.c_int(0)
+    check(lib.oovqe_eri_check_pq_symmetry(dptr(g_ao), N, batch, ctypes.byref(sym), stream_ptr()),
+          "oovqe_eri_check_pq_symmetry")
+    return ERI_PQ_SYMMETRIC if sym.value else 0
+
+
 def cas_eval(g_ao, h_ao, C, gamma, Gamma, nuc, n_occ, ncas, kap_row, kap_col, want_matrices=False,
-             want_integrals=False, work=None):
-    """The whole CAS path (oovqe_cas_eval).  gamma [nrdm,a,a], Gamma [nrdm,a,a,a,a]."""
+             want_integrals=False, work=None, eri_flags=0):
+    """The whole CAS path (oovqe_cas_eval).  gamma [nrdm,a,a], Gamma [nrdm,a,a,a,a].
+    eri_flags: see ops.eri_flags (0 = assume nothing about g_ao)."""
     lib = _lib.load()
     dev = _dev(g_ao)
     N = C.shape[0]
@@ -273,7 +295,7 @@ def cas_eval(g_ao, h_ao, C, gamma, Gamma, nuc, n_occ, ncas, kap_row, kap_col, wa
                              float(nuc), N, n_occ, ncas, dptr(kap_row, torch.int32),
                              dptr(kap_col, torch.int32), n_kappa, dptr(work), dptr(c0), dptr(c1),
                              dptr(c2), dptr(E), dptr(gvec), dptr(dE), dptr(fock), dptr(gmat),
-                             dptr(Gm), dptr(hmo), stream_ptr()), "oovqe_cas_eval")
+                             dptr(Gm), dptr(hmo), int(eri_flags), stream_ptr()), "oovqe_cas_eval")
     packed = small[1:2 + (nrdm - 1) + n_kappa] if nrdm > 1 else None   # [E, dE..., gvec[0]...]
     return dict(c0=c0, c1=c1, c2=c2, E=E, fock=fock, gmat=gmat, gvec=gvec, dE=dE[:nrdm - 1],
                 Gm=Gm, hmo=hmo, packed=packed)
@@ -284,8 +306,9 @@ class OoEvalPlan:
     Calling it costs one small allocation (the packed result) and one ctypes call."""
 
     def __init__(self, gates_dev, n_gates, n_theta, n_qubits, init_index, g_ao, h_ao, nuc, n_occ,
-                 ncas, kap_row, kap_col, derivatives=True):
+                 ncas, kap_row, kap_col, derivatives=True, eri_flags=0):
         self.lib = _lib.load()
+        self.eri_flags = int(eri_flags)
         self.dev = _dev(g_ao)
         self.N = h_ao.shape[0]
         self.n_theta, self.ncas, self.derivatives = n_theta, ncas, bool(derivatives)
@@ -308,7 +331,7 @@ class OoEvalPlan:
         out = torch.empty(self.out_size, dtype=F64, device=self.dev)
         rc = self.lib.oovqe_oo_eval(ctypes.c_void_p(theta.data_ptr()), *self._pre,
                                     ctypes.c_void_p(C.data_ptr()), *self._post,
-                                    ctypes.c_void_p(out.data_ptr()), stream_ptr())
+                                    ctypes.c_void_p(out.data_ptr()), self.eri_flags, stream_ptr())
         if rc != 0:
             check(rc, "oovqe_oo_eval")
         return out

@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--geoms", type=int, default=N_GEOM,
                     help="molecular geometries PER GPU (weak scaling: the job holds geoms x n_gpus)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--general-eri", action="store_true",
+                    help="treat g_ao as a general tensor (eri_flags = 0: every slab is read) in the "
+                         "headline run, for comparison with the default symmetric-integral path")
     ap.add_argument("--no-transform", action="store_true")
     ap.add_argument("--no-kupccd", action="store_true", help="skip the configs[4] kUpCCD CAS(8e,8o) extra")
     ap.add_argument("--no-berry", action="store_true",
@@ -306,6 +309,8 @@ def main():
     my_geoms = shard_geometries(n_geom_total, rank, world)
     pqc, batch, single, thetas = build_geometries(my_geoms)
     G = batch.G
+    if args.general_eri:
+        batch.eri_flags = 0
     n_out = 1 + batch.n_theta + batch.n_kappa
     results = torch.zeros((G, n_out), dtype=torch.float64, device="cuda")
 
@@ -361,8 +366,27 @@ def main():
     # launch covers >= 48 slabs per CU, the one-slab-per-wave T2 kernel below that
     n_cu = torch.cuda.get_device_properties(0).multi_processor_count
     t3_path = (args.steps / max(n_calls, 1)) * NAO ** 2 >= 48 * n_cu
-    # g_ao read once + T3 (8 N M^3) or T2 (8 N^2 M^2) written
-    bytes_per_eval = 8.0 * NAO ** 4 + (8.0 * NAO * M ** 3 if t3_path else 8.0 * NAO ** 2 * M ** 2)
+    # p<->q symmetric integrals (verified bit for bit when the batch was built, as PySCF's int2e
+    # is): the library reads only the N(N+1)/2 slabs p <= q -- the algorithmic bytes of the sweep
+    # are then 8 N^2 * N(N+1)/2 (half of SURVEY.md section 8(d)'s 8 N^4) + the packed J written
+    pq_sym = bool(batch.eri_flags & ops.ERI_PQ_SYMMETRIC)
+    tri = NAO * (NAO + 1) // 2
+    if pq_sym and t3_path:
+        bytes_per_eval = 8.0 * NAO ** 2 * tri + 8.0 * tri * M ** 2
+        kernel_name = ("half_tri_kernel<11,3> (J[p<=q,y,z] = sum_rs C[r,y] g[p,q,r,s] C[s,z] over the "
+                       "upper triangle of slabs; integrals verified p<->q symmetric)")
+    elif pq_sym:
+        bytes_per_eval = 8.0 * NAO ** 2 * tri + 8.0 * NAO ** 2 * M ** 2
+        kernel_name = ("half_transform_kernel<1,11,3>, slabs p <= q mirrored into T2[p,q] and T2[q,p] "
+                       "(integrals verified p<->q symmetric)")
+    elif t3_path:
+        # g_ao read once + T3 (8 N M^3) written
+        bytes_per_eval = 8.0 * NAO ** 4 + 8.0 * NAO * M ** 3
+        kernel_name = ("half_transform_fused_kernel<11,3> (T3[p,x,y,z] = sum_q C[q,x] "
+                       "sum_rs C[r,y] g[p,q,r,s] C[s,z])")
+    else:
+        bytes_per_eval = 8.0 * NAO ** 4 + 8.0 * NAO ** 2 * M ** 2
+        kernel_name = "half_transform_kernel<1,11,3> (T2[p,q,y,z] = sum_rs C[r,y] g[p,q,r,s] C[s,z])"
     # evaluations per launch from the calls made (the event pool brackets at most 8192 launches of
     # a long run: the average duration is then over those, the bytes are still per launch)
     evals_per_launch = args.steps / max(n_calls, 1)
@@ -372,11 +396,12 @@ def main():
     # WRITE_SIZE, separate passes; profiles/pmc_half_transform.json), scaled to this launch size
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_half_transform.json")
-    if os.path.exists(pmc_path) and t3_path:        # (the PMC passes were taken on the T3 kernel)
+    if os.path.exists(pmc_path) and t3_path:        # (the PMC passes were taken on the batched kernel)
         try:
             with open(pmc_path) as fh:
                 pmc = json.load(fh)
-            traffic = pmc["hbm_bytes_per_launch"] / 64.0 * evals_per_launch
+            if pmc.get("pq_symmetric", False) == pq_sym:
+                traffic = pmc["hbm_bytes_per_launch"] / 64.0 * evals_per_launch
         except Exception:
             traffic = None
 
@@ -404,9 +429,8 @@ def main():
             "parallelism": f"geometry-sharded x{world}, one all_gather at the end",
         },
         "roofline": {
-            "kernel": (("half_transform_fused_kernel<11,3> (T3[p,x,y,z] = sum_q C[q,x] "
-                        "sum_rs C[r,y] g[p,q,r,s] C[s,z])") if t3_path else
-                       "half_transform_kernel<1,11,3> (T2[p,q,y,z] = sum_rs C[r,y] g[p,q,r,s] C[s,z])"),
+            "kernel": kernel_name,
+            "eri_pq_symmetric": pq_sym,
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,

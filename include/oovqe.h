@@ -143,7 +143,19 @@ int oovqe_circuit_rdms(const double* theta, int n_theta, const oovqe_gate_t* gat
  * (oo_energy.py:221-224) WITHOUT materialising the N^4 MO tensor: only
  * Gm[n,x,y,z] = g_mo[n,x,y,z], x,y,z < n_occ+ncas, is formed.
  *
+ * eri_flags (oovqe_cas_eval / oovqe_oo_eval / oovqe_oo_eval_batch): properties of g_ao the caller
+ * vouches for.  OOVQE_ERI_PQ_SYMMETRIC: g_ao[p,q,:,:] == g_ao[q,p,:,:] EXACTLY (true for the
+ * integrals of real orbitals as PySCF's mol.intor('int2e') returns them, which is what
+ * Moldata_pyscf.int2e_ao holds, src/auto_oo/moldata_pyscf.py:31; verify with
+ * oovqe_eri_check_pq_symmetry).  The N^4 pass then reads only the N(N+1)/2 slabs p <= q: half the
+ * HBM traffic, identical results.  With eri_flags == 0 nothing is assumed about g_ao.
+ *
  * Stage 1 (the N^4 pass):  T2[p,q,y,z] = sum_rs C[r,y] g_ao[p,q,r,s] C[s,z],  y,z < M.       */
+#define OOVQE_ERI_PQ_SYMMETRIC 1u
+/* *symmetric = 1 when every g_ao[b][p,q,:,:] equals g_ao[b][q,p,:,:] bit for bit (one pass over the
+ * tensor; synchronises `stream`). */
+int oovqe_eri_check_pq_symmetry(const double* g_ao, int N, int batch, int* symmetric,
+                                oovqe_stream_t stream);
 int oovqe_cas_half_transform(const double* g_ao, const double* C, int N, int M, double* T2,
                              oovqe_stream_t stream);
 /* Stage 2: Gm[n,x,y,z] = sum_pq C[p,n] C[q,x] T2[p,q,y,z]; hmo[n,x] = (C^T h_ao C)[n,x].
@@ -175,7 +187,8 @@ int oovqe_cas_eval(const double* g_ao, const double* h_ao, const double* C, cons
                    const double* Gamma, int nrdm, double nuc, int N, int n_occ, int ncas,
                    const int32_t* kap_row, const int32_t* kap_col, int n_kappa, double* work,
                    double* c0, double* c1, double* c2, double* E, double* gvec, double* dE,
-                   double* fock, double* gmat, double* Gm, double* hmo, oovqe_stream_t stream);
+                   double* fock, double* gmat, double* Gm, double* hmo, unsigned eri_flags,
+                   oovqe_stream_t stream);
 int64_t oovqe_cas_eval_work_size(int N, int n_occ, int ncas, int nrdm);
 
 /* Inactive / active Fock matrices from FULL MO integrals h_mo [N,N], g_mo [N,N,N,N]: the public
@@ -248,7 +261,7 @@ int oovqe_oo_eval(const double* theta, int n_theta, const oovqe_gate_t* gates, i
                   int n_qubits, uint32_t init_index, const double* g_ao, const double* h_ao,
                   const double* C, double nuc, int N, int n_occ, int ncas, const int32_t* kap_row,
                   const int32_t* kap_col, int n_kappa, int derivatives, double* work, double* out,
-                  oovqe_stream_t stream);
+                  unsigned eri_flags, oovqe_stream_t stream);
 int64_t oovqe_oo_eval_work_size(int n_theta, int n_gates, int n_qubits, int N, int n_occ, int ncas,
                                 int derivatives);
 int64_t oovqe_oo_eval_out_size(int n_theta, int n_kappa, int ncas, int derivatives);
@@ -261,7 +274,8 @@ int oovqe_oo_eval_batch(const double* theta, int n_theta, const oovqe_gate_t* ga
                         int n_qubits, uint32_t init_index, const double* g_ao, const double* h_ao,
                         const double* C, const double* nuc, int N, int n_occ, int ncas,
                         const int32_t* kap_row, const int32_t* kap_col, int n_kappa, int derivatives,
-                        int batch, double* work, double* out, oovqe_stream_t stream);
+                        int batch, double* work, double* out, unsigned eri_flags,
+                        oovqe_stream_t stream);
 /* 1 when oovqe_circuit_rdms takes its one-workgroup LDS path for these sizes */
 int oovqe_circuit_rdms_is_small(int n_qubits, int ncas, int nvec, int n_gates);
 

@@ -754,6 +754,9 @@ def synthetic_problem(nao, seed, n_aux=None, enuc=31.0):
     B = rng.standard_normal((n_aux, n, n))
     B = 0.5 * (B + B.transpose(0, 2, 1))
     g = np.einsum('Lpq,Lrs->pqrs', B, B, optimize=True) / n_aux
+    # bit-for-bit p<->q and r<->s symmetry, as integral packages deliver it
+    g = 0.5 * (g + g.transpose(1, 0, 2, 3))
+    g = 0.5 * (g + g.transpose(0, 1, 3, 2))
     Qc, _ = np.linalg.qr(rng.standard_normal((n, n)))
     return dict(int1e_ao=h, int2e_ao=g, overlap=S, oao_mo_coeff=Qc, nuc=float(enuc))
 

@@ -424,3 +424,64 @@ def test_cas_eval_beyond_fused_shapes(N, nelec, ncas, nelecas):
     assert abs(res["E"].item() - E_ref.item()) < 1e-8 * max(1.0, abs(E_ref.item()))
     gv_ref = oo.kappa_matrix_to_vector(oo.analytic_gradient(gam[0], Gam[0]))
     assert (res["gvec"].cpu()[0] - gv_ref).abs().max() < 1e-8 * max(1.0, float(gv_ref.abs().max()))
+
+
+def test_eri_check_pq_symmetry():
+    """oovqe_eri_check_pq_symmetry: exact p<->q symmetry is detected; one flipped bit, a general
+    tensor, or one bad geometry of a stack turn the flag off."""
+    N = 11
+    P = R.synthetic_problem(N, 4242)
+    g = torch.tensor(P["int2e_ao"]).to(DEV).contiguous()
+    assert ops.eri_flags(g) == ops.ERI_PQ_SYMMETRIC
+    g2 = g.clone()
+    g2[3, 7, 2, 5] = g2[3, 7, 2, 5] * (1.0 + 2.0 ** -52)
+    assert ops.eri_flags(g2) == 0
+    rng = np.random.default_rng(5)
+    assert ops.eri_flags(torch.tensor(rng.standard_normal((N, N, N, N))).to(DEV)) == 0
+    stack = torch.stack([g, g, g]).contiguous()
+    assert ops.eri_flags(stack) == ops.ERI_PQ_SYMMETRIC
+    stack[2, 1, 0, 0, 0] += 1.0
+    assert ops.eri_flags(stack) == 0
+
+
+@pytest.mark.parametrize("path", ["auto", "t3x1", "t3x2", "mirror", "t2"])
+@pytest.mark.parametrize("N,nelec,ncas,nelecas", [(13, 16, 3, 4), (43, 16, 3, 4), (17, 8, 4, 4),
+                                                  (30, 14, 10, 8), (12, 16, 3, 4), (56, 12, 4, 4),
+                                                  (50, 40, 4, 4), (70, 40, 6, 6)])
+def test_cas_eval_pq_symmetric_integrals(N, nelec, ncas, nelecas, path, monkeypatch):
+    """eri_flags = ERI_PQ_SYMMETRIC (only the slabs p <= q of g_ao are read) against eri_flags = 0
+    on the same symmetric integrals, on every realisation: packed triangle + q->x kernel (forced by
+    OOVQE_FUSED_CHUNKS, which makes the call take the batched plan), mirrored T2 (one-chunk and
+    streaming half-transform kernels), staged fallback.  Same energy, coefficients, gradients and
+    g_mo to rounding; the flag-free result is itself checked against the oracle."""
+    if path.startswith("t3x"):
+        monkeypatch.setenv("OOVQE_FUSED_CHUNKS", path[3:])
+    elif path == "mirror":
+        monkeypatch.setenv("OOVQE_FUSED_CHUNKS", "1")
+        monkeypatch.setenv("OOVQE_SYM_MIRROR", "1")
+    elif path == "t2":
+        monkeypatch.setenv("OOVQE_CAS_UNFUSED", "1")
+    P = R.synthetic_problem(N, 1300 + N)
+    mol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec)
+    oo = R.OracleOOEnergy(mol, ncas, nelecas, P["oao_mo_coeff"])
+    no = len(oo.occ_idx)
+    C = oo.mo_coeff
+    rng = np.random.default_rng(N)
+    nrdm = 3
+    gam = torch.stack([_rand(rng, ncas, ncas) for _ in range(nrdm)]).to(DEV).contiguous()
+    Gam = torch.stack([_rand(rng, ncas, ncas, ncas, ncas) for _ in range(nrdm)]).to(DEV).contiguous()
+    rows, cols = X.tril_tables(N, oo.params_idx)
+    g_dev = oo.int2e_ao.to(DEV).contiguous()
+    assert ops.eri_flags(g_dev) == ops.ERI_PQ_SYMMETRIC
+    args = (g_dev, oo.int1e_ao.to(DEV).contiguous(), C.to(DEV).contiguous(), gam, Gam, oo.nuc, no, ncas,
+            torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV))
+    full = ops.cas_eval(*args, want_matrices=True, want_integrals=True, eri_flags=0)
+    sym = ops.cas_eval(*args, want_matrices=True, want_integrals=True, eri_flags=ops.ERI_PQ_SYMMETRIC)
+    for key in ("c0", "c1", "c2", "E", "gvec", "dE", "fock", "gmat", "Gm", "hmo"):
+        a, b = full[key], sym[key]
+        scale = max(1.0, float(a.abs().max()))
+        assert (a - b).abs().max() <= 1e-12 * scale, key
+    E_ref = oo.energy_from_mo_coeff(C, gam[0].cpu(), Gam[0].cpu())
+    assert abs(sym["E"].item() - E_ref.item()) < 1e-8 * max(1.0, abs(E_ref.item()))
+    gv_ref = oo.kappa_matrix_to_vector(oo.analytic_gradient(gam[0].cpu(), Gam[0].cpu()))
+    assert (sym["gvec"].cpu()[0] - gv_ref).abs().max() < 1e-8 * max(1.0, float(gv_ref.abs().max()))

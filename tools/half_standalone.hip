@@ -50,6 +50,35 @@ int main()
                fp.qc, fp.nbuf, fp.wpg, fp.lds_bytes, tot2 / reps * 1e3, best2 * 1e3,
                (double)ng * 8 / (tot2 / reps * 1e-3) / 1e12);
     }
+    for (int mode = SYM_MIRROR; mode <= 3; ++mode) {   // 3 = persistent packed-triangle kernel
+        // p <= q slabs only (the random g is not symmetric: timing only)
+        float tot3 = 0, best3 = 1e30f, totq = 0;
+        for (int r = 0; r < reps + 5; ++r) {
+            (void)hipEventRecord(e0, 0);
+            int rc = mode == 3 ? half_tri_batched(g, C, N, M, T2, G, nullptr) : half_transform_batched(g, C, N, M, T2, G, nullptr, mode);
+            (void)hipEventRecord(e1, 0);
+            (void)hipEventSynchronize(e1);
+            if (rc) { printf("error: %s\n", oovqe_last_error()); return 1; }
+            float ms;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (r >= 5) { tot3 += ms; if (ms < best3) best3 = ms; }
+            if (mode >= SYM_PACKED) {
+                double* T3 = T2 + (size_t)G * N * (N + 1) / 2 * M * M;
+                (void)hipEventRecord(e0, 0);
+                rc = sym_q_contract_batched(T2, C, T3, N, M, G, nullptr);
+                (void)hipEventRecord(e1, 0);
+                (void)hipEventSynchronize(e1);
+                if (rc) { printf("error: %s\n", oovqe_last_error()); return 1; }
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                if (r >= 5) totq += ms;
+            }
+        }
+        const double tb = (double)G * N * (N + 1) / 2 * N * N * 8;
+        printf("sym %s: avg %.1f us best %.1f us -> %.2f TB/s of the triangle", mode == SYM_MIRROR ? "mirror" : mode == SYM_PACKED ? "packed" : "packed-persistent",
+               tot3 / reps * 1e3, best3 * 1e3, tb / (tot3 / reps * 1e-3) / 1e12);
+        if (mode >= SYM_PACKED) printf("; q->x kernel %.1f us", totq / reps * 1e3);
+        printf("\n");
+    }
     const double bytes = (double)ng * 8;
     printf("half_transform batched N=%d M=%d G=%d: avg %.1f us best %.1f us -> %.2f TB/s (g_ao read)\n", N, M, G,
            tot / reps * 1e3, best * 1e3, bytes / (tot / reps * 1e-3) / 1e12);
