@@ -533,18 +533,173 @@ void sym_q_contract_kernel(const double* __restrict__ J, const double* __restric
     }
 }
 
-// Exact (bitwise) test of g[p,q,:,:] == g[q,p,:,:]: one workgroup per (p < q, geometry).
+// ------------------------------------------------------------------------------------------
+// q -> x and p -> n in ONE launch on the packed triangle: one workgroup per (16-wide (y z) tile,
+// geometry) computes
+//   T3s[p][x][yz] = sum_q C[q,x] J[tri(min(p,q), max(p,q))][yz]     (MFMA, all p, kept in LDS)
+//   Gm[n,x,yz]    = sum_p C[p,n] T3s[p][x][yz]                      (MFMA, B operand from LDS)
+// for its slice of (y z): the slice of J is used by this workgroup only (its second use, as a
+// column entry, comes from L2), T3 never goes to memory, and the small-circuit workgroups ride
+// along as the extra grid column blockIdx.x == nty (as they do on K1, contract.hip).
+// ------------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(SMALL_THREADS, 2)   // (a 128-VGPR build for two workgroups per CU is slower)
+void sym_gm_kernel(const double* __restrict__ J, const double* __restrict__ C,
+                   double* __restrict__ Gm, int N, int M, int packed, oovqe_circuit_job_t cj,
+                   int host_circuit)
+{
+    // packed: the columns of J are the pairs y <= z (half_tri_kernel, tiled == 2); each result goes
+    // to Gm[n,x,y,z] and Gm[n,x,z,y]
+    extern __shared__ double lds[];
+    const int m2 = M * M;
+    const int ncol = packed ? M * (M + 1) / 2 : m2;
+    const int nty = (ncol + 15) / 16;
+    if ((int)blockIdx.x == nty) {
+        if (host_circuit && (int)blockIdx.y < cj.count)
+            circuit_rdm_small_body(cj.theta, cj.n_theta, cj.gates, cj.n_gates, cj.n_qubits, cj.ncas,
+                                   cj.init_index, cj.n_tan, nullptr, nullptr, cj.gamma, cj.Gamma,
+                                   (int)blockIdx.y, lds);
+        return;
+    }
+    constexpr int NW = SMALL_THREADS / 64;
+    constexpr int PW = (4 * KS + NW - 1) / NW;       // rows p per wave
+    const int ty = blockIdx.x;
+    const long tri = (long)N * (N + 1) / 2;
+    // J is tile-major [ty][t][16] (half_tri_kernel, tiled): this workgroup's slice is contiguous
+    J += ((size_t)blockIdx.y * nty + ty) * tri * 16;
+    C += (size_t)blockIdx.y * N * N;
+    Gm += (size_t)blockIdx.y * N * M * m2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lq = lane >> 4, lr = lane & 15;
+    const int LDP = M * 16 + 8;                      // row stride of T3s (doubles)
+    double* T3s = lds;                               // [4 KS][LDP], rows p >= N are zero
+    const int yz = 16 * ty + lr;                     // column of J
+    int off1 = yz, off2 = -1;                        // positions y*M + z (and z*M + y) in Gm[n,x,:,:]
+    if (packed) {
+        int y, z;
+        tri_decode(yz < ncol ? yz : 0, M, y, z);
+        off1 = y * M + z;
+        if (y != z) off2 = z * M + y;
+    }
+
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t csrd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double*>(C), 0, (int)((size_t)N * N * sizeof(double)), 0x00020000);
+    // ---- step 1: A = C^T (m = x = lr, k = q = 4ks + lq), B = J rows (k = q, n = yz); the columns
+    // beyond the last one of the last tile hold unwritten memory: they only reach output columns
+    // never stored
+    {
+        const __amdgpu_buffer_rsrc_t jsrd = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<double*>(J), 0, (int)(tri * 16 * sizeof(double)), 0x00020000);
+        double af[KS];
+        // triangle row index of the pair (p, q): t = base(lo) + hi with base(a) = a(2N - a + 1)/2 - a;
+        // per lane and k-step: q and base(q), fixed for the whole kernel (32-bit arithmetic)
+        int qk[KS], baseq[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int q = 4 * ks + lq;
+            qk[ks] = q < N ? q : N - 1;
+            baseq[ks] = qk[ks] * (2 * N - qk[ks] + 1) / 2 - qk[ks];
+            // coefficients through the descriptor: out-of-range lanes (q >= N, x >= M) get an
+            // out-of-range offset and read 0 (a select or a branch around a plain load makes the
+            // compiler wait for each load separately)
+            const v2u v = __builtin_amdgcn_raw_buffer_load_b64(
+                csrd, (q < N && lr < M) ? (unsigned)((q * N + lr) * (int)sizeof(double)) : 0x7fffffffu, 0, 0);
+            af[ks] = __builtin_bit_cast(double, v);
+        }
+        // PH rows at a time: PH * KS loads of a lane in flight, <= 128 VGPRs (two workgroups per CU)
+        constexpr int PH = (PW + 1) / 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double bf[PH][KS];
+#pragma unroll
+            for (int i = 0; i < PH; ++i) {
+                const int p = wave + NW * (h * PH + i);
+                const int pc = p < N ? p : N - 1;                       // wave-uniform
+                const int basep = pc * (2 * N - pc + 1) / 2 - pc;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int t = qk[ks] < pc ? baseq[ks] + pc : basep + qk[ks];
+                    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(
+                        jsrd, (unsigned)((t * 16 + lr) * (int)sizeof(double)), 0, 0);
+                    bf[i][ks] = __builtin_bit_cast(double, v);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PH; ++i) {
+                const int p = wave + NW * (h * PH + i);
+                d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc = mfma_f64(af[ks], bf[i][ks], acc);
+                // rows p in [N, 4 KS) are the zero padding of step 2's k range
+                double* row = T3s + (size_t)(p < 4 * KS ? p : 0) * LDP + lr;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int x = lq + 4 * j;
+                    if (x < M && p < 4 * KS) row[x * 16] = p < N ? acc[j] : 0.0;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- step 2: output tile (n tile nt, x): A = C^T (m = n = 16 nt + lr, k = p = 4ks + lq) from
+    // L2, B = T3s[p][x][yz] from LDS; D rows n = 16 nt + lq + 4j, columns yz
+    const int ntn = (N + 15) / 16;
+    int cur_nt = -1;
+    double cf[KS];
+    for (int tile = wave; tile < ntn * M; tile += NW) {
+        const int nt = tile / M, x = tile - nt * M;
+        if (nt != cur_nt) {
+            const int n = 16 * nt + lr;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int pp = 4 * ks + lq;
+                const v2u v = __builtin_amdgcn_raw_buffer_load_b64(
+                    csrd, (pp < N && n < N) ? (unsigned)((pp * N + n) * (int)sizeof(double)) : 0x7fffffffu, 0, 0);
+                cf[ks] = __builtin_bit_cast(double, v);
+            }
+            cur_nt = nt;
+        }
+        double tf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) tf[ks] = T3s[(size_t)(4 * ks + lq) * LDP + x * 16 + lr];
+        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = mfma_f64(cf[ks], tf[ks], acc);
+        if (yz < ncol) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = 16 * nt + lq + 4 * j;
+                if (n < N) {
+                    double* dst = Gm + ((size_t)n * M + x) * m2;
+                    dst[off1] = acc[j];
+                    if (off2 >= 0) dst[off2] = acc[j];
+                }
+            }
+        }
+    }
+}
+
+// Exact (bitwise) symmetry tests, one workgroup per (slab (p,q), geometry):
+//   bit 0 of *mismatch: some g[p,q,:,:] != g[q,p,:,:];  bit 1: some g[p,q,r,s] != g[p,q,s,r]
 __global__ __launch_bounds__(256)
-void eri_pq_check_kernel(const unsigned long long* __restrict__ g, int N, int* __restrict__ mismatch)
+void eri_symmetry_check_kernel(const unsigned long long* __restrict__ g, int N, int* __restrict__ mismatch)
 {
     const int p = blockIdx.x, q = blockIdx.y;
-    if (p >= q) return;
     const size_t n2 = (size_t)N * N;
     const unsigned long long* a = g + (size_t)blockIdx.z * n2 * n2 + ((size_t)p * N + q) * n2;
     const unsigned long long* b = g + (size_t)blockIdx.z * n2 * n2 + ((size_t)q * N + p) * n2;
-    bool bad = false;
-    for (size_t i = threadIdx.x; i < n2; i += 256) bad |= a[i] != b[i];
-    if (bad) atomicOr(mismatch, 1);
+    bool bad_pq = false, bad_rs = false;
+    for (size_t i = threadIdx.x; i < n2; i += 256) {
+        const unsigned long long v = a[i];
+        if (p < q) bad_pq |= v != b[i];
+        const int r = (int)(i / N), c = (int)(i - (size_t)r * N);
+        if (r < c) bad_rs |= v != a[(size_t)c * N + r];
+    }
+    if (bad_pq) atomicOr(mismatch, 1);
+    if (bad_rs) atomicOr(mismatch, 2);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -894,7 +1049,7 @@ void half_transform_fused_kernel(const double* __restrict__ g, const double* __r
 template <int KCH, int NST>
 __global__ __launch_bounds__(HALF_WAVES * 64)
 void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
-                     double* __restrict__ J, int N, int M, int phase_rounds)
+                     double* __restrict__ J, int N, int M, int phase_rounds, int tiled)
 {
     constexpr int NP = NST / 2, NS1 = NST % 2;
     constexpr int NPA = NP > 0 ? NP : 1;
@@ -908,10 +1063,21 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
     const long tri = (long)N * (N + 1) / 2;
     const size_t slab_elems = (size_t)N * N;
     double* dump = lds;             // [64] sink for lanes outside the M x M tile
-    double* stg = lds + 64;         // [phase_rounds][HALF_WAVES][M2]
+    int* ctab = reinterpret_cast<int*>(lds + 64);   // [ncol <= 256] column -> position y*M + z in a tile
+    double* stg = lds + 64 + 128;   // [phase_rounds][HALF_WAVES][M2]
     g += (size_t)blockIdx.y * slab_elems * slab_elems;
     C += (size_t)blockIdx.y * N * N;
-    J += (size_t)blockIdx.y * tri * M2;
+    // tiled == 0: J[t][M2].  tiled == 1: J[ty][t][16], 16-wide tiles of the M2 (y z) columns
+    // outermost (the layout sym_gm_kernel streams).  tiled == 2 (r <-> s symmetric integrals,
+    // J[y][z] == J[z][y]): the same with the M(M+1)/2 columns y <= z only.
+    const int ncol = tiled == 2 ? M * (M + 1) / 2 : M2;
+    const int nty = (ncol + 15) / 16;
+    J += (size_t)blockIdx.y * tri * (tiled ? nty * 16 : M2);
+    if (tid < ncol) {               // read after the first barrier of the phase loop
+        int y = tid / M, z = tid - y * M;
+        if (tiled == 2) tri_decode(tid, M, y, z);
+        ctab[tid] = y * M + z;
+    }
 
     // per-lane byte offsets inside a slab: see half_transform_fused_kernel
     constexpr int MINK = KCH == 4 ? 1 : KCH == 8 ? 5 : KCH == 11 ? 9 : KCH;
@@ -1055,10 +1221,14 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
         }
         __syncthreads();
         const int nslot = (end - base) * HALF_WAVES;
-        for (int e = tid; e < nslot * M2; e += HALF_WAVES * 64) {
-            const int slot = e / M2, idx = e - slot * M2;
+        for (int e = tid; e < nslot * ncol; e += HALF_WAVES * 64) {
+            const int slot = e / ncol, c = e - slot * ncol;
             const long t = (long)(base + slot / HALF_WAVES) * SW + blockIdx.x * HALF_WAVES + slot % HALF_WAVES;
-            if (t < tri) J[(size_t)t * M2 + idx] = stg[e];
+            if (t < tri) {
+                const double v = stg[(size_t)slot * M2 + ctab[c]];
+                if (tiled) J[((size_t)(c >> 4) * tri + t) * 16 + (c & 15)] = v;
+                else J[(size_t)t * M2 + c] = v;
+            }
         }
         __syncthreads();
     }
@@ -1881,27 +2051,27 @@ static int half_transform_batched(const double* g_ao, const double* C, int N, in
     return 0;
 }
 
-extern "C" int oovqe_eri_check_pq_symmetry(const double* g_ao, int N, int batch, int* symmetric,
-                                           oovqe_stream_t stream)
+extern "C" int oovqe_eri_symmetry_flags(const double* g_ao, int N, int batch, unsigned* eri_flags,
+                                        oovqe_stream_t stream)
 {
-    OOVQE_REQUIRE(g_ao && symmetric, "eri_check_pq_symmetry: null pointer");
-    OOVQE_REQUIRE(N >= 1 && N <= 65535 && batch >= 1 && batch <= 65535, "eri_check_pq_symmetry: N=%d batch=%d",
+    OOVQE_REQUIRE(g_ao && eri_flags, "eri_symmetry_flags: null pointer");
+    OOVQE_REQUIRE(N >= 1 && N <= 65535 && batch >= 1 && batch <= 65535, "eri_symmetry_flags: N=%d batch=%d",
                   N, batch);
     hipStream_t st = (hipStream_t)stream;
     int* flag = nullptr;
-    OOVQE_CHECK_HIP(hipMalloc(&flag, sizeof(int)), "eri_check_pq_symmetry");
+    OOVQE_CHECK_HIP(hipMalloc(&flag, sizeof(int)), "eri_symmetry_flags");
     hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), st);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(eri_pq_check_kernel, dim3(N, N, batch), dim3(256), 0, st,
+        hipLaunchKernelGGL(eri_symmetry_check_kernel, dim3(N, N, batch), dim3(256), 0, st,
                            reinterpret_cast<const unsigned long long*>(g_ao), N, flag);
         e = hipGetLastError();
     }
-    int bad = 1;
+    int bad = 3;
     if (e == hipSuccess) e = hipMemcpyAsync(&bad, flag, sizeof(int), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(flag);
-    OOVQE_CHECK_HIP(e, "eri_check_pq_symmetry");
-    *symmetric = bad ? 0 : 1;
+    OOVQE_CHECK_HIP(e, "eri_symmetry_flags");
+    *eri_flags = ((bad & 1) ? 0u : OOVQE_ERI_PQ_SYMMETRIC) | ((bad & 2) ? 0u : OOVQE_ERI_RS_SYMMETRIC);
     return 0;
 }
 
@@ -1920,6 +2090,42 @@ static int sym_q_contract_batched(const double* J, const double* C, double* T3, 
         hipLaunchKernelGGL(sym_q_contract_kernel<12>, dim3(N, batch), dim3(threads), 0, st, J, C, T3, N, M);
     oovqe_profile_mark_stop(st);
     OOVQE_CHECK_LAUNCH("cas_eval/sym_q_contract");
+    return 0;
+}
+
+// Gm [G][N][M^3] from the packed triangle J in one launch (+ the circuit workgroups of cj, if any)
+static int sym_gm_batched(const double* J, const double* C, double* Gm, int N, int M, int batch,
+                          hipStream_t st, const oovqe_circuit_job_t* cj, bool packed)
+{
+    OOVQE_REQUIRE(M >= 1 && M <= 16 && N >= 1 && N <= 48, "sym_gm: N=%d M=%d", N, M);
+    const int ksteps = (N + 3) / 4;
+    const int KSr = ksteps <= 4 ? 4 : ksteps <= 8 ? 8 : 12;
+    size_t lds_bytes = (size_t)4 * KSr * (M * 16 + 8) * sizeof(double);
+    if (cj && cj->lds_bytes > lds_bytes) lds_bytes = cj->lds_bytes;
+    const unsigned nty = (unsigned)(((packed ? M * (M + 1) / 2 : M * M) + 15) / 16);
+    oovqe_circuit_job_t job;
+    memset(&job, 0, sizeof(job));
+    if (cj) job = *cj;
+#define OOVQE_LAUNCH_GM(KS_)                                                                      \
+    do {                                                                                          \
+        static size_t attr_bytes = 0;                                                             \
+        if (lds_bytes > attr_bytes) {                                                             \
+            OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)sym_gm_kernel<KS_>,                  \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                                (int)lds_bytes), "cas_eval/sym_gm");              \
+            attr_bytes = lds_bytes;                                                               \
+        }                                                                                         \
+        hipLaunchKernelGGL(sym_gm_kernel<KS_>, dim3(nty + (cj ? 1 : 0), batch),                   \
+                           dim3(SMALL_THREADS), lds_bytes, st, J, C, Gm, N, M, packed ? 1 : 0,    \
+                           job, cj ? 1 : 0);                                                      \
+    } while (0)
+    oovqe_profile_mark_start_l(st, 2);
+    if (KSr == 4) OOVQE_LAUNCH_GM(4);
+    else if (KSr == 8) OOVQE_LAUNCH_GM(8);
+    else OOVQE_LAUNCH_GM(12);
+    oovqe_profile_mark_stop(st);
+#undef OOVQE_LAUNCH_GM
+    OOVQE_CHECK_LAUNCH("cas_eval/sym_gm");
     return 0;
 }
 
@@ -2035,7 +2241,7 @@ static int half_transform_fused_batched(const double* g_ao, const double* C, int
 
 // Packed-triangle stage 1 (p <-> q symmetric integrals, M <= 16, N <= 48): J [G][N(N+1)/2][M^2].
 static int half_tri_batched(const double* g_ao, const double* C, int N, int M, double* J, int batch,
-                            hipStream_t st)
+                            hipStream_t st, int tiled = 0)
 {
     OOVQE_REQUIRE(M >= 1 && M <= 16 && N >= M && N <= 48, "cas_eval: half_tri N=%d M=%d", N, M);
     const int ksteps = (N + 3) / 4, nrb = (N + 15) / 16;
@@ -2046,10 +2252,11 @@ static int half_tri_batched(const double* g_ao, const double* C, int N, int M, d
     if (W > (tri + HALF_WAVES - 1) / HALF_WAVES) W = (tri + HALF_WAVES - 1) / HALF_WAVES;
     const long n_rounds = (tri + W * HALF_WAVES - 1) / (W * HALF_WAVES);
     const size_t round_bytes = (size_t)HALF_WAVES * M * M * sizeof(double);
-    long phase = (long)((160 * 1024 - 64 * sizeof(double)) / round_bytes) & ~1L;   // even
+    const size_t fixed_bytes = (64 + 128) * sizeof(double);   // dump + column table
+    long phase = (long)((160 * 1024 - fixed_bytes) / round_bytes) & ~1L;   // even
     OOVQE_REQUIRE(phase >= 2, "cas_eval: half_tri staging does not fit LDS (M=%d)", M);
     if (phase > ((n_rounds + 1) & ~1L)) phase = (n_rounds + 1) & ~1L;
-    const size_t lds_bytes = 64 * sizeof(double) + (size_t)phase * round_bytes;
+    const size_t lds_bytes = fixed_bytes + (size_t)phase * round_bytes;
 #define OOVQE_LAUNCH_TRI(KC_, NS_)                                                                \
     do {                                                                                          \
         static bool attr_done = false;                                                            \
@@ -2060,7 +2267,8 @@ static int half_tri_batched(const double* g_ao, const double* C, int N, int M, d
             attr_done = true;                                                                     \
         }                                                                                         \
         hipLaunchKernelGGL((half_tri_kernel<KC_, NS_>), dim3((unsigned)W, batch),                 \
-                           dim3(HALF_WAVES * 64), lds_bytes, st, g_ao, C, J, N, M, (int)phase);   \
+                           dim3(HALF_WAVES * 64), lds_bytes, st, g_ao, C, J, N, M, (int)phase,    \
+                           tiled);                                                                \
     } while (0)
     oovqe_profile_mark_start(st);
     if (kch == 4 && nrb == 1) OOVQE_LAUNCH_TRI(4, 1);
@@ -2202,28 +2410,39 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
     const double* Gm_in = nullptr;
     // p <-> q symmetric integrals (verified by the caller): only the slabs p <= q are read
     const bool pq_sym = (eri_flags & OOVQE_ERI_PQ_SYMMETRIC) != 0;
+    // r <-> s symmetric as well: J[p,q,y,z] == J[p,q,z,y], the packed path keeps the columns y <= z
+    const bool rs_sym = (eri_flags & OOVQE_ERI_RS_SYMMETRIC) != 0 && getenv("OOVQE_SYM_NO_RS") == nullptr;
     const int half_sym = pq_sym ? SYM_MIRROR : SYM_FULL;
     const long tri = (long)N * (N + 1) / 2;
+    const long nty16 = (m2 + 15) / 16 * 16;               // tile-major J rows are padded to 16
     const bool sym_packed = fused && pq_sym && getenv("OOVQE_SYM_MIRROR") == nullptr &&
-                            tri * m2 + 2 * (long)N * m3 <= 2 * (long)N * N * m2;
+                            tri * nty16 + 2 * (long)N * m3 <= 2 * (long)N * N * m2;
     if (sym_packed) {
         // packed triangle J (instead of the fused kernel: its q -> x contraction needs whole rows
         // of slabs), then the small q -> x kernel; from T3 on the same launches as the fused path
-        double* Jp = work;                                       // [G][tri][M^2]
-        double* T3 = Jp + nb * tri * m2;                         // [G][N][M^3]
+        double* Jp = work;                                       // [G][tri][M^2] or [G][nty][tri][16]
+        double* T3 = Jp + nb * tri * nty16;                      // [G][N][M^3]
         double* Gmw = T3 + nb * N * m3;                          // [G][N][M^3]
-        // test hook OOVQE_SYM_SIMPLE: the one-slab-per-wave kernel (direct stores) instead
-        if (getenv("OOVQE_SYM_SIMPLE") != nullptr) {
+        // test hooks: OOVQE_SYM_SIMPLE = the one-slab-per-wave kernel (direct stores) instead of the
+        // persistent one; OOVQE_SYM_TWO_STEP = q -> x kernel, then K1, instead of the one-launch
+        // kernel (both on the row-major J)
+        const bool simple = getenv("OOVQE_SYM_SIMPLE") != nullptr;
+        const bool two_step = simple || getenv("OOVQE_SYM_TWO_STEP") != nullptr;
+        if (simple) {
             if ((rc = half_transform_batched(g_ao, C, N, M, Jp, batch, stream, SYM_PACKED))) return rc;
-        } else if ((rc = half_tri_batched(g_ao, C, N, M, Jp, batch, st))) {
+        } else if ((rc = half_tri_batched(g_ao, C, N, M, Jp, batch, st, two_step ? 0 : rs_sym ? 2 : 1))) {
             return rc;
         }
-        if ((rc = sym_q_contract_batched(Jp, C, T3, N, M, batch, st))) return rc;
-        oovqe_profile_mark_start_l(st, 2);
-        if ((rc = oovqe_mode_contract_batched_circ(T3, C, Gmw, 1, N, N, m3, N, 0, batch, (long)N * m3,
-                                                   (long)N * N, (long)N * m3, st, cj)))
-            return rc;
-        oovqe_profile_mark_stop(st);
+        if (!two_step) {
+            if ((rc = sym_gm_batched(Jp, C, Gmw, N, M, batch, st, cj, rs_sym))) return rc;
+        } else {
+            if ((rc = sym_q_contract_batched(Jp, C, T3, N, M, batch, st))) return rc;
+            oovqe_profile_mark_start_l(st, 2);
+            if ((rc = oovqe_mode_contract_batched_circ(T3, C, Gmw, 1, N, N, m3, N, 0, batch, (long)N * m3,
+                                                       (long)N * N, (long)N * m3, st, cj)))
+                return rc;
+            oovqe_profile_mark_stop(st);
+        }
         Gm_in = Gmw;
     } else if (fused) {
         double* T3 = work;                                       // [G][nchunk][N][M^3]

@@ -245,12 +245,14 @@ def cas_energy_gradient(Gm, hmo, gamma, Gamma, nuc, n_occ, ncas, kap_row, kap_co
 
 
 ERI_PQ_SYMMETRIC = 1   # include/oovqe.h: OOVQE_ERI_PQ_SYMMETRIC
+ERI_RS_SYMMETRIC = 2   # include/oovqe.h: OOVQE_ERI_RS_SYMMETRIC
 
 
 def eri_flags(g_ao):
     """eri_flags for a resident g_ao ([N,N,N,N] or a stack [G,N,N,N,N]): ERI_PQ_SYMMETRIC when
-    g[p,q,:,:] == g[q,p,:,:] bit for bit (oovqe_eri_check_pq_symmetry; one pass over the tensor,
-    synchronises the stream).  The caller must not modify g_ao afterwards."""
+    g[p,q,:,:] == g[q,p,:,:] and ERI_RS_SYMMETRIC when g[p,q,r,s] == g[p,q,s,r], bit for bit
+    (oovqe_eri_symmetry_flags; one pass over the tensor, synchronises the stream).  The caller must
+    not modify g_ao afterwards."""
     lib = _lib.load()
     _dev(g_ao)
     if g_ao.dtype != F64 or not g_ao.is_contiguous() or g_ao.dim() not in (4, 5):
@@ -259,10 +261,10 @@ def eri_flags(g_ao):
     batch = g_ao.shape[0] if g_ao.dim() == 5 else 1
     if tuple(g_ao.shape[-4:]) != (N, N, N, N) or batch > 65535 or N > 65535:
         return 0
-    sym = ctypes.c_int(0)
-    check(lib.oovqe_eri_check_pq_symmetry(dptr(g_ao), N, batch, ctypes.byref(sym), stream_ptr()),
-          "oovqe_eri_check_pq_symmetry")
-    return ERI_PQ_SYMMETRIC if sym.value else 0
+    flags = ctypes.c_uint(0)
+    check(lib.oovqe_eri_symmetry_flags(dptr(g_ao), N, batch, ctypes.byref(flags), stream_ptr()),
+          "oovqe_eri_symmetry_flags")
+    return int(flags.value)
 
 
 def cas_eval(g_ao, h_ao, C, gamma, Gamma, nuc, n_occ, ncas, kap_row, kap_col, want_matrices=False,

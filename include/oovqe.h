@@ -147,15 +147,19 @@ int oovqe_circuit_rdms(const double* theta, int n_theta, const oovqe_gate_t* gat
  * vouches for.  OOVQE_ERI_PQ_SYMMETRIC: g_ao[p,q,:,:] == g_ao[q,p,:,:] EXACTLY (true for the
  * integrals of real orbitals as PySCF's mol.intor('int2e') returns them, which is what
  * Moldata_pyscf.int2e_ao holds, src/auto_oo/moldata_pyscf.py:31; verify with
- * oovqe_eri_check_pq_symmetry).  The N^4 pass then reads only the N(N+1)/2 slabs p <= q: half the
+ * oovqe_eri_symmetry_flags).  The N^4 pass then reads only the N(N+1)/2 slabs p <= q: half the
  * HBM traffic, identical results.  With eri_flags == 0 nothing is assumed about g_ao.
  *
  * Stage 1 (the N^4 pass):  T2[p,q,y,z] = sum_rs C[r,y] g_ao[p,q,r,s] C[s,z],  y,z < M.       */
 #define OOVQE_ERI_PQ_SYMMETRIC 1u
-/* *symmetric = 1 when every g_ao[b][p,q,:,:] equals g_ao[b][q,p,:,:] bit for bit (one pass over the
- * tensor; synchronises `stream`). */
-int oovqe_eri_check_pq_symmetry(const double* g_ao, int N, int batch, int* symmetric,
-                                oovqe_stream_t stream);
+/* OOVQE_ERI_RS_SYMMETRIC: g_ao[p,q,r,s] == g_ao[p,q,s,r] EXACTLY (equally true of PySCF's int2e).
+ * The half-transformed slabs are then symmetric in (y,z); together with OOVQE_ERI_PQ_SYMMETRIC the
+ * batched path stores and contracts only the columns y <= z. */
+#define OOVQE_ERI_RS_SYMMETRIC 2u
+/* *eri_flags = the OOVQE_ERI_* bits that hold bit for bit for every geometry of the stack g_ao
+ * [batch][N^4] (one pass over the tensor; synchronises `stream`). */
+int oovqe_eri_symmetry_flags(const double* g_ao, int N, int batch, unsigned* eri_flags,
+                             oovqe_stream_t stream);
 int oovqe_cas_half_transform(const double* g_ao, const double* C, int N, int M, double* T2,
                              oovqe_stream_t stream);
 /* Stage 2: Gm[n,x,y,z] = sum_pq C[p,n] C[q,x] T2[p,q,y,z]; hmo[n,x] = (C^T h_ao C)[n,x].

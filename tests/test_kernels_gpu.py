@@ -426,36 +426,51 @@ def test_cas_eval_beyond_fused_shapes(N, nelec, ncas, nelecas):
     assert (res["gvec"].cpu()[0] - gv_ref).abs().max() < 1e-8 * max(1.0, float(gv_ref.abs().max()))
 
 
-def test_eri_check_pq_symmetry():
-    """oovqe_eri_check_pq_symmetry: exact p<->q symmetry is detected; one flipped bit, a general
-    tensor, or one bad geometry of a stack turn the flag off."""
+def test_eri_symmetry_flags():
+    """oovqe_eri_symmetry_flags: exact p<->q and r<->s symmetry are detected separately; one flipped
+    bit, a general tensor, or one bad geometry of a stack turn the flags off."""
     N = 11
+    BOTH = ops.ERI_PQ_SYMMETRIC | ops.ERI_RS_SYMMETRIC
     P = R.synthetic_problem(N, 4242)
     g = torch.tensor(P["int2e_ao"]).to(DEV).contiguous()
-    assert ops.eri_flags(g) == ops.ERI_PQ_SYMMETRIC
+    assert ops.eri_flags(g) == BOTH
     g2 = g.clone()
     g2[3, 7, 2, 5] = g2[3, 7, 2, 5] * (1.0 + 2.0 ** -52)
     assert ops.eri_flags(g2) == 0
+    g2[3, 7, 5, 2] = g2[3, 7, 2, 5]          # r<->s repaired, p<->q still broken
+    assert ops.eri_flags(g2) == ops.ERI_RS_SYMMETRIC
     rng = np.random.default_rng(5)
-    assert ops.eri_flags(torch.tensor(rng.standard_normal((N, N, N, N))).to(DEV)) == 0
+    A = torch.tensor(rng.standard_normal((N, N, N, N))).to(DEV)
+    assert ops.eri_flags(A) == 0
+    assert ops.eri_flags((A + A.transpose(0, 1)).contiguous()) == ops.ERI_PQ_SYMMETRIC
+    assert ops.eri_flags((A + A.transpose(2, 3)).contiguous()) == ops.ERI_RS_SYMMETRIC
     stack = torch.stack([g, g, g]).contiguous()
-    assert ops.eri_flags(stack) == ops.ERI_PQ_SYMMETRIC
+    assert ops.eri_flags(stack) == BOTH
     stack[2, 1, 0, 0, 0] += 1.0
-    assert ops.eri_flags(stack) == 0
+    assert ops.eri_flags(stack) == ops.ERI_RS_SYMMETRIC
 
 
-@pytest.mark.parametrize("path", ["auto", "t3x1", "t3x2", "mirror", "t2"])
+@pytest.mark.parametrize("flags", [1, 3])
+@pytest.mark.parametrize("path", ["auto", "t3x1", "t3x2", "two_step", "simple", "mirror", "t2"])
 @pytest.mark.parametrize("N,nelec,ncas,nelecas", [(13, 16, 3, 4), (43, 16, 3, 4), (17, 8, 4, 4),
                                                   (30, 14, 10, 8), (12, 16, 3, 4), (56, 12, 4, 4),
                                                   (50, 40, 4, 4), (70, 40, 6, 6)])
-def test_cas_eval_pq_symmetric_integrals(N, nelec, ncas, nelecas, path, monkeypatch):
-    """eri_flags = ERI_PQ_SYMMETRIC (only the slabs p <= q of g_ao are read) against eri_flags = 0
-    on the same symmetric integrals, on every realisation: packed triangle + q->x kernel (forced by
-    OOVQE_FUSED_CHUNKS, which makes the call take the batched plan), mirrored T2 (one-chunk and
-    streaming half-transform kernels), staged fallback.  Same energy, coefficients, gradients and
+def test_cas_eval_pq_symmetric_integrals(N, nelec, ncas, nelecas, path, flags, monkeypatch):
+    """eri_flags = ERI_PQ_SYMMETRIC (only the slabs p <= q of g_ao are read), alone and together with
+    ERI_RS_SYMMETRIC (only the columns y <= z of the packed triangle are kept), against eri_flags = 0
+    on the same symmetric integrals, on every realisation: packed triangle + the one-launch
+    q->x / p->n kernel (forced by OOVQE_FUSED_CHUNKS, which makes the call take the batched plan) and
+    its two-launch and simple-kernel variants, mirrored T2 (one-chunk and streaming half-transform
+    kernels), staged fallback.  Same energy, coefficients, gradients and
     g_mo to rounding; the flag-free result is itself checked against the oracle."""
     if path.startswith("t3x"):
         monkeypatch.setenv("OOVQE_FUSED_CHUNKS", path[3:])
+    elif path == "two_step":      # packed triangle, then the q -> x kernel and K1 as two launches
+        monkeypatch.setenv("OOVQE_FUSED_CHUNKS", "1")
+        monkeypatch.setenv("OOVQE_SYM_TWO_STEP", "1")
+    elif path == "simple":        # packed triangle written by the one-slab-per-wave kernel
+        monkeypatch.setenv("OOVQE_FUSED_CHUNKS", "1")
+        monkeypatch.setenv("OOVQE_SYM_SIMPLE", "1")
     elif path == "mirror":
         monkeypatch.setenv("OOVQE_FUSED_CHUNKS", "1")
         monkeypatch.setenv("OOVQE_SYM_MIRROR", "1")
@@ -472,11 +487,11 @@ def test_cas_eval_pq_symmetric_integrals(N, nelec, ncas, nelecas, path, monkeypa
     Gam = torch.stack([_rand(rng, ncas, ncas, ncas, ncas) for _ in range(nrdm)]).to(DEV).contiguous()
     rows, cols = X.tril_tables(N, oo.params_idx)
     g_dev = oo.int2e_ao.to(DEV).contiguous()
-    assert ops.eri_flags(g_dev) == ops.ERI_PQ_SYMMETRIC
+    assert ops.eri_flags(g_dev) == ops.ERI_PQ_SYMMETRIC | ops.ERI_RS_SYMMETRIC
     args = (g_dev, oo.int1e_ao.to(DEV).contiguous(), C.to(DEV).contiguous(), gam, Gam, oo.nuc, no, ncas,
             torch.tensor(rows).to(DEV), torch.tensor(cols).to(DEV))
     full = ops.cas_eval(*args, want_matrices=True, want_integrals=True, eri_flags=0)
-    sym = ops.cas_eval(*args, want_matrices=True, want_integrals=True, eri_flags=ops.ERI_PQ_SYMMETRIC)
+    sym = ops.cas_eval(*args, want_matrices=True, want_integrals=True, eri_flags=flags)
     for key in ("c0", "c1", "c2", "E", "gvec", "dE", "fock", "gmat", "Gm", "hmo"):
         a, b = full[key], sym[key]
         scale = max(1.0, float(a.abs().max()))

@@ -1,3 +1,4 @@
 set -e
-timeout -k 10 60 tools/bin/hs_base > gpurun_out/hs_sym.log 2>&1
-timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "pq_symmetr or streaming or beyond_fused or half_transform_sizes" > gpurun_out/t_sym.log 2>&1
+timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -q -x -k "pq_symmetr" > gpurun_out/t_sym.log 2>&1
+timeout -k 10 600 python -m pytest tests/test_full_size_gpu.py tests/test_api_gpu.py -q -x > gpurun_out/t_sym2.log 2>&1
+timeout -k 10 600 python bench.py --no-cpu-baseline --no-berry --no-transform --no-kupccd > gpurun_out/b_sym.json 2> gpurun_out/b_sym.err
