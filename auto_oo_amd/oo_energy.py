@@ -135,7 +135,7 @@ class OO_energy:
     def _eri_flags(self, g_ao=None):
         """Symmetry flags of a resident two-electron tensor (ops.eri_flags), checked once per tensor
         object: int2e_ao is set once and never modified in place, as in the reference
-        (moldata_pyscf.py:31, oo_energy.py:104).  PySCF integrals are exactly p<->q symmetric, so
+        (moldata_pyscf.py:31, oo_energy.py:155).  PySCF integrals are exactly p<->q symmetric, so
         the N^4 pass reads half of the tensor; anything else is treated as a general tensor."""
         g_ao = self.int2e_ao if g_ao is None else g_ao
         cache = self.__dict__.setdefault("_eri_flag_cache", {})
