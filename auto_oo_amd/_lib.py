@@ -124,7 +124,9 @@ SIGNATURES = {
                                            c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, c_int32_p, c_int32_p, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
-                                           ctypes.c_uint, c_stream]),
+                                           ctypes.c_uint, c_double_p, c_stream]),
+    "oovqe_eri_packed_size": (ctypes.c_int64, [ctypes.c_int]),
+    "oovqe_eri_pack": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, c_stream]),
     "oovqe_circuit_rdms_is_small": (ctypes.c_int, [ctypes.c_int] * 4),
 }
 

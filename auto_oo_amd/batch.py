@@ -73,6 +73,15 @@ class OO_pqc_batch:
         # exact p<->q symmetry of every geometry's integrals (true for PySCF's int2e): the N^4 pass
         # then reads only the slabs p <= q.  int2e_ao must not be modified in place afterwards.
         self.eri_flags = ops.eri_flags(self.int2e_ao)
+        # both symmetries: keep a packed resident copy (slabs p <= q, blocks on/above each slab's
+        # diagonal: about a third of the tensor) for the batched N^4 pass to stream
+        self._eri_packed = None
+        both = ops.ERI_PQ_SYMMETRIC | ops.ERI_RS_SYMMETRIC
+        psz = self.lib.oovqe_eri_packed_size(N)
+        if (self.eri_flags & both) == both and psz > 0 and self._n_occ + ncas <= 16:
+            self._eri_packed = torch.empty((self.G, psz), dtype=F64, device=self.device)
+            check(self.lib.oovqe_eri_pack(dptr(self.int2e_ao), N, self.G, dptr(self._eri_packed),
+                                          stream_ptr()), "oovqe_eri_pack")
         self._plans = {}
 
     def set_oao_mo_coeff(self, g, oao_mo_coeff):
@@ -113,7 +122,7 @@ class OO_pqc_batch:
             dptr(self.int1e_ao), dptr(self.mo_coeff), dptr(self.nuc), self.nao, self._n_occ,
             self.ncas, dptr(self._kap_row, torch.int32), dptr(self._kap_col, torch.int32),
             self.n_kappa, int(bool(derivatives)), G, dptr(work), dptr(out), int(self.eri_flags),
-            stream_ptr()),
+            dptr(self._eri_packed) if self.eri_flags == 3 else None, stream_ptr()),
             "oovqe_oo_eval_batch")
         return out
 

@@ -1035,6 +1035,28 @@ void half_transform_fused_kernel(const double* __restrict__ g, const double* __r
     }
 }
 
+// Packed copy of p <-> q and r <-> s symmetric integrals for half_tri_kernel<.,.,2>: slab t = (p <= q)
+// of the triangle, row r with its columns 16*(r/16) .. N-1 only, rows back to back (for N = 43:
+// 1241 of 1849 doubles per slab, 946 of 1849 slabs: 34 % of the tensor).  One workgroup per slab.
+__global__ __launch_bounds__(256)
+void eri_pack_kernel(const double* __restrict__ g, double* __restrict__ out, int N, unsigned slab_pk)
+{
+    const long t = blockIdx.x;
+    const long tri = (long)N * (N + 1) / 2;
+    int p, q;
+    tri_decode(t, N, p, q);
+    const double* src = g + (size_t)blockIdx.y * N * N * N * N + ((size_t)p * N + q) * N * N;
+    double* dst = out + ((size_t)blockIdx.y * tri + t) * slab_pk;
+    for (int idx = threadIdx.x; idx < N * N; idx += 256) {
+        const int r = idx / N, c = idx - r * N;
+        const int rb = r / 16;
+        if (c < 16 * rb) continue;
+        // rows before block rb: sum_{b < rb} 16 (N - 16 b) = 16 rb N - 128 rb (rb - 1)
+        const int off = 16 * rb * N - 128 * rb * (rb - 1) + (r - 16 * rb) * (N - 16 * rb) + (c - 16 * rb);
+        dst[off] = src[idx];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Stage 1 over the upper triangle of slabs (p <-> q symmetric integrals; M <= 16, N <= 48),
 // persistent and software-pipelined like half_transform_fused_kernel, whose load path it shares:
@@ -1046,7 +1068,7 @@ void half_transform_fused_kernel(const double* __restrict__ g, const double* __r
 // the read stream costs far more than its bytes.
 // Algorithmic HBM bytes per geometry: 8 N^2 * N(N+1)/2 read + 8 M^2 * N(N+1)/2 written.
 // ------------------------------------------------------------------------------------------
-template <int KCH, int NST>
+template <int KCH, int NST, int RS>
 __global__ __launch_bounds__(HALF_WAVES * 64)
 void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
                      double* __restrict__ J, int N, int M, int phase_rounds, int tiled)
@@ -1055,6 +1077,7 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
     constexpr int NPA = NP > 0 ? NP : 1;
     constexpr int NCF = NST * 4;
     static_assert(KCH <= NCF, "C fragments must cover every k-step");
+    static_assert(NP <= 1, "row blocks above a pair are not handled by the offsets below");
     extern __shared__ double lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1065,7 +1088,21 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
     double* dump = lds;             // [64] sink for lanes outside the M x M tile
     int* ctab = reinterpret_cast<int*>(lds + 64);   // [ncol <= 256] column -> position y*M + z in a tile
     double* stg = lds + 64 + 128;   // [phase_rounds][HALF_WAVES][M2]
-    g += (size_t)blockIdx.y * slab_elems * slab_elems;
+    // RS == 2: g is the PACKED copy made by eri_pack_kernel: per slab t = (p <= q), row r holds its
+    // columns 16*(r/16) .. N-1 only (the 16x16 blocks on and above the diagonal), rows back to back
+    constexpr bool rs = RS != 0, pk = RS == 2;
+    int len_rb[NST], org_rb[NST];
+    unsigned base_rb[NST];              // bytes from the start of the slab to its row block rb
+    unsigned slab_pk = 0;
+#pragma unroll
+    for (int rb = 0; rb < NST; ++rb) {
+        len_rb[rb] = pk ? N - 16 * rb : N;
+        org_rb[rb] = pk ? 16 * rb : 0;
+        base_rb[rb] = pk ? slab_pk : (unsigned)(16 * rb * N * sizeof(double));
+        const int rows = N - 16 * rb < 16 ? N - 16 * rb : 16;
+        slab_pk += (unsigned)(rows * (N - 16 * rb) * sizeof(double));
+    }
+    g += (size_t)blockIdx.y * (pk ? (size_t)tri * (slab_pk / sizeof(double)) : slab_elems * slab_elems);
     C += (size_t)blockIdx.y * N * N;
     // tiled == 0: J[t][M2].  tiled == 1: J[ty][t][16], 16-wide tiles of the M2 (y z) columns
     // outermost (the layout sym_gm_kernel streams).  tiled == 2 (r <-> s symmetric integrals,
@@ -1076,35 +1113,58 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
     if (tid < ncol) {               // read after the first barrier of the phase loop
         int y = tid / M, z = tid - y * M;
         if (tiled == 2) tri_decode(tid, M, y, z);
-        ctab[tid] = y * M + z;
+        ctab[tid] = (y * M + z) | ((z * M + y) << 16);   // position of (y,z) and of (z,y) in a tile
     }
+    // r <-> s symmetric integrals (tiled == 2): a slab is itself symmetric, G = L + L^T + D with D
+    // its diagonal 16x16 blocks and L the blocks above them.  Only D and L are LOADED (rows of a
+    // lower block get an out-of-range offset: no traffic), the MFMA chain forms
+    // T = C^T (L + D/2) C, and the burst writes J = T + T^T.  For N = 43: 67 % of the slab.
+    // (RS != 0 goes with tiled == 2; a template parameter: the k-steps of lower blocks vanish at
+    // compile time.  RS == 1 reads the full layout, where the rows keep their 8 N-byte pitch and
+    // the skipped parts mostly share cache lines with the loaded ones: 7 % faster only; RS == 2
+    // streams the packed copy.)
+    const double wA_lo = rs ? 0.5 : 1.0, wB_lo = rs ? 0.0 : 1.0, wB_hi = rs ? 0.5 : 1.0, wD = rs ? 0.5 : 1.0;
 
-    // per-lane byte offsets inside a slab: see half_transform_fused_kernel
+    // per-lane byte offsets inside a slab (see half_transform_fused_kernel), one per row block:
+    // row r = 4i + lq of block rb = i/4 starts base_rb + (r - 16 rb) * len_rb doubles into the slab
+    // and holds the columns org_rb ..; lanes whose column lies left of the block's origin (below
+    // the diagonal) and, in the last k-step, lanes whose row is >= N get an out-of-range offset
     constexpr int MINK = KCH == 4 ? 1 : KCH == 8 ? 5 : KCH == 11 ? 9 : KCH;
     const int i_last = (N - 1) / 4;
-    const unsigned slab_bytes = (unsigned)(slab_elems * sizeof(double));
-    const unsigned total_bytes = (unsigned)(slab_elems * slab_elems * sizeof(double));
+    const unsigned slab_bytes = pk ? slab_pk : (unsigned)(slab_elems * sizeof(double));
+    const unsigned total_bytes = pk ? (unsigned)(tri * slab_pk) : (unsigned)(slab_elems * slab_elems * sizeof(double));
     const bool row_ok_last = 4 * i_last + lq < N;
-    unsigned offp[NPA], offp_last[NPA];
+    unsigned offp[NPA][2];              // pair pp, row block 2pp + {0, 1}
     bool last_even[NPA];
 #pragma unroll
     for (int pp = 0; pp < NP; ++pp) {
         const int col = pp * 32 + 2 * lr;
         const int cc = col + 1 < N ? col : (N >= 2 ? N - 2 : 0);
-        offp[pp] = (unsigned)((lq * N + cc) * sizeof(double));
-        offp_last[pp] = row_ok_last ? offp[pp] : total_bytes;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rb = 2 * pp + h;
+            const bool below = rs && h == 1 && lr < 8;      // first block's columns in the second block's rows
+            offp[pp][h] = below ? total_bytes : (unsigned)((lq * len_rb[rb] + cc - org_rb[rb]) * sizeof(double));
+        }
         last_even[pp] = col == N - 1;
     }
     const int col1 = NP * 32 + lr;
-    const unsigned offs = (unsigned)((lq * N + (col1 < N ? col1 : N - 1)) * sizeof(double));
-    const unsigned offs_last = row_ok_last ? offs : total_bytes;
+    unsigned offs[NST];                 // single tile (column block NST-1), row block rb
+#pragma unroll
+    for (int rb = 0; rb < NST; ++rb)
+        offs[rb] = (unsigned)((lq * len_rb[rb] + (col1 < N ? col1 : N - 1) - org_rb[rb]) * sizeof(double));
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double*>(g), 0, (int)total_bytes, 0x00020000);
-    const unsigned rowblk_bytes = (unsigned)(4 * N * sizeof(double));
+    // scalar part: slab + row block + rows 4(i - 4 rb) of it; k-steps past the last row are dropped
     auto soff = [&](unsigned sb, int i) -> unsigned {
-        return (i < MINK || i <= i_last) ? sb + i * rowblk_bytes : total_bytes;
+        const int rb = i / 4;
+        const unsigned o = sb + base_rb[rb] + (unsigned)(4 * (i - 4 * rb) * len_rb[rb] * sizeof(double));
+        return (i < MINK || i <= i_last) ? o : total_bytes;
+    };
+    auto voff = [&](unsigned vo, int i) -> unsigned {
+        return (i >= MINK - 1 && i == i_last && !row_ok_last) ? total_bytes : vo;
     };
 
     const int SW = gridDim.x * HALF_WAVES;                  // waves per geometry
@@ -1113,6 +1173,7 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
     // round r of this wave: slab t = r*SW + gw of the triangle; past the end -> dropped loads
     auto slab_off = [&](int r) -> unsigned {
         const long t = (long)r * SW + gw;
+        if (pk) return __builtin_amdgcn_readfirstlane(t < tri ? (unsigned)t * slab_bytes : total_bytes);
         int p, q;
         tri_decode(t < tri ? t : 0, N, p, q);
         return __builtin_amdgcn_readfirstlane(t < tri ? (unsigned)(p * N + q) * slab_bytes : total_bytes);
@@ -1123,15 +1184,17 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
         for (int pp = 0; pp < NP; ++pp)
 #pragma unroll
             for (int i = 0; i < KCH; ++i) {
-                const v4u v = __builtin_amdgcn_raw_buffer_load_b128(
-                    rsrc, (i >= MINK - 1 && i == i_last) ? offp_last[pp] : offp[pp], soff(sb, i), 0);
+                const int blk = i / 4;                 // 16-row block of this k-step (compile time)
+                if (rs && blk > 2 * pp + 1) continue;  // rows below both blocks of the pair: lower blocks
+                // (row blocks above the pair, blk < 2pp, only exist for NST > 3: not instantiated)
+                const unsigned vo = offp[pp][blk == 2 * pp + 1 ? 1 : 0];
+                const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff(vo, i), soff(sb, i), 0);
                 ap[pp][i] = __builtin_bit_cast(d2u, v);
             }
         if constexpr (NS1) {
 #pragma unroll
             for (int i = 0; i < KCH; ++i) {
-                const v2u v = __builtin_amdgcn_raw_buffer_load_b64(
-                    rsrc, (i >= MINK - 1 && i == i_last) ? offs_last : offs, soff(sb, i), 0);
+                const v2u v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff(offs[i / 4], i), soff(sb, i), 0);
                 as[i] = __builtin_bit_cast(double, v);
             }
         }
@@ -1180,19 +1243,37 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
         for (int pp = 0; pp < NP; ++pp)
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                d4 xt = d4{0.0, 0.0, 0.0, 0.0};
+                // rows above the pair's blocks (xu), in its first block (xa), from its second on (xb)
+                d4 xu = d4{0.0, 0.0, 0.0, 0.0}, xa = xu, xb = xu;
 #pragma unroll
                 for (int i = 0; i < KCH; ++i) {
                     const double ev = last_even[pp] ? ap[pp][i].y : ap[pp][i].x;
-                    xt = mfma_f64(half == 0 ? ev : ap[pp][i].y, cfr[i], xt);
+                    const double av = half == 0 ? ev : ap[pp][i].y;
+                    const int blk = i / 4;
+                    if (rs && blk > 2 * pp + 1) continue;
+                    if (blk < 2 * pp) xu = mfma_f64(av, cfr[i], xu);
+                    else if (blk == 2 * pp) xa = mfma_f64(av, cfr[i], xa);
+                    else xb = mfma_f64(av, cfr[i], xb);
                 }
+                // tile rows m = lq + 4e: e < 2 are columns of the first block (xa is their diagonal
+                // block, xb lies below it), e >= 2 of the second (xa above, xb diagonal)
+                d4 xt;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    xt[e] = xu[e] + (e < 2 ? wA_lo : 1.0) * xa[e] + (e < 2 ? wB_lo : wB_hi) * xb[e];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) jt = mfma_f64(cpr[pp][half][i], xt[i], jt);
             }
         if constexpr (NS1) {
-            d4 xt = d4{0.0, 0.0, 0.0, 0.0};
+            d4 xu = d4{0.0, 0.0, 0.0, 0.0}, xd = xu;   // rows above / inside the tile's diagonal block
 #pragma unroll
-            for (int i = 0; i < KCH; ++i) xt = mfma_f64(as[i], cfr[i], xt);
+            for (int i = 0; i < KCH; ++i) {
+                if (i / 4 < NST - 1) xu = mfma_f64(as[i], cfr[i], xu);
+                else xd = mfma_f64(as[i], cfr[i], xd);
+            }
+            d4 xt;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xt[e] = xu[e] + wD * xd[e];
 #pragma unroll
             for (int i = 0; i < 4; ++i) jt = mfma_f64(cfr[NP * 8 + i], xt[i], jt);
         }
@@ -1225,7 +1306,9 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
             const int slot = e / ncol, c = e - slot * ncol;
             const long t = (long)(base + slot / HALF_WAVES) * SW + blockIdx.x * HALF_WAVES + slot % HALF_WAVES;
             if (t < tri) {
-                const double v = stg[(size_t)slot * M2 + ctab[c]];
+                const int cc2 = ctab[c];
+                double v = stg[(size_t)slot * M2 + (cc2 & 0xffff)];
+                if (rs) v += stg[(size_t)slot * M2 + (cc2 >> 16)];   // J = T + T^T
                 if (tiled) J[((size_t)(c >> 4) * tri + t) * 16 + (c & 15)] = v;
                 else J[(size_t)t * M2 + c] = v;
             }
@@ -2239,10 +2322,36 @@ static int half_transform_fused_batched(const double* g_ao, const double* C, int
     return 0;
 }
 
+static unsigned eri_slab_packed_elems(int N)
+{
+    unsigned n = 0;
+    for (int rb = 0; 16 * rb < N; ++rb) n += (unsigned)((N - 16 * rb < 16 ? N - 16 * rb : 16) * (N - 16 * rb));
+    return n;
+}
+
+extern "C" int64_t oovqe_eri_packed_size(int N)
+{
+    // doubles per geometry; 0: no packed form for this N (the batched packed-triangle kernels cover N <= 48)
+    if (N < 1 || N > 48) return 0;
+    return (int64_t)N * (N + 1) / 2 * eri_slab_packed_elems(N);
+}
+
+extern "C" int oovqe_eri_pack(const double* g_ao, int N, int batch, double* packed, oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(g_ao && packed, "eri_pack: null pointer");
+    OOVQE_REQUIRE(N >= 1 && N <= 48 && batch >= 1 && batch <= 65535, "eri_pack: N=%d batch=%d", N, batch);
+    hipLaunchKernelGGL(eri_pack_kernel, dim3((unsigned)(N * (N + 1) / 2), batch), dim3(256), 0,
+                       (hipStream_t)stream, g_ao, packed, N, eri_slab_packed_elems(N));
+    OOVQE_CHECK_LAUNCH("eri_pack");
+    return 0;
+}
+
 // Packed-triangle stage 1 (p <-> q symmetric integrals, M <= 16, N <= 48): J [G][N(N+1)/2][M^2].
 static int half_tri_batched(const double* g_ao, const double* C, int N, int M, double* J, int batch,
-                            hipStream_t st, int tiled = 0)
+                            hipStream_t st, int tiled = 0, bool packed_src = false)
 {
+    // packed_src: g_ao is the copy made by oovqe_eri_pack (tiled == 2 only)
+    OOVQE_REQUIRE(!packed_src || tiled == 2, "cas_eval: packed integrals need both symmetry flags");
     OOVQE_REQUIRE(M >= 1 && M <= 16 && N >= M && N <= 48, "cas_eval: half_tri N=%d M=%d", N, M);
     const int ksteps = (N + 3) / 4, nrb = (N + 15) / 16;
     const int kch = ksteps <= 4 ? 4 : ksteps <= 8 ? 8 : ksteps <= 11 ? 11 : 12;
@@ -2257,18 +2366,24 @@ static int half_tri_batched(const double* g_ao, const double* C, int N, int M, d
     OOVQE_REQUIRE(phase >= 2, "cas_eval: half_tri staging does not fit LDS (M=%d)", M);
     if (phase > ((n_rounds + 1) & ~1L)) phase = (n_rounds + 1) & ~1L;
     const size_t lds_bytes = fixed_bytes + (size_t)phase * round_bytes;
-#define OOVQE_LAUNCH_TRI(KC_, NS_)                                                                \
+#define OOVQE_LAUNCH_TRI2(KC_, NS_, RS_)                                                          \
     do {                                                                                          \
         static bool attr_done = false;                                                            \
         if (!attr_done) {                                                                         \
-            OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)half_tri_kernel<KC_, NS_>,           \
+            OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)half_tri_kernel<KC_, NS_, RS_>,      \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                                 160 * 1024), "cas_eval/half_tri");                \
             attr_done = true;                                                                     \
         }                                                                                         \
-        hipLaunchKernelGGL((half_tri_kernel<KC_, NS_>), dim3((unsigned)W, batch),                 \
+        hipLaunchKernelGGL((half_tri_kernel<KC_, NS_, RS_>), dim3((unsigned)W, batch),            \
                            dim3(HALF_WAVES * 64), lds_bytes, st, g_ao, C, J, N, M, (int)phase,    \
                            tiled);                                                                \
+    } while (0)
+#define OOVQE_LAUNCH_TRI(KC_, NS_)                                                                \
+    do {                                                                                          \
+        if (tiled == 2 && packed_src) OOVQE_LAUNCH_TRI2(KC_, NS_, 2);                             \
+        else if (tiled == 2) OOVQE_LAUNCH_TRI2(KC_, NS_, 1);                                      \
+        else OOVQE_LAUNCH_TRI2(KC_, NS_, 0);                                                      \
     } while (0)
     oovqe_profile_mark_start(st);
     if (kch == 4 && nrb == 1) OOVQE_LAUNCH_TRI(4, 1);
@@ -2281,6 +2396,7 @@ static int half_tri_batched(const double* g_ao, const double* C, int N, int M, d
     }
     oovqe_profile_mark_stop(st);
 #undef OOVQE_LAUNCH_TRI
+#undef OOVQE_LAUNCH_TRI2
     OOVQE_CHECK_LAUNCH("cas_eval/half_tri");
     return 0;
 }
@@ -2380,7 +2496,7 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
                             double* c2, double* E, double* gvec, double* dE, double* fock,
                             double* gmat, double* Gm, double* hmo, int batch, size_t out_stride,
                             oovqe_stream_t stream, const oovqe_circuit_job_t* cj = nullptr,
-                            unsigned eri_flags = 0)
+                            unsigned eri_flags = 0, const double* g_packed = nullptr)
 {
     // cj: circuit + RDM evaluations that produce gamma / Gamma; they ride along the p -> n
     // contraction launch (the caller has checked oovqe_contract_hosts_circuit for this shape)
@@ -2430,8 +2546,12 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
         const bool two_step = simple || getenv("OOVQE_SYM_TWO_STEP") != nullptr;
         if (simple) {
             if ((rc = half_transform_batched(g_ao, C, N, M, Jp, batch, stream, SYM_PACKED))) return rc;
-        } else if ((rc = half_tri_batched(g_ao, C, N, M, Jp, batch, st, two_step ? 0 : rs_sym ? 2 : 1))) {
-            return rc;
+        } else {
+            // the packed copy of the integrals (oovqe_eri_pack) is streamed when the caller holds one
+            const bool use_pk = !two_step && rs_sym && g_packed != nullptr;
+            if ((rc = half_tri_batched(use_pk ? g_packed : g_ao, C, N, M, Jp, batch, st,
+                                       two_step ? 0 : rs_sym ? 2 : 1, use_pk)))
+                return rc;
         }
         if (!two_step) {
             if ((rc = sym_gm_batched(Jp, C, Gmw, N, M, batch, st, cj, rs_sym))) return rc;
@@ -2620,7 +2740,7 @@ static int oo_eval_batched(const double* theta, int n_theta, const oovqe_gate_t*
                            const double* C, double nuc, const double* nuc_arr, int N, int n_occ,
                            int ncas, const int32_t* kap_row, const int32_t* kap_col, int n_kappa,
                            int derivatives, int batch, double* work, double* out,
-                           unsigned eri_flags, oovqe_stream_t stream)
+                           unsigned eri_flags, oovqe_stream_t stream, const double* g_packed = nullptr)
 {
     OOVQE_REQUIRE(theta && gates && g_ao && h_ao && C && work && out, "oo_eval: null pointer");
     OOVQE_REQUIRE(n_qubits == 2 * ncas, "oo_eval: n_qubits != 2*ncas");
@@ -2685,7 +2805,8 @@ static int oo_eval_batched(const double* theta, int n_theta, const oovqe_gate_t*
     double* c2 = c1 + na2;
     return cas_eval_batched(g_ao, h_ao, C, gamma, Gamma, nvec, nuc, nuc_arr, N, n_occ, ncas, kap_row,
                             kap_col, n_kappa, cas_work, c0, c1, c2, E, gvec, dE, nullptr, nullptr,
-                            nullptr, nullptr, batch, out_stride, stream, ride ? &cj : nullptr, eri_flags);
+                            nullptr, nullptr, batch, out_stride, stream, ride ? &cj : nullptr, eri_flags,
+                            g_packed);
 }
 
 extern "C" int oovqe_oo_eval(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
@@ -2705,12 +2826,12 @@ extern "C" int oovqe_oo_eval_batch(const double* theta, int n_theta, const oovqe
                                    const double* h_ao, const double* C, const double* nuc, int N,
                                    int n_occ, int ncas, const int32_t* kap_row, const int32_t* kap_col,
                                    int n_kappa, int derivatives, int batch, double* work, double* out,
-                                   unsigned eri_flags, oovqe_stream_t stream)
+                                   unsigned eri_flags, const double* g_packed, oovqe_stream_t stream)
 {
     OOVQE_REQUIRE(nuc, "oo_eval_batch: null nuc");
     return oo_eval_batched(theta, n_theta, gates, n_gates, n_qubits, init_index, g_ao, h_ao, C, 0.0,
                            nuc, N, n_occ, ncas, kap_row, kap_col, n_kappa, derivatives, batch, work,
-                           out, eri_flags, stream);
+                           out, eri_flags, stream, g_packed);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -374,11 +374,17 @@ def main():
     if pq_sym and t3_path:
         bytes_per_eval = 8.0 * NAO ** 2 * tri + 8.0 * tri * M ** 2
         rs_sym = bool(batch.eri_flags & ops.ERI_RS_SYMMETRIC)
-        if rs_sym:      # only the columns y <= z of each slab's result are written
-            bytes_per_eval = 8.0 * NAO ** 2 * tri + 8.0 * tri * (M * (M + 1) // 2)
+        if rs_sym:
+            # each slab is symmetric too: only its 16x16 blocks on and above the diagonal are
+            # read, and only the columns y <= z of its result are written
+            nb16 = [min(16, NAO - 16 * b) for b in range((NAO + 15) // 16)]
+            slab_elems = sum(nb16[r] * nb16[c] for r in range(len(nb16)) for c in range(r, len(nb16)))
+            bytes_per_eval = 8.0 * slab_elems * tri + 8.0 * tri * (M * (M + 1) // 2)
         kernel_name = ("half_tri_kernel<11,3> (J[p<=q,y,z] = sum_rs C[r,y] g[p,q,r,s] C[s,z] over the "
-                       "upper triangle of slabs; integrals verified p<->q"
-                       + (" and r<->s" if rs_sym else "") + " symmetric)")
+                       "upper triangle of slabs"
+                       + (", streaming the packed copy (16x16 blocks on/above each slab's diagonal)"
+                          if rs_sym else "")
+                       + "; integrals verified p<->q" + (" and r<->s" if rs_sym else "") + " symmetric)")
     elif pq_sym:
         bytes_per_eval = 8.0 * NAO ** 2 * tri + 8.0 * NAO ** 2 * M ** 2
         kernel_name = ("half_transform_kernel<1,11,3>, slabs p <= q mirrored into T2[p,q] and T2[q,p] "

@@ -160,6 +160,13 @@ int oovqe_circuit_rdms(const double* theta, int n_theta, const oovqe_gate_t* gat
  * [batch][N^4] (one pass over the tensor; synchronises `stream`). */
 int oovqe_eri_symmetry_flags(const double* g_ao, int N, int batch, unsigned* eri_flags,
                              oovqe_stream_t stream);
+/* Packed resident copy of integrals that carry BOTH flags, for oovqe_oo_eval_batch (g_packed): per
+ * geometry the slabs p <= q, each with its 16x16 blocks on and above the diagonal only, rows back
+ * to back -- 34 % of the tensor at N = 43; the batched N^4 pass then streams this copy instead of
+ * picking cache-line fragments out of g_ao.  oovqe_eri_packed_size: doubles per geometry (0 when
+ * this N has no packed form).  g_ao itself stays the argument of every other entry point. */
+int64_t oovqe_eri_packed_size(int N);
+int oovqe_eri_pack(const double* g_ao, int N, int batch, double* packed, oovqe_stream_t stream);
 int oovqe_cas_half_transform(const double* g_ao, const double* C, int N, int M, double* T2,
                              oovqe_stream_t stream);
 /* Stage 2: Gm[n,x,y,z] = sum_pq C[p,n] C[q,x] T2[p,q,y,z]; hmo[n,x] = (C^T h_ao C)[n,x].
@@ -272,14 +279,15 @@ int64_t oovqe_oo_eval_out_size(int n_theta, int n_kappa, int ncas, int derivativ
 /* The same for a BATCH of geometries in one call (the Berry-phase-loop batch of the north star;
  * examples/Tutorial_Berry_phase.ipynb): every per-geometry array is stacked along a leading batch
  * axis -- theta [G,n_theta], g_ao [G,N^4], h_ao [G,N^2], C [G,N^2], nuc [G] (device), work
- * G * oovqe_oo_eval_work_size(), out [G, oovqe_oo_eval_out_size()].  Still 5 launches: the batch is a
+ * G * oovqe_oo_eval_work_size(), out [G, oovqe_oo_eval_out_size()]; g_packed [G, oovqe_eri_packed_size()]
+ * or NULL.  Still 5 launches: the batch is a
  * grid dimension of every kernel, so small geometries fill the 256 CUs together. */
 int oovqe_oo_eval_batch(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
                         int n_qubits, uint32_t init_index, const double* g_ao, const double* h_ao,
                         const double* C, const double* nuc, int N, int n_occ, int ncas,
                         const int32_t* kap_row, const int32_t* kap_col, int n_kappa, int derivatives,
                         int batch, double* work, double* out, unsigned eri_flags,
-                        oovqe_stream_t stream);
+                        const double* g_packed, oovqe_stream_t stream);
 /* 1 when oovqe_circuit_rdms takes its one-workgroup LDS path for these sizes */
 int oovqe_circuit_rdms_is_small(int n_qubits, int ncas, int nvec, int n_gates);
 

@@ -500,3 +500,29 @@ def test_cas_eval_pq_symmetric_integrals(N, nelec, ncas, nelecas, path, flags, m
     assert abs(sym["E"].item() - E_ref.item()) < 1e-8 * max(1.0, abs(E_ref.item()))
     gv_ref = oo.kappa_matrix_to_vector(oo.analytic_gradient(gam[0].cpu(), Gam[0].cpu()))
     assert (sym["gvec"].cpu()[0] - gv_ref).abs().max() < 1e-8 * max(1.0, float(gv_ref.abs().max()))
+
+
+@pytest.mark.parametrize("N", [7, 16, 20, 33, 43, 48])
+def test_eri_pack_layout(N):
+    """oovqe_eri_pack: slab t = (p <= q) of the triangle, row r holding its columns 16*(r/16) .. N-1,
+    rows back to back (the copy half_tri_kernel streams when both symmetry flags hold)."""
+    import ctypes
+    from auto_oo_amd import _lib
+    lib = _lib.load()
+    G = 2
+    rng = np.random.default_rng(N)
+    g = rng.standard_normal((G, N, N, N, N))
+    psz = lib.oovqe_eri_packed_size(N)
+    ref = []
+    for b in range(G):
+        for p_ in range(N):
+            for q_ in range(p_, N):
+                for r_ in range(N):
+                    ref.append(g[b, p_, q_, r_, 16 * (r_ // 16):])
+    ref = np.concatenate(ref)
+    assert psz * G == ref.size
+    gd = torch.tensor(g).to(DEV).contiguous()
+    out = torch.full((G, psz), float("nan"), dtype=torch.float64, device=DEV)
+    _lib.check(lib.oovqe_eri_pack(_lib.dptr(gd), N, G, _lib.dptr(out), _lib.stream_ptr()), "oovqe_eri_pack")
+    assert np.array_equal(out.cpu().numpy().reshape(-1), ref)
+    assert lib.oovqe_eri_packed_size(49) == 0
