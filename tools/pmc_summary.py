@@ -30,7 +30,10 @@ def main():
     if general:
         alg = G * (8.0 * N ** 4 + 8.0 * N * M ** 3)
     else:
-        alg = G * (8.0 * N * N * tri + 8.0 * tri * (M * (M + 1) // 2))
+        # packed copy: slabs p <= q, 16x16 blocks on/above each slab's diagonal; columns y <= z written
+        nb = [min(16, N - 16 * b) for b in range((N + 15) // 16)]
+        slab = sum(nb[r] * nb[c] for r in range(len(nb)) for c in range(r, len(nb)))
+        alg = G * (8.0 * slab * tri + 8.0 * tri * (M * (M + 1) // 2))
     out = {
         "kernel": f"{sub}, batched launch over {G} geometries (N={N}, M={M})",
         "pq_symmetric": not general,
