@@ -608,37 +608,35 @@ void sym_gm_kernel(const double* __restrict__ J, const double* __restrict__ C,
                 csrd, (q < N && lr < M) ? (unsigned)((q * N + lr) * (int)sizeof(double)) : 0x7fffffffu, 0, 0);
             af[ks] = __builtin_bit_cast(double, v);
         }
-        // PH rows at a time: PH * KS loads of a lane in flight, <= 128 VGPRs (two workgroups per CU)
-        constexpr int PH = (PW + 1) / 2;
+        // all PW rows of the wave at once: PW * KS loads of a lane in flight (one memory round trip
+        // for step 1), then the MFMA chains
+        double bf[PW][KS];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            double bf[PH][KS];
+        for (int i = 0; i < PW; ++i) {
+            const int p = wave + NW * i;
+            const int pc = p < N ? p : N - 1;                           // wave-uniform
+            const int basep = pc * (2 * N - pc + 1) / 2 - pc;
 #pragma unroll
-            for (int i = 0; i < PH; ++i) {
-                const int p = wave + NW * (h * PH + i);
-                const int pc = p < N ? p : N - 1;                       // wave-uniform
-                const int basep = pc * (2 * N - pc + 1) / 2 - pc;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const int t = qk[ks] < pc ? baseq[ks] + pc : basep + qk[ks];
-                    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(
-                        jsrd, (unsigned)((t * 16 + lr) * (int)sizeof(double)), 0, 0);
-                    bf[i][ks] = __builtin_bit_cast(double, v);
-                }
+            for (int ks = 0; ks < KS; ++ks) {
+                const int t = qk[ks] < pc ? baseq[ks] + pc : basep + qk[ks];
+                const v2u v = __builtin_amdgcn_raw_buffer_load_b64(
+                    jsrd, (unsigned)((t * 16 + lr) * (int)sizeof(double)), 0, 0);
+                bf[i][ks] = __builtin_bit_cast(double, v);
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < PH; ++i) {
-                const int p = wave + NW * (h * PH + i);
-                d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+        for (int i = 0; i < PW; ++i) {
+            const int p = wave + NW * i;
+            d4 acc = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) acc = mfma_f64(af[ks], bf[i][ks], acc);
-                // rows p in [N, 4 KS) are the zero padding of step 2's k range
-                double* row = T3s + (size_t)(p < 4 * KS ? p : 0) * LDP + lr;
+            for (int ks = 0; ks < KS; ++ks) acc = mfma_f64(af[ks], bf[i][ks], acc);
+            // rows p in [N, 4 KS) are the zero padding of step 2's k range
+            double* row = T3s + (size_t)(p < 4 * KS ? p : 0) * LDP + lr;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int x = lq + 4 * j;
-                    if (x < M && p < 4 * KS) row[x * 16] = p < N ? acc[j] : 0.0;
-                }
+            for (int j = 0; j < 4; ++j) {
+                const int x = lq + 4 * j;
+                if (x < M && p < 4 * KS) row[x * 16] = p < N ? acc[j] : 0.0;
             }
         }
     }
