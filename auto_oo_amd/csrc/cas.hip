@@ -1034,8 +1034,18 @@ void half_transform_fused_kernel(const double* __restrict__ g, const double* __r
 }
 
 // Packed copy of p <-> q and r <-> s symmetric integrals for half_tri_kernel<.,.,2>: slab t = (p <= q)
-// of the triangle, row r with its columns 16*(r/16) .. N-1 only, rows back to back (for N = 43:
-// 1241 of 1849 doubles per slab, 946 of 1849 slabs: 34 % of the tensor).  One workgroup per slab.
+// of the triangle; of each slab only the upper triangle, row r holding its columns (r & ~1) .. N-1
+// (an even start keeps the 16-byte column-pair loads inside the row; the element left of the
+// diagonal in an odd row is stored as 0) and the DIAGONAL HALVED, so that the slab product needs no
+// weights: G = U + U^T with U = this triangle.  Rows back to back: row r starts
+// 2k(N-k+1) + (r&1)(N-2k) doubles into the slab, k = r/2.  For N = 43: 968 of 1849 doubles per
+// slab, 946 of 1849 slabs: 27 % of the tensor.  One workgroup per slab.
+__device__ __host__ inline unsigned eri_tri_row_start(int r, int N)
+{
+    const int k = r >> 1;
+    return (unsigned)(2 * k * (N - k + 1) + (r & 1) * (N - 2 * k));
+}
+
 __global__ __launch_bounds__(256)
 void eri_pack_kernel(const double* __restrict__ g, double* __restrict__ out, int N, unsigned slab_pk)
 {
@@ -1047,11 +1057,10 @@ void eri_pack_kernel(const double* __restrict__ g, double* __restrict__ out, int
     double* dst = out + ((size_t)blockIdx.y * tri + t) * slab_pk;
     for (int idx = threadIdx.x; idx < N * N; idx += 256) {
         const int r = idx / N, c = idx - r * N;
-        const int rb = r / 16;
-        if (c < 16 * rb) continue;
-        // rows before block rb: sum_{b < rb} 16 (N - 16 b) = 16 rb N - 128 rb (rb - 1)
-        const int off = 16 * rb * N - 128 * rb * (rb - 1) + (r - 16 * rb) * (N - 16 * rb) + (c - 16 * rb);
-        dst[off] = src[idx];
+        const int e = r & ~1;
+        if (c < e) continue;
+        const double v = src[idx];
+        dst[eri_tri_row_start(r, N) + (c - e)] = c < r ? 0.0 : (c == r ? 0.5 * v : v);
     }
 }
 
@@ -1086,20 +1095,10 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
     double* dump = lds;             // [64] sink for lanes outside the M x M tile
     int* ctab = reinterpret_cast<int*>(lds + 64);   // [ncol <= 256] column -> position y*M + z in a tile
     double* stg = lds + 64 + 128;   // [phase_rounds][HALF_WAVES][M2]
-    // RS == 2: g is the PACKED copy made by eri_pack_kernel: per slab t = (p <= q), row r holds its
-    // columns 16*(r/16) .. N-1 only (the 16x16 blocks on and above the diagonal), rows back to back
+    // RS == 2: g is the PACKED copy made by eri_pack_kernel: per slab t = (p <= q) the upper triangle
+    // with the diagonal halved, row r = its columns (r & ~1) .. N-1, rows back to back
     constexpr bool rs = RS != 0, pk = RS == 2;
-    int len_rb[NST], org_rb[NST];
-    unsigned base_rb[NST];              // bytes from the start of the slab to its row block rb
-    unsigned slab_pk = 0;
-#pragma unroll
-    for (int rb = 0; rb < NST; ++rb) {
-        len_rb[rb] = pk ? N - 16 * rb : N;
-        org_rb[rb] = pk ? 16 * rb : 0;
-        base_rb[rb] = pk ? slab_pk : (unsigned)(16 * rb * N * sizeof(double));
-        const int rows = N - 16 * rb < 16 ? N - 16 * rb : 16;
-        slab_pk += (unsigned)(rows * (N - 16 * rb) * sizeof(double));
-    }
+    const unsigned slab_pk = (unsigned)(eri_tri_row_start(N, N) * sizeof(double));
     g += (size_t)blockIdx.y * (pk ? (size_t)tri * (slab_pk / sizeof(double)) : slab_elems * slab_elems);
     C += (size_t)blockIdx.y * N * N;
     // tiled == 0: J[t][M2].  tiled == 1: J[ty][t][16], 16-wide tiles of the M2 (y z) columns
@@ -1121,48 +1120,55 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
     // compile time.  RS == 1 reads the full layout, where the rows keep their 8 N-byte pitch and
     // the skipped parts mostly share cache lines with the loaded ones: 7 % faster only; RS == 2
     // streams the packed copy.)
-    const double wA_lo = rs ? 0.5 : 1.0, wB_lo = rs ? 0.0 : 1.0, wB_hi = rs ? 0.5 : 1.0, wD = rs ? 0.5 : 1.0;
+    // (the packed copy carries the weights itself: halved diagonal, nothing below it)
+    constexpr bool wts = rs && !pk;
+    const double wA_lo = wts ? 0.5 : 1.0, wB_lo = wts ? 0.0 : 1.0, wB_hi = wts ? 0.5 : 1.0, wD = wts ? 0.5 : 1.0;
 
-    // per-lane byte offsets inside a slab (see half_transform_fused_kernel), one per row block:
-    // row r = 4i + lq of block rb = i/4 starts base_rb + (r - 16 rb) * len_rb doubles into the slab
-    // and holds the columns org_rb ..; lanes whose column lies left of the block's origin (below
-    // the diagonal) and, in the last k-step, lanes whose row is >= N get an out-of-range offset
+    // Byte offsets inside a slab (see half_transform_fused_kernel): a per-lane part (VGPR) and a
+    // wave-uniform part per k-step (SGPR).  Lanes that must not load (row >= N in the last k-step,
+    // columns below the diagonal with rs) get an out-of-range offset: dropped, no traffic.
+    //   full layout: row r = 4i + lq starts r * N doubles into the slab;
+    //   packed     : row r starts 2k(N-k+1) + (r&1)(N-2k), k = r/2, and holds the columns >= (r & ~1);
+    //                with r = 4i + lq, element (r, c) sits at  (4iN - 8i^2)  [uniform]
+    //                + (2hN - 2h^2 + bN - 2hb) + c  [lane; h = lq>>1, b = lq&1]  - 4 i lq  [lane step per
+    //                k-step]; the row's first column is r & ~1 = 4i + 2h.
     constexpr int MINK = KCH == 4 ? 1 : KCH == 8 ? 5 : KCH == 11 ? 9 : KCH;
     const int i_last = (N - 1) / 4;
     const unsigned slab_bytes = pk ? slab_pk : (unsigned)(slab_elems * sizeof(double));
     const unsigned total_bytes = pk ? (unsigned)(tri * slab_pk) : (unsigned)(slab_elems * slab_elems * sizeof(double));
     const bool row_ok_last = 4 * i_last + lq < N;
-    unsigned offp[NPA][2];              // pair pp, row block 2pp + {0, 1}
+    const int h2 = lq >> 1, b2l = lq & 1;
+    const int lane_row = pk ? 2 * h2 * N - 2 * h2 * h2 + b2l * N - 2 * h2 * b2l : lq * N;
+    const unsigned lstep = pk ? (unsigned)(4 * lq * sizeof(double)) : 0u;   // subtracted once per k-step
+    unsigned offp[NPA][2];              // pair pp: [0] rows of blocks <= 2pp, [1] rows of block 2pp+1 (full layout)
+    int colp[NPA];
     bool last_even[NPA];
 #pragma unroll
     for (int pp = 0; pp < NP; ++pp) {
         const int col = pp * 32 + 2 * lr;
         const int cc = col + 1 < N ? col : (N >= 2 ? N - 2 : 0);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int rb = 2 * pp + h;
-            const bool below = rs && h == 1 && lr < 8;      // first block's columns in the second block's rows
-            offp[pp][h] = below ? total_bytes : (unsigned)((lq * len_rb[rb] + cc - org_rb[rb]) * sizeof(double));
-        }
+        colp[pp] = col;
+        offp[pp][0] = (unsigned)((lane_row + cc) * (int)sizeof(double));
+        offp[pp][1] = (wts && lr < 8) ? total_bytes : offp[pp][0];   // first block's columns below the diagonal
         last_even[pp] = col == N - 1;
     }
     const int col1 = NP * 32 + lr;
-    unsigned offs[NST];                 // single tile (column block NST-1), row block rb
-#pragma unroll
-    for (int rb = 0; rb < NST; ++rb)
-        offs[rb] = (unsigned)((lq * len_rb[rb] + (col1 < N ? col1 : N - 1) - org_rb[rb]) * sizeof(double));
+    const int col1c = col1 < N ? col1 : N - 1;
+    const unsigned offs = (unsigned)((lane_row + col1c) * (int)sizeof(double));
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<double*>(g), 0, (int)total_bytes, 0x00020000);
-    // scalar part: slab + row block + rows 4(i - 4 rb) of it; k-steps past the last row are dropped
+    // scalar part of k-step i; k-steps past the last row are dropped
     auto soff = [&](unsigned sb, int i) -> unsigned {
-        const int rb = i / 4;
-        const unsigned o = sb + base_rb[rb] + (unsigned)(4 * (i - 4 * rb) * len_rb[rb] * sizeof(double));
+        const unsigned o = pk ? sb + (unsigned)((4 * i * N - 8 * i * i) * (int)sizeof(double))
+                              : sb + (unsigned)(4 * i * N * sizeof(double));
         return (i < MINK || i <= i_last) ? o : total_bytes;
     };
-    auto voff = [&](unsigned vo, int i) -> unsigned {
-        return (i >= MINK - 1 && i == i_last && !row_ok_last) ? total_bytes : vo;
+    // lane part of k-step i for a lane whose (first) column is col
+    auto voff = [&](unsigned vo, int col, int i) -> unsigned {
+        const bool drop = (i >= MINK - 1 && i == i_last && !row_ok_last) || (pk && col < 4 * i + 2 * h2);
+        return drop ? total_bytes : vo - (unsigned)i * lstep;
     };
 
     const int SW = gridDim.x * HALF_WAVES;                  // waves per geometry
@@ -1186,13 +1192,13 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
                 if (rs && blk > 2 * pp + 1) continue;  // rows below both blocks of the pair: lower blocks
                 // (row blocks above the pair, blk < 2pp, only exist for NST > 3: not instantiated)
                 const unsigned vo = offp[pp][blk == 2 * pp + 1 ? 1 : 0];
-                const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff(vo, i), soff(sb, i), 0);
+                const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff(vo, colp[pp], i), soff(sb, i), 0);
                 ap[pp][i] = __builtin_bit_cast(d2u, v);
             }
         if constexpr (NS1) {
 #pragma unroll
             for (int i = 0; i < KCH; ++i) {
-                const v2u v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff(offs[i / 4], i), soff(sb, i), 0);
+                const v2u v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff(offs, col1c, i), soff(sb, i), 0);
                 as[i] = __builtin_bit_cast(double, v);
             }
         }
@@ -2320,12 +2326,7 @@ static int half_transform_fused_batched(const double* g_ao, const double* C, int
     return 0;
 }
 
-static unsigned eri_slab_packed_elems(int N)
-{
-    unsigned n = 0;
-    for (int rb = 0; 16 * rb < N; ++rb) n += (unsigned)((N - 16 * rb < 16 ? N - 16 * rb : 16) * (N - 16 * rb));
-    return n;
-}
+static unsigned eri_slab_packed_elems(int N) { return eri_tri_row_start(N, N); }
 
 extern "C" int64_t oovqe_eri_packed_size(int N)
 {

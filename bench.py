@@ -315,13 +315,18 @@ def main():
     results = torch.zeros((G, n_out), dtype=torch.float64, device="cuda")
 
     def run(n_evals):
-        """n_evals evaluations as batched calls over this rank's shard (last call partial)."""
+        """n_evals evaluations as batched calls over this rank's shard (last call partial).  Each
+        call returns its own [b, 1 + n_theta + n_kappa] result tensor; the rows of the last full
+        sweep over the shard are what the final exchange gathers."""
         done, calls = 0, 0
+        last = None
         while done < n_evals:
             b = min(G, n_evals - done)
-            results[:b] = batch.energy_and_gradient(thetas, count=b)
+            last = batch.energy_and_gradient(thetas, count=b)
             done += b
             calls += 1
+        if last is not None:
+            results[:last.shape[0]] = last
         return calls
 
     # set-up (not part of W or K): every code path of the timed region runs once, so that lazily
@@ -375,14 +380,13 @@ def main():
         bytes_per_eval = 8.0 * NAO ** 2 * tri + 8.0 * tri * M ** 2
         rs_sym = bool(batch.eri_flags & ops.ERI_RS_SYMMETRIC)
         if rs_sym:
-            # each slab is symmetric too: only its 16x16 blocks on and above the diagonal are
-            # read, and only the columns y <= z of its result are written
-            nb16 = [min(16, NAO - 16 * b) for b in range((NAO + 15) // 16)]
-            slab_elems = sum(nb16[r] * nb16[c] for r in range(len(nb16)) for c in range(r, len(nb16)))
+            # each slab is symmetric too: the packed copy holds its upper triangle only, and only
+            # the columns y <= z of its result are written
+            slab_elems = sum(NAO - (r & ~1) for r in range(NAO))   # upper triangle, even row starts
             bytes_per_eval = 8.0 * slab_elems * tri + 8.0 * tri * (M * (M + 1) // 2)
         kernel_name = ("half_tri_kernel<11,3> (J[p<=q,y,z] = sum_rs C[r,y] g[p,q,r,s] C[s,z] over the "
                        "upper triangle of slabs"
-                       + (", streaming the packed copy (16x16 blocks on/above each slab's diagonal)"
+                       + (", streaming the packed copy (upper triangle of each slab)"
                           if rs_sym else "")
                        + "; integrals verified p<->q" + (" and r<->s" if rs_sym else "") + " symmetric)")
     elif pq_sym:

@@ -504,9 +504,9 @@ def test_cas_eval_pq_symmetric_integrals(N, nelec, ncas, nelecas, path, flags, m
 
 @pytest.mark.parametrize("N", [7, 16, 20, 33, 43, 48])
 def test_eri_pack_layout(N):
-    """oovqe_eri_pack: slab t = (p <= q) of the triangle, row r holding its columns 16*(r/16) .. N-1,
+    """oovqe_eri_pack: slab t = (p <= q) of the triangle; of each slab the upper triangle with the
+    diagonal halved, row r holding its columns (r & ~1) .. N-1 (0 left of the diagonal in odd rows),
     rows back to back (the copy half_tri_kernel streams when both symmetry flags hold)."""
-    import ctypes
     from auto_oo_amd import _lib
     lib = _lib.load()
     G = 2
@@ -518,7 +518,12 @@ def test_eri_pack_layout(N):
         for p_ in range(N):
             for q_ in range(p_, N):
                 for r_ in range(N):
-                    ref.append(g[b, p_, q_, r_, 16 * (r_ // 16):])
+                    e = r_ & ~1
+                    row = g[b, p_, q_, r_, e:].copy()
+                    if r_ > e:
+                        row[0] = 0.0
+                    row[r_ - e] *= 0.5
+                    ref.append(row)
     ref = np.concatenate(ref)
     assert psz * G == ref.size
     gd = torch.tensor(g).to(DEV).contiguous()

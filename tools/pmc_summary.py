@@ -30,9 +30,8 @@ def main():
     if general:
         alg = G * (8.0 * N ** 4 + 8.0 * N * M ** 3)
     else:
-        # packed copy: slabs p <= q, 16x16 blocks on/above each slab's diagonal; columns y <= z written
-        nb = [min(16, N - 16 * b) for b in range((N + 15) // 16)]
-        slab = sum(nb[r] * nb[c] for r in range(len(nb)) for c in range(r, len(nb)))
+        # packed copy: slabs p <= q, upper triangle of each slab (even row starts); columns y <= z written
+        slab = sum(N - (r & ~1) for r in range(N))
         alg = G * (8.0 * slab * tri + 8.0 * tri * (M * (M + 1) // 2))
     out = {
         "kernel": f"{sub}, batched launch over {G} geometries (N={N}, M={M})",
