@@ -50,19 +50,19 @@ int main()
                fp.qc, fp.nbuf, fp.wpg, fp.lds_bytes, tot2 / reps * 1e3, best2 * 1e3,
                (double)ng * 8 / (tot2 / reps * 1e-3) / 1e12);
     }
-    for (int mode = SYM_MIRROR; mode <= 3; ++mode) {   // 3 = persistent packed-triangle kernel
+    for (int mode = SYM_MIRROR; mode <= 5; ++mode) {   // 3 = persistent packed-triangle kernel, 4 = + r<->s on the full layout, 5 = packed integrals
         // p <= q slabs only (the random g is not symmetric: timing only)
         float tot3 = 0, best3 = 1e30f, totq = 0;
         for (int r = 0; r < reps + 5; ++r) {
             (void)hipEventRecord(e0, 0);
-            int rc = mode == 3 ? half_tri_batched(g, C, N, M, T2, G, nullptr) : half_transform_batched(g, C, N, M, T2, G, nullptr, mode);
+            int rc = mode == 5 ? half_tri_batched(g, C, N, M, T2, G, nullptr, 2, true) : mode == 4 ? half_tri_batched(g, C, N, M, T2, G, nullptr, 2, false) : mode == 3 ? half_tri_batched(g, C, N, M, T2, G, nullptr) : half_transform_batched(g, C, N, M, T2, G, nullptr, mode);
             (void)hipEventRecord(e1, 0);
             (void)hipEventSynchronize(e1);
             if (rc) { printf("error: %s\n", oovqe_last_error()); return 1; }
             float ms;
             (void)hipEventElapsedTime(&ms, e0, e1);
             if (r >= 5) { tot3 += ms; if (ms < best3) best3 = ms; }
-            if (mode >= SYM_PACKED) {
+            if (mode == SYM_PACKED || mode == 3) {
                 double* T3 = T2 + (size_t)G * N * (N + 1) / 2 * M * M;
                 (void)hipEventRecord(e0, 0);
                 rc = sym_q_contract_batched(T2, C, T3, N, M, G, nullptr);
@@ -74,9 +74,9 @@ int main()
             }
         }
         const double tb = (double)G * N * (N + 1) / 2 * N * N * 8;
-        printf("sym %s: avg %.1f us best %.1f us -> %.2f TB/s of the triangle", mode == SYM_MIRROR ? "mirror" : mode == SYM_PACKED ? "packed" : "packed-persistent",
+        printf("sym %s: avg %.1f us best %.1f us -> %.2f TB/s of the triangle", mode == SYM_MIRROR ? "mirror" : mode == SYM_PACKED ? "packed" : mode == 3 ? "packed-persistent" : mode == 4 ? "persistent rs full-layout" : "persistent rs packed-integrals",
                tot3 / reps * 1e3, best3 * 1e3, tb / (tot3 / reps * 1e-3) / 1e12);
-        if (mode >= SYM_PACKED) printf("; q->x kernel %.1f us", totq / reps * 1e3);
+        if (mode == SYM_PACKED || mode == 3) printf("; q->x kernel %.1f us", totq / reps * 1e3);
         printf("\n");
     }
     const double bytes = (double)ng * 8;
