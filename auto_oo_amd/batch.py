@@ -73,8 +73,8 @@ class OO_pqc_batch:
         # exact p<->q symmetry of every geometry's integrals (true for PySCF's int2e): the N^4 pass
         # then reads only the slabs p <= q.  int2e_ao must not be modified in place afterwards.
         self.eri_flags = ops.eri_flags(self.int2e_ao)
-        # both symmetries: keep a packed resident copy (slabs p <= q, blocks on/above each slab's
-        # diagonal: about a third of the tensor) for the batched N^4 pass to stream
+        # both symmetries: keep a packed resident copy (slabs p <= q, upper triangle of each slab:
+        # about a quarter of the tensor) for the batched N^4 pass to stream
         self._eri_packed = None
         both = ops.ERI_PQ_SYMMETRIC | ops.ERI_RS_SYMMETRIC
         psz = self.lib.oovqe_eri_packed_size(N)

@@ -161,9 +161,10 @@ int oovqe_circuit_rdms(const double* theta, int n_theta, const oovqe_gate_t* gat
 int oovqe_eri_symmetry_flags(const double* g_ao, int N, int batch, unsigned* eri_flags,
                              oovqe_stream_t stream);
 /* Packed resident copy of integrals that carry BOTH flags, for oovqe_oo_eval_batch (g_packed): per
- * geometry the slabs p <= q, each with its 16x16 blocks on and above the diagonal only, rows back
- * to back -- 34 % of the tensor at N = 43; the batched N^4 pass then streams this copy instead of
- * picking cache-line fragments out of g_ao.  oovqe_eri_packed_size: doubles per geometry (0 when
+ * geometry the slabs p <= q, of each slab the upper triangle with the diagonal halved (row r = its
+ * columns (r & ~1) .. N-1, 0 left of the diagonal, rows back to back) -- 27 % of the tensor at
+ * N = 43; the batched N^4 pass then streams this copy instead of picking cache-line fragments out
+ * of g_ao.  oovqe_eri_packed_size: doubles per geometry (0 when
  * this N has no packed form).  g_ao itself stays the argument of every other entry point. */
 int64_t oovqe_eri_packed_size(int N);
 int oovqe_eri_pack(const double* g_ao, int N, int batch, double* packed, oovqe_stream_t stream);
