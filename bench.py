@@ -38,7 +38,8 @@ sys.path.insert(0, ROOT)
 METRIC = ("OO-VQE energy+grad evals/sec (formaldimine CAS(4e,3o)/cc-pVDZ); "
           "2e-transform fp64 TFLOP/s vs roofline")
 NAO, NELEC, NCAS, NELECAS = 43, 16, 3, 4
-N_GEOM = 64
+N_GEOM = 256         # geometries per GPU (7 GB of g_ao + 1.9 GB packed copy in 288 GB of HBM)
+N_GEOM_BERRY = 64    # geometries per GPU of the Berry-loop extra (each holds its own OO_pqc object)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # AMD spec, vector = matrix fp64
 
@@ -46,8 +47,8 @@ FP64_PEAK_TFLOPS = 78.6        # AMD spec, vector = matrix fp64 (SURVEY.md secti
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=25600)
-    ap.add_argument("--warmup", type=int, default=640)
+    ap.add_argument("--steps", type=int, default=102400)
+    ap.add_argument("--warmup", type=int, default=2560)
     ap.add_argument("--geoms", type=int, default=N_GEOM,
                     help="molecular geometries PER GPU (weak scaling: the job holds geoms x n_gpus)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -415,7 +416,7 @@ def main():
             with open(pmc_path) as fh:
                 pmc = json.load(fh)
             if pmc.get("pq_symmetric", False) == pq_sym:
-                traffic = pmc["hbm_bytes_per_launch"] / 64.0 * evals_per_launch
+                traffic = pmc["hbm_bytes_per_launch"] / pmc.get("geometries_per_launch", 64) * evals_per_launch
         except Exception:
             traffic = None
 
@@ -473,7 +474,8 @@ def main():
         torch.cuda.synchronize()
         out["single_eval_us"] = (time.perf_counter() - t1) / 500 * 1e6
     if not args.no_berry:
-        berry = berry_loop_extra(my_geoms, n_geom_total, dist, world, args.backend)
+        nb = min(N_GEOM_BERRY, len(my_geoms))          # first nb geometries of every rank's shard
+        berry = berry_loop_extra(my_geoms[:nb], nb * world, dist, world, args.backend)
         if rank == 0:
             out["berry_loop"] = berry
     if rank == 0:

@@ -5,16 +5,18 @@ usage: python tools/pmc_summary.py <fetch_csv> <write_csv> <kernel substring> <t
 import csv, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-N, M, G = 43, 9, 64
+N, M, G = 43, 9, 256
 
 
 def rows(path, sub, counter):
-    vals = []
+    """counter values of the full-batch launches (the largest grid) of the kernel"""
+    recs = []
     with open(path) as fh:
         for r in csv.DictReader(fh):
-            if sub in r["Kernel_Name"] and r["Counter_Name"] == counter and int(r["Grid_Size"]) >= 64 * 512:
-                vals.append(float(r["Counter_Value"]))
-    return vals
+            if sub in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                recs.append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+    top = max(g for g, _ in recs)
+    return [v for g, v in recs if g == top]
 
 
 def main():
@@ -36,8 +38,9 @@ def main():
     out = {
         "kernel": f"{sub}, batched launch over {G} geometries (N={N}, M={M})",
         "pq_symmetric": not general,
+        "geometries_per_launch": G,
         "source": ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_bench.sh "
-                   f"{tag}) on bench.py --steps 6400 --warmup 640; profiles/{os.path.basename(fetch_csv)}, "
+                   f"{tag}) on bench.py --steps 25600 --warmup 2560; profiles/{os.path.basename(fetch_csv)}, "
                    f"{os.path.basename(write_csv)}"),
         "FETCH_SIZE_KB_raw": fk,
         "WRITE_SIZE_KB_raw": wk,
