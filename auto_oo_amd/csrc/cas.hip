@@ -56,6 +56,14 @@ namespace {
 // Algorithmic HBM bytes: 8 N^4 read + 8 N^2 M^2 written.
 // ------------------------------------------------------------------------------------------
 constexpr int HALF_WAVES = 8;
+// Cache policy of the g_ao stream (gfx950 buffer-load aux bits: 1 = sc0, 2 = nt, 16 = sc1).  Every
+// byte is used once, but the non-temporal hint only pays where the stream is irregular or short:
+// measured (tools/half_standalone.hip, stream_standalone.hip) packed triangle 109 -> 101 us,
+// r<->s triangle on the full layout 157 -> 143 us, streaming kernel with one 16-wide tile
+// (M <= 16) 323 -> 293 us (N = 64) and 367 -> 327 us (N = 128); but whole-slab streams get
+// slower with it (fused kernel 319 -> 339 us, p <= q slabs 177 -> 185 us, MFMA-heavy streaming
+// kernels 2810 -> 3295 us).  sc0 changes nothing, sc1 is slower.
+constexpr int AUX_PLAIN = 0, AUX_NT = 2;
 
 // Slab enumeration.  sym == 0: all N^2 slabs, t = p*N + q.  sym != 0 (the caller has verified
 // g[p,q,:,:] == g[q,p,:,:] exactly): only the N(N+1)/2 slabs p <= q are read, row-major over the
@@ -392,7 +400,7 @@ void half_stream_kernel(const double* __restrict__ g, const double* __restrict__
         const unsigned sb = (unsigned)lkc * KCH * rowblk_bytes;
 #pragma unroll
         for (int i = 0; i < KCH; ++i) {
-            const v2u v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, vo, sb + i * rowblk_bytes, 0);
+            const v2u v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, vo, sb + i * rowblk_bytes, ZT == 1 ? AUX_NT : AUX_PLAIN);
             dst[i] = __builtin_bit_cast(double, v);
         }
         if (++lkc == nkc) {
@@ -831,14 +839,14 @@ void half_transform_fused_kernel(const double* __restrict__ g, const double* __r
 #pragma unroll
             for (int i = 0; i < KCH; ++i) {
                 const v4u v = __builtin_amdgcn_raw_buffer_load_b128(
-                    rsrc, (i >= MINK - 1 && i == i_last) ? offp_last[pp] : offp[pp], soff(sb, i), 0);
+                    rsrc, (i >= MINK - 1 && i == i_last) ? offp_last[pp] : offp[pp], soff(sb, i), AUX_PLAIN);
                 ap[pp][i] = __builtin_bit_cast(d2u, v);
             }
         if constexpr (NS1) {
 #pragma unroll
             for (int i = 0; i < KCH; ++i) {
                 const v2u v = __builtin_amdgcn_raw_buffer_load_b64(
-                    rsrc, (i >= MINK - 1 && i == i_last) ? offs_last : offs, soff(sb, i), 0);
+                    rsrc, (i >= MINK - 1 && i == i_last) ? offs_last : offs, soff(sb, i), AUX_PLAIN);
                 as[i] = __builtin_bit_cast(double, v);
             }
         }
@@ -1192,13 +1200,13 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
                 if (rs && blk > 2 * pp + 1) continue;  // rows below both blocks of the pair: lower blocks
                 // (row blocks above the pair, blk < 2pp, only exist for NST > 3: not instantiated)
                 const unsigned vo = offp[pp][blk == 2 * pp + 1 ? 1 : 0];
-                const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff(vo, colp[pp], i), soff(sb, i), 0);
+                const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff(vo, colp[pp], i), soff(sb, i), rs ? AUX_NT : AUX_PLAIN);
                 ap[pp][i] = __builtin_bit_cast(d2u, v);
             }
         if constexpr (NS1) {
 #pragma unroll
             for (int i = 0; i < KCH; ++i) {
-                const v2u v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff(offs, col1c, i), soff(sb, i), 0);
+                const v2u v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff(offs, col1c, i), soff(sb, i), rs ? AUX_NT : AUX_PLAIN);
                 as[i] = __builtin_bit_cast(double, v);
             }
         }
