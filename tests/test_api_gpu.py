@@ -314,7 +314,7 @@ def test_orbital_optimization_fixed_rdms():
     assert abs(ooo.energy_from_kappa(newk, g1, g2).item() - energy_l[0]) < 1e-8
 
 
-@pytest.mark.parametrize("N,G", [(13, 100), (20, 37), (13, 300)])
+@pytest.mark.parametrize("N,G", [(13, 100), (20, 37), (13, 300), (47, 7), (32, 13), (33, 12), (16, 49)])
 def test_batched_evaluation_many_small_geometries(N, G):
     """Batch sizes that are no multiple of anything, on shapes where the library picks the
     persistent T3 path by itself (G * N^2 slabs fill the chip): every geometry of the batch equals
