@@ -454,6 +454,9 @@ def main():
             "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes,
             "algorithmic_bytes_per_eval": bytes_per_eval,
+            # SURVEY.md section 8(d)'s figure reads the full tensor (every integral 4x): for reference
+            "full_tensor_bytes_per_eval": 8.0 * NAO ** 4,
+            "full_tensor_equivalent_GBs": 8.0 * NAO ** 4 * evals_per_launch / kern_s / 1e9,
             "evals_per_launch": evals_per_launch,
             "avg_launch_us": kern_s * 1e6,
             "all_launches_avg_us": {k: (v[0] / v[1] * 1e3 if v[1] else None) for k, v in kern_by.items()},
