@@ -91,6 +91,30 @@ class OO_pqc_batch:
         self.oao_mo_coeff[g].copy_(c)
         self.mo_coeff[g].copy_(ops.matmul_nn(self.oao_coeff[g].contiguous(), c))
 
+    def set_molecule(self, g, mol, oao_mo_coeff=None):
+        """Replace geometry g of the batch (the next point of a Berry-phase loop, say): integrals,
+        OAO basis, nuclear repulsion and orbitals.  The symmetry flags of the batch are re-verified
+        for the new integrals and its slice of the packed copy is rebuilt -- never write into
+        ``int2e_ao`` directly, the flags and the packed copy would go stale."""
+        if mol.nao != self.nao:
+            raise ValueError("all geometries of a batch must share nao")
+        self.int2e_ao[g].copy_(ops.as_device(mol.int2e_ao, self.device))
+        self.int1e_ao[g].copy_(ops.as_device(mol.int1e_ao, self.device))
+        self.oao_coeff[g].copy_(ops.as_device(mol.oao_coeff, self.device))
+        self.nuc[g] = float(mol.nuc)
+        if oao_mo_coeff is None:
+            mol.run_rhf()
+            oao_mo_coeff = mo_ao_to_mo_oao(mol.hf.mo_coeff, mol.overlap)
+        self.set_oao_mo_coeff(g, oao_mo_coeff)
+        flags_g = ops.eri_flags(self.int2e_ao[g])
+        self.eri_flags &= flags_g
+        if self._eri_packed is not None:
+            if self.eri_flags == (ops.ERI_PQ_SYMMETRIC | ops.ERI_RS_SYMMETRIC):
+                check(self.lib.oovqe_eri_pack(dptr(self.int2e_ao[g]), self.nao, 1, dptr(self._eri_packed[g]),
+                                              stream_ptr()), "oovqe_eri_pack")
+            else:
+                self._eri_packed = None
+
     def _plan(self, derivatives, slot=0):
         key = (bool(derivatives), slot)
         if key not in self._plans:

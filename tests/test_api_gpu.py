@@ -363,3 +363,43 @@ def test_many_occupied_orbitals_use_the_staged_path():
     eg = batch.energy_and_gradient(torch.stack((theta, theta)))
     assert abs(eg[1, 0].item() - E.item()) < 1e-11
     assert (eg[1, 1:] - grad).abs().max().item() < 1e-11
+
+
+def test_batch_set_molecule_keeps_flags_and_packed_copy_consistent():
+    """OO_pqc_batch.set_molecule: replacing a geometry re-verifies the integrals' symmetry and
+    rebuilds its slice of the packed copy (symmetric replacement: still the packed path, results
+    equal the single evaluation); a non-symmetric replacement switches the batch to the general
+    pipeline, with the same per-geometry results."""
+    from auto_oo_amd.synthetic import synthetic_problem
+    N, G = 20, 37
+    ncas, nelecas, nelec = 2, 2, 6
+    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="ucc")
+    base = [synthetic_problem(N, 900 + g) for g in range(4)]
+    mols = [aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"] + 0.01 * g, nelec)
+            for g, P in ((g, base[g % 3]) for g in range(G))]
+    coeffs = [base[g % 3]["oao_mo_coeff"] for g in range(G)]
+    batch = aoo.OO_pqc_batch(pqc, mols, ncas, nelecas, oao_mo_coeffs=coeffs)
+    assert batch.eri_flags == 3 and batch._eri_packed is not None
+    rng = np.random.default_rng(11)
+    thetas = torch.tensor(rng.uniform(0, 2 * np.pi, (G, pqc.theta_shape)))
+
+    def check_geometry(g, mol, coeff):
+        eg = batch.energy_and_gradient(thetas).cpu()
+        single = aoo.OO_pqc(pqc, mol, ncas, nelecas, oao_mo_coeff=coeff)
+        E, grad = single.energy_and_gradient(thetas[g])
+        assert abs(eg[g, 0].item() - E.item()) < 1e-11
+        assert (eg[g, 1:] - grad.cpu()).abs().max() < 1e-11
+
+    P = base[3]
+    new_mol = aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"] + 5.0, nelec)
+    batch.set_molecule(5, new_mol, P["oao_mo_coeff"])
+    assert batch.eri_flags == 3 and batch._eri_packed is not None
+    check_geometry(5, new_mol, P["oao_mo_coeff"])
+    check_geometry(4, mols[4], coeffs[4])
+    g_bad = P["int2e_ao"].copy()
+    g_bad[1, 2, 3, 4] += 1e-3                       # breaks p<->q and r<->s symmetry
+    bad_mol = aoo.Moldata(P["int1e_ao"], g_bad, P["overlap"], P["nuc"], nelec)
+    batch.set_molecule(7, bad_mol, P["oao_mo_coeff"])
+    assert batch.eri_flags == 0 and batch._eri_packed is None
+    check_geometry(7, bad_mol, P["oao_mo_coeff"])
+    check_geometry(5, new_mol, P["oao_mo_coeff"])
