@@ -550,8 +550,11 @@ void sym_q_contract_kernel(const double* __restrict__ J, const double* __restric
 // column entry, comes from L2), T3 never goes to memory, and the small-circuit workgroups ride
 // along as the extra grid column blockIdx.x == nty (as they do on K1, contract.hip).
 // ------------------------------------------------------------------------------------------
-template <int KS>
-__global__ __launch_bounds__(SMALL_THREADS, 2)   // (a 128-VGPR build for two workgroups per CU is slower)
+// WPE = waves per SIMD the register allocation aims at: 2 (one workgroup per CU, all J rows of a
+// wave loaded at once) or 4 (128 VGPRs, two workgroups per CU, two rows at a time: for grids of
+// several resident rounds).
+template <int KS, int WPE>
+__global__ __launch_bounds__(SMALL_THREADS, WPE)
 void sym_gm_kernel(const double* __restrict__ J, const double* __restrict__ C,
                    double* __restrict__ Gm, int N, int M, int packed, oovqe_circuit_job_t cj,
                    int host_circuit)
@@ -616,35 +619,39 @@ void sym_gm_kernel(const double* __restrict__ J, const double* __restrict__ C,
                 csrd, (q < N && lr < M) ? (unsigned)((q * N + lr) * (int)sizeof(double)) : 0x7fffffffu, 0, 0);
             af[ks] = __builtin_bit_cast(double, v);
         }
-        // all PW rows of the wave at once: PW * KS loads of a lane in flight (one memory round trip
-        // for step 1), then the MFMA chains
-        double bf[PW][KS];
+        // PB rows of the wave at a time: PB * KS loads of a lane in flight, then their MFMA chains
+        constexpr int PB = WPE >= 4 ? 2 : PW;
 #pragma unroll
-        for (int i = 0; i < PW; ++i) {
-            const int p = wave + NW * i;
-            const int pc = p < N ? p : N - 1;                           // wave-uniform
-            const int basep = pc * (2 * N - pc + 1) / 2 - pc;
+        for (int h = 0; h < PW; h += PB) {
+            double bf[PB][KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int t = qk[ks] < pc ? baseq[ks] + pc : basep + qk[ks];
-                const v2u v = __builtin_amdgcn_raw_buffer_load_b64(
-                    jsrd, (unsigned)((t * 16 + lr) * (int)sizeof(double)), 0, 0);
-                bf[i][ks] = __builtin_bit_cast(double, v);
+            for (int i = 0; i < PB; ++i) {
+                const int p = wave + NW * (h + i);
+                const int pc = p < N ? p : N - 1;                       // wave-uniform
+                const int basep = pc * (2 * N - pc + 1) / 2 - pc;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int t = qk[ks] < pc ? baseq[ks] + pc : basep + qk[ks];
+                    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(
+                        jsrd, (unsigned)((t * 16 + lr) * (int)sizeof(double)), 0, 0);
+                    bf[i][ks] = __builtin_bit_cast(double, v);
+                }
             }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < PW; ++i) {
-            const int p = wave + NW * i;
-            d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+            for (int i = 0; i < PB; ++i) {
+                if (h + i >= PW) continue;
+                const int p = wave + NW * (h + i);
+                d4 acc = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) acc = mfma_f64(af[ks], bf[i][ks], acc);
-            // rows p in [N, 4 KS) are the zero padding of step 2's k range
-            double* row = T3s + (size_t)(p < 4 * KS ? p : 0) * LDP + lr;
+                for (int ks = 0; ks < KS; ++ks) acc = mfma_f64(af[ks], bf[i][ks], acc);
+                // rows p in [N, 4 KS) are the zero padding of step 2's k range
+                double* row = T3s + (size_t)(p < 4 * KS ? p : 0) * LDP + lr;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int x = lq + 4 * j;
-                if (x < M && p < 4 * KS) row[x * 16] = p < N ? acc[j] : 0.0;
+                for (int j = 0; j < 4; ++j) {
+                    const int x = lq + 4 * j;
+                    if (x < M && p < 4 * KS) row[x * 16] = p < N ? acc[j] : 0.0;
+                }
             }
         }
     }
@@ -2201,18 +2208,25 @@ static int sym_gm_batched(const double* J, const double* C, double* Gm, int N, i
     oovqe_circuit_job_t job;
     memset(&job, 0, sizeof(job));
     if (cj) job = *cj;
-#define OOVQE_LAUNCH_GM(KS_)                                                                      \
+#define OOVQE_LAUNCH_GM2(KS_, WPE_)                                                               \
     do {                                                                                          \
         static size_t attr_bytes = 0;                                                             \
         if (lds_bytes > attr_bytes) {                                                             \
-            OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)sym_gm_kernel<KS_>,                  \
+            OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)sym_gm_kernel<KS_, WPE_>,            \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                                 (int)lds_bytes), "cas_eval/sym_gm");              \
             attr_bytes = lds_bytes;                                                               \
         }                                                                                         \
-        hipLaunchKernelGGL(sym_gm_kernel<KS_>, dim3(nty + (cj ? 1 : 0), batch),                   \
+        hipLaunchKernelGGL((sym_gm_kernel<KS_, WPE_>), dim3(nty + (cj ? 1 : 0), batch),           \
                            dim3(SMALL_THREADS), lds_bytes, st, J, C, Gm, N, M, packed ? 1 : 0,    \
                            job, cj ? 1 : 0);                                                      \
+    } while (0)
+    const bool multi_round = (long)(nty + (cj ? 1 : 0)) * batch > 2L * device_cu_count() &&
+                             2 * lds_bytes <= 160 * 1024 && getenv("OOVQE_GM_ONE_PER_CU") == nullptr;
+#define OOVQE_LAUNCH_GM(KS_)                                                                      \
+    do {                                                                                          \
+        if (multi_round) OOVQE_LAUNCH_GM2(KS_, 4);                                                \
+        else OOVQE_LAUNCH_GM2(KS_, 2);                                                            \
     } while (0)
     oovqe_profile_mark_start_l(st, 2);
     if (KSr == 4) OOVQE_LAUNCH_GM(4);
@@ -2220,6 +2234,7 @@ static int sym_gm_batched(const double* J, const double* C, double* Gm, int N, i
     else OOVQE_LAUNCH_GM(12);
     oovqe_profile_mark_stop(st);
 #undef OOVQE_LAUNCH_GM
+#undef OOVQE_LAUNCH_GM2
     OOVQE_CHECK_LAUNCH("cas_eval/sym_gm");
     return 0;
 }

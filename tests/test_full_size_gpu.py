@@ -84,6 +84,35 @@ def test_batched_evaluation_64_geometries_properties():
         assert (fd - eg[:, 1 + k]).abs().max().item() < 2e-7
 
 
+def test_batched_evaluation_256_geometries_matches_smaller_batches():
+    """The bench's launch shape (N = 43, 256 geometries per call: one workgroup per geometry in the
+    N^4 pass, four burst phases, the two-workgroups-per-CU build of the q->x / p->n kernel):
+    geometry g of the big batch equals geometry g of a 64-geometry batch holding the same
+    molecules, and a single un-batched evaluation."""
+    import auto_oo_amd as aoo
+    from auto_oo_amd.synthetic import synthetic_problem
+    N, ncas, nelecas, nelec, G = 43, 3, 4, 16, 256
+    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="ucc")
+    base = [synthetic_problem(N, 9500 + g) for g in range(6)]
+    mols = [aoo.Moldata(base[g % 6]["int1e_ao"], base[g % 6]["int2e_ao"], base[g % 6]["overlap"],
+                        base[g % 6]["nuc"] + 0.001 * g, nelec) for g in range(G)]
+    coeffs = [base[g % 6]["oao_mo_coeff"] for g in range(G)]
+    big = aoo.OO_pqc_batch(pqc, mols, ncas, nelecas, oao_mo_coeffs=coeffs)
+    assert big.eri_flags == 3 and big._eri_packed is not None
+    rng = np.random.default_rng(6)
+    thetas = torch.tensor(rng.uniform(0, 2 * np.pi, (G, pqc.theta_shape)), device=DEV)
+    eg = big.energy_and_gradient(thetas).clone()
+    assert torch.isfinite(eg).all()
+    small = aoo.OO_pqc_batch(pqc, mols[100:164], ncas, nelecas, oao_mo_coeffs=coeffs[100:164])
+    eg_s = small.energy_and_gradient(thetas[100:164].contiguous())
+    assert (eg_s - eg[100:164]).abs().max().item() < 1e-11
+    for g in (0, 131, 255):
+        single = aoo.OO_pqc(pqc, mols[g], ncas, nelecas, oao_mo_coeff=coeffs[g])
+        E, grad = single.energy_and_gradient(thetas[g])
+        assert abs(eg[g, 0].item() - E.item()) < 1e-11
+        assert (eg[g, 1:] - grad).abs().max().item() < 1e-11
+
+
 def test_expm_n200_orthogonality_and_inverse():
     """configs[2]: expm(-K) of a 200 x 200 skew-symmetric K is orthogonal, expm(K) is its inverse,
     and the exponential of a sum of commuting generators (K, 0.5 K) factorises."""
