@@ -270,3 +270,21 @@ def test_active_space_helpers_match_oracle():
     assert abs(e0.item() - s0.item()) < 1e-12 and (e1 - s1).abs().max() < 1e-13 and torch.equal(e2, s2)
     f0, f1, f2 = molecular_hamiltonian_coefficients(1.25, h, g)
     assert f0 == 1.25 and f1 is h and torch.equal(f2, 0.5 * g)
+
+
+def test_packed_eri_size_and_synthetic_symmetry():
+    """Host-side pieces of the symmetric-integral path (no GPU): oovqe_eri_packed_size follows the
+    documented layout (slabs p <= q, row r = its columns (r & ~1) .. N-1), N > 48 has no packed
+    form, and the synthetic generator delivers bit-for-bit p<->q / r<->s symmetric integrals (what
+    the device-side flag check relies on in bench.py and the tests)."""
+    from auto_oo_amd import _lib
+    from auto_oo_amd.synthetic import synthetic_problem
+    lib = _lib.load()
+    for N in (1, 2, 7, 16, 17, 32, 33, 43, 48):
+        slab = sum(N - (r & ~1) for r in range(N))
+        assert lib.oovqe_eri_packed_size(N) == N * (N + 1) // 2 * slab
+    assert lib.oovqe_eri_packed_size(43) == 946 * 967
+    assert lib.oovqe_eri_packed_size(49) == 0 and lib.oovqe_eri_packed_size(0) == 0
+    g = synthetic_problem(13, 77)["int2e_ao"]
+    assert np.array_equal(g, g.transpose(1, 0, 2, 3))
+    assert np.array_equal(g, g.transpose(0, 1, 3, 2))
