@@ -2378,9 +2378,24 @@ static int half_tri_batched(const double* g_ao, const double* C, int N, int M, d
     const int ksteps = (N + 3) / 4, nrb = (N + 15) / 16;
     const int kch = ksteps <= 4 ? 4 : ksteps <= 8 ? 8 : ksteps <= 11 ? 11 : 12;
     const long tri = (long)N * (N + 1) / 2;
-    long W = device_cu_count() / batch;                       // one 8-wave workgroup per CU
+    // Workgroups per geometry (one 8-wave workgroup is resident per CU).  When the batch divides
+    // the CU count, W = n_cu / batch fills the chip in one resident round.  Otherwise a larger W
+    // whose W * batch workgroups run in several rounds can waste less of the last one (96
+    // geometries: W = 8, three rounds of 256, instead of W = 2 on 192 CUs); cost model: resident
+    // rounds x (slab rounds per workgroup + ~3 for prologue and burst).
+    const long n_cu = device_cu_count();
+    const long w_max = (tri + HALF_WAVES - 1) / HALF_WAVES;
+    long W = n_cu / batch;
     if (W < 1) W = 1;
-    if (W > (tri + HALF_WAVES - 1) / HALF_WAVES) W = (tri + HALF_WAVES - 1) / HALF_WAVES;
+    if (W > w_max) W = w_max;
+    if (getenv("OOVQE_TRI_PLAIN_W") == nullptr) {   // (test / measurement hook: keep W = n_cu / batch)
+        auto cost = [&](long w) {
+            return ((long)batch * w + n_cu - 1) / n_cu * ((tri + w * HALF_WAVES - 1) / (w * HALF_WAVES) + 3);
+        };
+        long best = cost(W);
+        for (long w = 1; w <= 16 && w <= w_max; ++w)
+            if (cost(w) < best) { best = cost(w); W = w; }
+    }
     const long n_rounds = (tri + W * HALF_WAVES - 1) / (W * HALF_WAVES);
     const size_t round_bytes = (size_t)HALF_WAVES * M * M * sizeof(double);
     const size_t fixed_bytes = (64 + 128) * sizeof(double);   // dump + column table
