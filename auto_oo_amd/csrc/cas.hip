@@ -2221,7 +2221,9 @@ static int sym_gm_batched(const double* J, const double* C, double* Gm, int N, i
                            dim3(SMALL_THREADS), lds_bytes, st, J, C, Gm, N, M, packed ? 1 : 0,    \
                            job, cj ? 1 : 0);                                                      \
     } while (0)
-    const bool multi_round = (long)(nty + (cj ? 1 : 0)) * batch > 2L * device_cu_count() &&
+    // (measurement hooks: OOVQE_GM_TWO_PER_CU / OOVQE_GM_ONE_PER_CU force a build; 128 geometries:
+    // 45 -> 38 us with two per CU, 64 geometries: no difference)
+    const bool multi_round = ((long)(nty + (cj ? 1 : 0)) * batch > (long)device_cu_count() || getenv("OOVQE_GM_TWO_PER_CU")) &&
                              2 * lds_bytes <= 160 * 1024 && getenv("OOVQE_GM_ONE_PER_CU") == nullptr;
 #define OOVQE_LAUNCH_GM(KS_)                                                                      \
     do {                                                                                          \

@@ -23,3 +23,20 @@ for _ in range(10):
     L = torch.linalg.cholesky(P); x = torch.cholesky_solve(g, L)
 torch.cuda.synchronize()
 print(f"GPU cholesky+solve n=331: {(time.perf_counter()-t0)/10*1e3:.2f} ms")
+# eigenvalues only (what a damped Newton step needs besides a linear solve)
+H1 = H[0].contiguous()
+torch.linalg.eigvalsh(H1); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(5):
+    ev = torch.linalg.eigvalsh(H1)
+torch.cuda.synchronize()
+print(f"GPU eigvalsh n=331: {(time.perf_counter()-t0)/5*1e3:.2f} ms")
+t0 = time.perf_counter()
+for _ in range(5):
+    ev = torch.linalg.eigvalsh(Hc)
+print(f"CPU eigvalsh n=331: {(time.perf_counter()-t0)/5*1e3:.2f} ms")
+t0 = time.perf_counter()
+for _ in range(5):
+    x = torch.linalg.solve(P, g)
+torch.cuda.synchronize()
+print(f"GPU LU solve n=331: {(time.perf_counter()-t0)/5*1e3:.2f} ms")
