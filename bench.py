@@ -6,14 +6,20 @@
 
 Workload (BASELINE.json configs[1], SURVEY.md section 8(d) "C2"): formaldimine CAS(4e,3o)/cc-pVDZ
 SHAPE on synthetic tensors -- N=43 AOs, 6 doubly occupied, 3 active orbitals, UCCD (4 thetas),
-327 non-redundant kappas.  A step is ONE evaluation: E = energy_from_parameters(theta) and the
-full gradient (dE/dtheta, dE/dkappa) for one molecular geometry whose AO integrals are already
-resident in HBM.  Each rank owns its shard of 64 synthetic geometries (geometry g lives on rank
-g mod N: the Berry-phase-loop partition of the north star) and evaluates them in batched calls
-(OO_pqc_batch: the geometry index is a grid dimension of every kernel), so K steps are
-ceil(K / shard) calls, each reading a different 27 MB integral tensor per evaluation.  Per-GPU
-work is fixed ("scaling": "weak"); the only collective is one all_gather of the per-geometry
-energies/gradients at the end of the timed region.
+327 non-redundant kappas.  One EVALUATION is E = energy_from_parameters(theta) and the full
+gradient (dE/dtheta, dE/dkappa) for one molecular geometry whose AO integrals are already resident
+in HBM.  A STEP is one pass of the hot path over the rank's batch: ONE batched call
+(OO_pqc_batch: the geometry index is a grid dimension of every kernel) evaluating all
+G = --geoms (default 256) synthetic geometries of the rank's shard (geometry g lives on rank
+g mod N: the Berry-phase-loop partition of the north star), each reading its own 27 MB integral
+tensor.  `--steps K` therefore times exactly K full batched calls = K x G evaluations per GPU;
+`value` = n_gpus x K x G / elapsed (evaluations per second), `config.evals_per_step` = G.
+Per-GPU work is fixed ("scaling": "weak"); the only collective is one all_gather of the
+per-geometry energies/gradients at the end of the timed region.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself (a
+torch.distributed.run child process, started before anything touches the GPU); under torchrun the
+ranks read RANK / LOCAL_RANK / WORLD_SIZE as usual.
 
 The JSON line also carries
   roofline      -- dominant kernel (the N^4 half-transform sweep) against the HBM roofline,
@@ -47,8 +53,9 @@ FP64_PEAK_TFLOPS = 78.6        # AMD spec, vector = matrix fp64 (SURVEY.md secti
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=102400)
-    ap.add_argument("--warmup", type=int, default=2560)
+    ap.add_argument("--steps", type=int, default=400,
+                    help="timed steps; one step = one batched call over the rank's --geoms geometries")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--geoms", type=int, default=N_GEOM,
                     help="molecular geometries PER GPU (weak scaling: the job holds geoms x n_gpus)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -62,6 +69,11 @@ def parse():
     ap.add_argument("--transform-n", type=int, default=200)
     ap.add_argument("--prime-seconds", type=float, default=0.5,
                     help="set-up time spent keeping the GPU busy before the W warm-up steps")
+    ap.add_argument("--berry-geoms", type=int, default=N_GEOM_BERRY,
+                    help="geometries of the configs[3] Berry-phase-loop extra: this many IN TOTAL for the "
+                         "strong-scaling figure (split over the GPUs) and this many PER GPU for the weak one")
+    ap.add_argument("--master-port", type=int, default=0,
+                    help="rendezvous port when bench.py starts the ranks itself (0 = pick a free one)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal of the "
                          "N>1 path on a one-GPU box: all ranks share cuda:0)")
@@ -85,14 +97,12 @@ def build_geometries(my_geoms):
     return pqc, batch, single, thetas
 
 
-def cpu_baseline(seconds_budget=20.0):
+def cpu_baseline(seconds_budget=24.0):
     """Reference algorithm (3 simulations + 3 full N^5 transforms + autograd jacobian per
-    evaluation, oo_pqc.py:64-101,132-134) restated in plain torch, on the host cores."""
+    evaluation, oo_pqc.py:64-101,132-134) restated in plain torch, on the host cores: SURVEY.md
+    section 8(d) -- all host threads (os.cpu_count()) and one thread, warm-up 3, median of >= 20
+    evaluations (fewer only if the time budget runs out; the sample says how many)."""
     from oracle import cpu_ref as R
-    # a 1-GPU box is given a 16-core share of the host (more threads only oversubscribe the
-    # many tiny torch ops of the reference algorithm)
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
     P = R.synthetic_problem(NAO, 20260 + 2)
     mol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], NELEC)
     pqc = R.OraclePQC(NCAS, NELECAS, "ucc")
@@ -104,22 +114,35 @@ def cpu_baseline(seconds_budget=20.0):
         g = oo.full_gradient(theta)
         return e, g
 
-    one()  # warm-up (builds the JW operators once, as the reference caches them)
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        one()
-        n += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget or n >= 200:
-            break
+    def median_rate(threads, budget):
+        torch.set_num_threads(threads)
+        for _ in range(3):
+            one()
+        ts = []
+        t_start = time.perf_counter()
+        while len(ts) < 20 or (time.perf_counter() - t_start < budget and len(ts) < 60):
+            t0 = time.perf_counter()
+            one()
+            ts.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start > budget and len(ts) >= 5:
+                break
+        ts.sort()
+        return 1.0 / ts[len(ts) // 2], len(ts)
+
+    n_threads_before = torch.get_num_threads()
+    cores = os.cpu_count() or 1
+    v_all, n_all = median_rate(cores, seconds_budget / 2)
+    v_one, n_one = median_rate(1, seconds_budget / 2)
+    torch.set_num_threads(n_threads_before)
     e, g = one()
-    return dict(value=n / el, unit="evals/s", cores=cores, kind="port",
-                sample=f"{n} energy+full-gradient evaluations of geometry 0 (N={NAO}), "
-                       f"torch {torch.__version__} CPU, {cores} threads"), float(e), g
+    return dict(value=v_all, unit="evals/s", cores=cores, kind="port",
+                one_thread_value=v_one,
+                sample=f"median of {n_all} (all {cores} host threads) / {n_one} (1 thread) energy+full-"
+                       f"gradient evaluations of geometry 0 (N={NAO}) after 3 warm-up evaluations, "
+                       f"torch {torch.__version__} CPU"), float(e), g
 
 
-def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl"):
+def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl", mode="weak"):
     """BASELINE.json configs[3]: for every geometry of this rank's shard, from a shared (theta0, C0):
     energy + full gradient + full (n_theta+n_kappa)^2 Hessian + one damped Newton step
     (oo_pqc.py:172-196); one all_gather of the new energies at the end.  Returns geometries/s."""
@@ -184,7 +207,8 @@ def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl"):
         el, el_b = float(tmax[0].item()), float(tmax[1].item())
     return {"geometries": n_geom, "seconds": el, "geometries_per_s": n_geom / el,
             "per_geometry_ms": el / max(len(objs), 1) * 1e3, "hessian_dim": objs[0].n_kappa + pqc.theta_shape,
-            "scaling": f"weak ({len(objs)} geometries per GPU, geometry g on rank g mod n_gpus)",
+            "scaling": (f"{mode} ({n_geom} geometries in the job, {len(objs)} on this GPU, geometry g on "
+                        f"rank g mod n_gpus)"),
             "lockstep": {"seconds": el_b, "geometries_per_s": n_geom / el_b,
                          "per_geometry_ms": el_b / max(len(objs), 1) * 1e3,
                          "max_abs_energy_difference_vs_sequential": agree,
@@ -194,15 +218,14 @@ def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl"):
 
 
 def kupccd_extra():
-    """BASELINE.json configs[4]: kUpCCD CAS(8e,8o), 16-qubit register simulated in its 4900-determinant
-    (N_alpha, N_beta) sector: gate-apply rate, state + RDMs + reverse-mode theta-gradient per second,
-    and one full OO evaluation (E + full gradient) on a synthetic N=43 geometry."""
+    """BASELINE.json configs[4]: kUpCCD CAS(8e,8o), k = 1 and 2 layers (56 / 112 thetas,
+    ansatze/kUpCCD.py:16-33), 16-qubit register simulated in its 4900-determinant (N_alpha, N_beta)
+    sector: state, state + RDMs + reverse-mode theta-gradient per second, and one full OO evaluation
+    (E + full gradient) on a synthetic N=43 geometry.  The sector state lives in LDS, so the gate-apply
+    figure is LDS traffic (batch x gates x 2 x sector_dim x 8 B), not HBM bytes."""
     import auto_oo_amd as aoo
     from auto_oo_amd.synthetic import synthetic_problem
-    ncas, nelecas, D = 8, 8, 1 << 16
-    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="kupccd", k=1)
-    eng = pqc._sector
-    n_theta = int(pqc.theta_shape)
+    ncas, nelecas = 8, 8
     rng = np.random.default_rng(6)
     c1 = torch.tensor(rng.standard_normal((ncas, ncas)), device="cuda")
     c2 = torch.tensor(rng.standard_normal((ncas,) * 4), device="cuda")
@@ -221,28 +244,34 @@ def kupccd_extra():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps
 
-    out = {"n_theta": n_theta, "n_gates": pqc._n_gates, "sector_dim": eng.Dc, "batches": []}
-    for batch in (1, 256):
-        th = torch.tensor(rng.uniform(0, 2 * np.pi, (batch, n_theta)), device="cuda")
-        t_state = timed(lambda: eng.state(th))
-
-        def full():
-            psi_c = eng.state(th)
-            eng.rdms(psi_c)
-            return eng.adjoint(th, psi_c, c1, c2)
-        t_full = timed(full, warm=2, reps=5)
-        out["batches"].append({
-            "batch": batch, "state_us": t_state * 1e6,
-            "gate_apply_GBs_dense_complex128_equivalent": batch * pqc._n_gates * 2.0 * D * 16 / t_state / 1e9,
-            "gate_apply_GBs_sector_in_lds": batch * pqc._n_gates * 2.0 * eng.Dc * 8 / t_state / 1e9,
-            "state_rdm_grad_evals_per_s": batch / t_full})
     P = synthetic_problem(NAO, 20265)
     mol = aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], NELEC)
-    oo = aoo.OO_pqc(pqc, mol, ncas, nelecas, oao_mo_coeff=P["oao_mo_coeff"])
-    th1 = torch.tensor(rng.uniform(0, 2 * np.pi, n_theta), device="cuda")
-    out["oo_eval_us"] = timed(lambda: oo.energy_and_gradient(th1), warm=3, reps=20) * 1e6
-    out["n_kappa"] = oo.n_kappa
-    return out
+    layers = []
+    for k in (1, 2):
+        pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="kupccd", k=k)
+        eng = pqc._sector
+        n_theta = int(pqc.theta_shape)
+        rec = {"k": k, "n_theta": n_theta, "n_gates": pqc._n_gates, "sector_dim": eng.Dc, "batches": []}
+        for batch in (1, 256):
+            th = torch.tensor(rng.uniform(0, 2 * np.pi, (batch, n_theta)), device="cuda")
+            t_state = timed(lambda: eng.state(th))
+
+            def full():
+                psi_c = eng.state(th)
+                eng.rdms(psi_c)
+                return eng.adjoint(th, psi_c, c1, c2)
+            t_full = timed(full, warm=2, reps=5)
+            rec["batches"].append({
+                "batch": batch, "state_us": t_state * 1e6,
+                "gate_apply_lds_GBs": batch * pqc._n_gates * 2.0 * eng.Dc * 8 / t_state / 1e9,
+                "state_rdm_grad_us": t_full * 1e6,
+                "state_rdm_grad_evals_per_s": batch / t_full})
+        oo = aoo.OO_pqc(pqc, mol, ncas, nelecas, oao_mo_coeff=P["oao_mo_coeff"])
+        th1 = torch.tensor(rng.uniform(0, 2 * np.pi, n_theta), device="cuda")
+        rec["oo_eval_us"] = timed(lambda: oo.energy_and_gradient(th1), warm=3, reps=20) * 1e6
+        rec["n_kappa"] = oo.n_kappa
+        layers.append(rec)
+    return {"layers": layers}
 
 
 def transform_microbench(N):
@@ -283,11 +312,39 @@ def transform_microbench(N):
                 note="four chained fp64-MFMA mode contractions; algorithmic 8 N^5 flop")
 
 
+def launch_command(n_ranks, port, argv):
+    """The driver's own multi-GPU command line (one rank per GPU, rendezvous on 127.0.0.1)."""
+    import socket
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+            f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+            os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks as a child
+    torch.distributed.run job and return its exit code.  Nothing in this process has touched the
+    GPU yet (no exec of a GPU-initialised process: the launcher is a plain child process)."""
+    import subprocess
+    cmd = launch_command(args.gpus, args.master_port, sys.argv[1:])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("OOVQE_BENCH_ECHO_RANK"):
+        print(f"bench.py: rank {rank} of {world}", file=sys.stderr, flush=True)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     if args.backend == "gloo":
@@ -315,27 +372,23 @@ def main():
     n_out = 1 + batch.n_theta + batch.n_kappa
     results = torch.zeros((G, n_out), dtype=torch.float64, device="cuda")
 
-    def run(n_evals):
-        """n_evals evaluations as batched calls over this rank's shard (last call partial).  Each
-        call returns its own [b, 1 + n_theta + n_kappa] result tensor; the rows of the last full
-        sweep over the shard are what the final exchange gathers."""
-        done, calls = 0, 0
+    def run(n_calls):
+        """n_calls steps: each one batched call over ALL G geometries of this rank's shard.  Each
+        call returns its own [G, 1 + n_theta + n_kappa] result tensor; the rows of the last call
+        are what the final exchange gathers."""
         last = None
-        while done < n_evals:
-            b = min(G, n_evals - done)
-            last = batch.energy_and_gradient(thetas, count=b)
-            done += b
-            calls += 1
+        for _ in range(n_calls):
+            last = batch.energy_and_gradient(thetas)
         if last is not None:
-            results[:last.shape[0]] = last
-        return calls
+            results.copy_(last)
+        return n_calls
 
     # set-up (not part of W or K): every code path of the timed region runs once, so that lazily
     # loaded code objects (ours and torch's index_put/copy kernels used by the final exchange: ~30 ms
     # the first time a fresh box reads them from disk) are resident, and the GPU clocks have ramped.
     t_prime = time.perf_counter()
     while time.perf_counter() - t_prime < args.prime_seconds:
-        run(8 * G)
+        run(8)
         torch.cuda.synchronize()
     gather_results(results, my_geoms, n_geom_total, dist)
     run(args.warmup)
@@ -363,7 +416,7 @@ def main():
     # per-launch breakdown of one evaluation call, from a separate untimed pass (bracketing every
     # launch costs dispatch gaps, so it is kept out of the timed region)
     ops.profile_begin(detail=True)
-    run(16 * G)
+    run(16)
     torch.cuda.synchronize()
     kern_by = ops.profile_end()[2]
     kern_s = kern_total_ms * 1e-3 / kern_count if kern_count else float("nan")
@@ -371,7 +424,7 @@ def main():
     # which stage-1 kernel the library picks (cas.hip: fused_plan): the persistent T3 kernel once a
     # launch covers >= 48 slabs per CU, the one-slab-per-wave T2 kernel below that
     n_cu = torch.cuda.get_device_properties(0).multi_processor_count
-    t3_path = (args.steps / max(n_calls, 1)) * NAO ** 2 >= 48 * n_cu
+    t3_path = G * NAO ** 2 >= 48 * n_cu
     # p<->q symmetric integrals (verified bit for bit when the batch was built, as PySCF's int2e
     # is): the library reads only the N(N+1)/2 slabs p <= q -- the algorithmic bytes of the sweep
     # are then 8 N^2 * N(N+1)/2 (half of SURVEY.md section 8(d)'s 8 N^4) + the packed J written
@@ -404,7 +457,9 @@ def main():
         kernel_name = "half_transform_kernel<1,11,3> (T2[p,q,y,z] = sum_rs C[r,y] g[p,q,r,s] C[s,z])"
     # evaluations per launch from the calls made (the event pool brackets at most 8192 launches of
     # a long run: the average duration is then over those, the bytes are still per launch)
-    evals_per_launch = args.steps / max(n_calls, 1)
+    evals_per_launch = float(G)
+    if kern_count < min(args.steps, 8192):
+        raise SystemExit(f"roofline: only {kern_count} of {args.steps} stage-1 launches were bracketed")
     alg_bytes = bytes_per_eval * evals_per_launch                   # per launch (batched)
     achieved = alg_bytes / kern_s / 1e9
     # HBM traffic of that kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 [gfx950 correction] +
@@ -422,7 +477,7 @@ def main():
 
     out = {
         "metric": METRIC,
-        "value": world * args.steps / elapsed,
+        "value": world * args.steps * G / elapsed,
         "unit": "evals/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -435,9 +490,10 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": (f"configs[1] shape: N={NAO} AOs, n_occ=6, CAS(4e,3o), UCCD n_theta=4, "
-                         f"n_kappa={batch.n_kappa}; one energy + full-gradient evaluation per "
-                         f"step; {n_geom_total} synthetic geometries ({args.geoms} per GPU, geometry g "
-                         f"on rank g mod n_gpus), evaluated in batched calls of up to {G} geometries"),
+                         f"n_kappa={batch.n_kappa}; one step = one batched call evaluating energy + full "
+                         f"gradient of all {G} geometries of the rank ({n_geom_total} synthetic "
+                         f"geometries in the job, geometry g on rank g mod n_gpus); value = evaluations/s"),
+            "evals_per_step": G,
             "geometries_per_rank": G,
             "batched_calls": n_calls,
             "host_submit_us_per_call": t_submit / max(n_calls, 1) * 1e6,
@@ -477,10 +533,19 @@ def main():
         torch.cuda.synchronize()
         out["single_eval_us"] = (time.perf_counter() - t1) / 500 * 1e6
     if not args.no_berry:
-        nb = min(N_GEOM_BERRY, len(my_geoms))          # first nb geometries of every rank's shard
-        berry = berry_loop_extra(my_geoms[:nb], nb * world, dist, world, args.backend)
+        # configs[3]: the 64-geometry Berry-phase-loop workload.  "strong": --berry-geoms geometries in
+        # the whole job, split over the GPUs (the north star's >= 6x at 8 GPUs is about this one);
+        # "weak": --berry-geoms geometries per GPU (the same run when n_gpus = 1).
+        nb = max(args.berry_geoms, world)
+        strong_geoms = shard_geometries(nb, rank, world)
+        strong = berry_loop_extra(strong_geoms, nb, dist, world, args.backend, "strong")
+        if world > 1:
+            weak_geoms = shard_geometries(nb * world, rank, world)
+            weak = berry_loop_extra(weak_geoms, nb * world, dist, world, args.backend, "weak")
+        else:
+            weak = dict(strong, scaling=f"weak ({nb} geometries per GPU; identical to the strong run at 1 GPU)")
         if rank == 0:
-            out["berry_loop"] = berry
+            out["berry_loop"] = {"strong": strong, "weak": weak}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             cb, e_ref, g_ref = cpu_baseline()
