@@ -116,3 +116,18 @@ def unpack_eri_s8(packed, n):
     out[:, :, pq[0], pq[1]] = full
     out[:, :, pq[1], pq[0]] = full
     return out
+
+
+def get_formal_geo(alpha, phi):
+    """Z-matrix of formaldimine H2C=NH with the N-H bond at bending angle ``alpha`` (degrees,
+    H-N-C) and dihedral ``phi`` (degrees), the molecule of every reference test and notebook
+    (src/auto_oo/utils/miscellaneous.py:34-45: N-C 1.498047, C-H 1.066797, N-H 0.987109 Angstrom,
+    H-C-N 118.359375 degrees).  Returns the multi-line Z-matrix string PySCF-style parsers take."""
+    r_nc, r_ch, r_nh, a_hcn = 1.498047, 1.066797, 0.987109, 118.359375
+    rows = ("N",
+            f"C 1 {r_nc}",
+            f"H 2 {r_ch}  1 {a_hcn}",
+            f"H 2 {r_ch}  1 {a_hcn} 3 180",
+            f"H 1 {r_nh}  2 {alpha} 3 {phi}")
+    pad = " " * 20
+    return "\n" + "".join(pad + r + "\n" for r in rows) + pad

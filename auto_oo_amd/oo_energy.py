@@ -236,18 +236,18 @@ class OO_energy:
         return ops.cas_finish_transform(T2, self.int1e_ao, C, self._M)
 
     def _eri_flags(self, g_ao=None):
-        """Symmetry flags of a resident two-electron tensor (ops.eri_flags), checked once per tensor
-        object: int2e_ao is set once and never modified in place, as in the reference
-        (moldata_pyscf.py:31, oo_energy.py:155).  PySCF integrals are exactly p<->q symmetric, so
-        the N^4 pass reads half of the tensor; anything else is treated as a general tensor."""
+        """Symmetry flags of a resident two-electron tensor (ops.eri_flags), verified once per
+        tensor STATE: the cache key is the tensor object and its autograd version counter, so an
+        in-place edit of ``int2e_ao`` (the reference lets users mutate it) re-verifies instead of
+        keeping a stale "symmetric" promise -- same rule as the ``mo_coeff`` cache below.  PySCF
+        integrals are exactly p<->q symmetric, so the N^4 pass reads half of the tensor; anything
+        else is treated as a general tensor."""
         g_ao = self.int2e_ao if g_ao is None else g_ao
-        cache = self.__dict__.setdefault("_eri_flag_cache", {})
-        hit = cache.get(id(g_ao))
-        if hit is None or hit[0] is not g_ao:
-            hit = (g_ao, ops.eri_flags(g_ao))
-            cache.clear()
-            cache[id(g_ao)] = hit
-        return hit[1]
+        hit = self.__dict__.get("_eri_flag_cache")
+        if hit is None or hit[0] is not g_ao or hit[1] != g_ao._version:
+            hit = (g_ao, g_ao._version, ops.eri_flags(g_ao))
+            self.__dict__["_eri_flag_cache"] = hit
+        return hit[2]
 
     def _cas_eval(self, mo_coeff, gamma_sets, Gamma_sets, want_matrices=False):
         """Fused energy / Fock / orbital gradient for a stack of RDM sets (set 0 = RDMs, sets k>=1

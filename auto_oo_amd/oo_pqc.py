@@ -9,10 +9,59 @@ import numpy as np
 import torch
 
 from . import ops
+from .autodiff import differentiable_scalar, needs_autodiff, unwrap
 from .newton_raphson import NewtonStep
-from .oo_energy import OO_energy
+from .oo_energy import OO_energy, _OrbitalRotationRule, _is_zero, _matvec
 
 F64 = torch.float64
+
+
+class _ParametersEnergyModel(_OrbitalRotationRule):
+    """E(theta, kappa) = OO_pqc.energy_from_parameters as torch sees it (oo_pqc.py:64-95): value,
+    gradient (dE/dtheta from the tangent-state kernels; dE/dkappa through C0 expm(-K), see
+    _OrbitalRotationRule) and, at kappa = 0, the second derivatives = the three analytic Hessian
+    blocks (oo_pqc.py:103-148), which is where test/test_oo_pqc.py:113-125 takes them."""
+
+    def value(self, theta, kappa):
+        C, _, _ = self.rotated(kappa)
+        return self.oo._evaluate(theta, C, derivatives=False)["E"].reshape(())
+
+    def grad(self, theta, kappa):
+        oo = self.oo
+        C, U, K = self.rotated(kappa)
+        if U is None:                       # kappa = 0: one fused pass gives both blocks
+            res = oo._evaluate(theta, C)
+            return res["dE"].reshape(theta.shape), res["gvec"][0].reshape(kappa.shape)
+        if getattr(oo.pqc, "_use_sector", False):
+            dE = oo._evaluate_adjoint(theta, C)["dE"]
+            g1, g2 = oo.pqc.get_rdms(theta)
+            res = oo._cas_eval(C, g1[None].contiguous(), g2[None].contiguous(), want_matrices=True)
+        else:
+            res = oo._evaluate(theta, C, derivatives=True, want_matrices=True)
+            dE = res["dE"]
+        gk = self.kappa_gradient(res["fock"], res["gvec"][0], U, K)
+        return dE.reshape(theta.shape), gk.reshape(kappa.shape)
+
+    def hvp(self, xs, vs, needs=None):
+        theta, kappa = (unwrap(x) for x in xs)
+        if not _is_zero(kappa):
+            raise NotImplementedError("second derivatives of energy_from_parameters are available at "
+                                      "kappa = 0 (where the reference's tests take them); move the "
+                                      "rotation into oao_mo_coeff and differentiate at kappa = 0")
+        H = getattr(self, "_H", None)
+        if H is None:
+            H = self._H = self.oo.full_hessian(theta)
+        nt = theta.numel()
+        vt, vk = vs
+        out_t = out_k = None
+        if vt is not None:
+            out_t, out_k = _matvec(H[:nt, :nt], vt), _matvec(H[nt:, :nt], vt)
+        if vk is not None:
+            bt, bk = _matvec(H[:nt, nt:], vk), _matvec(H[nt:, nt:], vk)
+            out_t = bt if out_t is None else out_t + bt
+            out_k = bk if out_k is None else out_k + bk
+        return (None if out_t is None else out_t.reshape(theta.shape),
+                None if out_k is None else out_k.reshape(kappa.shape))
 
 
 class OO_pqc(OO_energy):
@@ -49,15 +98,18 @@ class OO_pqc(OO_energy):
         if not want_matrices and not getattr(self.pqc, "_use_sector", False):
             # one C call: circuit (+tangents) -> RDM sets -> CAS path, persistent workspace
             plans = self.__dict__.setdefault("_plans2", {})
-            key = (bool(derivatives), id(self.pqc), id(self.int2e_ao), id(self.int1e_ao))
-            plan = plans.get(key)
-            if plan is None:
+            # the plan bakes in the integrals' symmetry flags: it is valid for one STATE of the
+            # tensors (object + in-place version counter); an edited int2e_ao gets a fresh plan
+            state = (id(self.pqc), id(self.int2e_ao), self.int2e_ao._version, id(self.int1e_ao))
+            hit = plans.get(bool(derivatives))
+            if hit is None or hit[0] != state:
                 pqc = self.pqc
                 plan = ops.OoEvalPlan(pqc._gates_dev, pqc._n_gates, self._n_theta(), pqc.n_qubits,
                                       pqc._init_index, self.int2e_ao, self.int1e_ao, self.nuc,
                                       self._n_occ, self.ncas, self._kap_row, self._kap_col,
                                       derivatives=derivatives, eri_flags=self._eri_flags())
-                plans[key] = plan
+                plans[bool(derivatives)] = hit = (state, plan)
+            plan = hit[1]
             th = self.pqc._theta2d(theta).reshape(-1)
             return plan.unpack(plan(th, self._t(mo_coeff)))
         if derivatives:
@@ -77,7 +129,16 @@ class OO_pqc(OO_energy):
 
     # ---- reference API ------------------------------------------------------------------------------
     def energy_from_parameters(self, theta, kappa=None):
-        """oo_pqc.py:64-84"""
+        """oo_pqc.py:64-84.  Differentiable by torch (autograd.functional.jacobian / hessian,
+        torch.func.jacrev / hessian): first order in (theta, kappa) anywhere, second order at
+        kappa = 0 -- the derivative rules call the analytic kernels (_ParametersEnergyModel)."""
+        if needs_autodiff(theta, kappa):
+            theta_d, = self._diff_args(theta)
+            if kappa is None:
+                kappa_d = torch.zeros(self.n_kappa, dtype=F64, device=self.device)
+            else:
+                kappa_d, = self._diff_args(kappa)
+            return differentiable_scalar(_ParametersEnergyModel(self), theta_d, kappa_d)
         if kappa is None:
             mo_coeff = self.mo_coeff
         else:

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib, excitations as X, ops
+from .autodiff import VectorWithJacobian, needs_autodiff
 from .sector import SectorEngine
 
 
@@ -114,6 +115,10 @@ class Parameterized_circuit():
                                         self.ncas, self._init_index, tangents=True)
         return gamma[0], Gamma[0]
 
+    def _rdms_and_jacobians(self, theta):
+        gamma, Gamma = self.rdms_with_derivatives(theta)
+        return (gamma[0], Gamma[0]), (gamma[1:], Gamma[1:])
+
     # ---- reference API ----------------------------------------------------------------------------
     def _qnode(self, theta):
         """State as a complex128 vector of length 2^n (pqc.py:133,165-172).  The UCC(S)D / kUpCCD
@@ -151,9 +156,14 @@ class Parameterized_circuit():
         return g1[0], g2[0]
 
     def get_rdms(self, theta, restricted=True):
-        """pqc.py:220-221"""
+        """pqc.py:220-221.  Differentiable by torch with respect to theta (first order): the
+        Jacobians are the derivative RDMs of the tangent-state kernels."""
         if not restricted:
             raise NotImplementedError("unrestricted RDMs are not built (never used on the hot path)")
+        if needs_autodiff(theta):
+            th = torch.as_tensor(theta).to(device=self.device, dtype=torch.float64).contiguous()
+            out = VectorWithJacobian.apply(self._rdms_and_jacobians, th)
+            return out[0], out[1]
         th = self._theta2d(theta)
         if self._use_sector:
             g1, g2 = self._sector.rdms(self._sector.state(th))
