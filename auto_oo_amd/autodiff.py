@@ -20,7 +20,21 @@ module is pure host logic (no kernel calls): a *model* object supplies
 
 The kernel-backed models live next to the classes that own the kernels (oo_energy.py, oo_pqc.py).
 """
+import contextlib
+
 import torch
+from torch._functorch.pyfunctorch import temporarily_clear_interpreter_stack
+
+
+@contextlib.contextmanager
+def kernel_scope():
+    """Run kernel-calling code on plain tensors: inside a torch.func transform every torch op --
+    even a reshape of a plain tensor -- returns a tensor wrapped at the current level, which has no
+    data pointer to hand to the C ABI.  This scope suspends the transform stack (and grad mode);
+    derivative rules compute their kernel results inside it and combine them with the (wrapped)
+    tangents outside."""
+    with temporarily_clear_interpreter_stack(), torch.no_grad():
+        yield
 
 
 def needs_autodiff(*tensors):
@@ -45,6 +59,17 @@ def unwrap(t):
                                       "time (a batched primal reached a second-derivative rule)")
         t = torch._C._functorch.get_unwrapped(t)
     return t
+
+
+def is_zero_tangent(t):
+    """True for None and for a tangent / cotangent that is identically zero in every batch entry
+    (torch.func hands zeros, not None, to a jvp rule for inputs that are not differentiated).
+    Looks at the raw data under the wrappers, so it is safe under vmap."""
+    if t is None:
+        return True
+    while isinstance(t, torch.Tensor) and torch._C._functorch.is_functorch_wrapped_tensor(t):
+        t = torch._C._functorch.get_unwrapped(t)
+    return not bool((t != 0).any())
 
 
 def _loop_vmap(apply, n_out):
@@ -73,7 +98,8 @@ class ScalarGradient(torch.autograd.Function):
 
     @staticmethod
     def forward(model, *xs):
-        gs = model.grad(*xs)
+        with kernel_scope():
+            gs = model.grad(*xs)
         return tuple(torch.zeros_like(x) if g is None else g for x, g in zip(xs, gs))
 
     @staticmethod
@@ -108,7 +134,8 @@ class ScalarValue(torch.autograd.Function):
 
     @staticmethod
     def forward(model, *xs):
-        return model.value(*xs)
+        with kernel_scope():
+            return model.value(*xs)
 
     @staticmethod
     def setup_context(ctx, inputs, output):
@@ -150,7 +177,8 @@ class VectorWithJacobian(torch.autograd.Function):
 
     @staticmethod
     def forward(fn, x):
-        ys, jacs = fn(x)
+        with kernel_scope():
+            ys, jacs = fn(x)
         return tuple(ys) + tuple(jacs)
 
     @staticmethod

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib, excitations as X, ops
-from .autodiff import differentiable_scalar, needs_autodiff, unwrap
+from .autodiff import differentiable_scalar, is_zero_tangent, kernel_scope, needs_autodiff, unwrap
 from .newton_raphson import NewtonStep
 
 F64 = torch.float64
@@ -83,7 +83,10 @@ def non_redundant_indices(occ_idx, act_idx, virt_idx, freeze_active):
 # derivative rules of the cost functions for torch's autodiff (auto_oo_amd/autodiff.py)
 # ------------------------------------------------------------------------------------------------
 def _is_zero(t):
-    return t is None or not bool((t != 0).any())
+    if t is None:
+        return True
+    with kernel_scope():
+        return not bool((t != 0).any())
 
 
 def _matvec(H, v):
@@ -149,12 +152,14 @@ class _KappaEnergyModel(_OrbitalRotationRule):
         if not _is_zero(kappa):
             raise NotImplementedError("second derivatives of energy_from_kappa are available at "
                                       "kappa = 0 (where the reference's tests take them)")
-        if (vs[1] is not None or vs[2] is not None) or (needs is not None and (needs[1] or needs[2])):
+        if (not is_zero_tangent(vs[1]) or not is_zero_tangent(vs[2])
+                or (needs is not None and (needs[1] or needs[2]))):
             raise NotImplementedError("second derivatives of energy_from_kappa involving the RDMs "
                                       "are not built")
         H = getattr(self, "_H", None)
         if H is None:
-            H = self._H = self.oo.analytic_hessian_matrix(one_rdm, two_rdm)
+            with kernel_scope():
+                H = self._H = self.oo.analytic_hessian_matrix(one_rdm, two_rdm)
         out = _matvec(H, vs[0])
         return (None if out is None else out.reshape(kappa.shape)), None, None
 

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .autodiff import differentiable_scalar, needs_autodiff, unwrap
+from .autodiff import differentiable_scalar, kernel_scope, needs_autodiff, unwrap
 from .newton_raphson import NewtonStep
 from .oo_energy import OO_energy, _OrbitalRotationRule, _is_zero, _matvec
 
@@ -50,7 +50,8 @@ class _ParametersEnergyModel(_OrbitalRotationRule):
                                       "rotation into oao_mo_coeff and differentiate at kappa = 0")
         H = getattr(self, "_H", None)
         if H is None:
-            H = self._H = self.oo.full_hessian(theta)
+            with kernel_scope():
+                H = self._H = self.oo.full_hessian(theta)
         nt = theta.numel()
         vt, vk = vs
         out_t = out_k = None

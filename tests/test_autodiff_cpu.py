@@ -20,6 +20,7 @@ class ToyModel:
 
     def value(self, x, y):
         self.calls["value"] += 1
+        assert x.reshape(-1).data_ptr() and y.detach().data_ptr()
         with torch.no_grad():
             return plain(x, y)
 
@@ -33,13 +34,20 @@ class ToyModel:
 
     def grad(self, x, y):
         self.calls["grad"] += 1
+        assert x.reshape(-1).data_ptr() and y.detach().data_ptr()
         s, ds, c, dc = self._pieces(x, y)
         yy = torch.stack((y[1], y[0]))
         return ds * c + 2 * x * y[0] * y[1], s * dc + (x ** 2).sum() * yy
 
     def hvp(self, xs, vs, needs=None):
         self.calls["hvp"] += 1
-        x, y = xs
+        from auto_oo_amd.autodiff import unwrap
+        from auto_oo_amd.autodiff import kernel_scope
+        x, y = (unwrap(t) for t in xs)
+        with kernel_scope():
+            # what a kernel call needs: real storage, also after a view op (which a transform
+            # level would wrap again outside kernel_scope)
+            assert x.data_ptr() and y.reshape(1, -1).data_ptr() and x.detach().data_ptr()
         vx = torch.zeros_like(x) if vs[0] is None else vs[0]
         vy = torch.zeros_like(y) if vs[1] is None else vs[1]
         n = x.numel()
@@ -167,3 +175,15 @@ def test_vector_with_jacobian():
     jf = torch.func.jacfwd(wrapped)(t)
     for a, p in zip(jf, jp):
         assert torch.allclose(a, p, atol=1e-13)
+
+
+def test_is_zero_tangent_under_vmap():
+    from auto_oo_amd.autodiff import is_zero_tangent
+    seen = []
+
+    def f(t):
+        seen.append(is_zero_tangent(t))
+        return t.sum()
+    torch.func.vmap(f)(torch.zeros(3, 2))
+    torch.func.vmap(f)(torch.eye(3))
+    assert seen == [True, False] and is_zero_tangent(None)
