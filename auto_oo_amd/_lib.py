@@ -128,6 +128,12 @@ SIGNATURES = {
     "oovqe_eri_packed_size": (ctypes.c_int64, [ctypes.c_int]),
     "oovqe_eri_pack": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, c_stream]),
     "oovqe_circuit_rdms_is_small": (ctypes.c_int, [ctypes.c_int] * 4),
+    "oovqe_newton_direction": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                              ctypes.c_int, c_double_p, c_double_p, c_double_p,
+                                              c_double_p, c_stream]),
+    "oovqe_newton_direction_work_size": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int]),
+    "oovqe_newton_direction_max_n": (ctypes.c_int, []),
 }
 
 _lib = None

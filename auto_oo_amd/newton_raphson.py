@@ -1,35 +1,52 @@
-"""Damped Newton step with augmented Hessian and backtracking line search.
+"""Damped Newton step with augmented Hessian and backtracking line search, on the device.
 
-Mirror of the reference's ``NewtonStep`` (src/auto_oo/utils/newton_raphson.py:12-224): same
-hyper-parameters, same control flow, same printed messages.  It is a host-side driver over the
-cost function; the (n_theta + n_kappa)-sized ``eigh`` runs through torch on the device (SURVEY.md
-section 2 row 8: out of scope as a kernel).
+Drop-in for the reference's ``NewtonStep`` (src/auto_oo/utils/newton_raphson.py:47-211: same
+constructor, same method names and return values, same acceptance rule), built differently:
+
+* the direction comes from ONE kernel launch (``oovqe_newton_direction``: blocked Householder
+  tridiagonalisation, Sturm multisection for the lowest eigenvalue, the reference's level shift
+  ``mu + rho |lambda_low|`` and a pivoted tridiagonal solve) instead of two ``eigh`` calls and an
+  explicit inverse (newton_raphson.py:78-129);
+* the line search keeps energies on the device and reads back once per trial (one small tensor:
+  old energy, trial energy, Armijo slope, lowest eigenvalue) instead of once per comparison
+  (newton_raphson.py:131-192).
+
+``BatchedNewtonStep`` (an extension) takes the same step for G independent problems in lockstep:
+one launch with G workgroups for the directions, one readback per line-search trial for all of them.
 """
 import torch
 
+from . import _lib, ops
+
 
 def wolfe(t, grad, dp, alpha=1e-4):
-    """newton_raphson.py:12-13"""
+    """Armijo term alpha * t * <grad, dp> (newton_raphson.py:12-13)."""
     return alpha * t * torch.dot(grad, dp)
 
 
 def split_list_shapes(parameters, paramshapes):
-    """newton_raphson.py:214-224"""
-    chunks = []
-    num = 0
+    """Cut a flat parameter vector back into tensors of the given shapes (newton_raphson.py:214-224)."""
+    out, start = [], 0
     for shape in paramshapes:
-        shapesize = 1
-        for s in shape:
-            shapesize *= int(s)
-        chunks.append(parameters[num:num + shapesize].reshape(shape))
-        num += shapesize
-    return chunks
+        count = 1
+        for extent in shape:
+            count *= int(extent)
+        out.append(parameters[start:start + count].reshape(shape))
+        start += count
+    return out
+
+
+def _flatten(parameters):
+    shapes = [tuple(p.shape) for p in parameters]
+    return torch.cat([p.reshape(-1) for p in parameters]), shapes
 
 
 class NewtonStep():
     def __init__(self, alpha=0.0001, beta=.5, mu=1e-6, rho=1.1, lmax=20, lambda_min=1e-6,
                  aug=True, verbose=1):
-        """newton_raphson.py:47-77"""
+        """Hyper-parameters of newton_raphson.py:47-77: Armijo constant ``alpha``, step reduction
+        ``beta``, level shift ``mu + rho |lambda_low|`` applied when the lowest Hessian eigenvalue
+        is below ``lambda_min`` (``aug``), at most ``lmax`` reductions of the step."""
         self.alpha = alpha
         self.beta = beta
         self.mu = mu
@@ -39,89 +56,114 @@ class NewtonStep():
         self.aug = aug
         self.verbose = verbose
 
+    # ---- direction ----------------------------------------------------------------------------
+    def _direction(self, gradient, hessian):
+        """(dp, lowest eigenvalue, shift) as device tensors; no host synchronisation."""
+        dev = _lib.require_device()
+        g = ops.as_device(gradient, dev).reshape(-1)
+        H = ops.as_device(hessian, dev)
+        if g.numel() <= _lib.load().oovqe_newton_direction_max_n():
+            return ops.newton_direction(H, g, self.lambda_min, self.mu, self.rho, self.aug)
+        # beyond one workgroup's LDS (n > 480, e.g. N = 200 orbitals): torch's device eigh (rocSOLVER)
+        vals, vecs = torch.linalg.eigh(H)
+        low = vals[0]
+        nu = torch.where((low < self.lambda_min) & bool(self.aug), self.mu + self.rho * low.abs(),
+                         torch.zeros_like(low))
+        return -(vecs @ ((vecs.T @ g) / (vals + nu))), low, nu
+
     def newton_step(self, gradient, hessian):
-        """newton_raphson.py:78-129"""
-        vhessian, whessian = torch.linalg.eigh(hessian)
-        lowest_eigenvalue = vhessian[0].item()
+        """newton_raphson.py:78-129 -> (dp, lowest Hessian eigenvalue as a float)."""
+        dp, low, nu = self._direction(gradient, hessian)
+        lowest_eigenvalue, shift = torch.stack((low, nu)).tolist()
         if self.verbose:
             print("lowest eigval hessian =", lowest_eigenvalue)
-        if lowest_eigenvalue < self.lambda_min and self.aug:
-            if self.verbose:
-                print("augmenting hessian...")
-            # The reference diagonalises H + c*1 again (newton_raphson.py:116-120); its eigenvectors
-            # are those of H and its eigenvalues are shifted by c, so the second eigh (7 ms for the
-            # 331 x 331 Hessian of configs[3], half of the whole step) is replaced by the shift.
-            vhessian = vhessian + (self.mu + self.rho * abs(lowest_eigenvalue))
-            if self.verbose:
-                print("Lowest eigenvalue of augmented hessian:", vhessian[0].item())
-        hessian_inv = whessian @ torch.diag(1 / vhessian) @ whessian.T
-        dp = - (hessian_inv @ gradient)
+            if shift != 0.0:
+                print("augmenting hessian... lowest eigenvalue of augmented hessian:",
+                      lowest_eigenvalue + shift)
         return dp, lowest_eigenvalue
 
-    def backtracking(self, objective_fn, parameters, dp, gradient):
-        """newton_raphson.py:131-192"""
-        nargs = len(parameters)
-        t = 1.
-        energy = objective_fn(*parameters).item()
-        parameters_tot = torch.cat([parameter.flatten() for parameter in parameters])
-        paramshapes = [tuple(parameter.shape) for parameter in parameters]
-        newp = parameters_tot + (t * dp)
-        test_energy = objective_fn(*split_list_shapes(newp, paramshapes))
-        if test_energy > energy + wolfe(t, gradient, dp, alpha=self.alpha):
-            assert (wolfe(t, gradient, dp, alpha=self.alpha) < 0)
-            num = 0
+    # ---- line search --------------------------------------------------------------------------
+    def _search(self, objective_fn, parameters, dp, gradient, extra=None):
+        """Backtracking with the acceptance rule of newton_raphson.py:146-183.  Returns
+        (new parameters, new energy, host values of `extra`)."""
+        flat, shapes = _flatten(parameters)
+        dp = dp.to(flat.device)
+        slope = self.alpha * torch.dot(ops.as_device(gradient, flat.device).reshape(-1), dp)
+        at = lambda step: objective_fn(*split_list_shapes(flat + step * dp, shapes)).reshape(())  # noqa: E731
+        e_old = objective_fn(*parameters).reshape(())
+        e_try = at(1.0)
+        pack = [e_old.to(flat.device), e_try.to(flat.device), slope]
+        if extra is not None:
+            pack += [x.reshape(()) for x in extra]
+        host = torch.stack(pack).tolist()                      # the one readback of the common case
+        old, trial, slope_h = host[0], host[1], host[2]
+        step, reductions = 1.0, 0
+        if trial > old + step * slope_h:
+            if not slope_h < 0:
+                raise AssertionError("Newton direction is not a descent direction")
             if self.verbose:
-                print("test_energy:", test_energy.item(), "... old energy:", energy)
+                print("test_energy:", trial, "... old energy:", old)
                 print("do backtracking line search...")
-            while test_energy > energy + wolfe(t, gradient, dp, alpha=self.alpha):
-                t = self.beta * t
+            while trial > old + step * slope_h:
+                step *= self.beta
+                reductions += 1
                 if self.verbose:
-                    print("t =", t)
-                newp = parameters_tot + (t * dp)
-                test_energy = objective_fn(*split_list_shapes(newp, paramshapes))
-                num += 1
-                if num > self.lmax:
-                    t = 0.
-                    test_energy = objective_fn(*parameters)
+                    print("t =", step)
+                trial = at(step).item()
+                if reductions > self.lmax:
+                    # newton_raphson.py:177-183: after lmax + 1 reductions the search gives up and
+                    # returns the old parameters (whatever the last trial said)
+                    step, trial = 0.0, old
                     if self.verbose:
                         print("Warning: line search failed. Output previous parameters.")
                     break
-        new_energy = test_energy.item()
-        newp = parameters_tot + (t * dp)
         if self.verbose:
-            print("new energy:", new_energy)
-            print("old energy:", energy)
-        if nargs > 1:
-            new_parameters = tuple(split_list_shapes(newp, paramshapes))
-        else:
-            new_parameters = newp
-        return new_parameters, new_energy
+            print("new energy:", trial)
+            print("old energy:", old)
+        new_flat = flat + step * dp
+        new = tuple(split_list_shapes(new_flat, shapes)) if len(parameters) > 1 else new_flat
+        return new, trial, host[3:]
+
+    def backtracking(self, objective_fn, parameters, dp, gradient):
+        """newton_raphson.py:131-192 -> (new parameters, new energy)."""
+        new, energy, _ = self._search(objective_fn, parameters, dp, gradient)
+        return new, energy
 
     def damped_newton_step(self, objective_fn, parameters, gradient, hessian):
-        """newton_raphson.py:194-211"""
-        dp, lowest_eigenvalue = self.newton_step(gradient, hessian)
-        new_parameters, new_energy = self.backtracking(objective_fn, parameters, dp, gradient)
-        return new_parameters, lowest_eigenvalue
+        """newton_raphson.py:194-211 -> (new parameters, lowest Hessian eigenvalue).  One launch
+        for the direction, the lowest eigenvalue rides on the line search's readback."""
+        dp, low, nu = self._direction(gradient, hessian)
+        new, _, (lowest_eigenvalue, shift) = self._search(objective_fn, parameters, dp, gradient,
+                                                          extra=(low, nu))
+        if self.verbose:
+            print("lowest eigval hessian =", lowest_eigenvalue)
+            if shift != 0.0:
+                print("hessian was augmented by", shift)
+        return new, lowest_eigenvalue
 
 
 class BatchedNewtonStep(NewtonStep):
     """Extension (not in the reference): the same damped Newton step for G INDEPENDENT problems at
     once -- e.g. the geometries of a rank's shard, or independent Berry-phase loops in lockstep.
-    One batched ``eigh`` replaces G sequential ones (331 x 331 on MI355X: 16 ms for 64 matrices
-    against 7.3 ms each), and the line search synchronises with the host once per trial instead of
-    once per problem.  Per problem the arithmetic is that of ``NewtonStep`` (newton_raphson.py:78-211)."""
+    The G directions are one launch of G workgroups, and the line search synchronises with the
+    host once per trial instead of once per problem.  Per problem the arithmetic is that of
+    ``NewtonStep`` (newton_raphson.py:78-211)."""
 
     def newton_steps(self, gradients, hessians):
         """gradients [G, n], hessians [G, n, n] -> (dp [G, n], lowest eigenvalues [G])"""
-        v, w = torch.linalg.eigh(hessians)
-        low = v[:, 0]
+        dev = _lib.require_device()
+        g = ops.as_device(gradients, dev)
+        H = ops.as_device(hessians, dev)
+        if g.shape[-1] <= _lib.load().oovqe_newton_direction_max_n():
+            dp, low, _ = ops.newton_direction(H, g, self.lambda_min, self.mu, self.rho, self.aug)
+            return dp, low
+        vals, vecs = torch.linalg.eigh(H)
+        low = vals[:, 0]
+        shift = torch.zeros_like(low)
         if self.aug:
-            shift = torch.where(low < self.lambda_min, self.mu + self.rho * low.abs(),
-                                torch.zeros_like(low))
-            v = v + shift[:, None]
-        proj = torch.einsum("gji,gj->gi", w, gradients)          # w^T g
-        dp = -torch.einsum("gij,gj->gi", w, proj / v)
-        return dp, low
+            shift = torch.where(low < self.lambda_min, self.mu + self.rho * low.abs(), shift)
+        proj = torch.einsum("gji,gj->gi", vecs, g) / (vals + shift[:, None])
+        return -torch.einsum("gij,gj->gi", vecs, proj), low
 
     def damped_newton_steps(self, objective_fns, parameters, gradients, hessians):
         """objective_fns[g](*parameters[g]) -> 0-d tensor; parameters[g] = tuple of tensors.
@@ -136,7 +178,7 @@ class BatchedNewtonStep(NewtonStep):
                                 for g in range(G)])
 
         energy = evaluate(flat)
-        slope = self.alpha * (gradients * dp).sum(dim=1)          # wolfe(t) = t * slope
+        slope = self.alpha * (ops.as_device(gradients, flat.device) * dp).sum(dim=1)   # wolfe(t) = t * slope
         t = torch.ones(G, dtype=flat.dtype, device=flat.device)
         test = evaluate(flat + t[:, None] * dp)
         active = test > energy + t * slope
@@ -146,13 +188,13 @@ class BatchedNewtonStep(NewtonStep):
                 raise AssertionError("Newton direction is not a descent direction")
             t = torch.where(active, self.beta * t, t)
             num += 1
+            trial = evaluate(flat + t[:, None] * dp)
             if num > self.lmax:
-                # newton_raphson.py:177-183: give up on the problems still failing
+                # newton_raphson.py:177-183: give up on the problems still searching
                 t = torch.where(active, torch.zeros_like(t), t)
                 if self.verbose:
                     print("Warning: line search failed. Output previous parameters.")
                 break
-            trial = evaluate(flat + t[:, None] * dp)
             test = torch.where(active, trial, test)
             active = active & (test > energy + t * slope)
         newp = flat + t[:, None] * dp

@@ -412,3 +412,38 @@ def circuit_hessian(theta, gates_dev, n_gates, n_qubits, ncas, init_index, c1, c
                                              dptr(pairs_dev, torch.int32), n_pairs, n_theta, dptr(H),
                                              stream_ptr()), "oovqe_circuit_hessian_assemble")
     return H
+
+
+_NEWTON_WORK = {}
+
+
+def newton_direction(hessian, gradient, lambda_min=1e-6, mu=1e-6, rho=1.1, aug=True):
+    """dp = -(H + nu I)^-1 g with the reference's level shift (newton_raphson.py:78-129), on the
+    device in one launch (``oovqe_newton_direction``).  hessian [n,n] or [G,n,n], gradient [n] or
+    [G,n] -> (dp, lowest eigenvalues [G] (0-d for one problem), shifts nu)."""
+    lib = _lib.load()
+    dev = _dev(hessian)
+    single = hessian.dim() == 2
+    H = hessian.reshape(-1, hessian.shape[-1], hessian.shape[-1])
+    g = gradient.reshape(H.shape[0], -1)
+    G, n = g.shape
+    if n > lib.oovqe_newton_direction_max_n():
+        raise _lib.OovqeError(f"newton_direction: n = {n} exceeds the one-workgroup kernel "
+                              f"({lib.oovqe_newton_direction_max_n()})")
+    key = (n, G, str(dev))
+    work = _NEWTON_WORK.get(key)
+    if work is None:
+        _NEWTON_WORK.clear()
+        work = torch.empty(lib.oovqe_newton_direction_work_size(n, G), dtype=F64, device=dev)
+        _NEWTON_WORK[key] = work
+    H = H if H.is_contiguous() else H.contiguous()
+    g = g if g.is_contiguous() else g.contiguous()
+    dpc = torch.empty((G, n), dtype=F64, device=dev)
+    low = torch.empty(G, dtype=F64, device=dev)
+    nu = torch.empty(G, dtype=F64, device=dev)
+    check(lib.oovqe_newton_direction(dptr(H), dptr(g), n, G, float(lambda_min), float(mu), float(rho),
+                                     int(bool(aug)), dptr(work), dptr(dpc), dptr(low), dptr(nu),
+                                     stream_ptr()), "oovqe_newton_direction")
+    if single:
+        return dpc[0], low[0], nu[0]
+    return dpc, low, nu

@@ -181,8 +181,8 @@ def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl", mode="weak")
         dist.barrier()
     el = time.perf_counter() - t0
 
-    # the same steps for all geometries of the shard in lockstep (independent loops): one batched
-    # eigh and one host synchronisation per line-search trial (BatchedNewtonStep, an extension)
+    # the same steps for all geometries of the shard in lockstep (independent loops): one launch for
+    # all Newton directions and one host synchronisation per line-search trial (BatchedNewtonStep)
     bopt = aoo.BatchedNewtonStep(verbose=0)
 
     def lockstep():
@@ -193,7 +193,7 @@ def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl", mode="weak")
                                             [(theta0, k) for k in kap], grads, hess)
         return torch.stack([oo.energy_from_parameters(n[0], n[1]) for oo, n in zip(objs, new)])
 
-    lockstep()                                     # warm-up (batched eigh workspace)
+    lockstep()                                     # warm-up (workspace of the batched direction kernel)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -216,9 +216,32 @@ def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl", mode="weak")
             "lockstep": {"seconds": el_b, "geometries_per_s": n_geom / el_b,
                          "per_geometry_ms": el_b / max(len(objs), 1) * 1e3,
                          "max_abs_energy_difference_vs_sequential": agree,
-                         "note": "independent geometries stepped together: batched eigh, one host "
-                                 "sync per line-search trial (BatchedNewtonStep)"},
+                         "note": "independent geometries stepped together: one oovqe_newton_direction "
+                                 "launch (a workgroup per geometry), one host sync per line-search "
+                                 "trial (BatchedNewtonStep)"},
+            "newton_direction_us": newton_direction_timing(objs, theta0),
             "mean_energy_after_step": float(full.mean().item())}
+
+
+def newton_direction_timing(objs, theta0):
+    """The direction kernel alone (tridiagonalisation + Sturm multisection + solve, newton.hip) on
+    the shard's real Hessians: one problem per launch and all of them in one launch."""
+    from auto_oo_amd import ops
+    grads = torch.stack([oo.full_gradient(theta0) for oo in objs])
+    hess = torch.stack([oo.full_hessian(theta0) for oo in objs])
+
+    def timed(fn, reps):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e6
+    return {"n": int(grads.shape[1]), "single": timed(lambda: ops.newton_direction(hess[0], grads[0]), 20),
+            "batch": int(grads.shape[0]),
+            "batched_launch": timed(lambda: ops.newton_direction(hess, grads), 10)}
 
 
 def kupccd_extra():

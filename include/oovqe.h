@@ -234,6 +234,22 @@ int oovqe_circuit_hessian_assemble(const double* gamma, const double* Gamma, con
                                    const double* c2, int ncas, const int32_t* pairs, int n_pairs,
                                    int n_theta, double* H, oovqe_stream_t stream);
 
+/* ---- f1: damped-Newton direction (the caller of the path) --------------------------------------
+ * replaces NewtonStep.newton_step (src/auto_oo/utils/newton_raphson.py:78-129): lowest eigenvalue
+ * of the (n_theta + n_kappa)^2 Hessian, level shift nu = mu + rho |lambda_low| when
+ * lambda_low < lambda_min and aug != 0 (the reference's augmented Hessian, :107-120), and
+ * dp = -(H + nu I)^-1 g (:121-128), for `batch` independent problems, one workgroup each:
+ * blocked Householder tridiagonalisation + Sturm multisection + pivoted tridiagonal solve.
+ * hessian [batch,n,n] (symmetric, not modified), gradient [batch,n], dp [batch,n],
+ * lowest_eigenvalue [batch], shift [batch] (nu; may be NULL); n <= oovqe_newton_direction_max_n();
+ * work: oovqe_newton_direction_work_size(n, batch) doubles. */
+int oovqe_newton_direction(const double* hessian, const double* gradient, int n, int batch,
+                           double lambda_min, double mu, double rho, int aug, double* work,
+                           double* dp, double* lowest_eigenvalue, double* shift,
+                           oovqe_stream_t stream);
+int64_t oovqe_newton_direction_work_size(int n, int batch);
+int oovqe_newton_direction_max_n(void);
+
 /* ---- a10/a11/a13 at scale: particle-number-sector engine with reverse-mode gradients -------------
  * For circuits that conserve (N_alpha, N_beta) -- UCCD, UCCSD, kUpCCD -- the state lives in a
  * sector of C(a,N_alpha)*C(a,N_beta) determinants (4 900 of 65 536 for CAS(8e,8o)); the sector

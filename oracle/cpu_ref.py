@@ -738,6 +738,61 @@ class OracleOOPQC(OracleOOEnergy):
 
 
 # ----------------------------------------------------------------------------------------------
+# Damped Newton step of the reference on CPU tensors (utils/newton_raphson.py:78-211): two eigh
+# calls, explicit inverse, backtracking with the Armijo rule.  Checker for the device-side step.
+# ----------------------------------------------------------------------------------------------
+class OracleNewtonStep:
+    def __init__(self, alpha=0.0001, beta=.5, mu=1e-6, rho=1.1, lmax=20, lambda_min=1e-6, aug=True):
+        """newton_raphson.py:47-77"""
+        self.alpha, self.beta, self.mu, self.rho = alpha, beta, mu, rho
+        self.lmax, self.lambda_min, self.aug = lmax, lambda_min, aug
+
+    def newton_step(self, gradient, hessian):
+        """newton_raphson.py:107-128"""
+        vals, vecs = torch.linalg.eigh(hessian)
+        lowest = vals[0].item()
+        if lowest < self.lambda_min and self.aug:
+            hessian = hessian + (self.mu + self.rho * abs(lowest)) * torch.eye(hessian.shape[0],
+                                                                               dtype=hessian.dtype)
+            vals, vecs = torch.linalg.eigh(hessian)
+        dp = -((vecs @ torch.diag(1 / vals) @ vecs.T) @ gradient)
+        return dp, lowest
+
+    def backtracking(self, objective_fn, parameters, dp, gradient):
+        """newton_raphson.py:142-192"""
+        def cut(flat):
+            out, k = [], 0
+            for p in parameters:
+                out.append(flat[k:k + p.numel()].reshape(p.shape))
+                k += p.numel()
+            return out
+        armijo = lambda t: self.alpha * t * torch.dot(gradient, dp)      # noqa: E731  (:12-13)
+        t = 1.
+        energy = objective_fn(*parameters).item()
+        flat = torch.cat([p.flatten() for p in parameters])
+        test = objective_fn(*cut(flat + t * dp))
+        if test > energy + armijo(t):
+            assert armijo(t) < 0
+            num = 0
+            while test > energy + armijo(t):
+                t = self.beta * t
+                test = objective_fn(*cut(flat + t * dp))
+                num += 1
+                if num > self.lmax:
+                    t = 0.
+                    test = objective_fn(*parameters)
+                    break
+        newp = flat + t * dp
+        return (tuple(cut(newp)) if len(parameters) > 1 else newp), test.item()
+
+    def damped_newton_step(self, objective_fn, parameters, gradient, hessian):
+        """newton_raphson.py:194-211"""
+        dp, lowest = self.newton_step(gradient, hessian)
+        new_parameters, _ = self.backtracking(objective_fn, parameters, dp, gradient)
+        return new_parameters, lowest
+
+
+# ----------------------------------------------------------------------------------------------
 # Synthetic inputs "of the named shape" (SURVEY.md section 8(d)); shared by tests and bench.
 # ----------------------------------------------------------------------------------------------
 def synthetic_problem(nao, seed, n_aux=None, enuc=31.0):

@@ -1,0 +1,234 @@
+"""Row f1: the damped Newton step on the device (oovqe_newton_direction + NewtonStep /
+BatchedNewtonStep) against the reference's algorithm restated on CPU (oracle.OracleNewtonStep:
+two eigh calls + explicit inverse, utils/newton_raphson.py:78-211), the reference's own Newton
+property tests (test/utils/test_newton_raphson.py:99-130) run on the device, and BASELINE
+configs[3]'s unit of work at N = 43: full 331 x 331 Hessian (all three blocks) and one damped
+Newton step against the oracle, sequential == lockstep on 64 geometries."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import auto_oo_amd as aoo            # noqa: E402
+from auto_oo_amd import ops          # noqa: E402
+from oracle import cpu_ref as R      # noqa: E402
+from tests.test_api_gpu import _setup   # noqa: E402
+
+
+def _reference_direction(H, g, lambda_min=1e-6, mu=1e-6, rho=1.1, aug=True):
+    opt = R.OracleNewtonStep(mu=mu, rho=rho, lambda_min=lambda_min, aug=aug)
+    return opt.newton_step(g, H)
+
+
+def _sym(rng, n, kind):
+    A = rng.standard_normal((n, n))
+    if kind == "indefinite":
+        S = A + A.T
+    elif kind == "pd":
+        S = A @ A.T / n + 0.5 * np.eye(n)
+    elif kind == "near_singular":          # lowest eigenvalue in (0, lambda_min): shifted too
+        Q, _ = np.linalg.qr(A)
+        ev = np.linspace(0.5, 3.0, n)
+        ev[0] = 3e-7
+        S = (Q * ev) @ Q.T
+    else:                                   # diagonal: reflectors with tau = 0
+        S = np.diag(rng.standard_normal(n))
+    return 0.5 * (S + S.T)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 16, 17, 18, 33, 100, 331, 480])
+@pytest.mark.parametrize("kind", ["indefinite", "pd", "near_singular", "diagonal"])
+def test_newton_direction_vs_eigh(n, kind):
+    rng = np.random.default_rng(1000 * n + len(kind))
+    H = torch.tensor(_sym(rng, n, kind))
+    g = torch.tensor(rng.standard_normal(n))
+    dp_ref, low_ref = _reference_direction(H, g)
+    dp, low, nu = ops.newton_direction(H.cuda(), g.cuda())
+    scale = float(H.abs().max())
+    assert abs(low.item() - low_ref) < 1e-12 * max(1.0, scale) * n
+    expect_nu = 1e-6 + 1.1 * abs(low_ref) if low_ref < 1e-6 else 0.0
+    assert abs(nu.item() - expect_nu) < 1e-11 * max(1.0, scale) * n
+    # compare as residuals of the shifted system (the step itself is ill-conditioned by design
+    # when the shifted lowest eigenvalue is ~1e-6): (H + nu) dp + g = 0
+    Hs = H + nu.item() * torch.eye(n, dtype=torch.float64)
+    res = (Hs @ dp.cpu() + g).abs().max() / (1.0 + g.abs().max())
+    assert res < 1e-9, res
+    cond = float(torch.linalg.cond(Hs))
+    assert (dp.cpu() - dp_ref).abs().max() <= 1e-13 * cond * (1.0 + dp_ref.abs().max()) * n
+
+
+def test_newton_direction_batch_and_no_augmentation():
+    rng = np.random.default_rng(7)
+    n, G = 58, 19
+    Hs = torch.tensor(np.stack([_sym(rng, n, "indefinite" if k % 2 else "pd") for k in range(G)]))
+    gs = torch.tensor(rng.standard_normal((G, n)))
+    dp, low, nu = ops.newton_direction(Hs.cuda(), gs.cuda())
+    dp_na, low_na, nu_na = ops.newton_direction(Hs.cuda(), gs.cuda(), aug=False)
+    assert torch.equal(low, low_na) and float(nu_na.abs().max()) == 0.0
+    for k in range(G):
+        d1, l1, _ = ops.newton_direction(Hs[k].cuda(), gs[k].cuda())
+        assert torch.equal(d1, dp[k]) and torch.equal(l1, low[k])      # batch == one by one, bitwise
+        dr, lr = _reference_direction(Hs[k], gs[k])
+        assert abs(low[k].item() - lr) < 1e-11
+        assert (dp[k].cpu() - dr).abs().max() < 1e-8 * (1 + dr.abs().max())
+        dr_na, _ = _reference_direction(Hs[k], gs[k], aug=False)      # plain H^-1 g, indefinite or not
+        assert (dp_na[k].cpu() - dr_na).abs().max() < 1e-8 * (1 + dr_na.abs().max())
+    with pytest.raises(aoo._lib.OovqeError):
+        ops.newton_direction(torch.eye(481, dtype=torch.float64, device="cuda"),
+                             torch.ones(481, dtype=torch.float64, device="cuda"))
+
+
+def _quartic_problems(G, n, seed):
+    rng = np.random.default_rng(seed)
+    mats, x0s = [], []
+    for g in range(G):
+        A = rng.standard_normal((n, n))
+        S = A + A.T if g % 2 else A @ A.T + 0.1 * np.eye(n)      # odd g: indefinite at the start
+        mats.append(torch.tensor(S))
+        x0s.append(torch.tensor(rng.standard_normal(n)) * (3.0 if g >= G - 2 else 0.3))
+    return mats, x0s
+
+
+def test_damped_newton_step_vs_oracle_and_batched():
+    """NewtonStep.damped_newton_step == oracle step (incl. augmented Hessians and backtracking);
+    BatchedNewtonStep == NewtonStep problem by problem."""
+    n, G = 12, 6
+    mats, x0s = _quartic_problems(G, n, 11)
+
+    def make(S):
+        def f(a, b):
+            x = torch.cat((a, b))
+            Sx = S.to(x.device)
+            return 0.5 * x @ Sx @ x + 0.25 * (x ** 4).sum()       # quartic term: line search matters
+        return f
+    fns = [make(S) for S in mats]
+    grads = torch.stack([mats[g] @ x0s[g] + x0s[g] ** 3 for g in range(G)])
+    hess = torch.stack([mats[g] + torch.diag(3 * x0s[g] ** 2) for g in range(G)])
+    params_cpu = [(x[:5].clone(), x[5:].clone()) for x in x0s]
+    params_dev = [(a.cuda(), b.cuda()) for a, b in params_cpu]
+    opt, ref = aoo.NewtonStep(verbose=0), R.OracleNewtonStep()
+    new_b, low_b = aoo.BatchedNewtonStep(verbose=0).damped_newton_steps(fns, params_dev, grads.cuda(),
+                                                                       hess.cuda())
+    backtracked = 0
+    for g in range(G):
+        new_s, low_s = opt.damped_newton_step(fns[g], params_dev[g], grads[g].cuda(), hess[g].cuda())
+        new_r, low_r = ref.damped_newton_step(fns[g], params_cpu[g], grads[g], hess[g])
+        assert isinstance(low_s, float) and abs(low_s - low_r) < 1e-11
+        full = torch.cat([x.flatten() for x in new_r]) - torch.cat([x.flatten() for x in params_cpu[g]])
+        dp_r, _ = ref.newton_step(grads[g], hess[g])
+        backtracked += int((full - dp_r).abs().max() > 1e-6)
+        for a, b, c in zip(new_s, new_r, new_b[g]):
+            assert a.shape == b.shape and (a.cpu() - b).abs().max() < 1e-9 * max(1.0, float(b.abs().max()))
+            assert (c - a).abs().max() < 1e-12 * max(1.0, float(b.abs().max()))
+        assert abs(low_b[g].item() - low_s) < 1e-13
+    assert backtracked >= 1                      # the far starts really exercise the line search
+    # single-argument objective: a flat tensor comes back (newton_raphson.py:187-190)
+    f1 = lambda x: fns[0](x[:5], x[5:])          # noqa: E731
+    new1, _ = opt.damped_newton_step(f1, (x0s[0].cuda(),), grads[0].cuda(), hess[0].cuda())
+    assert isinstance(new1, torch.Tensor) and new1.shape == (n,)
+    # a non-descent direction with a rejected first trial is an assertion, as in the reference
+    with pytest.raises(AssertionError):
+        opt.backtracking(lambda x: (x ** 2).sum(), (torch.ones(3, dtype=torch.float64, device="cuda"),),
+                         torch.ones(3, dtype=torch.float64, device="cuda"),
+                         torch.ones(3, dtype=torch.float64, device="cuda") * 2)
+
+
+def _newton_optimize(cost, x0, max_iterations, conv_tol, **kw):
+    from torch.autograd.functional import jacobian, hessian
+    opt = aoo.NewtonStep(verbose=0, **kw)
+    theta = x0
+    energies = [cost(theta).item()]
+    for n in range(max_iterations):
+        theta, _ = opt.damped_newton_step(cost, (theta,), jacobian(cost, theta), hessian(cost, theta))
+        energies.append(cost(theta).item())
+        if n > 1 and abs(energies[-1] - energies[-2]) < conv_tol:
+            break
+    return energies, theta
+
+
+@pytest.mark.parametrize("dim,max_iterations,conv_tol,lambda_min,rho,mu",
+                         [(2, 20, 1e-12, 1e-6, 2, 1e-4), (4, 20, 1e-12, 1e-6, 2, 1e-4),
+                          (8, 50, 1e-10, 1e-6, 3, 1e-4)])
+def test_reference_property_type_a_on_device(dim, max_iterations, conv_tol, lambda_min, rho, mu):
+    """test/utils/test_newton_raphson.py:99-116 with the device-side step."""
+    gen = torch.Generator().manual_seed(dim)
+    a = torch.rand(dim, dim, generator=gen, dtype=torch.float64) - 0.5
+    a = (a.T + a).cuda()
+    va = torch.linalg.eigvalsh(a)
+
+    def cost(x):
+        u = torch.linalg.matrix_exp(-aoo.vector_to_skew_symmetric(x))
+        return ((u.T @ a @ u - torch.diag(va)) ** 2).sum()
+    x0 = (1e-5 * (torch.rand(dim * (dim - 1) // 2, generator=gen, dtype=torch.float64) - 0.5)).cuda()
+    energies, x = _newton_optimize(cost, x0, max_iterations, conv_tol, aug=True,
+                                   lambda_min=lambda_min, rho=rho, mu=mu)
+    assert abs(energies[-1]) < 1e-8
+    u = torch.linalg.matrix_exp(-aoo.vector_to_skew_symmetric(x))
+    assert torch.allclose(u.T @ a @ u, torch.diag(va), atol=1e-6)
+
+
+@pytest.mark.parametrize("t,max_iterations", [(4.0, 10), (3.0, 10), (0.00004, 100)])
+def test_reference_property_type_b_on_device(t, max_iterations):
+    """test/utils/test_newton_raphson.py:119-130: plain damped Newton with backtracking, n = 1."""
+    def cost(x):
+        return (-t * torch.log(torch.abs(x)) + torch.abs(x) - t + t * np.log(t)).sum()
+    energies, x = _newton_optimize(cost, torch.tensor([10.0], dtype=torch.float64, device="cuda"),
+                                   max_iterations, 1e-12, aug=False)
+    assert abs(energies[-1]) < 1e-8
+
+
+def test_config3_unit_of_work_at_cc_pvdz_shape():
+    """BASELINE configs[3] at N = 43: energy + full gradient + full 331 x 331 Hessian (theta-theta,
+    kappa-theta, kappa-kappa) + one damped Newton step, against the oracle (1e-8 abs, 1e-9 Ha)."""
+    ooo, opqc, oo, pqc = _setup(43, 20262)
+    theta = torch.full((pqc.theta_shape,), 0.1, dtype=torch.float64)
+    grad = oo.full_gradient(theta)
+    hess = oo.full_hessian(theta)
+    g_ref = ooo.full_gradient(theta)
+    h_ref = ooo.full_hessian(theta)
+    nt = pqc.theta_shape
+    assert hess.shape == (331, 331) and h_ref.shape == (331, 331)
+    assert (grad.cpu() - g_ref).abs().max() < 1e-8
+    assert (hess[:nt, :nt].cpu() - h_ref[:nt, :nt]).abs().max() < 1e-8      # circuit-circuit
+    assert (hess[nt:, :nt].cpu() - h_ref[nt:, :nt]).abs().max() < 1e-8      # orbital-circuit
+    assert (hess[:nt, nt:].cpu() - h_ref[:nt, nt:]).abs().max() < 1e-8
+    assert (hess[nt:, nt:].cpu() - h_ref[nt:, nt:]).abs().max() < 1e-8      # orbital-orbital
+    kappa = torch.zeros(oo.n_kappa, dtype=torch.float64)
+    new, low = aoo.NewtonStep(verbose=0).damped_newton_step(
+        oo.energy_from_parameters, (theta.cuda(), kappa.cuda()), grad, hess)
+    new_r, low_r = R.OracleNewtonStep().damped_newton_step(ooo.energy_from_parameters, (theta, kappa),
+                                                           g_ref, h_ref)
+    assert abs(low - low_r) < 1e-9
+    e_new = oo.energy_from_parameters(new[0], new[1]).item()
+    e_ref = ooo.energy_from_parameters(new_r[0], new_r[1]).item()
+    assert abs(e_new - e_ref) < 1e-9
+    assert e_new < oo.energy_from_parameters(theta).item()
+    assert (new[0].cpu() - new_r[0]).abs().max() < 1e-7 and (new[1].cpu() - new_r[1]).abs().max() < 1e-7
+
+
+def test_lockstep_newton_equals_sequential_on_64_geometries():
+    """configs[3]: 64 geometries stepped one by one (NewtonStep) and in lockstep (BatchedNewtonStep)."""
+    from auto_oo_amd.synthetic import synthetic_problem
+    N, G = 43, 64
+    pqc = aoo.Parameterized_circuit(3, 4, None, ansatz="ucc")
+    objs = []
+    for g in range(G):
+        P = synthetic_problem(N, 20262 + 1000 * g)
+        mol = aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], 16)
+        objs.append(aoo.OO_pqc(pqc, mol, 3, 4, oao_mo_coeff=P["oao_mo_coeff"]))
+    theta0 = torch.full((pqc.theta_shape,), 0.1, dtype=torch.float64, device="cuda")
+    kap = [torch.zeros(oo.n_kappa, dtype=torch.float64, device="cuda") for oo in objs]
+    grads = torch.stack([oo.full_gradient(theta0) for oo in objs])
+    hess = torch.stack([oo.full_hessian(theta0) for oo in objs])
+    new_b, low_b = aoo.BatchedNewtonStep(verbose=0).damped_newton_steps(
+        [oo.energy_from_parameters for oo in objs], [(theta0, k) for k in kap], grads, hess)
+    opt = aoo.NewtonStep(verbose=0)
+    for g in range(0, G, 7):
+        new_s, low_s = opt.damped_newton_step(objs[g].energy_from_parameters, (theta0, kap[g]),
+                                              grads[g], hess[g])
+        assert abs(low_b[g].item() - low_s) < 1e-13
+        e_b = objs[g].energy_from_parameters(*new_b[g]).item()
+        e_s = objs[g].energy_from_parameters(*new_s).item()
+        assert abs(e_b - e_s) < 1e-10
+        assert (new_b[g][1] - new_s[1]).abs().max() < 1e-10
