@@ -12,7 +12,9 @@ estimates the Berry phase from the overlaps <psi_b| G_{a->b} |psi_a> around the 
 
 Here the same operator is applied without ever forming a 2^n x 2^n matrix: a determinant |I> =
 |I_alpha, I_beta> goes to  sum_J  det U[J_alpha, I_alpha] det U[J_beta, I_beta] |J>  (U = C_{a->b}
-made exactly orthogonal by its polar factor; the spin sectors only mix inside themselves), so in
+made exactly orthogonal the way the notebook's route does it, see givens_orthogonal; the spin
+sectors only mix inside themselves; nothing needs det U = +1, which matters: the orbitals of a loop
+around a conical intersection come back with det U = -1), so in
 the (N_alpha, N_beta) sector the map is  psi' = M_alpha psi M_beta^T  with the minor matrices
 M[J, I] = det U[J, I] -- two small dense products on the device (``oovqe_matmul_nn``).  The sign
 that reorders the interleaved Jordan-Wigner operator string (alpha_0 beta_0 alpha_1 ...) into
@@ -51,6 +53,19 @@ def polar_orthogonal(mat):
     return u @ vt
 
 
+def givens_orthogonal(mat):
+    """The orthogonal matrix the notebook's route actually applies when the active block is not
+    orthogonal (it never is exactly: the Newton step also mixes active with inactive / virtual
+    orbitals): openfermion.bogoliubov_transform zeroes the upper triangle of its argument
+    (= the transposed block) with Givens rotations of adjacent columns and keeps only the signs of
+    the remaining diagonal, i.e. it uses the Q factor of block = Q R with a positive diagonal of R
+    (Gram-Schmidt on the block's columns).  Reproduces the ten overlaps printed in
+    examples/Tutorial_Berry_phase.ipynb (cell 32) to 1e-7; the polar factor differs from them by
+    up to 1.3e-2."""
+    q, r = np.linalg.qr(np.asarray(mat, dtype=np.float64))
+    return q * np.where(np.diag(r) < 0, -1.0, 1.0)
+
+
 def minor_matrix(U, strings, ncas):
     """M[J, I] = det U[occ(J), occ(I)] over the given occupation strings."""
     occ = [_occupied(s, ncas) for s in strings]
@@ -85,12 +100,18 @@ class ActiveSpaceRotation:
     the (N_alpha, N_beta) sector of a 2*ncas-qubit register (the sector every UCC / kUpCCD /
     GateFabric state of the package lives in)."""
 
-    def __init__(self, U, ncas, n_alpha, n_beta, device=None, orthogonalize=True):
+    def __init__(self, U, ncas, n_alpha, n_beta, device=None, orthogonalize="givens"):
+        """orthogonalize: "givens" (default; what the notebook's openfermion route does, see
+        givens_orthogonal), "polar" (closest orthogonal matrix), or False (U is used as it is)."""
         U = np.asarray(U, dtype=np.float64)
         if U.shape != (ncas, ncas):
             raise ValueError(f"U must be [{ncas}, {ncas}], got {U.shape}")
-        if orthogonalize:
+        if orthogonalize is True or orthogonalize == "givens":
+            U = givens_orthogonal(U)
+        elif orthogonalize == "polar":
             U = polar_orthogonal(U)
+        elif orthogonalize:
+            raise ValueError("orthogonalize must be 'givens', 'polar' or False")
         self.U, self.ncas = U, ncas
         self.strings_a, self.strings_b, self.index, self.sign = sector_tables(ncas, n_alpha, n_beta)
         self.M_alpha = minor_matrix(U, self.strings_a, ncas)
@@ -136,7 +157,7 @@ class ActiveSpaceRotation:
         return out
 
 
-def bogoliubov_atob_cas(mo_atob, active_indices, nelecas, device=None):
+def bogoliubov_atob_cas(mo_atob, active_indices, nelecas, device=None, orthogonalize="givens"):
     """Notebook cell 28: the active-space Bogoliubov transformation of ``mo_atob`` =
     oao_mo_coeff_a^T @ oao_mo_coeff_b, as an operator on (N_alpha, N_beta)-sector states
     (``nelecas`` electrons, closed shell or high-spin-first as ``hf_state`` fills the wires)."""
@@ -146,7 +167,7 @@ def bogoliubov_atob_cas(mo_atob, active_indices, nelecas, device=None):
     ncas = len(act)
     occ = [1 if i < nelecas else 0 for i in range(2 * ncas)]
     n_alpha, n_beta = sector_of(occ, ncas)
-    return ActiveSpaceRotation(U, ncas, n_alpha, n_beta, device=device)
+    return ActiveSpaceRotation(U, ncas, n_alpha, n_beta, device=device, orthogonalize=orthogonalize)
 
 
 def state_overlap(state_b, rotation, state_a):

@@ -832,3 +832,32 @@ def bogoliubov_unitary(U_act):
     ops = RdmOperators(ncas)
     K = sum(logU[p, q] * ops.E[p][q].toarray() for p in range(ncas) for q in range(ncas))
     return scipy.linalg.expm(K)
+
+
+def orbital_rotation_operator(U_act):
+    """The same operator from its action on determinants, valid for ANY orthogonal U (also
+    det U = -1, which is what a Berry-phase loop around a conical intersection returns to):
+    G a+_{q sigma} G^-1 = sum_p U_pq a+_{p sigma},  G |vac> = |vac>  (the notebook's gauge
+    G[0, 0] = 1, Tutorial_Berry_phase.ipynb cell 28), hence
+    G |m1 m2 ...> = b+_{m1} b+_{m2} ... |vac>.  Dense 2^n x 2^n from Jordan-Wigner operators."""
+    U_act = np.asarray(U_act, dtype=np.float64)
+    ncas = U_act.shape[0]
+    n = 2 * ncas
+    a = _jw_annihilators(n)
+    ad = [m.T.toarray() for m in a]
+    b_dag = []
+    for m in range(n):
+        q, spin = divmod(m, 2)
+        b_dag.append(sum(U_act[p, q] * ad[2 * p + spin] for p in range(ncas)))
+    D = 1 << n
+    vac = np.zeros(D)
+    vac[0] = 1.0
+    G = np.zeros((D, D))
+    for I in range(D):
+        modes = [m for m in range(n) if (I >> (n - 1 - m)) & 1]      # wire 0 = most significant bit
+        vec = vac
+        for m in reversed(modes):
+            vec = b_dag[m] @ vec
+        G[:, I] = vec
+    return G
+

@@ -31,6 +31,25 @@ def test_sector_minors_equal_operator_exponential(ncas, nelecas):
     outside = np.setdiff1d(np.arange(G_ref.shape[0]), idx)
     assert np.abs(G_ref[np.ix_(outside, idx)]).max() < 1e-12
     assert abs(G_ref[0, 0] - 1.0) < 1e-12             # the notebook's gauge: vacuum phase 1
+    # and the determinant-by-determinant definition (valid for improper rotations too) agrees
+    assert np.abs(R.orbital_rotation_operator(U) - G_ref).max() < 1e-12
+
+
+@pytest.mark.parametrize("ncas,nelecas", [(2, 2), (3, 4)])
+def test_sector_minors_for_an_improper_rotation(ncas, nelecas):
+    """det U = -1 (what the orbitals of a closed Berry-phase loop come back with): no real
+    logarithm exists, the minor form must equal the determinant-by-determinant operator."""
+    from auto_oo_amd.berry import ActiveSpaceRotation
+    from auto_oo_amd.sector import sector_of
+    U = _rotation(ncas, 3 * ncas + nelecas)
+    U[:, 0] *= -1.0
+    assert np.linalg.det(U) < 0
+    occ = [1 if i < nelecas else 0 for i in range(2 * ncas)]
+    na, nb = sector_of(occ, ncas)
+    rot = ActiveSpaceRotation(U, ncas, na, nb, orthogonalize=False)
+    G_ref = R.orbital_rotation_operator(U)
+    idx = rot.index.reshape(-1)
+    assert np.abs(G_ref[np.ix_(idx, idx)] - rot.dense()[np.ix_(idx, idx)]).max() < 1e-12
 
 
 def test_polar_factor_and_identity():
@@ -39,6 +58,11 @@ def test_polar_factor_and_identity():
     noisy = U + 1e-3 * np.random.default_rng(1).standard_normal((3, 3))
     Q = polar_orthogonal(noisy)
     assert np.abs(Q.T @ Q - np.eye(3)).max() < 1e-13 and np.abs(Q - U).max() < 5e-3
+    from auto_oo_amd.berry import givens_orthogonal
+    Qg = givens_orthogonal(noisy)
+    assert np.abs(Qg.T @ Qg - np.eye(3)).max() < 1e-13 and np.abs(Qg - U).max() < 1e-2
+    assert np.all(np.diag(Qg.T @ noisy) > 0) and np.abs(np.tril(Qg.T @ noisy, -1)).max() < 1e-13
+    assert np.abs(givens_orthogonal(U) - U).max() < 1e-13       # an orthogonal block is left alone
     eye = ActiveSpaceRotation(np.eye(3), 3, 2, 2)
     assert np.abs(eye.M_alpha - np.eye(eye.M_alpha.shape[0])).max() == 0.0
 
