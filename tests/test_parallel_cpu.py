@@ -69,8 +69,8 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     env["OOVQE_BENCH_ECHO_RANK"] = "1"
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
-                          "--master-port", "29656"], env=env, capture_output=True, text=True, timeout=300)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"],
+                         env=env, capture_output=True, text=True, timeout=300)   # the launcher picks a free port
     assert res.returncode != 0
     text = res.stdout + res.stderr
     assert "rank 0 of 2" in text and "rank 1 of 2" in text
