@@ -128,6 +128,8 @@ SIGNATURES = {
     "oovqe_eri_packed_size": (ctypes.c_int64, [ctypes.c_int]),
     "oovqe_eri_pack": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, c_stream]),
     "oovqe_circuit_rdms_is_small": (ctypes.c_int, [ctypes.c_int] * 4),
+    "oovqe_debug_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    "oovqe_debug_get_option": (ctypes.c_int, [ctypes.c_char_p]),
     "oovqe_newton_direction": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                               ctypes.c_int, c_double_p, c_double_p, c_double_p,
@@ -155,6 +157,33 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+class debug_options:
+    """Context manager for the library's test / measurement switches (include/oovqe.h:
+    oovqe_debug_set_option), e.g. ``with debug_options(cas_unfused=1): ...``.  Restores the previous
+    values on exit.  For tests/ and tools/; product code never sets them."""
+
+    def __init__(self, **options):
+        self.options = options
+        self.saved = {}
+
+    def __enter__(self):
+        lib = load()
+        for name, value in self.options.items():
+            key = name.encode()
+            old = lib.oovqe_debug_get_option(key)
+            if old < 0:
+                raise OovqeError(f"unknown debug option {name!r}")
+            self.saved[name] = old
+            check(lib.oovqe_debug_set_option(key, int(value)), "oovqe_debug_set_option")
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        for name, value in self.saved.items():
+            lib.oovqe_debug_set_option(name.encode(), value)
+        return False
 
 
 def check(rc, what):

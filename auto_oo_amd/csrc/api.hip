@@ -29,6 +29,29 @@ extern "C" int oovqe_device_count(void)
     return n;
 }
 
+// ---- test / measurement switches (common.h: oovqe_option_t) -------------------------------------
+static int g_opts[OOVQE_OPT_COUNT] = {0};
+static const char* const g_opt_names[OOVQE_OPT_COUNT] = {
+    "half_stream_old", "gm_two_per_cu", "gm_one_per_cu", "fused_chunks", "tri_plain_w", "cas_unfused",
+    "sym_no_rs", "sym_mirror", "sym_simple", "sym_two_step", "no_ride"};
+
+int oovqe_opt(int id) { return (id >= 0 && id < OOVQE_OPT_COUNT) ? g_opts[id] : 0; }
+
+extern "C" int oovqe_debug_set_option(const char* name, int value)
+{
+    for (int i = 0; name && i < OOVQE_OPT_COUNT; ++i)
+        if (strcmp(name, g_opt_names[i]) == 0) { g_opts[i] = value; return 0; }
+    oovqe_set_error("oovqe_debug_set_option: unknown option '%s'", name ? name : "(null)");
+    return OOVQE_ERR_ARG;
+}
+
+extern "C" int oovqe_debug_get_option(const char* name)
+{
+    for (int i = 0; name && i < OOVQE_OPT_COUNT; ++i)
+        if (strcmp(name, g_opt_names[i]) == 0) return g_opts[i];
+    return -1;
+}
+
 // ---- optional HIP-event timing of the evaluation kernels (bench.py: roofline + breakdown) -------
 // Events come from a pool created in oovqe_profile_begin (nothing is allocated inside the timed
 // region); launches beyond the pool size are simply not bracketed.  Label 0 is the dominant

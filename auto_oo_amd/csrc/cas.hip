@@ -2085,7 +2085,7 @@ static int half_transform_batched(const double* g_ao, const double* C, int N, in
         else OOVQE_LAUNCH_HALF(Z, 16, 0);   /* N > 48 (kch == 16 there) */                        \
     } while (0)
     // N > 48: persistent streaming kernel.  k-chunk depth with the least padding (ties: deeper)
-    const bool stream_old = getenv("OOVQE_HALF_STREAM_OLD") != nullptr;   // A/B hook for tools/
+    const bool stream_old = oovqe_opt(OOVQE_OPT_HALF_STREAM_OLD) != 0;   // A/B hook for tools/
     if (nrb > 3 && !stream_old) {
         int skch = 16, waste = 1 << 30;
         for (int k = 16; k >= 10; --k) {
@@ -2223,8 +2223,8 @@ static int sym_gm_batched(const double* J, const double* C, double* Gm, int N, i
     } while (0)
     // (measurement hooks: OOVQE_GM_TWO_PER_CU / OOVQE_GM_ONE_PER_CU force a build; 128 geometries:
     // 45 -> 38 us with two per CU, 64 geometries: no difference)
-    const bool multi_round = ((long)(nty + (cj ? 1 : 0)) * batch > (long)device_cu_count() || getenv("OOVQE_GM_TWO_PER_CU")) &&
-                             2 * lds_bytes <= 160 * 1024 && getenv("OOVQE_GM_ONE_PER_CU") == nullptr;
+    const bool multi_round = ((long)(nty + (cj ? 1 : 0)) * batch > (long)device_cu_count() || oovqe_opt(OOVQE_OPT_GM_TWO_PER_CU)) &&
+                             2 * lds_bytes <= 160 * 1024 && oovqe_opt(OOVQE_OPT_GM_ONE_PER_CU) == 0;
 #define OOVQE_LAUNCH_GM(KS_)                                                                      \
     do {                                                                                          \
         if (multi_round) OOVQE_LAUNCH_GM2(KS_, 4);                                                \
@@ -2265,9 +2265,8 @@ static int device_cu_count()
 static bool fused_plan(int N, int M, int batch, FusedPlan* fp)
 {
     if (M > 16 || N > 48 || N < 1) return false;
-    // test hooks: OOVQE_FUSED_CHUNKS=n forces n chunks of the q range (and the fused path)
-    const char* ce = getenv("OOVQE_FUSED_CHUNKS");   // read per call so that tests can switch it
-    const long chunks_env = ce ? atol(ce) : 0;
+    // test hook: option fused_chunks = n forces n chunks of the q range (and the fused path)
+    const long chunks_env = oovqe_opt(OOVQE_OPT_FUSED_CHUNKS);
     const long m2 = (long)M * M, m3 = m2 * M;
     const int n_cu = device_cu_count();
     // The persistent kernel pays off once the sweep is bandwidth-bound (>= ~6 slabs per wave on
@@ -2390,7 +2389,7 @@ static int half_tri_batched(const double* g_ao, const double* C, int N, int M, d
     long W = n_cu / batch;
     if (W < 1) W = 1;
     if (W > w_max) W = w_max;
-    if (getenv("OOVQE_TRI_PLAIN_W") == nullptr) {   // (test / measurement hook: keep W = n_cu / batch)
+    if (oovqe_opt(OOVQE_OPT_TRI_PLAIN_W) == 0) {   // (test / measurement hook: keep W = n_cu / batch)
         auto cost = [&](long w) {
             return ((long)batch * w + n_cu - 1) / n_cu * ((tri + w * HALF_WAVES - 1) / (w * HALF_WAVES) + 3);
         };
@@ -2559,18 +2558,18 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
     int rc;
     // fused path: T3 = stage 1 + q -> x in one kernel, then the small p -> n contraction gives
     // g_mo[n,x,y,z] directly; T2 path (M > 16 or N > 48): T2, U = C^T T2, q -> x in the column kernel
-    const bool unfused_env = getenv("OOVQE_CAS_UNFUSED") != nullptr;   // test hook, read per call
+    const bool unfused_env = oovqe_opt(OOVQE_OPT_CAS_UNFUSED) != 0;   // test hook, read per call
     FusedPlan fp;
     const bool fused = !unfused_env && fused_plan(N, M, batch, &fp);
     const double* Gm_in = nullptr;
     // p <-> q symmetric integrals (verified by the caller): only the slabs p <= q are read
     const bool pq_sym = (eri_flags & OOVQE_ERI_PQ_SYMMETRIC) != 0;
     // r <-> s symmetric as well: J[p,q,y,z] == J[p,q,z,y], the packed path keeps the columns y <= z
-    const bool rs_sym = (eri_flags & OOVQE_ERI_RS_SYMMETRIC) != 0 && getenv("OOVQE_SYM_NO_RS") == nullptr;
+    const bool rs_sym = (eri_flags & OOVQE_ERI_RS_SYMMETRIC) != 0 && oovqe_opt(OOVQE_OPT_SYM_NO_RS) == 0;
     const int half_sym = pq_sym ? SYM_MIRROR : SYM_FULL;
     const long tri = (long)N * (N + 1) / 2;
     const long nty16 = (m2 + 15) / 16 * 16;               // tile-major J rows are padded to 16
-    const bool sym_packed = fused && pq_sym && getenv("OOVQE_SYM_MIRROR") == nullptr &&
+    const bool sym_packed = fused && pq_sym && oovqe_opt(OOVQE_OPT_SYM_MIRROR) == 0 &&
                             tri * nty16 + 2 * (long)N * m3 <= 2 * (long)N * N * m2;
     if (sym_packed) {
         // packed triangle J (instead of the fused kernel: its q -> x contraction needs whole rows
@@ -2581,8 +2580,8 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
         // test hooks: OOVQE_SYM_SIMPLE = the one-slab-per-wave kernel (direct stores) instead of the
         // persistent one; OOVQE_SYM_TWO_STEP = q -> x kernel, then K1, instead of the one-launch
         // kernel (both on the row-major J)
-        const bool simple = getenv("OOVQE_SYM_SIMPLE") != nullptr;
-        const bool two_step = simple || getenv("OOVQE_SYM_TWO_STEP") != nullptr;
+        const bool simple = oovqe_opt(OOVQE_OPT_SYM_SIMPLE) != 0;
+        const bool two_step = simple || oovqe_opt(OOVQE_OPT_SYM_TWO_STEP) != 0;
         if (simple) {
             if ((rc = half_transform_batched(g_ao, C, N, M, Jp, batch, stream, SYM_PACKED))) return rc;
         } else {
@@ -2804,7 +2803,7 @@ static int oo_eval_batched(const double* theta, int n_theta, const oovqe_gate_t*
     // evaluation); otherwise it is launched here.  OOVQE_NO_RIDE=1 forces the separate launch.
     oovqe_circuit_job_t cj;
     bool ride = false;
-    if (oovqe_circuit_rdms_is_small(n_qubits, ncas, nvec, n_gates) && getenv("OOVQE_NO_RIDE") == nullptr) {
+    if (oovqe_circuit_rdms_is_small(n_qubits, ncas, nvec, n_gates) && oovqe_opt(OOVQE_OPT_NO_RIDE) == 0) {
         const int M = n_occ + ncas;
         const long m2 = (long)M * M, m3 = m2 * M;
         cj.theta = theta;
@@ -2820,7 +2819,7 @@ static int oo_eval_batched(const double* theta, int n_theta, const oovqe_gate_t*
         cj.init_index = init_index;
         cj.lds_bytes = oovqe_small_circuit_lds_bytes(n_qubits, ncas, nvec, n_gates);
         FusedPlan fp;
-        const bool fused = getenv("OOVQE_CAS_UNFUSED") == nullptr && fused_plan(N, M, batch, &fp);
+        const bool fused = oovqe_opt(OOVQE_OPT_CAS_UNFUSED) == 0 && fused_plan(N, M, batch, &fp);
         const long K = fused ? (long)fp.nchunk * N : N, B = fused ? m3 : (long)N * m2;
         ride = cj.lds_bytes <= 64 * 1024 && K <= 0x7fffffffL &&
                oovqe_contract_hosts_circuit(1, (int)K, N, B, 0, batch);

@@ -21,6 +21,25 @@ void oovqe_profile_mark_start(hipStream_t st);
 void oovqe_profile_mark_start_l(hipStream_t st, int label);
 void oovqe_profile_mark_stop(hipStream_t st);
 
+// Test / measurement switches between realisations that compute the same numbers (set through
+// oovqe_debug_set_option, never from the environment: the production path does not depend on the
+// caller's environment variables).  All default to 0.
+enum oovqe_option_t {
+    OOVQE_OPT_HALF_STREAM_OLD = 0,   // pre-persistent streaming kernel for N > 48
+    OOVQE_OPT_GM_TWO_PER_CU,         // force the 128-VGPR build of sym_gm_kernel
+    OOVQE_OPT_GM_ONE_PER_CU,         // force its one-workgroup-per-CU build
+    OOVQE_OPT_FUSED_CHUNKS,          // n > 0: force the batched plan with n chunks of q
+    OOVQE_OPT_TRI_PLAIN_W,           // W = CUs / batch in half_tri_kernel (no cost model)
+    OOVQE_OPT_CAS_UNFUSED,           // T2 path
+    OOVQE_OPT_SYM_NO_RS,             // ignore the r<->s flag
+    OOVQE_OPT_SYM_MIRROR,            // mirrored T2 instead of the packed triangle
+    OOVQE_OPT_SYM_SIMPLE,            // one-slab-per-wave triangle kernel
+    OOVQE_OPT_SYM_TWO_STEP,          // q->x kernel + K1 instead of the one-launch kernel
+    OOVQE_OPT_NO_RIDE,               // circuit + RDM step as its own launch
+    OOVQE_OPT_COUNT
+};
+int oovqe_opt(int id);
+
 #define OOVQE_CHECK_LAUNCH(name)                                                          \
     do {                                                                                  \
         hipError_t e__ = hipGetLastError();                                               \

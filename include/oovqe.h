@@ -62,6 +62,13 @@ typedef struct {
     int32_t  pos[4];     /* bit positions of mask_hi|mask_lo, ascending                        */
 } oovqe_gate_t;
 
+/* Test / measurement switches between realisations that compute the same numbers (which kernel
+ * variant a call takes): "half_stream_old", "gm_two_per_cu", "gm_one_per_cu", "fused_chunks" (int),
+ * "tri_plain_w", "cas_unfused", "sym_no_rs", "sym_mirror", "sym_simple", "sym_two_step", "no_ride".
+ * All 0 by default; the library never reads environment variables.  tests/ and tools/ only. */
+int oovqe_debug_set_option(const char* name, int value);
+int oovqe_debug_get_option(const char* name);
+
 /* ---- a1: four-index transform --------------------------------------------------------------
  * replaces general_4index_transform / uniform_4index_transform / int2e_transform
  * (src/auto_oo/oo_energy.py:21-30,33-41,49-51):

@@ -17,3 +17,19 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def lib_options():
+    """Set the library's test / measurement switches for one test (include/oovqe.h:
+    oovqe_debug_set_option) and restore them afterwards: ``lib_options(cas_unfused=1)``."""
+    from auto_oo_amd import _lib
+    active = []
+
+    def set_options(**options):
+        ctx = _lib.debug_options(**options)
+        ctx.__enter__()
+        active.append(ctx)
+    yield set_options
+    for ctx in reversed(active):
+        ctx.__exit__(None, None, None)

@@ -134,16 +134,16 @@ def test_errors_match_reference_behaviour():
 
 @pytest.mark.parametrize("mode", ["default", "no_ride", "t3x1", "t2"])
 @pytest.mark.parametrize("N,G", [(13, 5), (43, 3)])
-def test_batched_evaluation_matches_single(N, G, mode, monkeypatch):
+def test_batched_evaluation_matches_single(N, G, mode, lib_options):
     """OO_pqc_batch (one call for G geometries) == OO_pqc per geometry == oracle, for every launch
     structure of the evaluation: circuit workgroups riding along the K1 launch or launched on their
-    own (OOVQE_NO_RIDE), persistent T3 kernel or T2 kernels (library test hooks)."""
+    own (option no_ride), persistent T3 kernel or T2 kernels (library test hooks)."""
     if mode == "no_ride":
-        monkeypatch.setenv("OOVQE_NO_RIDE", "1")
+        lib_options(no_ride=1)
     elif mode == "t3x1":
-        monkeypatch.setenv("OOVQE_FUSED_CHUNKS", "1")
+        lib_options(fused_chunks=1)
     elif mode == "t2":
-        monkeypatch.setenv("OOVQE_CAS_UNFUSED", "1")
+        lib_options(cas_unfused=1)
     from auto_oo_amd.synthetic import synthetic_problem
     ncas, nelecas, nelec = 3, 4, 16
     pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="ucc")

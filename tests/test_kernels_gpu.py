@@ -230,14 +230,14 @@ def test_cas_pipeline_vs_oracle(N, seed):
 @pytest.mark.parametrize("N,seed,nelec,ncas,nelecas", [(13, 20261, 16, 3, 4), (43, 20262, 16, 3, 4),
                                                      (20, 7, 8, 2, 2), (16, 9, 4, 4, 4),
                                                      (27, 11, 8, 3, 2), (47, 12, 10, 3, 4)])
-def test_cas_eval_fused_matches_staged_and_oracle(N, seed, nelec, ncas, nelecas, path, monkeypatch):
+def test_cas_eval_fused_matches_staged_and_oracle(N, seed, nelec, ncas, nelecas, path, lib_options):
     """oovqe_cas_eval (4 launches, column kernel) against the staged kernels and the oracle, with
     a stack of RDM sets (set 0 = RDMs, sets >= 1 = arbitrary 'derivative' RDMs).  `path` forces the
     persistent T3 kernel with 1/3/6 chunks of the q range, or the T2 kernels (library test hooks)."""
     if path.startswith("t3x"):
-        monkeypatch.setenv("OOVQE_FUSED_CHUNKS", path[3:])
+        lib_options(fused_chunks=int(path[3:]))
     elif path == "t2":
-        monkeypatch.setenv("OOVQE_CAS_UNFUSED", "1")
+        lib_options(cas_unfused=1)
     P = R.synthetic_problem(N, seed)
     mol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec)
     pqc = R.OraclePQC(ncas, nelecas, "ucc")
@@ -356,14 +356,14 @@ def test_half_transform_sizes(N, M):
 
 @pytest.mark.parametrize("path", ["t3x1", "t3x2", "t2"])
 @pytest.mark.parametrize("N,nelec,ncas,nelecas", [(43, 16, 8, 8), (30, 14, 10, 8), (24, 12, 6, 6)])
-def test_cas_eval_large_active_space_random_rdms(N, nelec, ncas, nelecas, path, monkeypatch):
+def test_cas_eval_large_active_space_random_rdms(N, nelec, ncas, nelecas, path, lib_options):
     """CAS path with M = n_occ + ncas up to 13 (config-5-like active spaces) on every transform
     path; the kernels are linear in the RDMs, so random (unphysical) RDM sets exercise them fully.
     Checked against the oracle's energy, CAS coefficients and analytic orbital gradient."""
     if path.startswith("t3x"):
-        monkeypatch.setenv("OOVQE_FUSED_CHUNKS", path[3:])
+        lib_options(fused_chunks=int(path[3:]))
     else:
-        monkeypatch.setenv("OOVQE_CAS_UNFUSED", "1")
+        lib_options(cas_unfused=1)
     P = R.synthetic_problem(N, 500 + N)
     mol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec)
     oo = R.OracleOOEnergy(mol, ncas, nelecas, P["oao_mo_coeff"])
@@ -455,27 +455,27 @@ def test_eri_symmetry_flags():
 @pytest.mark.parametrize("N,nelec,ncas,nelecas", [(13, 16, 3, 4), (43, 16, 3, 4), (17, 8, 4, 4),
                                                   (30, 14, 10, 8), (12, 16, 3, 4), (56, 12, 4, 4),
                                                   (50, 40, 4, 4), (70, 40, 6, 6)])
-def test_cas_eval_pq_symmetric_integrals(N, nelec, ncas, nelecas, path, flags, monkeypatch):
+def test_cas_eval_pq_symmetric_integrals(N, nelec, ncas, nelecas, path, flags, lib_options):
     """eri_flags = ERI_PQ_SYMMETRIC (only the slabs p <= q of g_ao are read), alone and together with
     ERI_RS_SYMMETRIC (only the columns y <= z of the packed triangle are kept), against eri_flags = 0
     on the same symmetric integrals, on every realisation: packed triangle + the one-launch
-    q->x / p->n kernel (forced by OOVQE_FUSED_CHUNKS, which makes the call take the batched plan) and
+    q->x / p->n kernel (forced by option fused_chunks, which makes the call take the batched plan) and
     its two-launch and simple-kernel variants, mirrored T2 (one-chunk and streaming half-transform
     kernels), staged fallback.  Same energy, coefficients, gradients and
     g_mo to rounding; the flag-free result is itself checked against the oracle."""
     if path.startswith("t3x"):
-        monkeypatch.setenv("OOVQE_FUSED_CHUNKS", path[3:])
+        lib_options(fused_chunks=int(path[3:]))
     elif path == "two_step":      # packed triangle, then the q -> x kernel and K1 as two launches
-        monkeypatch.setenv("OOVQE_FUSED_CHUNKS", "1")
-        monkeypatch.setenv("OOVQE_SYM_TWO_STEP", "1")
+        lib_options(fused_chunks=1)
+        lib_options(sym_two_step=1)
     elif path == "simple":        # packed triangle written by the one-slab-per-wave kernel
-        monkeypatch.setenv("OOVQE_FUSED_CHUNKS", "1")
-        monkeypatch.setenv("OOVQE_SYM_SIMPLE", "1")
+        lib_options(fused_chunks=1)
+        lib_options(sym_simple=1)
     elif path == "mirror":
-        monkeypatch.setenv("OOVQE_FUSED_CHUNKS", "1")
-        monkeypatch.setenv("OOVQE_SYM_MIRROR", "1")
+        lib_options(fused_chunks=1)
+        lib_options(sym_mirror=1)
     elif path == "t2":
-        monkeypatch.setenv("OOVQE_CAS_UNFUSED", "1")
+        lib_options(cas_unfused=1)
     P = R.synthetic_problem(N, 1300 + N)
     mol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec)
     oo = R.OracleOOEnergy(mol, ncas, nelecas, P["oao_mo_coeff"])

@@ -43,7 +43,10 @@ def test_gather_world2_gloo(n_geom):
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 29600 + n_geom
+    import socket
+    with socket.socket() as sk:                    # a free rendezvous port (fixed ports collide with
+        sk.bind(("127.0.0.1", 0))                  # other jobs on a shared host)
+        port = sk.getsockname()[1]
     mp.spawn(_worker, args=(world, port, n_geom, 5, ret), nprocs=world, join=True)
     assert all(ret[r] for r in range(world)) and len(ret) == world
 
