@@ -70,6 +70,7 @@ constexpr int AUX_PLAIN = 0, AUX_NT = 2;
 // upper triangle, t = p(2N - p + 1)/2 + (q - p); the result goes to T2[p,q] AND T2[q,p] (sym == 1)
 // or to the packed triangle J[t] (sym == 2).
 constexpr int SYM_FULL = 0, SYM_MIRROR = 1, SYM_PACKED = 2;
+constexpr int OOVQE_TRI_MODE_DEFAULT = 1;      // realisation of the packed-triangle stage 1 (half_tri_batched)
 __device__ __forceinline__ void tri_decode(long t, int N, int& p, int& q)
 {
     const double b = 2.0 * N + 1.0;
@@ -1061,6 +1062,10 @@ __device__ __host__ inline unsigned eri_tri_row_start(int r, int N)
     return (unsigned)(2 * k * (N - k + 1) + (r & 1) * (N - 2 * k));
 }
 
+// Pitch of a packed slab in doubles: the triangle rounded up to an even count, so that every slab
+// (and every LDS slot it is copied to by 16-byte DMA lanes) starts on a 16-byte boundary.
+__device__ __host__ inline unsigned eri_slab_pitch(int N) { return (eri_tri_row_start(N, N) + 1u) & ~1u; }
+
 __global__ __launch_bounds__(256)
 void eri_pack_kernel(const double* __restrict__ g, double* __restrict__ out, int N, unsigned slab_pk)
 {
@@ -1070,6 +1075,7 @@ void eri_pack_kernel(const double* __restrict__ g, double* __restrict__ out, int
     tri_decode(t, N, p, q);
     const double* src = g + (size_t)blockIdx.y * N * N * N * N + ((size_t)p * N + q) * N * N;
     double* dst = out + ((size_t)blockIdx.y * tri + t) * slab_pk;
+    if (threadIdx.x == 0 && slab_pk > eri_tri_row_start(N, N)) dst[slab_pk - 1] = 0.0;   // the pad element
     for (int idx = threadIdx.x; idx < N * N; idx += 256) {
         const int r = idx / N, c = idx - r * N;
         const int e = r & ~1;
@@ -1113,7 +1119,7 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
     // RS == 2: g is the PACKED copy made by eri_pack_kernel: per slab t = (p <= q) the upper triangle
     // with the diagonal halved, row r = its columns (r & ~1) .. N-1, rows back to back
     constexpr bool rs = RS != 0, pk = RS == 2;
-    const unsigned slab_pk = (unsigned)(eri_tri_row_start(N, N) * sizeof(double));
+    const unsigned slab_pk = (unsigned)(eri_slab_pitch(N) * sizeof(double));
     g += (size_t)blockIdx.y * (pk ? (size_t)tri * (slab_pk / sizeof(double)) : slab_elems * slab_elems);
     C += (size_t)blockIdx.y * N * N;
     // tiled == 0: J[t][M2].  tiled == 1: J[ty][t][16], 16-wide tiles of the M2 (y z) columns
@@ -1333,6 +1339,486 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
             }
         }
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage 1 on the packed copy (both symmetries), slabs delivered by LDS-DMA.
+//
+// Same arithmetic and the same staging / burst of the results as half_tri_kernel<KCH,NST,2>; what
+// changes is how a slab reaches the matrix cores.  There every lane fetches its MFMA operands
+// straight from HBM: 8- and 16-byte pieces of ragged triangle rows, most of them straddling
+// 128-byte lines, a third of the lanes masked off, and two slabs of operand registers per wave
+// (234 VGPRs) to keep bytes in flight -- 4.7 TB/s where whole contiguous slabs stream at 5.7.
+// Here a wave copies its packed slab (7.7 KB at N = 43, contiguous) into a private LDS slot with
+// `global_load_lds_dwordx4` -- full 1 KB pieces, 16 bytes per lane, line-aligned, nothing masked
+// but the tail of the last piece, no VGPR destination -- two slots per wave, so the slab after
+// next is requested as soon as this one's operands have been read out of LDS into registers.
+// The fragment reads then happen on chip (ds_read with the triangle's row offsets, zero for the
+// positions below the diagonal) and cost ~60 LDS cycles per slab against the ~1000 cycles a CU
+// has per slab at the HBM-bound pace.  Ordering: only the issuing wave reads its slots, so its
+// own counted `s_waitcnt vmcnt` is the whole protocol (MI355X_MICROARCH.md, co-residence item 7);
+// the burst's barriers are raw `s_barrier`s that leave the DMAs in flight.
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void oovqe_lds_void;
+typedef const __attribute__((address_space(1))) void oovqe_glob_void;
+
+template <int KCH, int NST>
+__global__ __launch_bounds__(HALF_WAVES * 64)
+void half_tri_dma_kernel(const double* __restrict__ g, const double* __restrict__ C,
+                         double* __restrict__ J, int N, int M, int phase_rounds)
+{
+    constexpr int NP = NST / 2, NS1 = NST % 2;
+    constexpr int NPA = NP > 0 ? NP : 1;
+    constexpr int NCF = NST * 4;
+    static_assert(KCH <= NCF, "C fragments must cover every k-step");
+    static_assert(NP <= 1, "row blocks above a pair are not handled by the offsets below");
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane >> 4, lr = lane & 15;
+    const int M2 = M * M;
+    const long tri = (long)N * (N + 1) / 2;
+    const unsigned slab_d = eri_slab_pitch(N);                       // doubles per packed slab (even)
+    const unsigned slab_bytes = slab_d * (unsigned)sizeof(double);
+    const int npiece = (int)((slab_bytes + 1023u) / 1024u);          // 1 KB DMA pieces per slab
+    double* dump = lds;             // [64] sink for lanes outside the M x M tile
+    int* ctab = reinterpret_cast<int*>(lds + 64);   // [ncol <= 256] column -> position y*M + z in a tile
+    double* ring = lds + 64 + 128;  // [HALF_WAVES][2][slab_d]: two slots per wave
+    double* stg = ring + (size_t)HALF_WAVES * 2 * slab_d;   // [phase_rounds][HALF_WAVES][M2]
+    g += (size_t)blockIdx.y * (size_t)tri * slab_d;
+    C += (size_t)blockIdx.y * N * N;
+    const int ncol = M * (M + 1) / 2;                                // columns y <= z of J
+    const int nty = (ncol + 15) / 16;
+    J += (size_t)blockIdx.y * tri * nty * 16;                        // J[ty][t][16]
+    if (tid < ncol) {               // read after the first barrier of the phase loop
+        int y, z;
+        tri_decode(tid, M, y, z);
+        ctab[tid] = (y * M + z) | ((z * M + y) << 16);
+    }
+
+    const int SW = gridDim.x * HALF_WAVES;                  // waves per geometry
+    const int gw = blockIdx.x * HALF_WAVES + wave;
+    const int n_rounds = (int)((tri + SW - 1) / SW);        // the same for every wave of the grid
+    const int my_rounds = gw < tri ? (int)((tri - 1 - gw) / SW) + 1 : 0;   // rounds with a slab for this wave
+    double* my_ring = ring + (size_t)wave * 2 * slab_d;
+    // round r of this wave: slab t = r*SW + gw, into slot r & 1
+    auto dma = [&](int r) {
+        const char* src = reinterpret_cast<const char*>(g + ((size_t)r * SW + gw) * slab_d) + lane * 16;
+        char* dst = reinterpret_cast<char*>(my_ring + (size_t)(r & 1) * slab_d);
+        for (int p = 0; p < npiece; ++p) {
+            if ((unsigned)(p * 1024 + lane * 16) < slab_bytes)
+                __builtin_amdgcn_global_load_lds((oovqe_glob_void*)(src + p * 1024),
+                                                 (oovqe_lds_void*)(dst + p * 1024), 16, 0, AUX_NT);
+        }
+    };
+    if (my_rounds > 0) dma(0);
+    if (my_rounds > 1) dma(1);
+
+    // Offsets (in doubles) of this lane's operands inside a packed slab: row r = 4i + lq starts
+    // 2k(N-k+1) + (r&1)(N-2k) doubles in, k = r/2, and holds the columns (r & ~1) .. N-1.
+    // A position below the diagonal (or a row past N) reads as zero.
+    int colp[NPA];
+    bool last_even[NPA];
+    int offp[NPA][KCH];             // < 0: zero
+    int offs[KCH];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+        const int col = pp * 32 + 2 * lr;
+        const int cc = col + 1 < N ? col : (N >= 2 ? N - 2 : 0);
+        colp[pp] = col;
+        last_even[pp] = col == N - 1;
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int r = 4 * i + lq, e = r & ~1;
+            offp[pp][i] = (r < N && col >= e && col < N) ? (int)eri_tri_row_start(r, N) + cc - e : -1;
+        }
+    }
+    {
+        const int col1 = NP * 32 + lr;
+        const int col1c = col1 < N ? col1 : N - 1;
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int r = 4 * i + lq, e = r & ~1;
+            offs[i] = (r < N && col1 < N && col1c >= e) ? (int)eri_tri_row_start(r, N) + col1c - e : -1;
+        }
+    }
+
+    // C fragments: see half_transform_fused_kernel
+    double cfr[NCF];
+#pragma unroll
+    for (int j = 0; j < NCF; ++j) {
+        const int r = 4 * j + lq;
+        cfr[j] = C[(size_t)(r < N ? r : N - 1) * N + (lr < M ? lr : M - 1)];
+    }
+    double cpr[NPA][2][4];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = pp * 32 + 2 * (lq + 4 * i) + half;
+                cpr[pp][half][i] = C[(size_t)(col < N ? col : N - 1) * N + (lr < M ? lr : M - 1)];
+            }
+#pragma unroll
+    for (int j = 0; j < NCF; ++j) cfr[j] *= ((4 * j + lq) < N && lr < M) ? 1.0 : 0.0;
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                cpr[pp][half][i] *= ((pp * 32 + 2 * (lq + 4 * i) + half) < N && lr < M) ? 1.0 : 0.0;
+
+    // LDS destination of jt[i] = Jt[z = lq + 4i][y = lr] inside a staged tile: [y*M + z]
+    int tile_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int zz = lq + 4 * i;
+        tile_off[i] = (lr < M && zz < M) ? lr * M + zz : -1;
+    }
+
+    d2u ap[NPA][KCH];
+    double as[KCH];
+    // operands of the slab in slot `slot` out of LDS (the rows of the lower blocks of a column pair
+    // are below the diagonal altogether: skipped at compile time, as in half_tri_kernel)
+    auto fetch = [&](int slot) {
+        const double* sl = my_ring + (size_t)slot * slab_d;
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) {
+                if (i / 4 > 2 * pp + 1) continue;
+                const int o = offp[pp][i];
+                d2u v = *reinterpret_cast<const d2u*>(sl + (o >= 0 ? o : 0));
+                if (o < 0) v = d2u{0.0, 0.0};
+                ap[pp][i] = v;
+            }
+        if constexpr (NS1) {
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) {
+                const int o = offs[i];
+                const double v = sl[o >= 0 ? o : 0];
+                as[i] = o >= 0 ? v : 0.0;
+            }
+        }
+    };
+    auto compute = [&](int r, int base) {
+        d4 jt = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                d4 xu = d4{0.0, 0.0, 0.0, 0.0}, xa = xu, xb = xu;
+#pragma unroll
+                for (int i = 0; i < KCH; ++i) {
+                    const double ev = last_even[pp] ? ap[pp][i].y : ap[pp][i].x;
+                    const double av = half == 0 ? ev : ap[pp][i].y;
+                    const int blk = i / 4;
+                    if (blk > 2 * pp + 1) continue;
+                    if (blk < 2 * pp) xu = mfma_f64(av, cfr[i], xu);
+                    else if (blk == 2 * pp) xa = mfma_f64(av, cfr[i], xa);
+                    else xb = mfma_f64(av, cfr[i], xb);
+                }
+                d4 xt;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xt[e] = xu[e] + xa[e] + xb[e];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) jt = mfma_f64(cpr[pp][half][i], xt[i], jt);
+            }
+        if constexpr (NS1) {
+            d4 xu = d4{0.0, 0.0, 0.0, 0.0}, xd = xu;
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) {
+                if (i / 4 < NST - 1) xu = mfma_f64(as[i], cfr[i], xu);
+                else xd = mfma_f64(as[i], cfr[i], xd);
+            }
+            d4 xt;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xt[e] = xu[e] + xd[e];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) jt = mfma_f64(cfr[NP * 8 + i], xt[i], jt);
+        }
+        double* row = stg + ((size_t)(r - base) * HALF_WAVES + wave) * M2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double* dst = tile_off[i] >= 0 ? row + tile_off[i] : dump + lane;
+            *dst = jt[i];
+        }
+    };
+
+    for (int base = 0; base < n_rounds; base += phase_rounds) {
+        const int end = base + phase_rounds < n_rounds ? base + phase_rounds : n_rounds;
+        for (int it = base; it < end; ++it) {
+            if (it < my_rounds) {                         // wave-uniform
+                // round `it` has landed once at most the pieces of round it+1 are outstanding
+                // (vector-memory operations retire in issue order; the burst's stores count too
+                // and only make this wait conservative)
+                if (it + 1 < my_rounds) {
+                    switch (npiece) {                     // wave-uniform; the count is an immediate
+                    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+                    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                    }
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                fetch(it & 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // operands are in registers: the slot is free
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + 2 < my_rounds) dma(it + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(it, base);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int nslot = (end - base) * HALF_WAVES;
+        for (int e = tid; e < nslot * ncol; e += HALF_WAVES * 64) {
+            const int slot = e / ncol, c = e - slot * ncol;
+            const long t = (long)(base + slot / HALF_WAVES) * SW + blockIdx.x * HALF_WAVES + slot % HALF_WAVES;
+            if (t < tri) {
+                const int cc2 = ctab[c];
+                const double v = stg[(size_t)slot * M2 + (cc2 & 0xffff)] + stg[(size_t)slot * M2 + (cc2 >> 16)];
+                J[((size_t)(c >> 4) * tri + t) * 16 + (c & 15)] = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage 1 on the packed copy, slabs fetched as CONTIGUOUS 16-byte-per-lane register loads.
+//
+// The packed stream of half_tri_kernel<.,.,2> runs at 4.7 TB/s where whole slabs reach 5.7, and
+// neither the matrix cores nor the memory side is the reason: its operand-shaped loads leave a
+// third of the lanes masked, so the two slabs a wave keeps in flight occupy 132 VGPRs but carry
+// only 15 KB -- 124 KB per CU, against 236 KB for the whole-slab kernel (the LDS-DMA variant above
+// has the same cap: its in-flight bytes ARE its LDS ring).  Here a slab is fetched as it lies in
+// memory, NPC pieces of 1 KB per wave instruction, 4 VGPRs per piece: 32 VGPRs hold a 7.7 KB slab,
+// so a wave keeps R = 3 or 4 slabs in flight (186 / 247 KB per CU) in the register budget the old
+// kernel spends on two.  A landed slab is written to the wave's private LDS slot with
+// ds_write_b128, its registers are reloaded with the slab R rounds ahead, and the MFMA operands
+// are read back from LDS with the triangle's row offsets (zero below the diagonal) -- the same
+// fragment reads as half_tri_dma_kernel.  Straight-line rounds, unrolled R times, so the
+// compiler's vmcnt bookkeeping is exact; no barrier except around the result bursts.
+// ------------------------------------------------------------------------------------------
+template <int KCH, int NST, int NPC, int R>
+__global__ __launch_bounds__(HALF_WAVES * 64)
+void half_tri_reg_kernel(const double* __restrict__ g, const double* __restrict__ C,
+                         double* __restrict__ J, int N, int M, int phase_rounds)
+{
+    constexpr int NP = NST / 2, NS1 = NST % 2;
+    constexpr int NPA = NP > 0 ? NP : 1;
+    constexpr int NCF = NST * 4;
+    static_assert(KCH <= NCF, "C fragments must cover every k-step");
+    static_assert(NP <= 1, "row blocks above a pair are not handled by the offsets below");
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane >> 4, lr = lane & 15;
+    const int M2 = M * M;
+    const long tri = (long)N * (N + 1) / 2;
+    const unsigned slab_d = eri_slab_pitch(N);                       // doubles per packed slab (even)
+    const unsigned slab_bytes = slab_d * (unsigned)sizeof(double);
+    constexpr int SLOT_D = NPC * 128;                                // LDS slot of a wave, in doubles
+    double* dump = lds;             // [64] sink for lanes outside the M x M tile
+    int* ctab = reinterpret_cast<int*>(lds + 64);   // [ncol <= 256] column -> position y*M + z in a tile
+    double* slots = lds + 64 + 128; // [HALF_WAVES][SLOT_D]
+    double* stg = slots + (size_t)HALF_WAVES * SLOT_D;      // [phase_rounds][HALF_WAVES][M2]
+    g += (size_t)blockIdx.y * (size_t)tri * slab_d;
+    C += (size_t)blockIdx.y * N * N;
+    const int ncol = M * (M + 1) / 2;                                // columns y <= z of J
+    const int nty = (ncol + 15) / 16;
+    J += (size_t)blockIdx.y * tri * nty * 16;                        // J[ty][t][16]
+    if (tid < ncol) {               // read after the first barrier of the phase loop
+        int y, z;
+        tri_decode(tid, M, y, z);
+        ctab[tid] = (y * M + z) | ((z * M + y) << 16);
+    }
+
+    const int SW = gridDim.x * HALF_WAVES;                  // waves per geometry
+    const int gw = blockIdx.x * HALF_WAVES + wave;
+    const int n_rounds = (int)((tri + SW - 1) / SW);        // the same for every wave of the grid
+    double* my_slot = slots + (size_t)wave * SLOT_D;
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const unsigned total_bytes = (unsigned)(tri * slab_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double*>(g), 0, (int)total_bytes, 0x00020000);
+    const unsigned lane_off = (unsigned)lane * 16u;
+    // round r of this wave: slab t = r*SW + gw; past the end of the triangle -> out of range, dropped
+    auto load = [&](int r, v4u (&b)[NPC]) {
+        const long t = (long)r * SW + gw;
+        const unsigned sb = __builtin_amdgcn_readfirstlane(t < tri ? (unsigned)t * slab_bytes : total_bytes);
+#pragma unroll
+        for (int p = 0; p < NPC; ++p)
+            b[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off + (unsigned)p * 1024u, sb, AUX_NT);
+    };
+    v4u buf[R][NPC];
+#pragma unroll
+    for (int b = 0; b < R; ++b) load(b, buf[b]);
+
+    int colp[NPA];
+    bool last_even[NPA];
+    int offp[NPA][KCH];             // < 0: zero
+    int offs[KCH];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+        const int col = pp * 32 + 2 * lr;
+        const int cc = col + 1 < N ? col : (N >= 2 ? N - 2 : 0);
+        colp[pp] = col;
+        last_even[pp] = col == N - 1;
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int r = 4 * i + lq, e = r & ~1;
+            offp[pp][i] = (r < N && col >= e && col < N) ? (int)eri_tri_row_start(r, N) + cc - e : -1;
+        }
+    }
+    {
+        const int col1 = NP * 32 + lr;
+        const int col1c = col1 < N ? col1 : N - 1;
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int r = 4 * i + lq, e = r & ~1;
+            offs[i] = (r < N && col1 < N && col1c >= e) ? (int)eri_tri_row_start(r, N) + col1c - e : -1;
+        }
+    }
+
+    double cfr[NCF];
+#pragma unroll
+    for (int j = 0; j < NCF; ++j) {
+        const int r = 4 * j + lq;
+        cfr[j] = C[(size_t)(r < N ? r : N - 1) * N + (lr < M ? lr : M - 1)];
+    }
+    double cpr[NPA][2][4];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int col = pp * 32 + 2 * (lq + 4 * i) + half;
+                cpr[pp][half][i] = C[(size_t)(col < N ? col : N - 1) * N + (lr < M ? lr : M - 1)];
+            }
+#pragma unroll
+    for (int j = 0; j < NCF; ++j) cfr[j] *= ((4 * j + lq) < N && lr < M) ? 1.0 : 0.0;
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                cpr[pp][half][i] *= ((pp * 32 + 2 * (lq + 4 * i) + half) < N && lr < M) ? 1.0 : 0.0;
+
+    int tile_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int zz = lq + 4 * i;
+        tile_off[i] = (lr < M && zz < M) ? lr * M + zz : -1;
+    }
+
+    // one round: slab in `b` -> LDS slot -> (registers reloaded R rounds ahead) -> fragments -> MFMA
+    auto round = [&](int r, int base, v4u (&b)[NPC]) {
+#pragma unroll
+        for (int p = 0; p < NPC; ++p)
+            *reinterpret_cast<v4u*>(reinterpret_cast<char*>(my_slot) + p * 1024 + lane * 16) = b[p];
+        __builtin_amdgcn_sched_barrier(0);
+        load(r + R, b);
+        __builtin_amdgcn_sched_barrier(0);
+        d4 jt = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) {
+            d2u ap[KCH];
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) {
+                if (i / 4 > 2 * pp + 1) continue;
+                const int o = offp[pp][i];
+                d2u v = *reinterpret_cast<const d2u*>(my_slot + (o >= 0 ? o : 0));
+                if (o < 0) v = d2u{0.0, 0.0};
+                ap[i] = v;
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                d4 xu = d4{0.0, 0.0, 0.0, 0.0}, xa = xu, xb = xu;
+#pragma unroll
+                for (int i = 0; i < KCH; ++i) {
+                    const int blk = i / 4;
+                    if (blk > 2 * pp + 1) continue;
+                    const double ev = last_even[pp] ? ap[i].y : ap[i].x;
+                    const double av = half == 0 ? ev : ap[i].y;
+                    if (blk < 2 * pp) xu = mfma_f64(av, cfr[i], xu);
+                    else if (blk == 2 * pp) xa = mfma_f64(av, cfr[i], xa);
+                    else xb = mfma_f64(av, cfr[i], xb);
+                }
+                d4 xt;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xt[e] = xu[e] + xa[e] + xb[e];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) jt = mfma_f64(cpr[pp][half][i], xt[i], jt);
+            }
+        }
+        if constexpr (NS1) {
+            double as[KCH];
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) {
+                const int o = offs[i];
+                const double v = my_slot[o >= 0 ? o : 0];
+                as[i] = o >= 0 ? v : 0.0;
+            }
+            d4 xu = d4{0.0, 0.0, 0.0, 0.0}, xd = xu;
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) {
+                if (i / 4 < NST - 1) xu = mfma_f64(as[i], cfr[i], xu);
+                else xd = mfma_f64(as[i], cfr[i], xd);
+            }
+            d4 xt;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xt[e] = xu[e] + xd[e];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) jt = mfma_f64(cfr[NP * 8 + i], xt[i], jt);
+        }
+        if ((long)r * SW + gw < tri) {
+            double* row = stg + ((size_t)(r - base) * HALF_WAVES + wave) * M2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                double* dst = tile_off[i] >= 0 ? row + tile_off[i] : dump + lane;
+                *dst = jt[i];
+            }
+        }
+        // the fragment reads of this round retire (lgkmcnt) before the next round's ds_writes to
+        // the same slot are issued: same wave, LDS operations execute in order
+    };
+
+    // phase_rounds is a multiple of R: round `base` of every phase sits in register buffer 0
+    for (int base = 0; base < n_rounds; base += phase_rounds) {
+        const int end = base + phase_rounds < n_rounds ? base + phase_rounds : n_rounds;
+        for (int it = base; it < end; it += R) {
+#pragma unroll
+            for (int b = 0; b < R; ++b) {
+                round(it + b, base, buf[b]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // loads stay in flight
+        const int nslot = (end - base) * HALF_WAVES;
+        for (int e = tid; e < nslot * ncol; e += HALF_WAVES * 64) {
+            const int slot = e / ncol, c = e - slot * ncol;
+            const long t = (long)(base + slot / HALF_WAVES) * SW + blockIdx.x * HALF_WAVES + slot % HALF_WAVES;
+            if (t < tri) {
+                const int cc2 = ctab[c];
+                const double v = stg[(size_t)slot * M2 + (cc2 & 0xffff)] + stg[(size_t)slot * M2 + (cc2 >> 16)];
+                J[((size_t)(c >> 4) * tri + t) * 16 + (c & 15)] = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
 
@@ -2350,7 +2836,7 @@ static int half_transform_fused_batched(const double* g_ao, const double* C, int
     return 0;
 }
 
-static unsigned eri_slab_packed_elems(int N) { return eri_tri_row_start(N, N); }
+static unsigned eri_slab_packed_elems(int N) { return eri_slab_pitch(N); }
 
 extern "C" int64_t oovqe_eri_packed_size(int N)
 {
@@ -2400,6 +2886,86 @@ static int half_tri_batched(const double* g_ao, const double* C, int N, int M, d
     const long n_rounds = (tri + W * HALF_WAVES - 1) / (W * HALF_WAVES);
     const size_t round_bytes = (size_t)HALF_WAVES * M * M * sizeof(double);
     const size_t fixed_bytes = (64 + 128) * sizeof(double);   // dump + column table
+    // packed copy: three realisations of the same stage (option tri_mode; 0 = the default below):
+    //   1 half_tri_kernel<.,.,2>   operand-shaped loads, two slabs per wave in registers
+    //   2 half_tri_dma_kernel      LDS-DMA ring, two slots per wave
+    //   3 / 4 half_tri_reg_kernel  contiguous register loads, R = 3 / 4 slabs per wave in flight
+    const int tri_mode = oovqe_opt(OOVQE_OPT_TRI_MODE) ? oovqe_opt(OOVQE_OPT_TRI_MODE) : OOVQE_TRI_MODE_DEFAULT;
+    const size_t ring_bytes = (size_t)HALF_WAVES * 2 * eri_slab_packed_elems(N) * sizeof(double);
+    if (packed_src && tiled == 2 && tri_mode == 2 && fixed_bytes + ring_bytes + round_bytes <= 160 * 1024) {
+        long ph = (long)((160 * 1024 - fixed_bytes - ring_bytes) / round_bytes);
+        if (ph > n_rounds) ph = n_rounds;
+        const size_t lds_dma = fixed_bytes + ring_bytes + (size_t)ph * round_bytes;
+#define OOVQE_LAUNCH_TRI_DMA(KC_, NS_)                                                            \
+    do {                                                                                          \
+        static bool attr_done = false;                                                            \
+        if (!attr_done) {                                                                         \
+            OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)half_tri_dma_kernel<KC_, NS_>,       \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                                160 * 1024), "cas_eval/half_tri_dma");            \
+            attr_done = true;                                                                     \
+        }                                                                                         \
+        hipLaunchKernelGGL((half_tri_dma_kernel<KC_, NS_>), dim3((unsigned)W, batch),             \
+                           dim3(HALF_WAVES * 64), lds_dma, st, g_ao, C, J, N, M, (int)ph);        \
+    } while (0)
+        oovqe_profile_mark_start(st);
+        if (kch == 4 && nrb == 1) OOVQE_LAUNCH_TRI_DMA(4, 1);
+        else if (kch == 8 && nrb == 2) OOVQE_LAUNCH_TRI_DMA(8, 2);
+        else if (kch == 11 && nrb == 3) OOVQE_LAUNCH_TRI_DMA(11, 3);
+        else if (kch == 12 && nrb == 3) OOVQE_LAUNCH_TRI_DMA(12, 3);
+        else {
+            oovqe_set_error("cas_eval: no half_tri_dma variant for N=%d", N);
+            return OOVQE_ERR_ARG;
+        }
+        oovqe_profile_mark_stop(st);
+#undef OOVQE_LAUNCH_TRI_DMA
+        OOVQE_CHECK_LAUNCH("cas_eval/half_tri_dma");
+        return 0;
+    }
+    if (packed_src && tiled == 2 && (tri_mode == 3 || tri_mode == 4)) {
+        // pieces of 1 KB per slab for the largest N of each variant: N <= 16 / 32 / 44 / 48
+        const int npc = kch == 4 ? 2 : kch == 8 ? 5 : kch == 11 ? 8 : 10;
+        OOVQE_REQUIRE((size_t)npc * 1024 >= eri_slab_packed_elems(N) * sizeof(double),
+                      "cas_eval: half_tri_reg slab of N=%d exceeds %d KB", N, npc);
+        const int R = tri_mode;
+        const size_t slot_bytes = (size_t)HALF_WAVES * npc * 1024;
+        long ph = (long)((160 * 1024 - fixed_bytes - slot_bytes) / round_bytes) / R * R;
+        OOVQE_REQUIRE(ph >= R, "cas_eval: half_tri_reg staging does not fit LDS (M=%d)", M);
+        const long nr_up = (n_rounds + R - 1) / R * R;
+        if (ph > nr_up) ph = nr_up;
+        const size_t lds_reg = fixed_bytes + slot_bytes + (size_t)ph * round_bytes;
+#define OOVQE_LAUNCH_TRI_REG(KC_, NS_, NPC_, R_)                                                  \
+    do {                                                                                          \
+        static bool attr_done = false;                                                            \
+        if (!attr_done) {                                                                         \
+            OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)half_tri_reg_kernel<KC_, NS_, NPC_, R_>, \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                                160 * 1024), "cas_eval/half_tri_reg");            \
+            attr_done = true;                                                                     \
+        }                                                                                         \
+        hipLaunchKernelGGL((half_tri_reg_kernel<KC_, NS_, NPC_, R_>), dim3((unsigned)W, batch),   \
+                           dim3(HALF_WAVES * 64), lds_reg, st, g_ao, C, J, N, M, (int)ph);        \
+    } while (0)
+#define OOVQE_LAUNCH_TRI_REG_R(KC_, NS_, NPC_)                                                    \
+    do {                                                                                          \
+        if (R == 3) OOVQE_LAUNCH_TRI_REG(KC_, NS_, NPC_, 3);                                      \
+        else OOVQE_LAUNCH_TRI_REG(KC_, NS_, NPC_, 4);                                             \
+    } while (0)
+        oovqe_profile_mark_start(st);
+        if (kch == 4 && nrb == 1) OOVQE_LAUNCH_TRI_REG_R(4, 1, 2);
+        else if (kch == 8 && nrb == 2) OOVQE_LAUNCH_TRI_REG_R(8, 2, 5);
+        else if (kch == 11 && nrb == 3) OOVQE_LAUNCH_TRI_REG_R(11, 3, 8);
+        else if (kch == 12 && nrb == 3) OOVQE_LAUNCH_TRI_REG_R(12, 3, 10);
+        else {
+            oovqe_set_error("cas_eval: no half_tri_reg variant for N=%d", N);
+            return OOVQE_ERR_ARG;
+        }
+        oovqe_profile_mark_stop(st);
+#undef OOVQE_LAUNCH_TRI_REG_R
+#undef OOVQE_LAUNCH_TRI_REG
+        OOVQE_CHECK_LAUNCH("cas_eval/half_tri_reg");
+        return 0;
+    }
     long phase = (long)((160 * 1024 - fixed_bytes) / round_bytes) & ~1L;   // even
     OOVQE_REQUIRE(phase >= 2, "cas_eval: half_tri staging does not fit LDS (M=%d)", M);
     if (phase > ((n_rounds + 1) & ~1L)) phase = (n_rounds + 1) & ~1L;

@@ -36,6 +36,7 @@ enum oovqe_option_t {
     OOVQE_OPT_SYM_SIMPLE,            // one-slab-per-wave triangle kernel
     OOVQE_OPT_SYM_TWO_STEP,          // q->x kernel + K1 instead of the one-launch kernel
     OOVQE_OPT_NO_RIDE,               // circuit + RDM step as its own launch
+    OOVQE_OPT_TRI_MODE,              // packed-triangle stage 1: 1 operand loads, 2 LDS-DMA, 3/4 contiguous loads
     OOVQE_OPT_COUNT
 };
 int oovqe_opt(int id);
