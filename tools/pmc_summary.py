@@ -40,7 +40,7 @@ def main():
         "pq_symmetric": not general,
         "geometries_per_launch": G,
         "source": ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_bench.sh "
-                   f"{tag}) on bench.py --steps 25600 --warmup 2560; profiles/{os.path.basename(fetch_csv)}, "
+                   f"{tag}) on bench.py --steps 200 --warmup 20 (a step = one batched call over 256 geometries); profiles/{os.path.basename(fetch_csv)}, "
                    f"{os.path.basename(write_csv)}"),
         "FETCH_SIZE_KB_raw": fk,
         "WRITE_SIZE_KB_raw": wk,
