@@ -128,6 +128,8 @@ SIGNATURES = {
     "oovqe_eri_packed_size": (ctypes.c_int64, [ctypes.c_int]),
     "oovqe_eri_pack": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, c_stream]),
     "oovqe_circuit_rdms_is_small": (ctypes.c_int, [ctypes.c_int] * 4),
+    "oovqe_spin_rdms": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p,
+                                       c_double_p, c_stream]),
     "oovqe_debug_set_option": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "oovqe_debug_get_option": (ctypes.c_int, [ctypes.c_char_p]),
     "oovqe_newton_direction": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,

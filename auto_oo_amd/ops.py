@@ -151,6 +151,21 @@ def rdms(bra, ket, ncas):
     return gamma, Gamma
 
 
+def spin_rdms(bra, ket, n_qubits):
+    """bra, ket [batch, D] -> spin-orbital gamma [batch, n, n], Gamma [batch, n, n, n, n]
+    (oovqe_spin_rdms: the reference's restricted=False RDMs)."""
+    lib = _lib.load()
+    dev = _dev(bra)
+    batch, D = bra.shape
+    assert D == 1 << n_qubits and ket.shape == bra.shape
+    n = n_qubits
+    gamma = torch.empty((batch, n, n), dtype=F64, device=dev)
+    Gamma = torch.empty((batch, n, n, n, n), dtype=F64, device=dev)
+    check(lib.oovqe_spin_rdms(dptr(bra), dptr(ket), n, batch, dptr(gamma), dptr(Gamma), stream_ptr()),
+          "oovqe_spin_rdms")
+    return gamma, Gamma
+
+
 def rdms_tangent(psi, dpsi, ncas):
     """psi [batch, D], dpsi [batch, n_tan, D] (or None) -> gamma [batch, 1+n_tan, a, a],
     Gamma [batch, 1+n_tan, a, a, a, a]: set 0 = RDMs, set k = d/dtheta_k."""

@@ -139,27 +139,30 @@ class Parameterized_circuit():
     def get_rdms_from_state(self, state, restricted=True):
         """pqc.py:192-218: gamma_pq = (state @ (E_pq @ state)).real, Gamma_pqrs likewise with
         e_pqrs = E_pq E_rs - delta_qr E_ps -- the bilinear form (no conjugation) of the
-        reference: Re[psi^T E psi] = Re(psi)^T E Re(psi) - Im(psi)^T E Im(psi)."""
-        if not restricted:
-            raise NotImplementedError("unrestricted RDMs are not built (never used on the hot path)")
+        reference: Re[psi^T E psi] = Re(psi)^T E Re(psi) - Im(psi)^T E Im(psi).
+        ``restricted=False``: the spin-orbital RDMs <a+_p a_q>, <a+_p a+_q a_r a_s> over the 2 ncas
+        spin orbitals (utils/active_space.py:44-52,79-82)."""
         state = torch.as_tensor(state)
+        if restricted:
+            kernel = lambda v: ops.rdms(v, v, self.ncas)                   # noqa: E731
+        else:
+            kernel = lambda v: ops.spin_rdms(v, v, self.n_qubits)          # noqa: E731
         if state.is_complex():
             re = ops.as_device(state.real, self.device).reshape(1, -1)
             im = ops.as_device(state.imag, self.device).reshape(1, -1)
-            g1, g2 = ops.rdms(re, re, self.ncas)
+            g1, g2 = kernel(re)
             if bool((im != 0).any()):
-                i1, i2 = ops.rdms(im, im, self.ncas)
+                i1, i2 = kernel(im)
                 g1, g2 = g1 - i1, g2 - i2
             return g1[0], g2[0]
-        re = ops.as_device(state, self.device).reshape(1, -1)
-        g1, g2 = ops.rdms(re, re, self.ncas)
+        g1, g2 = kernel(ops.as_device(state, self.device).reshape(1, -1))
         return g1[0], g2[0]
 
     def get_rdms(self, theta, restricted=True):
         """pqc.py:220-221.  Differentiable by torch with respect to theta (first order): the
         Jacobians are the derivative RDMs of the tangent-state kernels."""
         if not restricted:
-            raise NotImplementedError("unrestricted RDMs are not built (never used on the hot path)")
+            return self.get_rdms_from_state(self.state_real(theta), restricted=False)
         if needs_autodiff(theta):
             th = torch.as_tensor(theta).to(device=self.device, dtype=torch.float64).contiguous()
             out = VectorWithJacobian.apply(self._rdms_and_jacobians, th)

@@ -143,6 +143,13 @@ int oovqe_circuit_rdms(const double* theta, int n_theta, const oovqe_gate_t* gat
                        double* psi, double* dpsi, double* gamma, double* Gamma, double* work,
                        oovqe_stream_t stream);
 
+/* Spin-orbital (unrestricted) RDMs, the restricted=False branch of
+ * Parameterized_circuit.get_rdms_from_state (src/auto_oo/pqc.py:192-218, operators
+ * utils/active_space.py:29-83): gamma [batch, n, n] = <a+_p a_q>, Gamma [batch, n, n, n, n] =
+ * <a+_p a+_q a_r a_s>, n = n_qubits spin orbitals, bilinear in (bra, ket) [batch, 2^n]. */
+int oovqe_spin_rdms(const double* bra, const double* ket, int n_qubits, int batch, double* gamma,
+                    double* Gamma, oovqe_stream_t stream);
+
 /* ---- a7/a8/a12/a13/a14: fused CAS energy + gradients ---------------------------------------
  * replaces int1e_transform + int2e_transform + molecular_hamiltonian_coefficients
  * (oo_energy.py:204-211; utils/active_space.py:111-212), the energy contraction

@@ -636,6 +636,26 @@ class RdmOperators:
         return self._torch_E, self._torch_e2
 
 
+def spin_rdms_from_state(state, ncas):
+    """pqc.py:192-218 with restricted=False: gamma_pq = Re[state @ (a+_p a_q @ state)],
+    Gamma_pqrs = Re[state @ (a+_p a+_q a_r a_s @ state)] over the 2 ncas spin orbitals
+    (active_space.py:44-52,79-82), dense Jordan-Wigner matrices (small registers only)."""
+    n = 2 * ncas
+    a = [m.toarray() for m in _jw_annihilators(n)]
+    ad = [m.T for m in a]
+    psi = np.asarray(state.detach().cpu() if isinstance(state, torch.Tensor) else state).astype(np.complex128)
+    one = np.zeros((n, n))
+    two = np.zeros((n, n, n, n))
+    kets = [a[s] @ psi for s in range(n)]
+    for p, q in itertools.product(range(n), repeat=2):
+        one[p, q] = (psi @ (ad[p] @ kets[q])).real
+    for r, s_ in itertools.product(range(n), repeat=2):
+        v = a[r] @ kets[s_]
+        for p, q in itertools.product(range(n), repeat=2):
+            two[p, q, r, s_] = (psi @ (ad[p] @ (ad[q] @ v))).real
+    return torch.tensor(one), torch.tensor(two)
+
+
 def rdms_from_state(state, ops: RdmOperators):
     """pqc.py:192-218 -- bilinear form state @ (E @ state) (no conjugation), then .real."""
     nc = ops.ncas

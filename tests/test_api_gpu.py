@@ -432,3 +432,32 @@ def test_in_place_edit_of_int2e_ao_reverifies_symmetry_flags():
     omol = R.OracleMol(P["int1e_ao"], g_mod, P["overlap"], P["nuc"], 16)
     ooo = R.OracleOOPQC(R.OraclePQC(3, 4, "ucc"), omol, 3, 4, P["oao_mo_coeff"])
     assert abs(e_new.item() - ooo.energy_from_parameters(theta).item()) < 1e-9
+
+
+@pytest.mark.parametrize("N,G", [(43, 9), (13, 40), (30, 11), (47, 5)])
+def test_packed_stage1_realisations_agree_bitwise(N, G, lib_options):
+    """The three realisations of stage 1 on the packed copy (operand-shaped HBM loads, LDS-DMA ring,
+    contiguous register loads with 3 / 4 slabs in flight; debug option tri_mode) form the same sums
+    in the same order: bit-identical energies and gradients, and equal to the oracle."""
+    from auto_oo_amd.synthetic import synthetic_problem
+    ncas, nelecas, nelec = 3, 4, 16
+    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="ucc")
+    mols, coeffs = [], []
+    for g in range(G):
+        P = synthetic_problem(N, 900 + g)
+        mols.append(aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec))
+        coeffs.append(P["oao_mo_coeff"])
+    batch = aoo.OO_pqc_batch(pqc, mols, ncas, nelecas, oao_mo_coeffs=coeffs)
+    assert batch._eri_packed is not None
+    thetas = torch.tensor(np.random.default_rng(2).uniform(0, 2 * np.pi, (G, pqc.theta_shape)))
+    lib_options(fused_chunks=1)                      # the batched (packed-triangle) plan at any batch size
+    outs = []
+    for mode in (1, 2, 3, 4):
+        lib_options(tri_mode=mode)
+        outs.append(batch.energy_and_gradient(thetas).clone())
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    omol = R.OracleMol(mols[0].int1e_ao, mols[0].int2e_ao, mols[0].overlap, mols[0].nuc, nelec)
+    ooo = R.OracleOOPQC(R.OraclePQC(ncas, nelecas, "ucc"), omol, ncas, nelecas, coeffs[0])
+    assert abs(outs[0][0, 0].item() - ooo.energy_from_parameters(thetas[0]).item()) < 1e-9
+    assert (outs[0][0, 1:].cpu() - ooo.full_gradient(thetas[0])).abs().max() < 1e-8

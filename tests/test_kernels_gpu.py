@@ -531,3 +531,29 @@ def test_eri_pack_layout(N):
     _lib.check(lib.oovqe_eri_pack(_lib.dptr(gd), N, G, _lib.dptr(out), _lib.stream_ptr()), "oovqe_eri_pack")
     assert np.array_equal(out.cpu().numpy().reshape(-1), ref)
     assert lib.oovqe_eri_packed_size(49) == 0
+
+
+@pytest.mark.parametrize("ncas,nelecas,ansatz", [(2, 2, "np_fabric"), (3, 4, "ucc"), (3, 2, "kupccd")])
+def test_unrestricted_rdms_vs_oracle(ncas, nelecas, ansatz):
+    """get_rdms(theta, restricted=False) (pqc.py:192-221 with the spin-orbital operators) against the
+    oracle's dense Jordan-Wigner matrices; spin-summing them gives the restricted 1-RDM back."""
+    import auto_oo_amd as aoo
+    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz=ansatz, n_layers=2, k=2)
+    theta = torch.tensor(np.random.default_rng(ncas).uniform(0, 2 * np.pi, pqc.theta_shape))
+    g1, g2 = pqc.get_rdms(theta, restricted=False)
+    n = 2 * ncas
+    assert g1.shape == (n, n) and g2.shape == (n, n, n, n)
+    state = pqc.qnode(theta)
+    r1, r2 = R.spin_rdms_from_state(state, ncas)
+    assert (g1.cpu() - r1).abs().max() < 1e-12 and (g2.cpu() - r2).abs().max() < 1e-12
+    s1, s2 = pqc.get_rdms_from_state(state, restricted=False)
+    assert torch.equal(s1, g1) and torch.equal(s2, g2)
+    gr, _ = pqc.get_rdms(theta)
+    spin_summed = g1[0::2, 0::2] + g1[1::2, 1::2]
+    assert (spin_summed - gr).abs().max() < 1e-12
+    assert abs(float(torch.trace(g1)) - nelecas) < 1e-12
+    # a complex state: Re[psi^T O psi] = re^T O re - im^T O im (bilinear, no conjugation)
+    phase = np.exp(0.3j)
+    c1, c2 = pqc.get_rdms_from_state(state * phase, restricted=False)
+    o1, o2 = R.spin_rdms_from_state(state.cpu() * phase, ncas)
+    assert (c1.cpu() - o1).abs().max() < 1e-12 and (c2.cpu() - o2).abs().max() < 1e-12
