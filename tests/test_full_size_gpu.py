@@ -131,14 +131,17 @@ def test_expm_n200_orthogonality_and_inverse():
     assert (U15 - U @ Uh).abs().max().item() < 1e-12
 
 
-def test_kupccd_cas88_state_rdm_gradient_properties():
-    """configs[4]: kUpCCD CAS(8e,8o) (16 qubits, 4900-determinant sector): normalisation, RDM sum
-    rules, and the reverse-mode theta-gradient against central differences of the energy."""
+@pytest.mark.parametrize("k", [1, 2])
+def test_kupccd_cas88_state_rdm_gradient_properties(k):
+    """configs[4]: kUpCCD CAS(8e,8o) (16 qubits, 4900-determinant sector), k = 1 and 2 layers (56 /
+    112 thetas, ansatze/kUpCCD.py:16-33): normalisation, RDM sum rules, and the reverse-mode
+    theta-gradient against central differences of the energy."""
     import auto_oo_amd as aoo
     from auto_oo_amd.synthetic import synthetic_problem
     ncas, nelecas, nelec, N = 8, 8, 16, 43
-    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="kupccd", k=1)
-    rng = np.random.default_rng(2)
+    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="kupccd", k=k)
+    assert int(pqc.theta_shape) == 56 * k
+    rng = np.random.default_rng(2 + k)
     th = torch.tensor(rng.uniform(0, 2 * np.pi, int(pqc.theta_shape)), device=DEV)
     psi = pqc.qnode(th)
     assert abs(torch.linalg.vector_norm(psi).item() - 1.0) < 1e-12

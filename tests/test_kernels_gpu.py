@@ -506,7 +506,9 @@ def test_cas_eval_pq_symmetric_integrals(N, nelec, ncas, nelecas, path, flags, l
 def test_eri_pack_layout(N):
     """oovqe_eri_pack: slab t = (p <= q) of the triangle; of each slab the upper triangle with the
     diagonal halved, row r holding its columns (r & ~1) .. N-1 (0 left of the diagonal in odd rows),
-    rows back to back (the copy half_tri_kernel streams when both symmetry flags hold)."""
+    rows back to back, the slab pitch rounded up to an even number of doubles with a zero pad element
+    (every slab starts on a 16-byte boundary; the copy half_tri_kernel streams when both symmetry
+    flags hold)."""
     from auto_oo_amd import _lib
     lib = _lib.load()
     G = 2
@@ -514,6 +516,7 @@ def test_eri_pack_layout(N):
     g = rng.standard_normal((G, N, N, N, N))
     psz = lib.oovqe_eri_packed_size(N)
     ref = []
+    odd = sum(N - (r & ~1) for r in range(N)) & 1
     for b in range(G):
         for p_ in range(N):
             for q_ in range(p_, N):
@@ -524,6 +527,8 @@ def test_eri_pack_layout(N):
                         row[0] = 0.0
                     row[r_ - e] *= 0.5
                     ref.append(row)
+                if odd:
+                    ref.append(np.zeros(1))
     ref = np.concatenate(ref)
     assert psz * G == ref.size
     gd = torch.tensor(g).to(DEV).contiguous()
