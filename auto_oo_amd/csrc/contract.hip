@@ -116,28 +116,13 @@ void contract_body(const double* __restrict__ T, const double* __restrict__ Cm,
     // a chunk (row kk, column j0 + jj), OOB for padding columns / rows; the chunk's first row is
     // added as a scalar offset and rows k >= K fall outside the descriptor (-> 0, the zero padding
     // the MFMAs rely on).
-    // LDS image of a chunk: k-steps are stored in PAIRS -- [pair p][lq][LDJ][2] holds rows
-    // 4(2p) + lq and 4(2p+1) + lq side by side, so ONE ds_read_b128 per tile delivers a lane's Cm
-    // fragments of two consecutive k-steps (half the LDS instructions of b64 reads, and b128 reads
-    // reach the LDS peak rate with one wave per SIMD); an odd last k-step follows as [lq][LDJ].
-    constexpr int NPAIR = KSTEPS / 2, REM = KSTEPS % 2;
-    constexpr int PAIR_D = 8 * LDJ;
     unsigned cvo[CREG];
 #pragma unroll
     for (int i = 0; i < CREG; ++i) {
         const int idx = tid + i * NTHREADS;
-        int kk, jj;
-        if (idx < NPAIR * PAIR_D) {
-            const int rest = idx >> 1, row = rest / LDJ;
-            jj = rest - row * LDJ;
-            kk = 4 * (2 * (row >> 2) + (idx & 1)) + (row & 3);
-        } else {
-            const int rest = idx - NPAIR * PAIR_D, q = rest / LDJ;
-            jj = rest - q * LDJ;
-            kk = 4 * (KSTEPS - 1) + q;
-        }
+        const int kk = idx / LDJ, jj = idx - kk * LDJ;
         const int j = j0 + jj;
-        const bool jok = idx < CHUNK && jj < NT * 16 && j < J;
+        const bool jok = kk < KC && jj < NT * 16 && j < J;
         cvo[i] = jok ? (unsigned)((kk * (long)ldc + j) * sizeof(double)) : OOB;
     }
     const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(
@@ -190,52 +175,28 @@ void contract_body(const double* __restrict__ T, const double* __restrict__ Cm,
             // the MFMAs of k-step 0, and the LDS staging stores in the region of the last k-step,
             // so their VALU work fills the 64-cycle MFMA issue gaps instead of running ahead of
             // the first MFMA after every barrier.
-            const double* bufp = lds + par * BUF + (lq * LDJ + lr) * 2;            // pair p, tile t: + p PAIR_D + 32 t
-            const double* bufr = lds + par * BUF + NPAIR * PAIR_D + lq * LDJ + lr;  // odd last k-step, tile t: + 16 t
-            d2 cv[NT];
-            if constexpr (NPAIR > 0) {
+            const double* buf = lds + par * BUF + lq * LDJ + lr;
+            double cv[2][NT];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) cv[t] = *reinterpret_cast<const d2*>(bufp + t * 32);
-            } else {
+            for (int t = 0; t < NT; ++t) cv[0][t] = buf[t * 16];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) cv[t].x = bufr[t * 16];
-            }
+            for (int s = 0; s < KSTEPS; ++s) {
+                if (s + 1 < KSTEPS) {
 #pragma unroll
-            for (int p = 0; p < NPAIR; ++p) {
+                    for (int t = 0; t < NT; ++t) cv[(s + 1) & 1][t] = buf[(s + 1) * 4 * LDJ + t * 16];
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    acc[t] = LAST ? mfma_f64(tcur[2 * p], cv[t].x, acc[t])
-                                  : mfma_f64(cv[t].x, tcur[2 * p], acc[t]);
-                if (p == 0) {
+                    acc[t] = LAST ? mfma_f64(tcur[s], cv[s & 1][t], acc[t])
+                                  : mfma_f64(cv[s & 1][t], tcur[s], acc[t]);
+                if (s == 0) {
                     stage_load(knext);
                     load_t(stn, knext, tnext);
                 }
+                if (s == KSTEPS - 1) stage_store(lds + (par ^ 1) * BUF);
                 __builtin_amdgcn_sched_barrier(0);
-                // second k-step of the pair; a tile's register is refilled with the next fragments
-                // right behind the MFMA that consumed it (13 MFMAs = 832 cycles ahead of its use)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    acc[t] = LAST ? mfma_f64(tcur[2 * p + 1], cv[t].y, acc[t])
-                                  : mfma_f64(cv[t].y, tcur[2 * p + 1], acc[t]);
-                    if (p + 1 < NPAIR) cv[t] = *reinterpret_cast<const d2*>(bufp + (p + 1) * PAIR_D + t * 32);
-                    else if (REM) cv[t].x = bufr[t * 16];
-                }
-                if (p == NPAIR - 1 && !REM) stage_store(lds + (par ^ 1) * BUF);
             }
-            if constexpr (REM) {
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[t] = LAST ? mfma_f64(tcur[KSTEPS - 1], cv[t].x, acc[t])
-                                  : mfma_f64(cv[t].x, tcur[KSTEPS - 1], acc[t]);
-                if (NPAIR == 0) {
-                    stage_load(knext);
-                    load_t(stn, knext, tnext);
-                }
-                stage_store(lds + (par ^ 1) * BUF);
-            }
-            __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             par ^= 1;
 #pragma unroll

@@ -272,6 +272,153 @@ void sector_gram_kernel(const double* __restrict__ psi_c, const double* __restri
     R[(((size_t)split * batch + b) * (MT * 16) + row) * (NT * 16) + col] = v;
 }
 
+// The same Gram with ONE workgroup per (state, c-slice) forming all MT x NT tiles at once: every row
+// of V is read once per workgroup (the tile-per-workgroup kernel above re-reads each row MT or NT
+// times, and its tiles of one state land on different XCDs: at batch 256 the 642 MB of V came from
+// HBM / Infinity Cache ~8 times, 965 us where the bytes take 110).  A lane fetches 32 contiguous
+// bytes (4 determinants) of its row per 16-determinant chunk -- four lanes cover a 128-byte line --
+// and k-step j of the chunk takes determinant 16 ch + 4 lq + j from lane group lq: any assignment
+// of determinants to k-steps gives the same sum as long as A and B use the same one.
+// PSI_VALU (a^2 a multiple of 16, e.g. 8 active orbitals): the extra row <psi| V_rs> = gamma_rs would
+// cost a whole row of tiles with one useful row in sixteen (MT = 5 instead of 4: a fifth of the
+// MFMAs); it is formed on the vector ALUs instead, from the B fragments the lanes hold anyway.
+template <int MT, int NT, bool PSI_VALU>
+__global__ __launch_bounds__(512)
+void sector_gram_rows_kernel(const double* __restrict__ psi_c, const double* __restrict__ V, int ncas,
+                             int Dc, int batch, int MTR, double* __restrict__ R)
+{
+    // MTR: row tiles of the result buffer R; blockIdx.z: which MT row tiles this workgroup forms
+    // (two half-height workgroups per state keep 4 waves per SIMD resident at 128 VGPRs each)
+    __shared__ double red[8][256];
+    const int mt0 = blockIdx.z * MT;
+    const int na2 = ncas * ncas;
+    const size_t b = blockIdx.x;
+    const int split = blockIdx.y, nsplit = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane >> 4, lr = lane & 15;
+    const double* Vb = V + b * (size_t)na2 * Dc;
+    const double* arow[MT];
+    double amask[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = (mt0 + mt) * 16 + lr;
+        arow[mt] = psi_c + b * (size_t)Dc;          // row a^2 = psi; also the dummy of padded rows
+        amask[mt] = m <= na2 ? 1.0 : 0.0;
+        if (m < na2) {
+            const int p = m / ncas, q = m - p * ncas;
+            arow[mt] = Vb + (size_t)(q * ncas + p) * Dc;
+        }
+    }
+    const double* brow[NT];
+    double bmask[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int nn = nt * 16 + lr;
+        brow[nt] = Vb + (size_t)(nn < na2 ? nn : 0) * Dc;
+        bmask[nt] = nn < na2 ? 1.0 : 0.0;
+    }
+    const int nchunk = (Dc + 15) / 16;
+    const int nslice = 8 * nsplit;
+    const int per = (nchunk + nslice - 1) / nslice;
+    const int sl = split * 8 + wave;
+    const int ch0 = sl * per, ch1 = (ch0 + per < nchunk) ? ch0 + per : nchunk;
+    d4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = d4{0.0, 0.0, 0.0, 0.0};
+    double gpart[NT];                                 // PSI_VALU: this lane's share of <psi| V_row>
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) gpart[nt] = 0.0;
+    const double* prow = psi_c + b * (size_t)Dc;
+    for (int ch = ch0; ch < ch1; ++ch) {
+        const int c0 = 16 * ch + 4 * lq;
+        // Dc is a multiple of 4 for every sector with an even number of strings per spin, but not in
+        // general: positions past the end are clamped and masked one by one
+        double km[4];
+        int cc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { cc[j] = c0 + j < Dc ? c0 + j : Dc - 1; km[j] = c0 + j < Dc ? 1.0 : 0.0; }
+        const bool whole = c0 + 3 < Dc && (Dc & 1) == 0;      // 16-byte loads need an even row pitch
+        double bv[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (whole) {
+                const d2 lo = *reinterpret_cast<const d2*>(brow[nt] + c0), hi = *reinterpret_cast<const d2*>(brow[nt] + c0 + 2);
+                bv[nt][0] = lo.x * bmask[nt]; bv[nt][1] = lo.y * bmask[nt];
+                bv[nt][2] = hi.x * bmask[nt]; bv[nt][3] = hi.y * bmask[nt];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[nt][j] = brow[nt][cc[j]] * (km[j] * bmask[nt]);
+            }
+        }
+        if (PSI_VALU && blockIdx.z == 0) {
+            double pv[4];
+            if (whole) {
+                const d2 lo = *reinterpret_cast<const d2*>(prow + c0), hi = *reinterpret_cast<const d2*>(prow + c0 + 2);
+                pv[0] = lo.x; pv[1] = lo.y; pv[2] = hi.x; pv[3] = hi.y;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pv[j] = prow[cc[j]] * km[j];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gpart[nt] += pv[j] * bv[nt][j];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            double av[4];
+            if (whole) {
+                const d2 lo = *reinterpret_cast<const d2*>(arow[mt] + c0), hi = *reinterpret_cast<const d2*>(arow[mt] + c0 + 2);
+                av[0] = lo.x * amask[mt]; av[1] = lo.y * amask[mt];
+                av[2] = hi.x * amask[mt]; av[3] = hi.y * amask[mt];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[j] = arow[mt][cc[j]] * (km[j] * amask[mt]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_f64(av[j], bv[nt][j], acc[mt][nt]);
+        }
+    }
+    // the 8 waves' partial tiles are summed through LDS in fixed order, tile by tile
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[wave][(lq + 4 * i) * 16 + lr] = acc[mt][nt][i];
+            __syncthreads();
+            if (tid < 256) {
+                double v = red[0][tid];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) v += red[w][tid];
+                const int row = (mt0 + mt) * 16 + tid / 16, col = nt * 16 + (tid & 15);
+                R[(((size_t)split * batch + b) * (MTR * 16) + row) * (NT * 16) + col] = v;
+            }
+            __syncthreads();
+        }
+    if (PSI_VALU && blockIdx.z == 0) {
+        // row a^2 of R: lane (lq, lr) holds the share of row nt*16 + lr over its determinants; the
+        // four lane groups and the eight waves meet in LDS, summed in fixed order
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            red[wave][lq * 16 + lr] = gpart[nt];
+            __syncthreads();
+            if (tid < 16) {
+                double v = 0.0;
+                for (int w = 0; w < 8; ++w)
+                    for (int g = 0; g < 4; ++g) v += red[w][g * 16 + tid];
+                R[(((size_t)split * batch + b) * (MTR * 16) + na2) * (NT * 16) + nt * 16 + tid] = v;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // gamma[rs] = R[a^2][rs];  Gamma[pq,rs] = R[pq][rs] - delta_qr gamma[ps]
 __global__ void sector_rdm_finish_kernel(const double* __restrict__ R, int ncas, int batch, int nsplit,
                                          double* __restrict__ gamma, double* __restrict__ Gamma)
@@ -555,8 +702,24 @@ extern "C" int oovqe_sector_rdms(const double* psi_c, int ncas, const uint32_t* 
                        V);
     OOVQE_CHECK_LAUNCH("sector_rdms/epq");
     const int nsplit = batch >= 32 ? 1 : (batch >= 8 ? 2 : 8);   // fill the chip at small batch
-    hipLaunchKernelGGL(sector_gram_kernel, dim3(MT * NT, batch, nsplit), dim3(256), 0, st, psi_c, V, ncas,
-                       Dc, batch, R);
+    // all tiles of a state in one workgroup (V read once) for the active spaces up to 8 orbitals; the
+    // tile-per-workgroup kernel beyond (more accumulators than a wave's registers hold)
+    const bool rows_kernel = batch * nsplit >= 32;     // few states: more, smaller workgroups fill the chip better
+    // (two half-height workgroups per state, <2, 4> with grid.z = 2, measured slower: 168 VGPRs keep
+    // one workgroup per CU anyway, and capped at 128 the kernel spills: 905 us against 629)
+    if (rows_kernel && MT == 5 && NT == 4)           // a = 8: psi row on the vector ALUs
+        hipLaunchKernelGGL((sector_gram_rows_kernel<4, 4, true>), dim3(batch, nsplit, 1), dim3(512), 0, st, psi_c, V, ncas, Dc, batch, MT, R);
+    else if (rows_kernel && MT == 4 && NT == 4)
+        hipLaunchKernelGGL((sector_gram_rows_kernel<4, 4, false>), dim3(batch, nsplit, 1), dim3(512), 0, st, psi_c, V, ncas, Dc, batch, MT, R);
+    else if (rows_kernel && MT == 3 && NT == 3)
+        hipLaunchKernelGGL((sector_gram_rows_kernel<3, 3, false>), dim3(batch, nsplit, 1), dim3(512), 0, st, psi_c, V, ncas, Dc, batch, MT, R);
+    else if (rows_kernel && MT == 2 && NT == 2)
+        hipLaunchKernelGGL((sector_gram_rows_kernel<2, 2, false>), dim3(batch, nsplit, 1), dim3(512), 0, st, psi_c, V, ncas, Dc, batch, MT, R);
+    else if (rows_kernel && MT == 2 && NT == 1)
+        hipLaunchKernelGGL((sector_gram_rows_kernel<1, 1, true>), dim3(batch, nsplit, 1), dim3(512), 0, st, psi_c, V, ncas, Dc, batch, MT, R);
+    else
+        hipLaunchKernelGGL(sector_gram_kernel, dim3(MT * NT, batch, nsplit), dim3(256), 0, st, psi_c, V, ncas,
+                           Dc, batch, R);
     OOVQE_CHECK_LAUNCH("sector_rdms/gram");
     hipLaunchKernelGGL(sector_rdm_finish_kernel, dim3((na2 * na2 + na2 + 255) / 256, batch), dim3(256),
                        0, st, R, ncas, batch, nsplit, gamma, Gamma);
