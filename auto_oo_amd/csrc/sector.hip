@@ -453,16 +453,16 @@ __global__ void sector_rdm_finish_kernel(const double* __restrict__ R, int ncas,
 //                                                            (W'_rs = sum_pq c2[pq,rs] V_qp)
 // c1e[ps] = c1[ps] - sum_q c2[p,q,q,s]
 __global__ void sector_coeff_kernel(const double* __restrict__ c1, const double* __restrict__ c2,
-                                    int ncas, double* __restrict__ M1, double* __restrict__ M2,
-                                    double* __restrict__ c1e)
+                                    int ncas, double* __restrict__ M12, double* __restrict__ c1e)
 {
+    // M12 [a^2][2 a^2] = [M1 | M2]: both products stream V once in ONE contraction with J = 2 a^2
     const int na2 = ncas * ncas;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < na2 * na2;
          idx += gridDim.x * blockDim.x) {
         const int k = idx / na2, j = idx - k * na2;
-        M1[idx] = c2[(size_t)j * na2 + k];
+        M12[(size_t)k * 2 * na2 + j] = c2[(size_t)j * na2 + k];
         const int kq = k / ncas, kp = k - kq * ncas;          // k = q*a + p  ->  pq = p*a + q
-        M2[idx] = c2[(size_t)(kp * ncas + kq) * na2 + j];
+        M12[(size_t)k * 2 * na2 + na2 + j] = c2[(size_t)(kp * ncas + kq) * na2 + j];
         if (idx < na2) {
             const int p = idx / ncas, s2 = idx - p * ncas;
             double v = c1[idx];
@@ -475,9 +475,8 @@ __global__ void sector_coeff_kernel(const double* __restrict__ c1, const double*
 // grid: (ceil(Dc/64), batch); block = 64 determinants x 4 slices of the (p,q) loop, summed in LDS
 // in fixed order; string tables staged in LDS.
 __global__ __launch_bounds__(256)
-void sector_lambda_kernel(const double* __restrict__ V, const double* __restrict__ W1,
-                          const double* __restrict__ W2, const double* __restrict__ c1e, Sector s,
-                          double* __restrict__ lam)
+void sector_lambda_kernel(const double* __restrict__ V, const double* __restrict__ W12,
+                          const double* __restrict__ c1e, Sector s, double* __restrict__ lam)
 {
     extern __shared__ double lds[];
     double* part = lds;                                         // [4][64]
@@ -497,8 +496,8 @@ void sector_lambda_kernel(const double* __restrict__ V, const double* __restrict
     double acc = 0.0;
     if (c < Dc) {
         const double* Vb = V + b * (size_t)na2 * Dc;
-        const double* W1b = W1 + b * (size_t)na2 * Dc;
-        const double* W2b = W2 + b * (size_t)na2 * Dc;
+        const double* W1b = W12 + b * (size_t)2 * na2 * Dc;    // [2 a^2][Dc]: W rows, then W' rows
+        const double* W2b = W1b + (size_t)na2 * Dc;
         const uint32_t x = sec_full(sg, c);
         for (int pq = slice; pq < na2; pq += 4) {
             const int p = pq / a, q = pq - p * a, qp = q * a + p;
@@ -747,26 +746,22 @@ extern "C" int oovqe_sector_adjoint(const double* theta, int n_theta, const oovq
     Sector s = make_sector(unrank_a, unrank_b, rank_a, rank_b, na, nb, ncas);
     const size_t nb_ = (size_t)batch;
     double* V = work;
-    double* W1 = V + nb_ * na2 * Dc;
-    double* W2 = W1 + nb_ * na2 * Dc;
-    double* lam = W2 + nb_ * na2 * Dc;
+    double* W12 = V + nb_ * na2 * Dc;                   // [batch][2 a^2][Dc]
+    double* lam = W12 + 2 * nb_ * na2 * Dc;
     double* R = lam + nb_ * Dc;
-    double* M1 = R + 8 * nb_ * (size_t)(MT * 16) * (NT * 16);
-    double* M2 = M1 + (size_t)na2 * na2;
-    double* c1e = M2 + (size_t)na2 * na2;
+    double* M12 = R + 8 * nb_ * (size_t)(MT * 16) * (NT * 16);
+    double* c1e = M12 + 2 * (size_t)na2 * na2;
     hipLaunchKernelGGL(sector_coeff_kernel, dim3((na2 * na2 + 255) / 256), dim3(256), 0, st, c1, c2, ncas,
-                       M1, M2, c1e);
+                       M12, c1e);
     OOVQE_CHECK_LAUNCH("sector_adjoint/coeff");
     int rc;
-    // W1[b][pq][c] = sum_rs M1[(rs),(pq)] V[b][rs][c]   ;   W2[b][rs][c] = sum_k M2[k,(rs)] V[b][k][c]
-    if ((rc = oovqe_mode_contract_batched(V, M1, W1, 1, na2, na2, Dc, na2, 0, batch, (long)na2 * Dc, 0,
-                                          (long)na2 * Dc, st)))
-        return rc;
-    if ((rc = oovqe_mode_contract_batched(V, M2, W2, 1, na2, na2, Dc, na2, 0, batch, (long)na2 * Dc, 0,
-                                          (long)na2 * Dc, st)))
+    // W12[b][j][c] = sum_k M12[k][j] V[b][k][c]: rows j < a^2: W_pq = sum_rs c2[pq,rs] V_rs,
+    // rows j >= a^2: W'_rs = sum_pq c2[pq,rs] V_qp -- one pass over V for both
+    if ((rc = oovqe_mode_contract_batched(V, M12, W12, 1, na2, 2 * na2, Dc, 2 * na2, 0, batch, (long)na2 * Dc,
+                                          0, (long)2 * na2 * Dc, st)))
         return rc;
     hipLaunchKernelGGL(sector_lambda_kernel, dim3((Dc + 63) / 64, batch), dim3(256),
-                       256 * sizeof(double) + 2 * ((size_t)1 << ncas) * sizeof(int32_t), st, V, W1, W2,
+                       256 * sizeof(double) + 2 * ((size_t)1 << ncas) * sizeof(int32_t), st, V, W12,
                        c1e, s, lam);
     OOVQE_CHECK_LAUNCH("sector_adjoint/lambda");
     const int nit = (Dc + SEC_THREADS - 1) / SEC_THREADS;
