@@ -332,11 +332,62 @@ def transform_microbench(N):
         ops.expm(K, -1.0)
     torch.cuda.synchronize()
     ex_us = (time.perf_counter() - t0) / 10 * 1e6
-    del g, o, w
+    del o, w
+    torch.cuda.empty_cache()
+    oo_eval = oo_evaluation_large(N, g, C)
+    del g
     torch.cuda.empty_cache()
     return dict(N=N, ms=med * 1e3, tflops=tf, peak_tflops=FP64_PEAK_TFLOPS,
                 frac=tf / FP64_PEAK_TFLOPS, flops=8.0 * N ** 5, expm_us=ex_us,
-                note="four chained fp64-MFMA mode contractions; algorithmic 8 N^5 flop")
+                note="four chained fp64-MFMA mode contractions; algorithmic 8 N^5 flop",
+                oo_evaluation=oo_eval)
+
+
+def oo_evaluation_large(N, g, C):
+    """configs[2] as ONE OO evaluation: N = 200, CAS(6e,6o), n_occ = 20 (M = 26) -- beyond the packed
+    batched kernels (N <= 48, M <= 16), so the library takes the streaming T2 path: persistent
+    half_stream_kernel over the N^4 tensor, K1 for q->x and p->n, Fock stage.  Timed on a general
+    tensor (every slab read) and on a p<->q / r<->s symmetric one (slabs p <= q only)."""
+    import auto_oo_amd as aoo
+    from auto_oo_amd import ops
+    ncas, nelecas, n_occ = 6, 6, 20
+    M = n_occ + ncas
+    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="ucc")
+    theta = torch.tensor(np.random.default_rng(8).uniform(0, 2 * np.pi, pqc.theta_shape), device="cuda")
+    g1, g2 = pqc.get_rdms(theta)
+    g1, g2 = g1[None].contiguous(), g2[None].contiguous()
+    rows, cols = aoo.excitations.tril_tables(N, aoo.non_redundant_indices(
+        np.arange(n_occ), n_occ + np.arange(ncas), np.arange(M, N), False))
+    kr, kc = torch.as_tensor(rows).to("cuda"), torch.as_tensor(cols).to("cuda")
+    Q, _ = torch.linalg.qr(C)
+    Q = Q.contiguous()
+    h = (C + C.T).contiguous()
+    work = torch.empty(aoo._lib.load().oovqe_cas_eval_work_size(N, n_occ, ncas, 1), dtype=torch.float64,
+                       device="cuda")
+
+    def timed(flags):
+        for _ in range(2):
+            ops.cas_eval(g, h, Q, g1, g2, 31.0, n_occ, ncas, kr, kc, work=work, eri_flags=flags)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ops.cas_eval(g, h, Q, g1, g2, 31.0, n_occ, ncas, kr, kc, work=work, eri_flags=flags)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 5
+    t_gen = timed(0)
+    # make the tensor exactly p<->q and r<->s symmetric in place (values stay O(1): timing only)
+    g.add_(g.transpose(0, 1).clone()).mul_(0.5)
+    g.add_(g.transpose(2, 3).clone()).mul_(0.5)
+    flags = ops.eri_flags(g)
+    t_sym = timed(flags)
+    full = 8.0 * N ** 4
+    return {"N": N, "ncas": ncas, "nelecas": nelecas, "n_occ": n_occ, "M": M, "n_kappa": int(kr.numel()),
+            "general_tensor": {"us": t_gen * 1e6, "stage1_bytes": full, "effective_GBs": full / t_gen / 1e9},
+            "symmetric_tensor": {"us": t_sym * 1e6, "eri_flags": int(flags),
+                                 "stage1_bytes": full * (N + 1) / (2.0 * N),
+                                 "effective_GBs": full * (N + 1) / (2.0 * N) / t_sym / 1e9},
+            "note": "energy + orbital gradient for one RDM set; effective_GBs = N^4 bytes the sweep must "
+                    "read / whole-evaluation time (the later stages are inside the time)"}
 
 
 def launch_command(n_ranks, port, argv):

@@ -164,3 +164,78 @@ def test_kupccd_cas88_state_rdm_gradient_properties(k):
         tm[j] -= h
         fd = (oo.energy_from_parameters(tp).item() - oo.energy_from_parameters(tm).item()) / (2 * h)
         assert abs(fd - grad[j].item()) < 1e-6 * max(1.0, abs(fd))
+
+
+def test_oo_evaluation_n96_cas66_vs_oracle():
+    """Beyond the packed-triangle envelope (N > 48, M = 16): one OO evaluation at N = 96 with a
+    CAS(6e,6o) active space (n_occ = 10) on the streaming T2 path against the oracle -- energy,
+    CAS coefficients and the analytic orbital gradient for the engine's own RDMs (1e-9 / 1e-8)."""
+    import auto_oo_amd as aoo
+    from auto_oo_amd.synthetic import synthetic_problem
+    from oracle import cpu_ref as R
+    N, ncas, nelecas, nelec = 96, 6, 6, 26
+    P = synthetic_problem(N, 20296)
+    mol = aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec)
+    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="ucc")
+    oo = aoo.OO_pqc(pqc, mol, ncas, nelecas, oao_mo_coeff=P["oao_mo_coeff"])
+    assert oo._M == 16 and oo.n_kappa == N * (N - 1) // 2 - 10 * 9 // 2 - 80 * 79 // 2
+    theta = torch.tensor(np.random.default_rng(4).uniform(0, 2 * np.pi, pqc.theta_shape))
+    E, grad = oo.energy_and_gradient(theta)
+    g1, g2 = pqc.get_rdms(theta)
+    omol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec)
+    ooo = R.OracleOOEnergy(omol, ncas, nelecas, P["oao_mo_coeff"])
+    e_ref = ooo.energy_from_mo_coeff(ooo.mo_coeff, g1.cpu(), g2.cpu()).item()
+    assert abs(E.item() - e_ref) < 1e-9
+    gk_ref = ooo.kappa_matrix_to_vector(ooo.analytic_gradient(g1.cpu(), g2.cpu()))
+    assert (grad[pqc.theta_shape:].cpu() - gk_ref).abs().max() < 1e-8
+    c0, c1, c2 = oo.get_active_integrals(oo.mo_coeff)
+    r0, r1, r2 = ooo.get_active_integrals(ooo.mo_coeff)
+    assert abs(c0.item() - float(r0)) < 1e-9
+    assert (c1.cpu() - r1).abs().max() < 1e-10 and (c2.cpu() - r2).abs().max() < 1e-10
+    # dE/dtheta against central differences of the engine's own energy
+    h = 1e-5
+    for j in torch.argsort(grad[:pqc.theta_shape].abs(), descending=True)[:2].tolist():
+        tp, tm = theta.clone(), theta.clone()
+        tp[j] += h
+        tm[j] -= h
+        fd = (oo.energy_from_parameters(tp).item() - oo.energy_from_parameters(tm).item()) / (2 * h)
+        assert abs(fd - grad[j].item()) < 1e-6 * max(1.0, abs(fd))
+
+
+def test_oo_evaluation_n200_cas66_fused_vs_staged():
+    """BASELINE configs[2] as an OO evaluation: N = 200, CAS(6e,6o), n_occ = 20 (M = 26).  The oracle
+    is out of reach (3 x 2.56 TFLOP on the CPU); the one-call evaluation (oovqe_cas_eval) is checked
+    against the staged kernels (half transform -> finish -> Fock stage, each parity-tested against the
+    oracle at smaller N) on identical inputs, plus size-independent properties."""
+    import auto_oo_amd as aoo
+    from auto_oo_amd import ops
+    N, ncas, nelecas, n_occ = 200, 6, 6, 20
+    M = n_occ + ncas
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    B = torch.randn((N, N, N), generator=gen, dtype=torch.float64, device=DEV)
+    B = 0.5 * (B + B.transpose(1, 2))
+    g = torch.einsum("Lpq,Lrs->pqrs", B[:24], B[:24]) / 24.0          # 8-fold symmetric, 12.8 GB
+    del B
+    h = torch.randn((N, N), generator=gen, dtype=torch.float64, device=DEV)
+    h = 0.5 * (h + h.T) / N ** 0.5
+    Q, _ = torch.linalg.qr(torch.randn((N, N), generator=gen, dtype=torch.float64, device=DEV))
+    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="ucc")
+    theta = torch.tensor(np.random.default_rng(8).uniform(0, 2 * np.pi, pqc.theta_shape))
+    g1, g2 = pqc.get_rdms(theta)
+    rows, cols = aoo.excitations.tril_tables(N, aoo.non_redundant_indices(
+        np.arange(n_occ), n_occ + np.arange(ncas), np.arange(M, N), False))
+    kr, kc = torch.as_tensor(rows).to(DEV), torch.as_tensor(cols).to(DEV)
+    fused = ops.cas_eval(g, h, Q.contiguous(), g1[None].contiguous(), g2[None].contiguous(), 31.0, n_occ, ncas,
+                         kr, kc, want_matrices=True, eri_flags=ops.eri_flags(g))
+    T2 = ops.cas_half_transform(g, Q.contiguous(), M)
+    Gm, hmo = ops.cas_finish_transform(T2, h, Q.contiguous(), M)
+    staged = ops.cas_energy_gradient(Gm, hmo, g1[None].contiguous(), g2[None].contiguous(), 31.0, n_occ, ncas,
+                                     kr, kc, want_matrices=True)
+    scale = float(staged["gvec"].abs().max())
+    assert abs(fused["E"].item() - staged["E"].item()) < 1e-9 * max(1.0, abs(staged["E"].item()))
+    assert (fused["gvec"] - staged["gvec"]).abs().max() < 1e-10 * max(1.0, scale)
+    assert (fused["c2"] - staged["c2"]).abs().max() < 1e-11 and (fused["c1"] - staged["c1"]).abs().max() < 1e-11
+    assert (fused["fock"] - staged["fock"]).abs().max() < 1e-10 * max(1.0, float(staged["fock"].abs().max()))
+    # orbital-gradient matrix is antisymmetric; virtual rows of the generalized Fock matrix vanish
+    assert (fused["gmat"] + fused["gmat"].T).abs().max() < 1e-12 * max(1.0, scale)
+    assert fused["fock"][M:].abs().max() == 0.0
