@@ -100,6 +100,11 @@ SIGNATURES = {
     "oovqe_circuit_hessian_assemble": (ctypes.c_int, [c_double_p, c_double_p, c_double_p, c_double_p,
                                                       ctypes.c_int, c_int32_p, ctypes.c_int,
                                                       ctypes.c_int, c_double_p, c_stream]),
+    "oovqe_circuit_hessian": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, ctypes.c_uint32, c_double_p,
+                                             c_double_p, c_int32_p, ctypes.c_int, c_double_p, c_double_p,
+                                             c_stream]),
+    "oovqe_circuit_hessian_work_size": (ctypes.c_int64, [ctypes.c_int] * 4),
     "oovqe_sector_state": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_uint32, c_int32_p, c_int32_p,
                                           c_int32_p, c_int32_p, ctypes.c_int, ctypes.c_int,

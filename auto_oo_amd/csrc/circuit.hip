@@ -415,6 +415,23 @@ void circuit_hessian_kernel(const double* __restrict__ gamma, const double* __re
     }
 }
 
+// operand lists of the theta-theta Hessian: per pair (j,k) the four (bra, ket) combinations
+// (psi_jk, psi), (psi_j, psi_k), (psi_k, psi_j), (psi, psi_jk); grid (ceil(D/256), 4 n_pairs)
+__global__ __launch_bounds__(256)
+void hessian_operands_kernel(const double* __restrict__ psi, const double* __restrict__ dpsi,
+                             const double* __restrict__ psi2, const int32_t* __restrict__ pairs,
+                             unsigned D, double* __restrict__ bra, double* __restrict__ ket)
+{
+    const unsigned x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= D) return;
+    const int row = blockIdx.y, pr = row >> 2, set = row & 3;
+    const int j = pairs[2 * pr], k = pairs[2 * pr + 1];
+    const double p0 = psi[x], p2 = psi2[(size_t)pr * D + x];
+    const double pj = dpsi[(size_t)j * D + x], pk = dpsi[(size_t)k * D + x];
+    bra[(size_t)row * D + x] = set == 0 ? p2 : set == 1 ? pj : set == 2 ? pk : p0;
+    ket[(size_t)row * D + x] = set == 0 ? p0 : set == 1 ? pk : set == 2 ? pj : p2;
+}
+
 }  // namespace
 
 extern "C" int oovqe_circuit_state(const double* theta, int n_theta, const oovqe_gate_t* gates,
@@ -564,4 +581,47 @@ extern "C" int oovqe_circuit_hessian_assemble(const double* gamma, const double*
                        gamma, Gamma, c1, c2, ncas, pairs, n_theta, H);
     OOVQE_CHECK_LAUNCH("circuit_hessian");
     return 0;
+}
+
+
+// d^2E/dtheta^2 for E = c0 + c1.gamma(theta) + c2.Gamma(theta) in ONE call (oo_pqc.py:103-111):
+// state + tangents, second tangents, the 4 n_pairs transition-RDM operand pairs, transition RDMs,
+// contraction -- five launches chained here instead of a dozen small tensor operations on the host
+// side (0.26 -> ~0.07 ms for the 4 x 4 block of configs[1]).  pairs [n_pairs][2] (j <= k).
+extern "C" int64_t oovqe_circuit_hessian_work_size(int n_theta, int n_qubits, int ncas, int n_pairs)
+{
+    const int64_t D = (int64_t)1 << n_qubits, na2 = (int64_t)ncas * ncas;
+    // psi | dpsi | psi2 | scratch | bra | ket | gamma | Gamma | rdm work
+    return D * (1 + n_theta + 2 * n_pairs + 8 * n_pairs) + 4 * n_pairs * (na2 + na2 * na2) +
+           4 * n_pairs * 2 * na2 * D;
+}
+
+extern "C" int oovqe_circuit_hessian(const double* theta, int n_theta, const oovqe_gate_t* gates,
+                                     int n_gates, int n_qubits, int ncas, uint32_t init_index,
+                                     const double* c1, const double* c2, const int32_t* pairs,
+                                     int n_pairs, double* work, double* H, oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(theta && gates && c1 && c2 && pairs && work && H, "circuit_hessian: null pointer");
+    OOVQE_REQUIRE(n_pairs >= 1 && 4 * n_pairs <= 65535, "circuit_hessian: n_pairs=%d", n_pairs);
+    const size_t D = (size_t)1 << n_qubits, na2 = (size_t)ncas * ncas;
+    double* psi = work;
+    double* dpsi = psi + D;
+    double* psi2 = dpsi + (size_t)n_theta * D;
+    double* scratch = psi2 + (size_t)n_pairs * D;
+    double* bra = scratch + (size_t)n_pairs * D;
+    double* ket = bra + 4 * (size_t)n_pairs * D;
+    double* g1 = ket + 4 * (size_t)n_pairs * D;
+    double* g2 = g1 + 4 * (size_t)n_pairs * na2;
+    double* rwork = g2 + 4 * (size_t)n_pairs * na2 * na2;
+    int rc;
+    if ((rc = oovqe_circuit_state(theta, n_theta, gates, n_gates, n_qubits, init_index, 1, psi, dpsi, stream)))
+        return rc;
+    if ((rc = oovqe_circuit_second_tangents(theta, n_theta, gates, n_gates, n_qubits, init_index, pairs,
+                                            n_pairs, psi2, scratch, stream)))
+        return rc;
+    hipLaunchKernelGGL(hessian_operands_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)(4 * n_pairs)),
+                       dim3(256), 0, (hipStream_t)stream, psi, dpsi, psi2, pairs, (unsigned)D, bra, ket);
+    OOVQE_CHECK_LAUNCH("circuit_hessian/operands");
+    if ((rc = oovqe_rdms(bra, ket, n_qubits, ncas, 4 * n_pairs, g1, g2, rwork, stream))) return rc;
+    return oovqe_circuit_hessian_assemble(g1, g2, c1, c2, ncas, pairs, n_pairs, n_theta, H, stream);
 }

@@ -177,10 +177,28 @@ class OO_pqc(OO_energy):
         return self.analytic_hessian_matrix(one_rdm, two_rdm)
 
     def full_hessian(self, theta):
-        """oo_pqc.py:136-148: [[theta-theta, (kappa-theta)^T], [kappa-theta, kappa-kappa]]."""
-        hessian_vqe_vqe = self.circuit_circuit_hessian(theta)
-        hessian_vqe_oo = self.orbital_circuit_hessian(theta)
-        hessian_oo_oo = self.orbital_orbital_hessian(theta)
+        """oo_pqc.py:136-148: [[theta-theta, (kappa-theta)^T], [kappa-theta, kappa-kappa]].  The
+        three blocks share ONE pass over the integrals: the RDMs and their theta-derivatives go
+        through the CAS path together (set 0 yields c1, c2 and the Fock matrix, sets k >= 1 the
+        kappa-theta columns), then the circuit block and the orbital block follow from those."""
+        pqc = self.pqc
+        if getattr(pqc, "_use_sector", False):
+            hessian_vqe_vqe = self.circuit_circuit_hessian(theta)
+            hessian_vqe_oo = self.orbital_circuit_hessian(theta)
+            hessian_oo_oo = self.orbital_orbital_hessian(theta)
+        else:
+            C = self._t(self.mo_coeff)
+            gamma, Gamma = pqc.rdms_with_derivatives(theta)
+            res = self._cas_eval(C, gamma, Gamma, want_matrices=True)
+            hessian_vqe_oo = res["gvec"][1:].T
+            n = self._n_theta()
+            hessian_vqe_vqe = ops.circuit_hessian(pqc._theta2d(theta).reshape(-1), pqc._gates_dev, pqc._n_gates,
+                                                  pqc.n_qubits, self.ncas, pqc._init_index, res["c1"],
+                                                  res["c2"]).reshape(n, n)
+            hessian_oo_oo = ops.orbital_hessian(self.int2e_ao, self.int1e_ao, C, gamma[0].contiguous(),
+                                                Gamma[0].contiguous(), res["fock"], self._n_occ, self.ncas,
+                                                self._kap_row, self._kap_col, want_matrix=True,
+                                                want_full=False)[0]
         return torch.cat((torch.cat((hessian_vqe_vqe, hessian_vqe_oo.T), dim=1),
                           torch.cat((hessian_vqe_oo, hessian_oo_oo), dim=1)), dim=0)
 

@@ -397,35 +397,30 @@ def _hessian_pair_tables(n_theta, dev):
     return tabs
 
 
+_CHESS_WORK = {}
+
+
 def circuit_hessian(theta, gates_dev, n_gates, n_qubits, ncas, init_index, c1, c2):
     """d^2E/dtheta^2 for E = c0 + c1.gamma(theta) + c2.Gamma(theta)  (oo_pqc.py:103-111):
-    second tangents + transition RDMs + contraction; theta [n_theta]."""
+    second tangents + transition RDMs + contraction in one library call (oovqe_circuit_hessian);
+    theta [n_theta]."""
     lib = _lib.load()
     dev = _dev(theta)
     n_theta = theta.numel()
-    D = 1 << n_qubits
     th2 = theta.reshape(1, n_theta).contiguous()
-    psi, dpsi = circuit_state(th2, gates_dev, n_gates, n_qubits, init_index, tangents=True)
-    psi, dpsi = psi[0], dpsi[0]
-    pairs_dev, jj, kk = _hessian_pair_tables(n_theta, dev)   # cached: no host->device copy per call
+    pairs_dev, _, _ = _hessian_pair_tables(n_theta, dev)   # cached: no host->device copy per call
     n_pairs = pairs_dev.shape[0]
-    psi2 = torch.empty((n_pairs, D), dtype=F64, device=dev)
-    scratch = torch.empty((n_pairs, D), dtype=F64, device=dev)
-    check(lib.oovqe_circuit_second_tangents(dptr(th2), n_theta, dptr(gates_dev, torch.uint8), n_gates,
-                                            n_qubits, ctypes.c_uint32(init_index),
-                                            dptr(pairs_dev, torch.int32), n_pairs, dptr(psi2),
-                                            dptr(scratch), stream_ptr()),
-          "oovqe_circuit_second_tangents")
-    # transition-RDM operand lists (pure data movement): per pair the four (bra, ket) combinations
-    psi_rep = psi.unsqueeze(0).expand(n_pairs, D)
-    bra = torch.stack((psi2, dpsi[jj], dpsi[kk], psi_rep), dim=1).reshape(4 * n_pairs, D).contiguous()
-    ket = torch.stack((psi_rep, dpsi[kk], dpsi[jj], psi2), dim=1).reshape(4 * n_pairs, D).contiguous()
-    g1, g2 = rdms(bra, ket, ncas)
+    key = (n_theta, n_qubits, ncas, str(dev))
+    work = _CHESS_WORK.get(key)
+    if work is None:
+        work = torch.empty(lib.oovqe_circuit_hessian_work_size(n_theta, n_qubits, ncas, n_pairs), dtype=F64,
+                           device=dev)
+        _CHESS_WORK[key] = work
     H = torch.empty((n_theta, n_theta), dtype=F64, device=dev)
-    check(lib.oovqe_circuit_hessian_assemble(dptr(g1), dptr(g2), dptr(c1.contiguous()),
-                                             dptr(c2.contiguous()), ncas,
-                                             dptr(pairs_dev, torch.int32), n_pairs, n_theta, dptr(H),
-                                             stream_ptr()), "oovqe_circuit_hessian_assemble")
+    check(lib.oovqe_circuit_hessian(dptr(th2), n_theta, dptr(gates_dev, torch.uint8), n_gates, n_qubits, ncas,
+                                    ctypes.c_uint32(init_index), dptr(c1.contiguous()), dptr(c2.contiguous()),
+                                    dptr(pairs_dev, torch.int32), n_pairs, dptr(work), dptr(H), stream_ptr()),
+          "oovqe_circuit_hessian")
     return H
 
 

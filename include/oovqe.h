@@ -265,6 +265,15 @@ int oovqe_newton_direction(const double* hessian, const double* gradient, int n,
 int64_t oovqe_newton_direction_work_size(int n, int batch);
 int oovqe_newton_direction_max_n(void);
 
+/* The theta-theta block in one call: the five launches above chained (state + tangents, second
+ * tangents, operand lists, transition RDMs, contraction).  pairs [n_pairs][2] with j <= k; H
+ * [n_theta, n_theta]; work: oovqe_circuit_hessian_work_size() doubles. */
+int oovqe_circuit_hessian(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
+                          int n_qubits, int ncas, uint32_t init_index, const double* c1,
+                          const double* c2, const int32_t* pairs, int n_pairs, double* work,
+                          double* H, oovqe_stream_t stream);
+int64_t oovqe_circuit_hessian_work_size(int n_theta, int n_qubits, int ncas, int n_pairs);
+
 /* ---- a10/a11/a13 at scale: particle-number-sector engine with reverse-mode gradients -------------
  * For circuits that conserve (N_alpha, N_beta) -- UCCD, UCCSD, kUpCCD -- the state lives in a
  * sector of C(a,N_alpha)*C(a,N_beta) determinants (4 900 of 65 536 for CAS(8e,8o)); the sector
