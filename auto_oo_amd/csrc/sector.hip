@@ -215,6 +215,36 @@ void sector_epq_kernel(const double* __restrict__ vec, Sector s, double* __restr
     V[(v * na2 + pq) * Dc + c] = sec_epq(vec + v * Dc, s, n, p, q, x, c);
 }
 
+// The same with ONE workgroup per (256 determinants, state) forming all a^2 vectors: the source
+// vector and the rank tables are staged in LDS once and each thread walks the (p, q) pairs of its
+// determinant -- 20 workgroups per state instead of 1 280 one-element-per-thread workgroups, and
+// the gathers E_pq needs come from LDS instead of L2 (batch 256: 327 -> ~150 us, the rate at which
+// the 642 MB of V can be written).  grid: (ceil(Dc/256), nvec_total)
+__global__ __launch_bounds__(256)
+void sector_epq_rows_kernel(const double* __restrict__ vec, Sector s, double* __restrict__ V)
+{
+    extern __shared__ double lds[];
+    const int Dc = s.na * s.nb, n = 2 * s.ncas, a = s.ncas, na2 = a * a;
+    const int ns = 1 << a;
+    double* src = lds;                                           // [Dc]
+    int32_t* ra = reinterpret_cast<int32_t*>(src + Dc + (Dc & 1));
+    int32_t* rb = ra + ns;
+    const size_t v = blockIdx.y;
+    for (int i = threadIdx.x; i < Dc; i += 256) src[i] = vec[v * Dc + i];
+    for (int i = threadIdx.x; i < ns; i += 256) { ra[i] = s.rank_a[i]; rb[i] = s.rank_b[i]; }
+    const Sector sg = s;
+    s.rank_a = ra;
+    s.rank_b = rb;
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Dc) return;
+    const uint32_t x = sec_full(sg, c);
+    double* out = V + v * (size_t)na2 * Dc + c;
+    for (int p = 0; p < a; ++p)
+#pragma unroll 4
+        for (int q = 0; q < a; ++q) out[(size_t)(p * a + q) * Dc] = sec_epq(src, s, n, p, q, x, c);
+}
+
 // ---- RDM Gram on the f64 MFMA -----------------------------------------------------------------
 // G[m][n] = sum_c A[m][c] B[n][c];  A rows m < a^2: V[qp] (m = pq), row a^2: psi;  B rows: V[rs].
 // grid: (MT*NT tiles, batch, ksplit); the 4 waves of a block split their c range again; operands
@@ -453,21 +483,25 @@ __global__ void sector_rdm_finish_kernel(const double* __restrict__ R, int ncas,
 //                                                            (W'_rs = sum_pq c2[pq,rs] V_qp)
 // c1e[ps] = c1[ps] - sum_q c2[p,q,q,s]
 __global__ void sector_coeff_kernel(const double* __restrict__ c1, const double* __restrict__ c2,
-                                    int ncas, double* __restrict__ M12, double* __restrict__ c1e)
+                                    int ncas, double* __restrict__ M12)
 {
-    // M12 [a^2][2 a^2] = [M1 | M2]: both products stream V once in ONE contraction with J = 2 a^2
-    const int na2 = ncas * ncas;
+    // M12 [a^2][2 a^2 + 1] = [M1 | M2 | s]: W, W' and the one-body term u = sum_k s_k V_k come out of
+    // ONE contraction over V (J = 2 a^2 + 1), so the lambda kernel never reads V itself.
+    //   s_k = c1e[k] + c1e[swap k],  c1e[ps] = c1[ps] - sum_q c2[p,q,q,s]
+    const int na2 = ncas * ncas, ldm = 2 * na2 + 1;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < na2 * na2;
          idx += gridDim.x * blockDim.x) {
         const int k = idx / na2, j = idx - k * na2;
-        M12[(size_t)k * 2 * na2 + j] = c2[(size_t)j * na2 + k];
+        M12[(size_t)k * ldm + j] = c2[(size_t)j * na2 + k];
         const int kq = k / ncas, kp = k - kq * ncas;          // k = q*a + p  ->  pq = p*a + q
-        M12[(size_t)k * 2 * na2 + na2 + j] = c2[(size_t)(kp * ncas + kq) * na2 + j];
-        if (idx < na2) {
-            const int p = idx / ncas, s2 = idx - p * ncas;
-            double v = c1[idx];
-            for (int q = 0; q < ncas; ++q) v -= c2[((size_t)(p * ncas + q) * ncas + q) * ncas + s2];
-            c1e[idx] = v;
+        M12[(size_t)k * ldm + na2 + j] = c2[(size_t)(kp * ncas + kq) * na2 + j];
+        if (j == 0) {
+            auto c1e = [&](int p, int s2) {
+                double v = c1[p * ncas + s2];
+                for (int q = 0; q < ncas; ++q) v -= c2[((size_t)(p * ncas + q) * ncas + q) * ncas + s2];
+                return v;
+            };
+            M12[(size_t)k * ldm + 2 * na2] = c1e(kq, kp) + c1e(kp, kq);
         }
     }
 }
@@ -475,8 +509,7 @@ __global__ void sector_coeff_kernel(const double* __restrict__ c1, const double*
 // grid: (ceil(Dc/64), batch); block = 64 determinants x 4 slices of the (p,q) loop, summed in LDS
 // in fixed order; string tables staged in LDS.
 __global__ __launch_bounds__(256)
-void sector_lambda_kernel(const double* __restrict__ V, const double* __restrict__ W12,
-                          const double* __restrict__ c1e, Sector s, double* __restrict__ lam)
+void sector_lambda_kernel(const double* __restrict__ W12, Sector s, double* __restrict__ lam)
 {
     extern __shared__ double lds[];
     double* part = lds;                                         // [4][64]
@@ -495,13 +528,12 @@ void sector_lambda_kernel(const double* __restrict__ V, const double* __restrict
     const size_t b = blockIdx.y;
     double acc = 0.0;
     if (c < Dc) {
-        const double* Vb = V + b * (size_t)na2 * Dc;
-        const double* W1b = W12 + b * (size_t)2 * na2 * Dc;    // [2 a^2][Dc]: W rows, then W' rows
+        const double* W1b = W12 + b * (size_t)(2 * na2 + 1) * Dc;    // [2 a^2 + 1][Dc]: W rows, W' rows, u
         const double* W2b = W1b + (size_t)na2 * Dc;
         const uint32_t x = sec_full(sg, c);
+        if (slice == 0) acc = W2b[(size_t)na2 * Dc + c];              // u = sum_pq c1e_pq (V_pq + V_qp)
         for (int pq = slice; pq < na2; pq += 4) {
-            const int p = pq / a, q = pq - p * a, qp = q * a + p;
-            acc += c1e[pq] * (Vb[(size_t)pq * Dc + c] + Vb[(size_t)qp * Dc + c]);
+            const int p = pq / a, q = pq - p * a;
             acc += sec_epq(W1b + (size_t)pq * Dc, s, n, p, q, x, c);      // E_pq W_pq
             acc += sec_epq(W2b + (size_t)pq * Dc, s, n, q, p, x, c);      // E_sr W'_rs (r=p, s=q)
         }
@@ -678,9 +710,9 @@ extern "C" int64_t oovqe_sector_work_size(int ncas, int na, int nb, int batch)
 {
     const int64_t Dc = (int64_t)na * nb, na2 = (int64_t)ncas * ncas;
     const int64_t MT = (na2 + 1 + 15) / 16, NT = (na2 + 15) / 16;
-    // V, W1, W2 [batch][a^2][Dc] | lam [batch][Dc] | R [8 splits][batch][MT*16][NT*16]
-    // | M1, M2 [a^4] | c1e [a^2]
-    return (int64_t)batch * (3 * na2 * Dc + Dc + 8 * MT * 16 * NT * 16) + 2 * na2 * na2 + na2;
+    // V [batch][a^2][Dc] | W12 [batch][2 a^2 + 1][Dc] | lam [batch][Dc] | R [8 splits][batch][MT*16][NT*16]
+    // | M12 [a^2][2 a^2 + 1]
+    return (int64_t)batch * (3 * na2 * Dc + 2 * Dc + 8 * MT * 16 * NT * 16) + 2 * na2 * na2 + na2;
 }
 
 extern "C" int oovqe_sector_rdms(const double* psi_c, int ncas, const uint32_t* unrank_a,
@@ -696,9 +728,16 @@ extern "C" int oovqe_sector_rdms(const double* psi_c, int ncas, const uint32_t* 
     const int MT = (na2 + 1 + 15) / 16, NT = (na2 + 15) / 16;
     Sector s = make_sector(unrank_a, unrank_b, rank_a, rank_b, na, nb, ncas);
     double* V = work;                                              // [batch][a^2][Dc]
-    double* R = work + (size_t)batch * (3 * (size_t)na2 * Dc + Dc); // [batch][MT*16][NT*16]
-    hipLaunchKernelGGL(sector_epq_kernel, dim3((Dc + 255) / 256, na2, batch), dim3(256), 0, st, psi_c, s,
-                       V);
+    double* R = work + (size_t)batch * (3 * (size_t)na2 * Dc + 2 * (size_t)Dc); // [splits][batch][MT*16][NT*16]
+    {
+        const size_t epq_lds = ((size_t)Dc + (Dc & 1)) * sizeof(double) + 2 * ((size_t)1 << ncas) * sizeof(int32_t);
+        // (few states: the one-element-per-thread grid has 64 x more workgroups to fill the chip with)
+        if (epq_lds <= 64 * 1024 && batch >= 8)
+            hipLaunchKernelGGL(sector_epq_rows_kernel, dim3((Dc + 255) / 256, batch), dim3(256), epq_lds, st, psi_c,
+                               s, V);
+        else
+            hipLaunchKernelGGL(sector_epq_kernel, dim3((Dc + 255) / 256, na2, batch), dim3(256), 0, st, psi_c, s, V);
+    }
     OOVQE_CHECK_LAUNCH("sector_rdms/epq");
     const int nsplit = batch >= 32 ? 1 : (batch >= 8 ? 2 : 8);   // fill the chip at small batch
     // all tiles of a state in one workgroup (V read once) for the active spaces up to 8 orbitals; the
@@ -746,23 +785,22 @@ extern "C" int oovqe_sector_adjoint(const double* theta, int n_theta, const oovq
     Sector s = make_sector(unrank_a, unrank_b, rank_a, rank_b, na, nb, ncas);
     const size_t nb_ = (size_t)batch;
     double* V = work;
-    double* W12 = V + nb_ * na2 * Dc;                   // [batch][2 a^2][Dc]
-    double* lam = W12 + 2 * nb_ * na2 * Dc;
+    double* W12 = V + nb_ * na2 * Dc;                   // [batch][2 a^2 + 1][Dc]
+    double* lam = W12 + nb_ * (2 * (size_t)na2 + 1) * Dc;
     double* R = lam + nb_ * Dc;
     double* M12 = R + 8 * nb_ * (size_t)(MT * 16) * (NT * 16);
-    double* c1e = M12 + 2 * (size_t)na2 * na2;
     hipLaunchKernelGGL(sector_coeff_kernel, dim3((na2 * na2 + 255) / 256), dim3(256), 0, st, c1, c2, ncas,
-                       M12, c1e);
+                       M12);
     OOVQE_CHECK_LAUNCH("sector_adjoint/coeff");
     int rc;
     // W12[b][j][c] = sum_k M12[k][j] V[b][k][c]: rows j < a^2: W_pq = sum_rs c2[pq,rs] V_rs,
-    // rows j >= a^2: W'_rs = sum_pq c2[pq,rs] V_qp -- one pass over V for both
-    if ((rc = oovqe_mode_contract_batched(V, M12, W12, 1, na2, 2 * na2, Dc, 2 * na2, 0, batch, (long)na2 * Dc,
-                                          0, (long)2 * na2 * Dc, st)))
+    // rows a^2 <= j < 2 a^2: W'_rs = sum_pq c2[pq,rs] V_qp, row 2 a^2: the one-body term -- one pass
+    // over V for all of them
+    if ((rc = oovqe_mode_contract_batched(V, M12, W12, 1, na2, 2 * na2 + 1, Dc, 2 * na2 + 1, 0, batch,
+                                          (long)na2 * Dc, 0, (long)(2 * na2 + 1) * Dc, st)))
         return rc;
     hipLaunchKernelGGL(sector_lambda_kernel, dim3((Dc + 63) / 64, batch), dim3(256),
-                       256 * sizeof(double) + 2 * ((size_t)1 << ncas) * sizeof(int32_t), st, V, W12,
-                       c1e, s, lam);
+                       256 * sizeof(double) + 2 * ((size_t)1 << ncas) * sizeof(int32_t), st, W12, s, lam);
     OOVQE_CHECK_LAUNCH("sector_adjoint/lambda");
     const int nit = (Dc + SEC_THREADS - 1) / SEC_THREADS;
 #define OOVQE_SEC_ADJ(MI)                                                                          \
