@@ -64,6 +64,12 @@ int main(int argc, char** argv)
             if (ms < best) best = ms;
         }
         printf("%s: %.2f ms = %.1f TFLOP/s\n", names[step], best, 2.0 * n4 * N / best / 1e9);
+#if OOVQE_K1_PROBE & 64
+        long long marks[128];
+        (void)hipMemcpyFromSymbol(marks, HIP_SYMBOL(g_k1_marks), sizeof(marks));
+        for (int m = 1; m < 64; ++m)
+            printf("   mark %3lld -> %3lld : %7lld\n", marks[2 * m - 2], marks[2 * m], marks[2 * m + 1] - marks[2 * m - 1]);
+#endif
     }
     return 0;
 }
