@@ -670,6 +670,11 @@ int oovqe_contract_hosts_circuit(long A, int K, int J, long B, int last, int bat
 int oovqe_mode_contract_batched_circ(const double* T, const double* Cm, double* out, long A, int K, int J,
                                      long B, int ldc, int last, int batch, long t_bs, long c_bs,
                                      long o_bs, hipStream_t st, const oovqe_circuit_job_t* cj);
+int oovqe_contract_pair_ok(const double* T, const double* out, long A, long B, int nt, int ngroups, int batch,
+                           long t_bs, long o_bs);
+int oovqe_contract_pair_launch(const double* T, const double* Cm, double* out, long A, int K, int J, long B,
+                               int ldc, int nt, int ngroups, int deep, int batch, long t_bs, long c_bs,
+                               long o_bs, hipStream_t st);
 
 int oovqe_mode_contract_batched(const double* T, const double* Cm, double* out, long A, int K, int J,
                                 long B, int ldc, int last, int batch, long t_bs, long c_bs, long o_bs,
@@ -702,7 +707,12 @@ int oovqe_mode_contract_batched_circ(const double* T, const double* Cm, double* 
     int rc;
     OOVQE_REQUIRE(!cj || (K <= 48 && nt <= 4 && (last || step_offsets_fit(12, B))),
                   "mode_contract: this shape cannot host circuit workgroups");
-    if (!last && !step_offsets_fit(3, B))
+    if (!last && !cj && !(K <= 48 && nt <= 4) && step_offsets_fit(deep ? 5 : 3, B) && !oovqe_opt(OOVQE_OPT_K1_NO_PAIR) &&
+        oovqe_contract_pair_ok(T, out, A, B, nt, ngroups, batch, t_bs, o_bs))
+        // two 16-wide strips per wave (contract_pair.hip)
+        rc = oovqe_contract_pair_launch(T, Cm, out, A, K, J, B, ldc, nt, ngroups, deep ? 1 : 0, batch, t_bs, c_bs,
+                                        o_bs, st);
+    else if (!last && !step_offsets_fit(3, B))
         rc = launch_wide(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, batch, t_bs, c_bs, o_bs, st);
     else if (K <= 48 && nt <= 4 && (last || step_offsets_fit(12, B)))
         rc = last ? launch_short<true>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, batch, t_bs,

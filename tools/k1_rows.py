@@ -18,3 +18,11 @@ for last, A, K, J, B in [(0, 1, 13, 13, 2197), (0, 13, 13, 13, 169), (0, 3, 43, 
         bad = ((out - ref).abs() > 1e-10).nonzero()
         print("INNER", A, K, J, B, "bad", len(bad), "a", sorted(set(bad[:, 0].tolist()))[:10], "j", sorted(set(bad[:, 1].tolist()))[:20],
               "b", sorted(set(bad[:, 2].tolist()))[:20])
+for A, K, J, B in [(1, 200, 200, 4000), (3, 96, 96, 96 * 96), (96, 96, 96, 96), (2, 100, 250, 40), (5, 77, 90, 1000), (2, 130, 208, 2046), (7, 60, 81, 34)]:
+    rng = np.random.default_rng(2)
+    T = torch.tensor(rng.standard_normal((A, K, B))); C = torch.tensor(rng.standard_normal((K, J)))
+    ref = torch.einsum("kj,akb->ajb", C, T)
+    out = ops.mode_contract(T.to(DEV), C.to(DEV), A, K, J, B, last=False).cpu().reshape(A, J, B)
+    bad = ((out - ref).abs() > 1e-10).nonzero()
+    print("INNER(pair?)", A, K, J, B, "bad", len(bad), "a", sorted(set(bad[:, 0].tolist()))[:10], "j", sorted(set(bad[:, 1].tolist()))[:20],
+          "b", sorted(set(bad[:, 2].tolist()))[:20])

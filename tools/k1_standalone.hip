@@ -1,5 +1,6 @@
 // Standalone timing of the K1 contraction kernel on the N=200 quarter transforms (tools only).
 #include "../auto_oo_amd/csrc/contract.hip"
+#include "../auto_oo_amd/csrc/contract_pair.hip"
 #include <vector>
 #include <string.h>
 int main(int argc, char** argv)
@@ -33,6 +34,7 @@ int main(int argc, char** argv)
         return 0;
     }
     const int N = argc > 1 ? atoi(argv[1]) : 200;
+    if (argc > 2 && !strcmp(argv[2], "nopair")) oovqe_debug_set_option("k1_no_pair", 1);
     const long n = N, n2 = n * n, n3 = n2 * n, n4 = n3 * n;
     double *g, *w, *C;
     (void)hipMalloc(&g, n4 * 8);
@@ -67,6 +69,8 @@ int main(int argc, char** argv)
 #if OOVQE_K1_PROBE & 64
         long long marks[128];
         (void)hipMemcpyFromSymbol(marks, HIP_SYMBOL(g_k1_marks), sizeof(marks));
+        if (step < 3 && !(argc > 2 && !strcmp(argv[2], "nopair")))
+            (void)hipMemcpyFromSymbol(marks, HIP_SYMBOL(g_k1p_marks), sizeof(marks));
         for (int m = 1; m < 64; ++m)
             printf("   mark %3lld -> %3lld : %7lld\n", marks[2 * m - 2], marks[2 * m], marks[2 * m + 1] - marks[2 * m - 1]);
 #endif
