@@ -8,6 +8,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
 N = 200
 out = {"workload": f"N = {N} four-index transform, 4 quarter steps = 4 dispatches of contract_kernel<13,.,5> per transform",
        "counters_per_dispatch": {}, "source": "tools/pmc_k1.sh (separate rocprofv3 --pmc passes, python program directly after --)"}
+per_kind = {}
 for d in "abcde":
     path = os.path.join(ROOT, "gpurun_out", f"k1_pmc_{d}", "p_counter_collection.csv")
     if not os.path.exists(path):
@@ -15,9 +16,11 @@ for d in "abcde":
     acc = {}
     with open(path) as fh:
         for r in csv.DictReader(fh):
-            if "contract_kernel<13" not in r["Kernel_Name"]:
+            if "contract_kernel<13" not in r["Kernel_Name"] and "contract_pair_kernel<13" not in r["Kernel_Name"]:
                 continue
             acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            kind = "pair" if "contract_pair_kernel" in r["Kernel_Name"] else "single"
+            per_kind.setdefault(kind, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     for k, v in acc.items():
         out["counters_per_dispatch"][k] = {"mean": sum(v) / len(v), "dispatches": len(v)}
 c = out["counters_per_dispatch"]
@@ -25,7 +28,7 @@ stats = os.path.join(ROOT, "gpurun_out", "k1_trace", "p_kernel_stats.csv")
 if os.path.exists(stats):
     with open(stats) as fh:
         for r in csv.DictReader(fh):
-            if "contract_kernel<13" in r["Name"]:
+            if "contract_kernel<13" in r["Name"] or "contract_pair_kernel<13" in r["Name"]:
                 out.setdefault("kernel_trace", []).append({"kernel": r["Name"][:80], "calls": int(r["Calls"]),
                                                            "avg_us": float(r["AverageNs"]) / 1e3})
 flops = 2.0 * N ** 5
@@ -47,6 +50,12 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     out["derived"]["hbm_bytes_per_quarter_step"] = hbm
     out["derived"]["algorithmic_bytes_per_quarter_step"] = 2.0 * 8.0 * N ** 4
     out["derived"]["hbm_over_algorithmic"] = hbm / (2.0 * 8.0 * N ** 4)
+out["counters_per_dispatch_by_kernel"] = {kind: {k: sum(v) / len(v) for k, v in d.items()} for kind, d in per_kind.items()}
+for kind, d in out["counters_per_dispatch_by_kernel"].items():
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:
+        d["mfma_busy_fraction"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / d["GRBM_GUI_ACTIVE"] / 128.0
+out["workload"] = (f"N = {N} four-index transform: quarter steps 1, 2 on contract_pair_kernel<13,5> (two strips per wave), "
+                   "step 3 (B = 200, 32-wide strips would pad) and step 4 (LAST) on contract_kernel<13,.,5>")
 with open(os.path.join(ROOT, "profiles", f"k1_n200_{tag}.json"), "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps(out, indent=1))
