@@ -350,7 +350,7 @@ void half_transform_kernel(const double* __restrict__ g, const double* __restric
 //     the s_waitcnt counts in the loop stay exact;
 //   * KCH is chosen per N so that nkc * KCH wastes at most a few k-steps (half_stream_plan).
 // ------------------------------------------------------------------------------------------
-template <int ZT, int KCH, int DEPTH>
+template <int ZT, int KCH, int DEPTH, bool RS>
 __global__ __launch_bounds__(HALF_WAVES * 64)
 void half_stream_kernel(const double* __restrict__ g, const double* __restrict__ C,
                         double* __restrict__ T2, int N, int M, int nst, int nkc, long nslabs, int sym)
@@ -359,10 +359,17 @@ void half_stream_kernel(const double* __restrict__ g, const double* __restrict__
     extern __shared__ double lds[];
     const int RT16 = nst * 16;
     double* Cl = lds;   // [RT16][LDM], zero padded
+    // RS (integrals symmetric under r <-> s, every slab a symmetric matrix): column tile S of a slab
+    // only reads the rows of the 16-row tiles R <= S, the diagonal tile weighted 1/2.  That sum is
+    // Z with J = Z + Z^T (the tile pair (R, S), R < S, contributes Y and its mirror image Y^T), so
+    // the stream carries 54 % of the bytes and 65 % of the first-product MFMAs at N = 200 and the
+    // slab's M x M result is symmetrised in registers (through a 16 x 17 LDS patch per wave) before
+    // it is stored.  No repacking of the integrals.
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane >> 4, lr = lane & 15;
+    double* patch = lds + (((size_t)RT16 * LDM + 511) / 512) * 512 + (size_t)wave * (16 * 17);   // (RS)
     g += (size_t)blockIdx.y * N * N * N * N;
     C += (size_t)blockIdx.y * N * N;
     T2 += (size_t)blockIdx.y * (sym == SYM_PACKED ? (size_t)nslabs : (size_t)N * N) * M * M;
@@ -385,6 +392,11 @@ void half_stream_kernel(const double* __restrict__ g, const double* __restrict__
     for (int y = 0; y < ZT; ++y) xt[y] = d4{0.0, 0.0, 0.0, 0.0};
 
     // load side of the chunk stream
+    auto tile_chunks = [&](int stile) {   // k-chunks column tile stile needs
+        if (!RS) return nkc;
+        const int c = ((stile + 1) * 4 + KCH - 1) / KCH;
+        return c < nkc ? c : nkc;
+    };
     int lk = 0, lst = 0, lkc = 0;
     auto issue = [&](double (&dst)[KCH]) {
         long sl = lk < n_mine ? slab0 + (long)lk * stride : 0;
@@ -393,9 +405,14 @@ void half_stream_kernel(const double* __restrict__ g, const double* __restrict__
             tri_decode(sl, N, p, q);
             sl = (long)__builtin_amdgcn_readfirstlane(p) * N + __builtin_amdgcn_readfirstlane(q);
         }
+        unsigned rows_bytes = slab_bytes;   // RS: rows past the diagonal tile are out of range
+        if (RS) {
+            const unsigned lim = (unsigned)(lst + 1) * 4u * rowblk_bytes;
+            rows_bytes = lim < slab_bytes ? lim : slab_bytes;
+        }
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<double*>(g) + (size_t)sl * N * N, 0,
-            lk < n_mine ? (int)slab_bytes : 0, 0x00020000);
+            lk < n_mine ? (int)rows_bytes : 0, 0x00020000);
         const int col = lst * 16 + lr;
         const unsigned vo = col < N ? (unsigned)((lq * N + col) * sizeof(double)) : 0x7fffffffu;
         const unsigned sb = (unsigned)lkc * KCH * rowblk_bytes;
@@ -404,7 +421,7 @@ void half_stream_kernel(const double* __restrict__ g, const double* __restrict__
             const v2u v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, vo, sb + i * rowblk_bytes, ZT == 1 ? AUX_NT : AUX_PLAIN);
             dst[i] = __builtin_bit_cast(double, v);
         }
-        if (++lkc == nkc) {
+        if (++lkc == tile_chunks(lst)) {
             lkc = 0;
             if (++lst == nst) { lst = 0; ++lk; }
         }
@@ -412,7 +429,13 @@ void half_stream_kernel(const double* __restrict__ g, const double* __restrict__
     // compute side.  Rows of Cl beyond N are zero and dropped loads return zero, so every k-step
     // runs unconditionally (straight-line MFMA stream, C fragments read ahead).
     int ck = 0, cst = 0, ckc = 0;
-    auto compute = [&](const double (&a)[KCH]) {
+    auto compute = [&](const double (&a_in)[KCH]) {
+        double a[KCH];
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            a[i] = a_in[i];
+            if (RS) a[i] *= ((ckc * KCH + i) >> 2) == cst ? 0.5 : 1.0;   // rows of the diagonal tile
+        }
         const double* cb = Cl + (size_t)(ckc * KCH * 4 + lq) * LDM + lr;
         double cf[KCH][ZT];
 #pragma unroll
@@ -423,7 +446,7 @@ void half_stream_kernel(const double* __restrict__ g, const double* __restrict__
         for (int i = 0; i < KCH; ++i)
 #pragma unroll
             for (int y = 0; y < ZT; ++y) xt[y] = mfma_f64(a[i], cf[i][y], xt[y]);
-        if (++ckc == nkc) {
+        if (++ckc == tile_chunks(cst)) {
             ckc = 0;
             const double* ca = Cl + (size_t)(cst * 16 + lq) * LDM + lr;
             double af[4][ZT];
@@ -441,6 +464,30 @@ void half_stream_kernel(const double* __restrict__ g, const double* __restrict__
             for (int y = 0; y < ZT; ++y) xt[y] = d4{0.0, 0.0, 0.0, 0.0};
             if (++cst == nst) {
                 cst = 0;
+                if (RS) {
+                    // J = Z + Z^T: tile (z, y) takes the transpose of tile (y, z)
+                    auto transposed = [&](const d4& t) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) patch[(lq + 4 * i) * 17 + lr] = t[i];
+                        d4 r;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) r[i] = patch[lr * 17 + lq + 4 * i];
+                        return r;
+                    };
+#pragma unroll
+                    for (int z = 0; z < ZT; ++z)
+#pragma unroll
+                        for (int y = z; y < ZT; ++y) {
+                            const d4 tzy = transposed(jt[z][y]);
+                            if (y == z) {
+                                jt[z][z] += tzy;
+                            } else {
+                                const d4 tyz = transposed(jt[y][z]);
+                                jt[z][y] += tyz;
+                                jt[y][z] += tzy;
+                            }
+                        }
+                }
                 // jt[z tile][y tile][i] = Jt[z = zt*16 + lq + 4i][y = yt*16 + lr] -> T2[slab][y][z]
                 if (ck < n_mine) {
                     long out1 = slab0 + (long)ck * stride, out2 = -1;
@@ -486,7 +533,12 @@ void half_stream_kernel(const double* __restrict__ g, const double* __restrict__
     __syncthreads();
     // the stream is padded to a multiple of DEPTH chunks: the padding chunks load nothing (their
     // slab index is past the wave's list) and add zeros
-    const int rounds = (n_mine * nchunks + DEPTH - 1) / DEPTH;
+    int slab_chunks = nchunks;
+    if (RS) {
+        slab_chunks = 0;
+        for (int t = 0; t < nst; ++t) slab_chunks += tile_chunks(t);
+    }
+    const int rounds = (n_mine * slab_chunks + DEPTH - 1) / DEPTH;
     for (int it = 0; it < rounds; ++it) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
@@ -2513,7 +2565,7 @@ void cas_final_kernel(const double* __restrict__ Fcol, const double* __restrict_
 }  // namespace
 
 static int half_transform_batched(const double* g_ao, const double* C, int N, int M, double* T2,
-                                  int batch, oovqe_stream_t stream, int sym = SYM_FULL);
+                                  int batch, oovqe_stream_t stream, int sym = SYM_FULL, bool rs = false);
 static int device_cu_count();
 
 extern "C" int oovqe_cas_half_transform(const double* g_ao, const double* C, int N, int M, double* T2,
@@ -2523,7 +2575,7 @@ extern "C" int oovqe_cas_half_transform(const double* g_ao, const double* C, int
 }
 
 static int half_transform_batched(const double* g_ao, const double* C, int N, int M, double* T2,
-                                  int batch, oovqe_stream_t stream, int sym)
+                                  int batch, oovqe_stream_t stream, int sym, bool rs)
 {
     OOVQE_REQUIRE(g_ao && C && T2, "cas_half_transform: null pointer");
     OOVQE_REQUIRE(batch >= 1 && batch <= 65535, "cas_half_transform: batch=%d", batch);
@@ -2580,12 +2632,20 @@ static int half_transform_batched(const double* g_ao, const double* C, int N, in
         }
         const int snkc = (ksteps + skch - 1) / skch;
         const long want = (nslabs + HALF_WAVES - 1) / HALF_WAVES;
+        // r <-> s symmetric slabs: upper tile triangle only (needs a 16 x 17 patch per wave in LDS)
+        const size_t lds_rs = lds_bytes + (size_t)HALF_WAVES * 16 * 17 * sizeof(double);
+        const bool use_rs = rs && lds_rs <= 160 * 1024;
 #define OOVQE_LAUNCH_STREAM(Z, KC_, D_)                                                           \
+    do {                                                                                          \
+        if (use_rs) OOVQE_LAUNCH_STREAM_RS(Z, KC_, D_, true, lds_rs);                             \
+        else OOVQE_LAUNCH_STREAM_RS(Z, KC_, D_, false, lds_bytes);                                \
+    } while (0)
+#define OOVQE_LAUNCH_STREAM_RS(Z, KC_, D_, RS_, lds_bytes)                                        \
     do {                                                                                          \
         static bool attr_done = false;                                                            \
         static size_t occ_lds = 0;                                                                \
         static int occ = 1;                                                                       \
-        const void* fn = (const void*)half_stream_kernel<Z, KC_, D_>;                             \
+        const void* fn = (const void*)half_stream_kernel<Z, KC_, D_, RS_>;                        \
         if (!attr_done) {                                                                         \
             OOVQE_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                                 160 * 1024), "cas_half_transform");               \
@@ -2602,7 +2662,7 @@ static int half_transform_batched(const double* g_ao, const double* C, int N, in
         long per = ((long)occ * device_cu_count()) / batch;                                       \
         if (per < 1) per = 1;                                                                     \
         if (per > want) per = want;                                                               \
-        hipLaunchKernelGGL((half_stream_kernel<Z, KC_, D_>), dim3((unsigned)per, batch),          \
+        hipLaunchKernelGGL((half_stream_kernel<Z, KC_, D_, RS_>), dim3((unsigned)per, batch),     \
                            dim3(HALF_WAVES * 64), lds_bytes, st, g_ao, C, T2, N, M, nrb, snkc,    \
                            nslabs, sym);                                                          \
     } while (0)
@@ -2625,6 +2685,7 @@ static int half_transform_batched(const double* g_ao, const double* C, int N, in
         oovqe_profile_mark_stop(st);
 #undef OOVQE_DISPATCH_STREAM
 #undef OOVQE_LAUNCH_STREAM
+#undef OOVQE_LAUNCH_STREAM_RS
         OOVQE_CHECK_LAUNCH("cas_half_transform");
         return 0;
     }
@@ -3193,7 +3254,7 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
                                          cj->gamma, cj->Gamma, nullptr, stream)))
                 return rc;
         }
-        if ((rc = half_transform_batched(g_ao, C, N, M, T2, batch, stream, half_sym))) return rc;
+        if ((rc = half_transform_batched(g_ao, C, N, M, T2, batch, stream, half_sym, rs_sym))) return rc;
         const size_t na2s = (size_t)ncas * ncas, na4s = na2s * na2s;
         for (int g = 0; g < batch; ++g) {
             const size_t gi = (size_t)g;
@@ -3220,7 +3281,7 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
         }
         return 0;
     } else {
-        if ((rc = half_transform_batched(g_ao, C, N, M, T2, batch, stream, half_sym))) return rc;
+        if ((rc = half_transform_batched(g_ao, C, N, M, T2, batch, stream, half_sym, rs_sym))) return rc;
         // U[n,(q y z)] = sum_p C[p,n] T2[p,(q y z)]
         oovqe_profile_mark_start_l(st, 2);
         if ((rc = oovqe_mode_contract_batched_circ(T2, C, U, 1, N, N, (long)N * m2, N, 0, batch,

@@ -381,13 +381,20 @@ def oo_evaluation_large(N, g, C):
     flags = ops.eri_flags(g)
     t_sym = timed(flags)
     full = 8.0 * N ** 4
+    # both flags, N > 48: slabs p <= q, and per slab the row tiles up to the diagonal one of every
+    # 16-column tile (half_stream_kernel<.., RS>)
+    nt16 = (N + 15) // 16
+    tri_rows = sum(min(N, 16 * (t + 1)) * min(16, N - 16 * t) for t in range(nt16))
+    sym_bytes = 8.0 * (N * (N + 1) / 2.0) * tri_rows
     return {"N": N, "ncas": ncas, "nelecas": nelecas, "n_occ": n_occ, "M": M, "n_kappa": int(kr.numel()),
             "general_tensor": {"us": t_gen * 1e6, "stage1_bytes": full, "effective_GBs": full / t_gen / 1e9},
             "symmetric_tensor": {"us": t_sym * 1e6, "eri_flags": int(flags),
-                                 "stage1_bytes": full * (N + 1) / (2.0 * N),
-                                 "effective_GBs": full * (N + 1) / (2.0 * N) / t_sym / 1e9},
-            "note": "energy + orbital gradient for one RDM set; effective_GBs = N^4 bytes the sweep must "
-                    "read / whole-evaluation time (the later stages are inside the time)"}
+                                 "stage1_bytes": sym_bytes,
+                                 "effective_GBs": sym_bytes / t_sym / 1e9},
+            "note": "energy + orbital gradient for one RDM set; effective_GBs = bytes of g_ao the stage-1 sweep "
+                    "must read (all of it; with both symmetry flags the slabs p <= q and in each slab the "
+                    "row tiles up to the diagonal one) / whole-evaluation time (the later stages are inside "
+                    "the time)"}
 
 
 def launch_command(n_ranks, port, argv):

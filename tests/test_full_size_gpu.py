@@ -239,3 +239,34 @@ def test_oo_evaluation_n200_cas66_fused_vs_staged():
     # orbital-gradient matrix is antisymmetric; virtual rows of the generalized Fock matrix vanish
     assert (fused["gmat"] + fused["gmat"].T).abs().max() < 1e-12 * max(1.0, scale)
     assert fused["fock"][M:].abs().max() == 0.0
+
+
+@pytest.mark.parametrize("N,n_occ,ncas", [(64, 4, 6), (100, 34, 6), (130, 14, 6), (96, 10, 6)])
+def test_cas_eval_large_n_rs_symmetry_reads_the_tile_triangle(N, n_occ, ncas):
+    """N > 48 with both symmetry flags: stage 1 reads, for every column tile of a slab, only the row
+    tiles up to the diagonal one (54-60 % of the bytes) and symmetrises the slab's result in
+    registers.  Same outputs as with the p <-> q flag alone and with no flag (one, two and three
+    16-wide tiles of occupied + active orbitals), to rounding."""
+    import auto_oo_amd as aoo
+    from auto_oo_amd import ops
+    M = n_occ + ncas
+    gen = torch.Generator(device=DEV).manual_seed(100 + N)
+    B = torch.randn((16, N, N), generator=gen, dtype=torch.float64, device=DEV)
+    B = 0.5 * (B + B.transpose(1, 2))
+    g = (torch.einsum("Lpq,Lrs->pqrs", B, B) / 16.0).contiguous()
+    h = torch.randn((N, N), generator=gen, dtype=torch.float64, device=DEV)
+    h = 0.5 * (h + h.T) / N ** 0.5
+    Q, _ = torch.linalg.qr(torch.randn((N, N), generator=gen, dtype=torch.float64, device=DEV))
+    rng = np.random.default_rng(N)
+    g1 = torch.tensor(rng.standard_normal((1, ncas, ncas))).to(DEV)
+    g2 = torch.tensor(rng.standard_normal((1, ncas, ncas, ncas, ncas))).to(DEV)
+    rows, cols = aoo.excitations.tril_tables(N, aoo.non_redundant_indices(
+        np.arange(n_occ), n_occ + np.arange(ncas), np.arange(M, N), False))
+    kr, kc = torch.as_tensor(rows).to(DEV), torch.as_tensor(cols).to(DEV)
+    assert ops.eri_flags(g) == 3
+    outs = [ops.cas_eval(g, h, Q.contiguous(), g1, g2, 3.0, n_occ, ncas, kr, kc, want_matrices=True,
+                         want_integrals=True, eri_flags=f) for f in (0, 1, 3)]
+    for key in ("c0", "c1", "c2", "E", "gvec", "fock", "gmat", "Gm", "hmo"):
+        scale = max(1.0, float(outs[0][key].abs().max()))
+        for o in outs[1:]:
+            assert (outs[0][key] - o[key]).abs().max() <= 2e-12 * scale, key
