@@ -2483,6 +2483,89 @@ void cas_panel_kernel(const double* __restrict__ Gm_in, const double* __restrict
     }
 }
 
+// Stage 3 from MO integrals in memory, one workgroup (one wave) per (general index n, RDM set k):
+// the same per-n arithmetic as cas_column_kernel (FI[n, :], column n of the generalized Fock
+// matrix, the per-n pieces of c0 / c1 / c2 and of the energy) reading g_mo[n, x, y, z] from memory
+// instead of LDS -- the staged path's M^3 block (140 KB at M = 26) does not fit there.  Replaces
+// the one-workgroup fock_kernel inside oovqe_cas_eval: 481 -> ~15 us at N = 200, M = 26.
+// cas_final_kernel assembles the outputs.
+constexpr int FROW_THREADS = 64;
+
+__global__ __launch_bounds__(FROW_THREADS)
+void fock_rows_kernel(const double* __restrict__ Gm, const double* __restrict__ hmo,
+                      const double* __restrict__ gamma, const double* __restrict__ Gamma, int N, int no,
+                      int na, double* __restrict__ Fcol, double* __restrict__ Epart,
+                      double* __restrict__ Cpart, double* __restrict__ c1, double* __restrict__ c2)
+{
+    __shared__ double FIn[64];
+    const int M = no + na, M2 = M * M, M3 = M2 * M;
+    const int na2 = na * na, na3 = na2 * na, na4 = na2 * na2;
+    const int n = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
+    const double* gn = Gm + (size_t)n * M3;
+    const double* gam = gamma + (size_t)k * na2;
+    const double* Gam = Gamma + (size_t)k * na4;
+    for (int x = tid; x < M; x += FROW_THREADS) {
+        double fi = hmo[(size_t)n * M + x];
+        for (int i = 0; i < no; ++i) fi += 2.0 * gn[x * M2 + i * M + i] - gn[i * M2 + i * M + x];
+        FIn[x] = fi;
+    }
+    __syncthreads();
+    for (int m = tid; m < M; m += FROW_THREADS) {
+        double val;
+        if (m < no) {
+            double fa = 0.0;
+            for (int v = 0; v < na; ++v)
+                for (int w = 0; w < na; ++w) {
+                    const int V = no + v, W = no + w;
+                    fa += gam[v * na + w] * (gn[m * M2 + V * M + W] - 0.5 * gn[W * M2 + V * M + m]);
+                }
+            val = 2.0 * ((k == 0 ? FIn[m] : 0.0) + fa);
+        } else {
+            const int v = m - no;
+            const double* Gv = Gam + (size_t)v * na3;
+            double acc = 0.0;
+            for (int w = 0; w < na; ++w) acc += FIn[no + w] * gam[v * na + w];
+            for (int w = 0; w < na; ++w)
+                for (int x = 0; x < na; ++x)
+                    for (int y = 0; y < na; ++y)
+                        acc += Gv[(w * na + x) * na + y] * gn[(no + w) * M2 + (no + x) * M + no + y];
+            val = acc;
+        }
+        Fcol[((size_t)k * M + m) * N + n] = val;
+    }
+    // E_k contribution of row p = n - no (active n only): lanes over (q, r, s), wave reduction
+    double part = 0.0;
+    if (n >= no && n < M) {
+        const int p = n - no;
+        const double* gp = gam + (size_t)p * na;
+        const double* Gp = Gam + (size_t)p * na3;
+        for (int q = tid; q < na; q += FROW_THREADS) part += FIn[no + q] * gp[q];
+        for (int idx = tid; idx < na3; idx += FROW_THREADS) {
+            int t = idx;
+            const int s2 = t % na; t /= na;
+            const int r = t % na; t /= na;
+            const int q = t;
+            part += 0.5 * gn[(no + q) * M2 + (no + r) * M + no + s2] * Gp[idx];
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (tid == 0) Epart[(size_t)k * N + n] = part;
+    if (k == 0) {
+        if (tid == 0) Cpart[n] = n < no ? hmo[(size_t)n * M + n] + FIn[n] : 0.0;
+        if (n >= no && n < M) {
+            const int p = n - no;
+            for (int q = tid; q < na; q += FROW_THREADS) c1[p * na + q] = FIn[no + q];
+            for (int idx = tid; idx < na3; idx += FROW_THREADS) {
+                int t = idx;
+                const int s2 = t % na; t /= na;
+                const int r = t % na; t /= na;
+                const int q = t;
+                c2[(size_t)p * na3 + idx] = 0.5 * gn[(no + q) * M2 + (no + r) * M + no + s2];
+            }
+        }
+    }
+}
+
 // Final assembly: orbital-gradient vectors, energy, c0, dE/dtheta.  One workgroup.
 __global__ __launch_bounds__(512)
 void cas_final_kernel(const double* __restrict__ Fcol, const double* __restrict__ Epart,
@@ -3138,6 +3221,27 @@ static int cas_energy_gradient_impl(const double* Gm, const double* hmo, const d
     return 0;
 }
 
+// The same stage from MO integrals in memory with a workgroup per (n, RDM set) and the final
+// assembly kernel; Fcol [nrdm][M][N], Epart [nrdm][N], Cpart [N] are scratch.
+static int cas_energy_gradient_rows(const double* Gm, const double* hmo, const double* gamma,
+                                    const double* Gamma, int nrdm, double nuc, const double* nuc_dev, int N,
+                                    int n_occ, int ncas, const int32_t* kap_row, const int32_t* kap_col,
+                                    int n_kappa, double* Fcol, double* Epart, double* Cpart, double* c0,
+                                    double* c1, double* c2, double* E, double* fock, double* gmat,
+                                    double* gvec, double* dE, oovqe_stream_t stream)
+{
+    const int M = n_occ + ncas;
+    OOVQE_REQUIRE(M <= 64 && nrdm <= 65535, "cas_energy_gradient: n_occ + ncas = %d, nrdm = %d", M, nrdm);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(fock_rows_kernel, dim3(N, nrdm), dim3(FROW_THREADS), 0, st, Gm, hmo, gamma, Gamma, N,
+                       n_occ, ncas, Fcol, Epart, Cpart, c1, c2);
+    OOVQE_CHECK_LAUNCH("cas_energy_gradient/rows");
+    hipLaunchKernelGGL(cas_final_kernel, dim3(1), dim3(512), 0, st, Fcol, Epart, Cpart, nuc, nrdm, N, M,
+                       kap_row, kap_col, n_kappa, c0, E, gvec, dE, fock, gmat, nuc_dev, (size_t)0);
+    OOVQE_CHECK_LAUNCH("cas_energy_gradient/final");
+    return 0;
+}
+
 // LDS of cas_column_kernel without the RDM sets (U[n] and g_mo[n] resident): decides between the
 // column kernel and the staged kernels for large N * M^2
 static size_t column_base_bytes(int N, int M)
@@ -3265,13 +3369,27 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
             if ((rc = oovqe_cas_finish_transform(T2g, h_ao + gi * N * N, C + gi * N * N, N, M, Gmg, hmog,
                                                  wk, stream)))
                 return rc;
-            if ((rc = cas_energy_gradient_impl(
-                     Gmg, hmog, gamma + gi * nrdm * na2s, Gamma + gi * nrdm * na4s, nrdm, nuc,
-                     nuc_arr ? nuc_arr + g : nullptr, N, n_occ, ncas, kap_row, kap_col, n_kappa,
-                     c0 + gi * out_stride, c1 + gi * out_stride, c2 + gi * out_stride, E + gi * out_stride,
-                     fock ? fock + gi * N * N : nullptr, gmat ? gmat + gi * N * N : nullptr,
-                     gvec + gi * out_stride, dE ? dE + gi * out_stride : nullptr, stream)))
-                return rc;
+            // scratch behind T3 and Y in this geometry's U block (N^2 M^2 >= N M^3 + N M + the three below)
+            double* Fc = wk + (size_t)N * m3 + (size_t)N * M;
+            double* Ep = Fc + (size_t)nrdm * M * N;
+            double* Cp = Ep + (size_t)nrdm * N;
+            const bool rows_fit = (size_t)N * m3 + (size_t)N * M + (size_t)nrdm * (M + 1) * N + N <=
+                                  (size_t)N * N * m2 && M <= 64;
+            if (rows_fit)
+                rc = cas_energy_gradient_rows(
+                    Gmg, hmog, gamma + gi * nrdm * na2s, Gamma + gi * nrdm * na4s, nrdm, nuc,
+                    nuc_arr ? nuc_arr + g : nullptr, N, n_occ, ncas, kap_row, kap_col, n_kappa, Fc, Ep, Cp,
+                    c0 + gi * out_stride, c1 + gi * out_stride, c2 + gi * out_stride, E + gi * out_stride,
+                    fock ? fock + gi * N * N : nullptr, gmat ? gmat + gi * N * N : nullptr,
+                    gvec + gi * out_stride, dE ? dE + gi * out_stride : nullptr, stream);
+            else
+                rc = cas_energy_gradient_impl(
+                    Gmg, hmog, gamma + gi * nrdm * na2s, Gamma + gi * nrdm * na4s, nrdm, nuc,
+                    nuc_arr ? nuc_arr + g : nullptr, N, n_occ, ncas, kap_row, kap_col, n_kappa,
+                    c0 + gi * out_stride, c1 + gi * out_stride, c2 + gi * out_stride, E + gi * out_stride,
+                    fock ? fock + gi * N * N : nullptr, gmat ? gmat + gi * N * N : nullptr,
+                    gvec + gi * out_stride, dE ? dE + gi * out_stride : nullptr, stream);
+            if (rc) return rc;
             if (Gm)
                 OOVQE_CHECK_HIP(hipMemcpyAsync(Gm + gi * N * m3, Gmg, (size_t)N * m3 * sizeof(double),
                                                hipMemcpyDeviceToDevice, st), "cas_eval: copy g_mo");
