@@ -708,11 +708,12 @@ int oovqe_mode_contract_batched_circ(const double* T, const double* Cm, double* 
     OOVQE_REQUIRE(!cj || (K <= 48 && nt <= 4 && (last || step_offsets_fit(12, B))),
                   "mode_contract: this shape cannot host circuit workgroups");
     if (!last && !cj && !(K <= 48 && nt <= 4) && step_offsets_fit(deep ? 5 : 3, B) && !oovqe_opt(OOVQE_OPT_K1_NO_PAIR) &&
+        !oovqe_opt(OOVQE_OPT_K1_FORCE_WIDE) &&
         oovqe_contract_pair_ok(T, out, A, B, nt, ngroups, batch, t_bs, o_bs))
         // two 16-wide strips per wave (contract_pair.hip)
         rc = oovqe_contract_pair_launch(T, Cm, out, A, K, J, B, ldc, nt, ngroups, deep ? 1 : 0, batch, t_bs, c_bs,
                                         o_bs, st);
-    else if (!last && !step_offsets_fit(3, B))
+    else if (!last && (!step_offsets_fit(3, B) || oovqe_opt(OOVQE_OPT_K1_FORCE_WIDE)))
         rc = launch_wide(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, batch, t_bs, c_bs, o_bs, st);
     else if (K <= 48 && nt <= 4 && (last || step_offsets_fit(12, B)))
         rc = last ? launch_short<true>(nt, T, Cm, out, A, K, J, B, ldc, ngroups, n_items, nbt, batch, t_bs,

@@ -562,3 +562,56 @@ def test_unrestricted_rdms_vs_oracle(ncas, nelecas, ansatz):
     c1, c2 = pqc.get_rdms_from_state(state * phase, restricted=False)
     o1, o2 = R.spin_rdms_from_state(state.cpu() * phase, ncas)
     assert (c1.cpu() - o1).abs().max() < 1e-12 and (c2.cpu() - o2).abs().max() < 1e-12
+
+
+@pytest.mark.parametrize("A,K,J,B", [(1, 60, 100, 70000), (3, 72, 208, 24578), (2, 100, 81, 40000),
+                                     (1, 200, 200, 66000), (40, 64, 128, 2048)])
+def test_mode_contract_two_strip_kernel(A, K, J, B, lib_options):
+    """INNER contractions large enough for contract_pair.hip (two 16-wide strips per wave: >= 5 tiles
+    of J, even B, >= 2048 strips): against the einsum on sampled columns and, element for element,
+    against the one-strip kernel (option k1_no_pair) -- 20- and 12-row K-chunks, J padded and not,
+    a last 32-column block that is mostly empty, several slabs."""
+    gen = torch.Generator(device=DEV).manual_seed(A * 7 + K)
+    T = torch.randn((A, K, B), generator=gen, dtype=torch.float64, device=DEV)
+    C = torch.randn((K, J), generator=gen, dtype=torch.float64, device=DEV)
+    out = ops.mode_contract(T, C, A, K, J, B, last=False).reshape(A, J, B)
+    lib_options(k1_no_pair=1)
+    one = ops.mode_contract(T, C, A, K, J, B, last=False).reshape(A, J, B)
+    assert (out - one).abs().max() <= 1e-12 * float(one.abs().max())
+    for sl in (slice(0, 300), slice(B // 2 - 111, B // 2 + 200), slice(B - 300, B)):
+        ref = torch.einsum("kj,akb->ajb", C, T[:, :, sl])
+        assert (out[:, :, sl] - ref).abs().max() < 1e-11 * max(1.0, float(ref.abs().max()))
+
+
+def test_mode_contract_strides_beyond_32_bit_row_offsets():
+    """B = 34M columns: 16 rows of out are more than 4 GB apart, the k-steps of a chunk cannot be
+    scalar offsets of one descriptor (contract_kernel<.., WIDE>: one descriptor per k-step, plain
+    stores).  13.3 GB in, 4.4 GB out; checked against the einsum on column windows at both ends and
+    in the middle."""
+    A, K, J, B = 1, 49, 16, 34_000_000
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    T = torch.empty((A, K, B), dtype=torch.float64, device=DEV)
+    for k in range(K):                       # (filled row by row: randn of 13 GB at once doubles the peak)
+        T[0, k] = torch.randn(B, generator=gen, dtype=torch.float64, device=DEV)
+    C = torch.randn((K, J), generator=gen, dtype=torch.float64, device=DEV)
+    out = ops.mode_contract(T, C, A, K, J, B, last=False).reshape(A, J, B)
+    for sl in (slice(0, 4096), slice(B // 2 - 1000, B // 2 + 3000), slice(B - 4096, B)):
+        # (a contiguous copy of the window: the library GEMM behind einsum returns wrong numbers for a
+        # view whose rows are 272 MB apart)
+        ref = torch.einsum("kj,akb->ajb", C, T[:, :, sl].contiguous())
+        assert (out[:, :, sl] - ref).abs().max() < 1e-11 * max(1.0, float(ref.abs().max()))
+    del T, out
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("A,K,J,B", [(1, 49, 16, 4000), (2, 100, 250, 40), (3, 60, 33, 1000), (1, 13, 13, 2197)])
+def test_mode_contract_long_stride_kernels_on_small_shapes(A, K, J, B, lib_options):
+    """The long-stride build of K1 (one descriptor per k-step, 64-bit store addresses), forced by
+    option k1_force_wide on shapes whose einsum is cheap: every tile count class, ragged edges."""
+    lib_options(k1_force_wide=1)
+    rng = np.random.default_rng(A * 31 + K)
+    T = _rand(rng, A, K, B)
+    C = _rand(rng, K, J)
+    ref = torch.einsum("kj,akb->ajb", C, T)
+    out = ops.mode_contract(T.to(DEV), C.to(DEV), A, K, J, B, last=False).cpu().reshape(A, J, B)
+    assert (out - ref).abs().max() < 1e-11 * max(1.0, float(ref.abs().max()))
