@@ -3,8 +3,11 @@
 Drop-in for the reference's ``auto_oo.Parameterized_circuit`` (src/auto_oo/pqc.py:86-235) for
 ``ansatz='ucc'`` (UCCD, and UCCSD with ``add_singles=True``), ``ansatz='np_fabric'`` (GateFabric)
 plus ``ansatz='kupccd'`` (the reference defines the kUpCCD operator, ansatze/kUpCCD.py:36-154, but
-never wires it into ``Parameterized_circuit``).  A custom PennyLane QNode as ``ansatz`` is not
-supported (there is no PennyLane here).  The PennyLane device argument ``dev`` is accepted and ignored: the
+never wires it into ``Parameterized_circuit``).  Where the reference accepts a custom PennyLane
+QNode as ``ansatz`` (pqc.py:162-163) this class accepts a custom GATE TABLE: a list of gates built
+with ``auto_oo_amd.excitations`` (``fde_gate``, ``fse_gate``, ``double_excitation_gate``,
+``orbital_rotation_gates``), or a callable ``(ncas, nelecas) -> gates``; there is no PennyLane
+here.  The PennyLane device argument ``dev`` is accepted and ignored: the
 state is produced by ``oovqe_circuit_state`` and the RDMs by ``oovqe_rdms*`` (include/oovqe.h).
 """
 import warnings
@@ -67,8 +70,23 @@ class Parameterized_circuit():
                 np.array([x for x in range(int(np.prod(self.full_theta_shape)))
                           if x not in self.redundant_idx]), device=self.device)
             self.theta_shape = n_theta
+        elif callable(ansatz) or isinstance(ansatz, (list, tuple)):
+            # custom circuit (the counterpart of a user QNode, pqc.py:162-163): a gate table over the
+            # engine's gate set, applied to the Hartree-Fock state in list order; parameter k of
+            # theta drives every gate whose theta_idx is k
+            gates = ansatz(ncas, nelecas) if callable(ansatz) else ansatz
+            if isinstance(gates, tuple) and len(gates) == 2 and isinstance(gates[1], (int, np.integer)):
+                gates = gates[0]                      # (gates, n_theta) as the built-in builders return
+            gates = list(gates)
+            if not gates or not all(isinstance(g, X.GateT) for g in gates):
+                raise ValueError("a custom ansatz is a non-empty list of excitations.GateT gates")
+            self._gates = gates
+            self.theta_shape = 1 + max(int(g.theta_idx) for g in gates)
+            if self.theta_shape < 1:
+                raise ValueError("a custom ansatz needs at least one parameterised gate")
+            ansatz = 'custom'
         else:
-            raise ValueError(f"unknown ansatz {ansatz!r}: expected 'ucc' or 'kupccd'")
+            raise ValueError(f"unknown ansatz {ansatz!r}: expected 'ucc', 'np_fabric', 'kupccd' or a gate table")
         self.ansatz = ansatz
         self.hfstate = X.hf_state(nelecas, self.n_qubits)
         self.wires = range(self.n_qubits)
