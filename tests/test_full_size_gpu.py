@@ -270,3 +270,31 @@ def test_cas_eval_large_n_rs_symmetry_reads_the_tile_triangle(N, n_occ, ncas):
         scale = max(1.0, float(outs[0][key].abs().max()))
         for o in outs[1:]:
             assert (outs[0][key] - o[key]).abs().max() <= 2e-12 * scale, key
+
+
+def test_batched_evaluation_beyond_n48_matches_single():
+    """Three geometries at N = 96, CAS(6e,6o), M = 16 in one call: the streaming stage 1 with a batch
+    dimension and the batched U = C^T T2 contraction (large enough, 3 x 768 strips, for the
+    two-strips-per-wave kernel) against the three single evaluations (one-strip kernel) -- both
+    symmetry flags and none."""
+    import auto_oo_amd as aoo
+    from auto_oo_amd.synthetic import synthetic_problem
+    N, ncas, nelecas, nelec, G = 96, 6, 6, 26, 3
+    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="ucc")
+    mols, coeffs = [], []
+    for g in range(G):
+        P = synthetic_problem(N, 3100 + g)
+        mols.append(aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"] + g, nelec))
+        coeffs.append(P["oao_mo_coeff"])
+    thetas = torch.tensor(np.random.default_rng(6).uniform(0, 2 * np.pi, (G, pqc.theta_shape)))
+    batch = aoo.OO_pqc_batch(pqc, mols, ncas, nelecas, oao_mo_coeffs=coeffs)
+    assert batch.eri_flags == 3
+    eg = batch.energy_and_gradient(thetas).cpu()
+    batch.eri_flags = 0
+    eg0 = batch.energy_and_gradient(thetas).cpu()
+    assert (eg - eg0).abs().max() < 1e-10 * max(1.0, float(eg0.abs().max()))
+    for g in range(G):
+        single = aoo.OO_pqc(pqc, mols[g], ncas, nelecas, oao_mo_coeff=coeffs[g])
+        E, grad = single.energy_and_gradient(thetas[g])
+        assert abs(eg[g, 0].item() - E.item()) < 1e-10
+        assert (eg[g, 1:] - grad.cpu()).abs().max() < 1e-10
