@@ -483,26 +483,31 @@ __global__ void sector_rdm_finish_kernel(const double* __restrict__ R, int ncas,
 //                                                            (W'_rs = sum_pq c2[pq,rs] V_qp)
 // c1e[ps] = c1[ps] - sum_q c2[p,q,q,s]
 __global__ void sector_coeff_kernel(const double* __restrict__ c1, const double* __restrict__ c2,
-                                    int ncas, double* __restrict__ M12)
+                                    int ncas, const uint32_t* __restrict__ unrank_a,
+                                    const uint32_t* __restrict__ unrank_b, double* __restrict__ M12)
 {
-    // M12 [a^2][2 a^2 + 1] = [M1 | M2 | s]: W, W' and the one-body term u = sum_k s_k V_k come out of
-    // ONE contraction over V (J = 2 a^2 + 1), so the lambda kernel never reads V itself.
-    //   s_k = c1e[k] + c1e[swap k],  c1e[ps] = c1[ps] - sum_q c2[p,q,q,s]
-    const int na2 = ncas * ncas, ldm = 2 * na2 + 1;
+    // M12 [a^2][2 a^2] = [M1 | M2]: W and W' come out of ONE contraction over V (J = 2 a^2).  The
+    // one-body term u = sum_k s_k V_k rides in M1: on the sector sum_p E_pp = N (the electron
+    // number), so adding s_k / N to the columns (p,p) of row k adds sum_p E_pp (s_k / N) V_k = s_k V_k
+    // to lambda = sum_j E_j W_j -- no extra column (129 -> 128: eight full 16-wide tiles), no extra
+    // row of W to write and read.   s_k = c1e[k] + c1e[swap k],  c1e[ps] = c1[ps] - sum_q c2[p,q,q,s]
+    const int na2 = ncas * ncas, ldm = 2 * na2;
+    const int nel = __popc(unrank_a[0]) + __popc(unrank_b[0]);
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < na2 * na2;
          idx += gridDim.x * blockDim.x) {
         const int k = idx / na2, j = idx - k * na2;
-        M12[(size_t)k * ldm + j] = c2[(size_t)j * na2 + k];
         const int kq = k / ncas, kp = k - kq * ncas;          // k = q*a + p  ->  pq = p*a + q
-        M12[(size_t)k * ldm + na2 + j] = c2[(size_t)(kp * ncas + kq) * na2 + j];
-        if (j == 0) {
+        double m1 = c2[(size_t)j * na2 + k];
+        if (j / ncas == j % ncas && nel > 0) {
             auto c1e = [&](int p, int s2) {
                 double v = c1[p * ncas + s2];
                 for (int q = 0; q < ncas; ++q) v -= c2[((size_t)(p * ncas + q) * ncas + q) * ncas + s2];
                 return v;
             };
-            M12[(size_t)k * ldm + 2 * na2] = c1e(kq, kp) + c1e(kp, kq);
+            m1 += (c1e(kq, kp) + c1e(kp, kq)) / nel;
         }
+        M12[(size_t)k * ldm + j] = m1;
+        M12[(size_t)k * ldm + na2 + j] = c2[(size_t)(kp * ncas + kq) * na2 + j];
     }
 }
 
@@ -528,10 +533,9 @@ void sector_lambda_kernel(const double* __restrict__ W12, Sector s, double* __re
     const size_t b = blockIdx.y;
     double acc = 0.0;
     if (c < Dc) {
-        const double* W1b = W12 + b * (size_t)(2 * na2 + 1) * Dc;    // [2 a^2 + 1][Dc]: W rows, W' rows, u
+        const double* W1b = W12 + b * (size_t)(2 * na2) * Dc;        // [2 a^2][Dc]: W rows, W' rows
         const double* W2b = W1b + (size_t)na2 * Dc;
         const uint32_t x = sec_full(sg, c);
-        if (slice == 0) acc = W2b[(size_t)na2 * Dc + c];              // u = sum_pq c1e_pq (V_pq + V_qp)
         for (int pq = slice; pq < na2; pq += 4) {
             const int p = pq / a, q = pq - p * a;
             acc += sec_epq(W1b + (size_t)pq * Dc, s, n, p, q, x, c);      // E_pq W_pq
@@ -790,14 +794,14 @@ extern "C" int oovqe_sector_adjoint(const double* theta, int n_theta, const oovq
     double* R = lam + nb_ * Dc;
     double* M12 = R + 8 * nb_ * (size_t)(MT * 16) * (NT * 16);
     hipLaunchKernelGGL(sector_coeff_kernel, dim3((na2 * na2 + 255) / 256), dim3(256), 0, st, c1, c2, ncas,
-                       M12);
+                       unrank_a, unrank_b, M12);
     OOVQE_CHECK_LAUNCH("sector_adjoint/coeff");
     int rc;
-    // W12[b][j][c] = sum_k M12[k][j] V[b][k][c]: rows j < a^2: W_pq = sum_rs c2[pq,rs] V_rs,
-    // rows a^2 <= j < 2 a^2: W'_rs = sum_pq c2[pq,rs] V_qp, row 2 a^2: the one-body term -- one pass
-    // over V for all of them
-    if ((rc = oovqe_mode_contract_batched(V, M12, W12, 1, na2, 2 * na2 + 1, Dc, 2 * na2 + 1, 0, batch,
-                                          (long)na2 * Dc, 0, (long)(2 * na2 + 1) * Dc, st)))
+    // W12[b][j][c] = sum_k M12[k][j] V[b][k][c]: rows j < a^2: W_pq = sum_rs c2[pq,rs] V_rs (+ the
+    // one-body term on the rows (p,p)), rows a^2 <= j < 2 a^2: W'_rs = sum_pq c2[pq,rs] V_qp -- one
+    // pass over V for all of them
+    if ((rc = oovqe_mode_contract_batched(V, M12, W12, 1, na2, 2 * na2, Dc, 2 * na2, 0, batch,
+                                          (long)na2 * Dc, 0, (long)(2 * na2) * Dc, st)))
         return rc;
     hipLaunchKernelGGL(sector_lambda_kernel, dim3((Dc + 63) / 64, batch), dim3(256),
                        256 * sizeof(double) + 2 * ((size_t)1 << ncas) * sizeof(int32_t), st, W12, s, lam);
