@@ -99,6 +99,9 @@ void contract_body(const double* __restrict__ T, const double* __restrict__ Cm,
     const long t_elems = LAST ? A * (long)K : A * (long)K * B;
     struct Strip {
         long tb;        // element index of T[a, 0, 16 bt] (INNER) / T[a, 0] (LAST): wave-uniform
+        long te;        // element index where the strip's readable part of T ends: its slab (INNER: the
+                        // zero-padded k-steps past K then read nothing instead of the next slab, whose
+                        // values, times the zero rows of Cm, could turn an Inf into a NaN here) / T (LAST)
         long a, bcol;
         unsigned tvo;   // this lane's byte offset inside a k-step block, or OOB
         long ob, oe;    // element indices in out: the strip's first result, the end of its slab
@@ -118,6 +121,7 @@ void contract_body(const double* __restrict__ T, const double* __restrict__ Cm,
             st.a = item * 16;
             tvalid = st.active && st.a + lr < A;
             st.tb = st.a * (long)K;
+            st.te = t_elems;
             st.tvo = tvalid ? (unsigned)((lr * (long)K + lq) * sizeof(double)) : OOB;
             st.ob = st.a * (long)J + j0;
             st.oe = A * (long)J;
@@ -130,12 +134,13 @@ void contract_body(const double* __restrict__ T, const double* __restrict__ Cm,
             st.bcol = bt * 16;
             tvalid = st.active && st.bcol + lr < B;
             st.tb = st.a * (long)K * B + bt * 16;
+            st.te = (st.a + 1) * (long)K * B;
             st.tvo = tvalid ? (unsigned)((lq * B + lr) * sizeof(double)) : OOB;
             st.ob = (st.a * (long)J + j0) * B + bt * 16;
             st.oe = (st.a * (long)J + J) * B;
             st.ovo = st.tvo;
         }
-        if (!st.active) st.tb = 0, st.ob = 0, st.oe = 0;
+        if (!st.active) st.tb = 0, st.te = 0, st.ob = 0, st.oe = 0;
 #if OOVQE_K1_PROBE & 16
         st.tb = 0;
 #endif
@@ -192,7 +197,7 @@ void contract_body(const double* __restrict__ T, const double* __restrict__ Cm,
     const unsigned step_bytes = WIDE ? 0u : (unsigned)(4 * tstride * (long)sizeof(double));
     auto load_t = [&](const Strip& st, int kbase, double* dst) {
         const long e0 = st.tb + (long)kbase * tstride;   // wave-uniform
-        long rem = (t_elems - e0) * (long)sizeof(double);
+        long rem = (st.te - e0) * (long)sizeof(double);
         rem = rem < 0 ? 0 : (rem > 0xFFFFFFFFL ? 0xFFFFFFFFL : rem);
         if constexpr (!WIDE) {
             const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
@@ -207,7 +212,7 @@ void contract_body(const double* __restrict__ T, const double* __restrict__ Cm,
 #pragma unroll
             for (int s2 = 0; s2 < KSTEPS; ++s2) {
                 const long e1 = e0 + (long)(4 * s2) * tstride;
-                long rem1 = (t_elems - e1) * (long)sizeof(double);
+                long rem1 = (st.te - e1) * (long)sizeof(double);
                 rem1 = rem1 < 0 ? 0 : (rem1 > 0xFFFFFFFFL ? 0xFFFFFFFFL : rem1);
                 const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<double*>(T) + e1, 0, (int)(unsigned)rem1, 0x00020000);
@@ -274,7 +279,7 @@ void contract_body(const double* __restrict__ T, const double* __restrict__ Cm,
                 const int s2 = q - CREG;
                 if (s2 == 0 || WIDE) {
                     const long e1 = stn.tb + (long)(pf_kn + (WIDE ? 4 * s2 : 0)) * tstride;   // wave-uniform
-                    long rem = (t_elems - e1) * (long)sizeof(double);
+                    long rem = (stn.te - e1) * (long)sizeof(double);
                     rem = rem < 0 ? 0 : (rem > 0xFFFFFFFFL ? 0xFFFFFFFFL : rem);
                     pf_rem = (unsigned)rem;
                     pf_tr = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(T) + e1, 0, (int)pf_rem, 0x00020000);

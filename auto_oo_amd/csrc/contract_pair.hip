@@ -70,10 +70,10 @@ void contract_pair_kernel(const double* __restrict__ T, const double* __restrict
     const int nchunks = (K + KC - 1) / KC;
     const long n_groups = (n_items + NW - 1) / NW;
     const unsigned grid_x = gridDim.x;
-    const long t_elems = A * (long)K * B;
 
     struct Strip {
         long tb;        // element index of T[a, 0, 32 bt]: wave-uniform
+        long te;        // element index where slab a of T ends (k-steps past K read nothing)
         long ob, oe;    // element indices in out: the strip's first result, the end of its slab
         unsigned vo;    // this lane's byte offset (row lq, columns 2 lr, 2 lr + 1), or OOB
         bool active;
@@ -87,10 +87,11 @@ void contract_pair_kernel(const double* __restrict__ T, const double* __restrict
         const long bt = (long)((unsigned)item - ai * (unsigned)nbt);
         const bool valid = st.active && bt * 32 + 2 * lr < B;
         st.tb = (long)ai * K * B + bt * 32;
+        st.te = ((long)ai + 1) * K * B;
         st.ob = ((long)ai * J + j0) * B + bt * 32;
         st.oe = ((long)ai * J + J) * B;
         st.vo = valid ? (unsigned)((lq * B + 2 * lr) * sizeof(double)) : OOB;
-        if (!st.active) st.tb = 0, st.ob = 0, st.oe = 0;
+        if (!st.active) st.tb = 0, st.te = 0, st.ob = 0, st.oe = 0;
         return st;
     };
 
@@ -134,7 +135,7 @@ void contract_pair_kernel(const double* __restrict__ T, const double* __restrict
                 const int s2 = q - CREG;
                 if (s2 == 0) {
                     const long e1 = stn.tb + (long)pf_kn * B;   // wave-uniform
-                    long rem = (t_elems - e1) * (long)sizeof(double);
+                    long rem = (stn.te - e1) * (long)sizeof(double);
                     rem = rem < 0 ? 0 : (rem > 0xFFFFFFFFL ? 0xFFFFFFFFL : rem);
                     pf_rem = (unsigned)rem;
                     pf_tr = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(T) + e1, 0, (int)pf_rem, 0x00020000);

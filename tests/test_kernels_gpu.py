@@ -615,3 +615,20 @@ def test_mode_contract_long_stride_kernels_on_small_shapes(A, K, J, B, lib_optio
     ref = torch.einsum("kj,akb->ajb", C, T)
     out = ops.mode_contract(T.to(DEV), C.to(DEV), A, K, J, B, last=False).cpu().reshape(A, J, B)
     assert (out - ref).abs().max() < 1e-11 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("A,K,J,B", [(3, 43, 40, 1000), (3, 50, 100, 70000)])
+def test_mode_contract_inner_slabs_do_not_leak(A, K, J, B):
+    """K is padded to the kernel's chunk depth with zero rows of Cm; the padded k-steps of slab a must
+    not read slab a + 1 (0 x Inf = NaN): an Inf / NaN planted in slab 1 stays in slab 1's results
+    (one-strip and two-strip kernels)."""
+    gen = torch.Generator(device=DEV).manual_seed(K)
+    T = torch.randn((A, K, B), generator=gen, dtype=torch.float64, device=DEV)
+    C = torch.randn((K, J), generator=gen, dtype=torch.float64, device=DEV)
+    T[1, 0, :] = float("inf")
+    T[1, 3, 5] = float("nan")
+    out = ops.mode_contract(T, C, A, K, J, B, last=False).reshape(A, J, B)
+    assert torch.isfinite(out[0]).all() and torch.isfinite(out[2]).all()
+    ref0 = torch.einsum("kj,kb->jb", C, T[0])
+    assert (out[0] - ref0).abs().max() < 1e-11 * max(1.0, float(ref0.abs().max()))
+    assert not torch.isfinite(out[1]).all()
