@@ -206,7 +206,8 @@ void contract_body(const double* __restrict__ T, const double* __restrict__ Cm,
             for (int s2 = 0; s2 < KSTEPS; ++s2) {
                 unsigned so = (unsigned)s2 * step_bytes;
                 so = so < (unsigned)rem ? so : (unsigned)rem;
-                dst[s2] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, st.tvo, so, 0));
+                const unsigned tvo = (!LAST || kbase + 4 * s2 + lq < K) ? st.tvo : OOB;
+                dst[s2] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, tvo, so, 0));
             }
         } else {
 #pragma unroll
@@ -286,7 +287,9 @@ void contract_body(const double* __restrict__ T, const double* __restrict__ Cm,
                 }
                 unsigned so = WIDE ? 0u : (unsigned)s2 * step_bytes;
                 so = so < pf_rem ? so : pf_rem;
-                tnext[s2] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(pf_tr, stn.tvo, so, 0));
+                // LAST: a row of T is followed by the next row, so the k-steps past K are masked per lane
+                const unsigned tvo = (!LAST || pf_kn + 4 * s2 + lq < K) ? stn.tvo : OOB;
+                tnext[s2] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(pf_tr, tvo, so, 0));
 #if OOVQE_K1_PROBE & 512
                 if (s2 == KSTEPS - 1) K1_MARK(52);
 #endif

@@ -632,3 +632,20 @@ def test_mode_contract_inner_slabs_do_not_leak(A, K, J, B):
     ref0 = torch.einsum("kj,kb->jb", C, T[0])
     assert (out[0] - ref0).abs().max() < 1e-11 * max(1.0, float(ref0.abs().max()))
     assert not torch.isfinite(out[1]).all()
+
+
+@pytest.mark.parametrize("A,K,J", [(100, 43, 40), (5000, 50, 100)])
+def test_mode_contract_last_rows_do_not_leak(A, K, J):
+    """LAST mode: the k-steps that pad K to the chunk depth would read the start of the next row of T;
+    they are masked per lane, so an Inf at the start of row a + 1 does not reach row a."""
+    gen = torch.Generator(device=DEV).manual_seed(K + 1)
+    T = torch.randn((A, K), generator=gen, dtype=torch.float64, device=DEV)
+    C = torch.randn((K, J), generator=gen, dtype=torch.float64, device=DEV)
+    T[7, 0] = float("inf")
+    T[40, 1] = float("nan")
+    out = ops.mode_contract(T, C, A, K, J, 1, last=True).reshape(A, J)
+    good = torch.ones(A, dtype=torch.bool, device=DEV)
+    good[7] = good[40] = False
+    assert torch.isfinite(out[good]).all()
+    ref = T[good] @ C
+    assert (out[good] - ref).abs().max() < 1e-11 * max(1.0, float(ref.abs().max()))
