@@ -649,3 +649,25 @@ def test_mode_contract_last_rows_do_not_leak(A, K, J):
     assert torch.isfinite(out[good]).all()
     ref = T[good] @ C
     assert (out[good] - ref).abs().max() < 1e-11 * max(1.0, float(ref.abs().max()))
+
+
+def test_mode_contract_random_shapes():
+    """Forty seeded random shapes through oovqe_mode_contract (INNER and LAST; one-chunk, 12- and
+    20-row chunk kernels; one-strip and two-strip kernels; ragged edges everywhere) against einsum."""
+    rng = np.random.default_rng(20262)
+    for trial in range(40):
+        last = trial % 4 == 3
+        K = int(rng.integers(1, 131))
+        J = int(rng.integers(1, 231))
+        if last:
+            A, B = int(rng.integers(1, 4000)), 1
+        else:
+            A = int(rng.integers(1, 5))
+            B = int(rng.choice([1, 2, 7, 16, 33, 250, 1000, 2999, 4096, 40002, 70000]))
+        gen = torch.Generator(device=DEV).manual_seed(trial)
+        T = torch.randn((A, K, B), generator=gen, dtype=torch.float64, device=DEV)
+        C = torch.randn((K, J), generator=gen, dtype=torch.float64, device=DEV)
+        out = ops.mode_contract(T, C, A, K, J, B, last=last).reshape(A, J, B)
+        ref = torch.einsum("kj,akb->ajb", C, T)
+        err = float((out - ref).abs().max())
+        assert err < 1e-11 * max(1.0, float(ref.abs().max())), (trial, last, A, K, J, B, err)
