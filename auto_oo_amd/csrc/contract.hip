@@ -21,13 +21,21 @@
 //     check instead of clamps and masks): measured on the N = 200 transform, the address
 //     arithmetic, clamps and masks of flat loads cost 8 % of the run time (52 -> 56 TFLOP/s);
 //   * f64 MFMA issues one 16x16x4 every 64 cycles per SIMD, so per 13 MFMAs (832 cycles) a wave
-//     needs 1 global load + 13 LDS reads: the kernel is MFMA-bound by construction.
+//     needs 1 global load + 13 LDS reads: the kernel is MFMA-bound by construction;
+//   * what keeps the matrix pipe fed in practice (round 2): the fragment read
+//     of tile t for the next k-step right behind the MFMA of tile t; one descriptor per chunk and
+//     the k-step as scalar offset; prefetch loads and LDS staging stores in parts between pairs of
+//     MFMAs; the last chunk of a strip tile-outer with the tile's four stores (range-checked
+//     buffer stores) behind the next tile's MFMAs; every wait for a prefetched load pinned inside
+//     the straight-line code that issued it, where it is counted exactly.
+//   INNER contractions with even B and many strips run on contract_pair.hip (two strips per wave).
 #include "common.h"
 #include "circuit_small.h"
 
 // tools/k1_standalone.hip ablations (bit mask): 1 no T loads, 2 no stores, 4 no Cm staging,
 // 8 no workgroup barrier, 16 every strip reads the first strip of T (cache hits), 32 every strip
-// writes the first strip of out.  Never set in the library build.
+// writes the first strip of out, 64 clock marks (with 512: around the loads and one tile's stores),
+// 128 / 256 sixty-four dependent VALU / SALU instructions per k-step.  Never set in the library build.
 #ifndef OOVQE_K1_PROBE
 #define OOVQE_K1_PROBE 0
 #endif
