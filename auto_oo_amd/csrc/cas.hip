@@ -2489,7 +2489,14 @@ void cas_panel_kernel(const double* __restrict__ Gm_in, const double* __restrict
 // instead of LDS -- the staged path's M^3 block (140 KB at M = 26) does not fit there.  Replaces
 // the one-workgroup fock_kernel inside oovqe_cas_eval: 481 -> ~15 us at N = 200, M = 26.
 // cas_final_kernel assembles the outputs.
-constexpr int FROW_THREADS = 64;
+constexpr int FROW_THREADS = 256;
+
+// doubles of LDS fock_rows_kernel needs for the slices of g_mo[n] it uses
+static size_t fock_rows_lds_elems(int no, int na)
+{
+    const size_t M = (size_t)no + na;
+    return 2 * M * no + 2 * (size_t)no * na * na + (size_t)na * na * na + 64 + 4;
+}
 
 __global__ __launch_bounds__(FROW_THREADS)
 void fock_rows_kernel(const double* __restrict__ Gm, const double* __restrict__ hmo,
@@ -2497,16 +2504,42 @@ void fock_rows_kernel(const double* __restrict__ Gm, const double* __restrict__ 
                       int na, double* __restrict__ Fcol, double* __restrict__ Epart,
                       double* __restrict__ Cpart, double* __restrict__ c1, double* __restrict__ c2)
 {
-    __shared__ double FIn[64];
+    extern __shared__ double lds[];
     const int M = no + na, M2 = M * M, M3 = M2 * M;
     const int na2 = na * na, na3 = na2 * na, na4 = na2 * na2;
     const int n = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
     const double* gn = Gm + (size_t)n * M3;
     const double* gam = gamma + (size_t)k * na2;
     const double* Gam = Gamma + (size_t)k * na4;
+    // the slices of g_mo[n] this index needs (2.7K of its 17.6K elements at M = 26), gathered by the
+    // whole workgroup in one round trip: one wave walking them load by load is a chain of cache misses
+    double* d1 = lds;                          // [M][no]      gn[x, i, i]
+    double* d2 = d1 + (size_t)M * no;          // [M][no]      gn[i, i, x]
+    double* o1 = d2 + (size_t)M * no;          // [no][na2]    gn[m, V, W]
+    double* o2 = o1 + (size_t)no * na2;        // [no][na2]    gn[W, V, m]
+    double* cube = o2 + (size_t)no * na2;      // [na3]        gn[act, act, act]
+    double* FIn = cube + na3;                  // [64]
+    double* red = FIn + 64;                    // [4]
+    for (int idx = tid; idx < M * no; idx += FROW_THREADS) {
+        const int x = idx / no, i = idx - x * no;
+        d1[idx] = gn[x * M2 + i * M + i];
+        d2[idx] = gn[i * M2 + i * M + x];
+    }
+    for (int idx = tid; idx < no * na2; idx += FROW_THREADS) {
+        const int m = idx / na2, vw = idx - m * na2, v = vw / na, w = vw - v * na;
+        o1[idx] = gn[m * M2 + (no + v) * M + no + w];
+        o2[idx] = gn[(no + w) * M2 + (no + v) * M + m];
+    }
+    for (int idx = tid; idx < na3; idx += FROW_THREADS) {
+        int t = idx;
+        const int y = t % na; t /= na;
+        const int x = t % na; t /= na;
+        cube[idx] = gn[(no + t) * M2 + (no + x) * M + no + y];
+    }
+    __syncthreads();
     for (int x = tid; x < M; x += FROW_THREADS) {
         double fi = hmo[(size_t)n * M + x];
-        for (int i = 0; i < no; ++i) fi += 2.0 * gn[x * M2 + i * M + i] - gn[i * M2 + i * M + x];
+        for (int i = 0; i < no; ++i) fi += 2.0 * d1[x * no + i] - d2[x * no + i];
         FIn[x] = fi;
     }
     __syncthreads();
@@ -2514,54 +2547,37 @@ void fock_rows_kernel(const double* __restrict__ Gm, const double* __restrict__ 
         double val;
         if (m < no) {
             double fa = 0.0;
-            for (int v = 0; v < na; ++v)
-                for (int w = 0; w < na; ++w) {
-                    const int V = no + v, W = no + w;
-                    fa += gam[v * na + w] * (gn[m * M2 + V * M + W] - 0.5 * gn[W * M2 + V * M + m]);
-                }
+            for (int vw = 0; vw < na2; ++vw) fa += gam[vw] * (o1[m * na2 + vw] - 0.5 * o2[m * na2 + vw]);
             val = 2.0 * ((k == 0 ? FIn[m] : 0.0) + fa);
         } else {
             const int v = m - no;
             const double* Gv = Gam + (size_t)v * na3;
             double acc = 0.0;
             for (int w = 0; w < na; ++w) acc += FIn[no + w] * gam[v * na + w];
-            for (int w = 0; w < na; ++w)
-                for (int x = 0; x < na; ++x)
-                    for (int y = 0; y < na; ++y)
-                        acc += Gv[(w * na + x) * na + y] * gn[(no + w) * M2 + (no + x) * M + no + y];
+            for (int idx = 0; idx < na3; ++idx) acc += Gv[idx] * cube[idx];
             val = acc;
         }
         Fcol[((size_t)k * M + m) * N + n] = val;
     }
-    // E_k contribution of row p = n - no (active n only): lanes over (q, r, s), wave reduction
+    // E_k contribution of row p = n - no (active n only): fixed-order sum (lanes, then waves)
     double part = 0.0;
     if (n >= no && n < M) {
         const int p = n - no;
         const double* gp = gam + (size_t)p * na;
         const double* Gp = Gam + (size_t)p * na3;
         for (int q = tid; q < na; q += FROW_THREADS) part += FIn[no + q] * gp[q];
-        for (int idx = tid; idx < na3; idx += FROW_THREADS) {
-            int t = idx;
-            const int s2 = t % na; t /= na;
-            const int r = t % na; t /= na;
-            const int q = t;
-            part += 0.5 * gn[(no + q) * M2 + (no + r) * M + no + s2] * Gp[idx];
-        }
+        for (int idx = tid; idx < na3; idx += FROW_THREADS) part += 0.5 * cube[idx] * Gp[idx];
     }
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-    if (tid == 0) Epart[(size_t)k * N + n] = part;
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0) Epart[(size_t)k * N + n] = (red[0] + red[1]) + (red[2] + red[3]);
     if (k == 0) {
         if (tid == 0) Cpart[n] = n < no ? hmo[(size_t)n * M + n] + FIn[n] : 0.0;
         if (n >= no && n < M) {
             const int p = n - no;
             for (int q = tid; q < na; q += FROW_THREADS) c1[p * na + q] = FIn[no + q];
-            for (int idx = tid; idx < na3; idx += FROW_THREADS) {
-                int t = idx;
-                const int s2 = t % na; t /= na;
-                const int r = t % na; t /= na;
-                const int q = t;
-                c2[(size_t)p * na3 + idx] = 0.5 * gn[(no + q) * M2 + (no + r) * M + no + s2];
-            }
+            for (int idx = tid; idx < na3; idx += FROW_THREADS) c2[(size_t)p * na3 + idx] = 0.5 * cube[idx];
         }
     }
 }
@@ -3233,8 +3249,10 @@ static int cas_energy_gradient_rows(const double* Gm, const double* hmo, const d
     const int M = n_occ + ncas;
     OOVQE_REQUIRE(M <= 64 && nrdm <= 65535, "cas_energy_gradient: n_occ + ncas = %d, nrdm = %d", M, nrdm);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(fock_rows_kernel, dim3(N, nrdm), dim3(FROW_THREADS), 0, st, Gm, hmo, gamma, Gamma, N,
-                       n_occ, ncas, Fcol, Epart, Cpart, c1, c2);
+    const size_t lds_bytes = fock_rows_lds_elems(n_occ, ncas) * sizeof(double);
+    OOVQE_REQUIRE(lds_bytes <= 64 * 1024, "cas_energy_gradient: %zu B of LDS", lds_bytes);
+    hipLaunchKernelGGL(fock_rows_kernel, dim3(N, nrdm), dim3(FROW_THREADS), lds_bytes, st, Gm, hmo, gamma, Gamma,
+                       N, n_occ, ncas, Fcol, Epart, Cpart, c1, c2);
     OOVQE_CHECK_LAUNCH("cas_energy_gradient/rows");
     hipLaunchKernelGGL(cas_final_kernel, dim3(1), dim3(512), 0, st, Fcol, Epart, Cpart, nuc, nrdm, N, M,
                        kap_row, kap_col, n_kappa, c0, E, gvec, dE, fock, gmat, nuc_dev, (size_t)0);
@@ -3374,7 +3392,8 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
             double* Ep = Fc + (size_t)nrdm * M * N;
             double* Cp = Ep + (size_t)nrdm * N;
             const bool rows_fit = (size_t)N * m3 + (size_t)N * M + (size_t)nrdm * (M + 1) * N + N <=
-                                  (size_t)N * N * m2 && M <= 64;
+                                  (size_t)N * N * m2 && M <= 64 &&
+                                  fock_rows_lds_elems(n_occ, ncas) * sizeof(double) <= 64 * 1024;
             if (rows_fit)
                 rc = cas_energy_gradient_rows(
                     Gmg, hmog, gamma + gi * nrdm * na2s, Gamma + gi * nrdm * na4s, nrdm, nuc,
