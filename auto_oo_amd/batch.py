@@ -91,6 +91,23 @@ class OO_pqc_batch:
         self.oao_mo_coeff[g].copy_(c)
         self.mo_coeff[g].copy_(ops.matmul_nn(self.oao_coeff[g].contiguous(), c))
 
+    def reverify_integrals(self):
+        """Call after writing into ``int2e_ao`` (or ``int1e_ao`` / ``oao_coeff`` / ``nuc``) in place,
+        e.g. when the integrals of many geometries are produced on the device: re-checks the
+        symmetry flags of the whole stack bit for bit, rebuilds the packed resident copy (or drops
+        it) and refreshes ``mo_coeff = S^-1/2 C_oao`` of every geometry."""
+        self.eri_flags = ops.eri_flags(self.int2e_ao)
+        both = ops.ERI_PQ_SYMMETRIC | ops.ERI_RS_SYMMETRIC
+        psz = self.lib.oovqe_eri_packed_size(self.nao)
+        if (self.eri_flags & both) == both and psz > 0 and self._n_occ + self.ncas <= 16:
+            if self._eri_packed is None:
+                self._eri_packed = torch.empty((self.G, psz), dtype=F64, device=self.device)
+            check(self.lib.oovqe_eri_pack(dptr(self.int2e_ao), self.nao, self.G, dptr(self._eri_packed),
+                                          stream_ptr()), "oovqe_eri_pack")
+        else:
+            self._eri_packed = None
+        torch.bmm(self.oao_coeff, self.oao_mo_coeff, out=self.mo_coeff)
+
     def set_molecule(self, g, mol, oao_mo_coeff=None):
         """Replace geometry g of the batch (the next point of a Berry-phase loop, say): integrals,
         OAO basis, nuclear repulsion and orbitals.  The symmetry flags of the batch are re-verified

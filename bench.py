@@ -44,7 +44,9 @@ sys.path.insert(0, ROOT)
 METRIC = ("OO-VQE energy+grad evals/sec (formaldimine CAS(4e,3o)/cc-pVDZ); "
           "2e-transform fp64 TFLOP/s vs roofline")
 NAO, NELEC, NCAS, NELECAS = 43, 16, 3, 4
-N_GEOM = 256         # geometries per GPU (7 GB of g_ao + 1.9 GB packed copy in 288 GB of HBM)
+N_GEOM = 256         # geometries per GPU (7 GB of g_ao + 1.9 GB packed copy in 288 GB of HBM; --geoms 1024:
+                     # 36 GB, +2...8 % evaluations/s depending on the box)
+N_GEOM_HOST = 4      # of them generated with numpy on the host (geometry 0 is the parity / CPU-baseline anchor)
 N_GEOM_BERRY = 64    # geometries per GPU of the Berry-loop extra (each holds its own OO_pqc object)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # AMD spec, vector = matrix fp64
@@ -81,17 +83,34 @@ def parse():
 
 
 def build_geometries(my_geoms):
+    """The rank's batch of synthetic geometries.  The first N_GEOM_HOST come from the numpy generator
+    (the seeds the CPU oracle uses: geometry 0 is the parity anchor); the others are generated on
+    the GPU with the same construction (auto_oo_amd.synthetic.synthetic_problem_device) and written
+    straight into the batch's stacked tensors -- every geometry has its own distinct 27 MB of
+    integrals in HBM, none of it ever on the host."""
     import auto_oo_amd as aoo
-    from auto_oo_amd.synthetic import synthetic_problem
+    from auto_oo_amd.synthetic import synthetic_problem, synthetic_problem_device
     pqc = aoo.Parameterized_circuit(NCAS, NELECAS, None, ansatz="ucc")
+    n_host = min(N_GEOM_HOST, len(my_geoms))
     mols, coeffs, thetas = [], [], []
-    for g in my_geoms:
+    for g in my_geoms[:n_host]:
         P = synthetic_problem(NAO, 20260 + 2 + 1000 * g)
         mols.append(aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], NELEC))
         coeffs.append(P["oao_mo_coeff"])
+    for g in my_geoms:
         rng = np.random.default_rng(777 + g)
         thetas.append(rng.uniform(0, 2 * np.pi, pqc.theta_shape))
-    batch = aoo.OO_pqc_batch(pqc, mols, NCAS, NELECAS, oao_mo_coeffs=coeffs)
+    pad = len(my_geoms) - n_host                     # slots filled on the device below
+    batch = aoo.OO_pqc_batch(pqc, mols + [mols[0]] * pad, NCAS, NELECAS, oao_mo_coeffs=coeffs + [coeffs[0]] * pad)
+    for slot in range(n_host, len(my_geoms)):
+        P = synthetic_problem_device(NAO, 20260 + 2 + 1000 * my_geoms[slot], "cuda")
+        batch.int2e_ao[slot].copy_(P["int2e_ao"])
+        batch.int1e_ao[slot].copy_(P["int1e_ao"])
+        batch.oao_coeff[slot].copy_(P["oao_coeff"])
+        batch.oao_mo_coeff[slot].copy_(P["oao_mo_coeff"])
+        batch.nuc[slot] = P["nuc"]
+    if pad:
+        batch.reverify_integrals()
     single = aoo.OO_pqc(pqc, mols[0], NCAS, NELECAS, oao_mo_coeff=coeffs[0])
     thetas = torch.tensor(np.stack(thetas), device="cuda")
     return pqc, batch, single, thetas

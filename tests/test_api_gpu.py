@@ -509,3 +509,45 @@ def test_custom_gate_table_ansatz_matches_gate_level_oracle():
         tm[j] -= h
         fd = (oo.energy_from_parameters(tp).item() - oo.energy_from_parameters(tm).item()) / (2 * h)
         assert abs(fd - g[j].item()) < 1e-7
+
+
+def test_device_generated_geometries_and_reverify_integrals():
+    """Integrals written into the batch's stacked tensors on the device (synthetic_problem_device, as
+    bench.py does for its 1024 geometries) + OO_pqc_batch.reverify_integrals(): flags re-verified,
+    packed copy rebuilt, mo_coeff refreshed -- every geometry then equals its single evaluation built
+    from the same tensors through Moldata; a broken symmetry is noticed."""
+    from auto_oo_amd.synthetic import synthetic_problem, synthetic_problem_device
+    from auto_oo_amd import ops
+    N, ncas, nelecas, nelec, G = 17, 3, 4, 8, 3
+    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="ucc")
+    P0 = synthetic_problem(N, 4100)
+    mol0 = aoo.Moldata(P0["int1e_ao"], P0["int2e_ao"], P0["overlap"], P0["nuc"], nelec)
+    batch = aoo.OO_pqc_batch(pqc, [mol0] * G, ncas, nelecas, oao_mo_coeffs=[P0["oao_mo_coeff"]] * G)
+    dev = []
+    for slot in range(1, G):
+        P = synthetic_problem_device(N, 4100 + slot, "cuda")
+        assert ops.eri_flags(P["int2e_ao"]) == 3
+        batch.int2e_ao[slot].copy_(P["int2e_ao"])
+        batch.int1e_ao[slot].copy_(P["int1e_ao"])
+        batch.oao_coeff[slot].copy_(P["oao_coeff"])
+        batch.oao_mo_coeff[slot].copy_(P["oao_mo_coeff"])
+        batch.nuc[slot] = P["nuc"] + slot
+        dev.append(P)
+    batch.reverify_integrals()
+    assert batch.eri_flags == 3 and batch._eri_packed is not None
+    thetas = torch.tensor(np.random.default_rng(2).uniform(0, 2 * np.pi, (G, pqc.theta_shape)))
+    eg = batch.energy_and_gradient(thetas).cpu()
+    for slot in range(1, G):
+        P = dev[slot - 1]
+        mol = aoo.Moldata(P["int1e_ao"].cpu().numpy(), P["int2e_ao"].cpu().numpy(), P["overlap"].cpu().numpy(),
+                          P["nuc"] + slot, nelec)
+        assert np.abs(mol.oao_coeff - P["oao_coeff"].cpu().numpy()).max() < 1e-12
+        single = aoo.OO_pqc(pqc, mol, ncas, nelecas, oao_mo_coeff=P["oao_mo_coeff"].cpu().numpy())
+        E, grad = single.energy_and_gradient(thetas[slot])
+        assert abs(eg[slot, 0].item() - E.item()) < 1e-10
+        assert (eg[slot, 1:] - grad.cpu()).abs().max() < 1e-10
+    batch.int2e_ao[1, 0, 1, 2, 3] += 1e-9            # r<->s and p<->q symmetry of geometry 1 broken
+    batch.reverify_integrals()
+    assert batch.eri_flags == 0 and batch._eri_packed is None
+    eg2 = batch.energy_and_gradient(thetas).cpu()
+    assert (eg2[2] - eg[2]).abs().max() < 1e-10      # other geometries: same numbers on the general path
