@@ -1,11 +1,11 @@
-// K2: matrix exponential U = expm(sign * X) by scaling-and-squaring with a degree-16 Taylor
-// polynomial evaluated in Paterson-Stockmeyer form (6 matrix products + s squarings, all on
-// the fp64 MFMA).  Replaces math.expm(-K) = torch.linalg.matrix_exp (reference
+// K2: matrix exponential U = expm(sign * X) by scaling-and-squaring with a Taylor polynomial of
+// degree 8, 12 or 16 (by the scaled norm) evaluated in Paterson-Stockmeyer form (4, 5 or 6 matrix
+// products + s squarings, all on the fp64 MFMA).  Replaces math.expm(-K) = torch.linalg.matrix_exp (reference
 // src/auto_oo/oo_energy.py:226-230) together with the kappa -> skew-matrix scatter
 // (oo_energy.py:63-87,213-219).
 //
-// With ||A||_1 <= 1/2 after scaling the truncation error is 0.5^17/17! = 2e-20, i.e. the result
-// is accurate to fp64 rounding (times the 2^s growth of the squarings), independent of the
+// With ||A||_1 <= 1/2 after scaling the truncation error of degree 16 is 0.5^17/17! = 2e-20 (degree
+// 12 up to 0.3: 3e-17, degree 8 up to 0.06: 3e-17), i.e. the result is accurate to fp64 rounding (times the 2^s growth of the squarings), independent of the
 // reference's own (Pade / Taylor) degree choice.
 //
 //   N <= 48 : ONE workgroup, all six N x N matrices resident in LDS (<= 115 KiB), the number
@@ -20,6 +20,10 @@ int oovqe_mode_contract_impl(const double* T, const double* Cm, double* out, lon
 namespace {
 
 constexpr double THETA = 0.5;
+// Taylor degree by the scaled 1-norm t: the remainder t^(m+1)/(m+1)! stays below 3e-17 for degree 8
+// up to 0.06, degree 12 up to 0.3, degree 16 up to 0.5 -- one / two / three Horner products with A^4
+// after the three products that form A^2, A^3, A^4 (orbital-rotation steps are usually small)
+constexpr double THETA8 = 0.06, THETA12 = 0.3;
 constexpr int SMALL_MAX = 48;
 constexpr int EX_THREADS = 512;
 
@@ -73,7 +77,7 @@ void expm_small_kernel(const double* __restrict__ X, const double* __restrict__ 
 {
     extern __shared__ double lds[];
     __shared__ double colsum[SMALL_MAX];
-    __shared__ int s_shared;
+    __shared__ int s_shared, m_shared;
     const int nt = (N + 15) / 16, NP = nt * 16;
     const int LD = NP + 2;
     const int msz = NP * LD;
@@ -122,9 +126,10 @@ void expm_small_kernel(const double* __restrict__ X, const double* __restrict__ 
         int s = 0;
         while (nrm > THETA && s < 60) { nrm *= 0.5; ++s; }
         s_shared = s;
+        m_shared = nrm <= THETA8 ? 8 : nrm <= THETA12 ? 12 : 16;
     }
     __syncthreads();
-    const int s = s_shared;
+    const int s = s_shared, mdeg = m_shared;
     const double scale = ldexp(1.0, -s);
     for (int idx = tid; idx < N * N; idx += EX_THREADS) {
         const int r = idx / N, c = idx - r * N;
@@ -135,14 +140,12 @@ void expm_small_kernel(const double* __restrict__ X, const double* __restrict__ 
     lds_matmul(A2, A, A3, nt, ksteps, LD);
     lds_matmul(A2, A2, A4, nt, ksteps, LD);
     const double* f = INV_FACT;
-    // P = c16 A4 + (c12 I + c13 A + c14 A2 + c15 A3)
-    lds_combine(P, A4, f[16], A, A2, A3, f[12], f[13], f[14], f[15], N, LD);
-    lds_matmul(P, A4, T, nt, ksteps, LD);
-    lds_combine(P, T, 1.0, A, A2, A3, f[8], f[9], f[10], f[11], N, LD);
-    lds_matmul(P, A4, T, nt, ksteps, LD);
-    lds_combine(P, T, 1.0, A, A2, A3, f[4], f[5], f[6], f[7], N, LD);
-    lds_matmul(P, A4, T, nt, ksteps, LD);
-    lds_combine(P, T, 1.0, A, A2, A3, f[0], f[1], f[2], f[3], N, LD);
+    // top block: P = c_m A4 + (c_{m-4} I + c_{m-3} A + c_{m-2} A2 + c_{m-1} A3), then Horner in A4
+    lds_combine(P, A4, f[mdeg], A, A2, A3, f[mdeg - 4], f[mdeg - 3], f[mdeg - 2], f[mdeg - 1], N, LD);
+    for (int b0 = mdeg - 8; b0 >= 0; b0 -= 4) {
+        lds_matmul(P, A4, T, nt, ksteps, LD);
+        lds_combine(P, T, 1.0, A, A2, A3, f[b0], f[b0 + 1], f[b0 + 2], f[b0 + 3], N, LD);
+    }
     double* cur = P;
     double* oth = T;
     for (int i = 0; i < s; ++i) {
@@ -253,6 +256,7 @@ int expm_large(const double* X, double sign, int N, double* U, double* work, hip
     }
     int s = 0;
     while (nrm > THETA && s < 60) { nrm *= 0.5; ++s; }
+    const int mdeg = nrm <= THETA8 ? 8 : nrm <= THETA12 ? 12 : 16;
     const unsigned nb = (unsigned)((n2 + 255) / 256);
     scale_kernel<<<nb, 256, 0, st>>>(X, sign * ldexp(1.0, -s), n2, A);
     int rc;
@@ -261,13 +265,12 @@ int expm_large(const double* X, double sign, int N, double* U, double* work, hip
     MM(A2, A, A3);
     MM(A2, A2, A4);
     const double* f = H_INV_FACT;
-    combine_kernel<<<nb, 256, 0, st>>>(P, A4, f[16], A, A2, A3, f[12], f[13], f[14], f[15], N);
-    MM(P, A4, T);
-    combine_kernel<<<nb, 256, 0, st>>>(P, T, 1.0, A, A2, A3, f[8], f[9], f[10], f[11], N);
-    MM(P, A4, T);
-    combine_kernel<<<nb, 256, 0, st>>>(P, T, 1.0, A, A2, A3, f[4], f[5], f[6], f[7], N);
-    MM(P, A4, T);
-    combine_kernel<<<nb, 256, 0, st>>>(P, T, 1.0, A, A2, A3, f[0], f[1], f[2], f[3], N);
+    combine_kernel<<<nb, 256, 0, st>>>(P, A4, f[mdeg], A, A2, A3, f[mdeg - 4], f[mdeg - 3], f[mdeg - 2],
+                                       f[mdeg - 1], N);
+    for (int b0 = mdeg - 8; b0 >= 0; b0 -= 4) {
+        MM(P, A4, T);
+        combine_kernel<<<nb, 256, 0, st>>>(P, T, 1.0, A, A2, A3, f[b0], f[b0 + 1], f[b0 + 2], f[b0 + 3], N);
+    }
     double* cur = P;
     double* oth = T;
     for (int i = 0; i < s; ++i) {
