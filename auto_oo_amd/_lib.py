@@ -78,6 +78,12 @@ SIGNATURES = {
                                                                    ctypes.c_int, c_int32_p,
                                                                    c_int32_p, ctypes.c_int]
                                   + [c_double_p] * 8 + [c_stream]),
+    "oovqe_cas_energy_gradient_ws": (ctypes.c_int, [c_double_p] * 4 + [ctypes.c_int, ctypes.c_double,
+                                                                      ctypes.c_int, ctypes.c_int,
+                                                                      ctypes.c_int, c_int32_p,
+                                                                      c_int32_p, ctypes.c_int]
+                                     + [c_double_p] * 9 + [c_stream]),
+    "oovqe_cas_energy_gradient_work_size": (ctypes.c_int64, [ctypes.c_int] * 4),
     "oovqe_cas_eval": (ctypes.c_int, [c_double_p] * 5 + [ctypes.c_int, ctypes.c_double, ctypes.c_int,
                                                         ctypes.c_int, ctypes.c_int, c_int32_p,
                                                         c_int32_p, ctypes.c_int]

@@ -3260,6 +3260,36 @@ static int cas_energy_gradient_rows(const double* Gm, const double* hmo, const d
     return 0;
 }
 
+extern "C" int64_t oovqe_cas_energy_gradient_work_size(int N, int n_occ, int ncas, int nrdm)
+{
+    const int64_t M = n_occ + ncas;
+    return (int64_t)nrdm * (M + 1) * N + N;      // Fcol [nrdm][M][N] | Epart [nrdm][N] | Cpart [N]
+}
+
+extern "C" int oovqe_cas_energy_gradient_ws(const double* Gm, const double* hmo, const double* gamma,
+                                            const double* Gamma, int nrdm, double nuc, int N, int n_occ,
+                                            int ncas, const int32_t* kap_row, const int32_t* kap_col,
+                                            int n_kappa, double* c0, double* c1, double* c2, double* E,
+                                            double* fock, double* gmat, double* gvec, double* dE,
+                                            double* work, oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(Gm && hmo && gamma && Gamma && c0 && c1 && c2 && E && gvec && work,
+                  "cas_energy_gradient: null pointer");
+    OOVQE_REQUIRE(nrdm >= 1 && N >= 1 && n_occ >= 0 && ncas >= 1 && n_occ + ncas <= N,
+                  "cas_energy_gradient: bad sizes");
+    OOVQE_REQUIRE(n_kappa == 0 || (kap_row && kap_col), "cas_energy_gradient: null index table");
+    OOVQE_REQUIRE(nrdm == 1 || dE, "cas_energy_gradient: dE required when nrdm > 1");
+    const size_t M = (size_t)n_occ + ncas;
+    if (M > 64 || fock_rows_lds_elems(n_occ, ncas) * sizeof(double) > 64 * 1024)   // one-workgroup kernel
+        return cas_energy_gradient_impl(Gm, hmo, gamma, Gamma, nrdm, nuc, nullptr, N, n_occ, ncas, kap_row,
+                                        kap_col, n_kappa, c0, c1, c2, E, fock, gmat, gvec, dE, stream);
+    double* Fc = work;
+    double* Ep = Fc + (size_t)nrdm * M * N;
+    double* Cp = Ep + (size_t)nrdm * N;
+    return cas_energy_gradient_rows(Gm, hmo, gamma, Gamma, nrdm, nuc, nullptr, N, n_occ, ncas, kap_row, kap_col,
+                                    n_kappa, Fc, Ep, Cp, c0, c1, c2, E, fock, gmat, gvec, dE, stream);
+}
+
 // LDS of cas_column_kernel without the RDM sets (U[n] and g_mo[n] resident): decides between the
 // column kernel and the staged kernels for large N * M^2
 static size_t column_base_bytes(int N, int M)

@@ -235,9 +235,11 @@ def cas_finish_transform(T2, h_ao, C, M, Gm=None, hmo=None, work=None):
 
 
 def cas_energy_gradient(Gm, hmo, gamma, Gamma, nuc, n_occ, ncas, kap_row, kap_col,
-                        want_matrices=True):
+                        want_matrices=True, one_workgroup=False):
     """gamma [nrdm, a, a], Gamma [nrdm, a, a, a, a]; set 0 = the RDMs, sets >= 1 = derivative RDMs.
-    Returns dict(c0, c1, c2, E, fock, gmat, gvec [nrdm, n_kappa], dE [nrdm-1])."""
+    Returns dict(c0, c1, c2, E, fock, gmat, gvec [nrdm, n_kappa], dE [nrdm-1]).
+    ``one_workgroup``: the round-1 entry point oovqe_cas_energy_gradient (no scratch, one workgroup
+    per RDM set) instead of oovqe_cas_energy_gradient_ws."""
     lib = _lib.load()
     dev = _dev(Gm)
     N = Gm.shape[0]
@@ -251,11 +253,20 @@ def cas_energy_gradient(Gm, hmo, gamma, Gamma, nuc, n_occ, ncas, kap_row, kap_co
     gmat = torch.empty((N, N), dtype=F64, device=dev) if want_matrices else None
     gvec = torch.empty((nrdm, n_kappa), dtype=F64, device=dev)
     dE = torch.empty(max(nrdm - 1, 1), dtype=F64, device=dev)
-    check(lib.oovqe_cas_energy_gradient(dptr(Gm), dptr(hmo), dptr(gamma), dptr(Gamma), nrdm,
-                                        float(nuc), N, n_occ, ncas, dptr(kap_row, torch.int32),
-                                        dptr(kap_col, torch.int32), n_kappa, dptr(c0), dptr(c1),
-                                        dptr(c2), dptr(E), dptr(fock), dptr(gmat), dptr(gvec),
-                                        dptr(dE), stream_ptr()), "oovqe_cas_energy_gradient")
+    if one_workgroup:
+        check(lib.oovqe_cas_energy_gradient(dptr(Gm), dptr(hmo), dptr(gamma), dptr(Gamma), nrdm,
+                                            float(nuc), N, n_occ, ncas, dptr(kap_row, torch.int32),
+                                            dptr(kap_col, torch.int32), n_kappa, dptr(c0), dptr(c1),
+                                            dptr(c2), dptr(E), dptr(fock), dptr(gmat), dptr(gvec),
+                                            dptr(dE), stream_ptr()), "oovqe_cas_energy_gradient")
+        return dict(c0=c0, c1=c1, c2=c2, E=E, fock=fock, gmat=gmat, gvec=gvec, dE=dE[:nrdm - 1])
+    # a workgroup per (general index, RDM set) + the assembly launch
+    work = torch.empty(int(lib.oovqe_cas_energy_gradient_work_size(N, n_occ, ncas, nrdm)), dtype=F64, device=dev)
+    check(lib.oovqe_cas_energy_gradient_ws(dptr(Gm), dptr(hmo), dptr(gamma), dptr(Gamma), nrdm,
+                                           float(nuc), N, n_occ, ncas, dptr(kap_row, torch.int32),
+                                           dptr(kap_col, torch.int32), n_kappa, dptr(c0), dptr(c1),
+                                           dptr(c2), dptr(E), dptr(fock), dptr(gmat), dptr(gvec),
+                                           dptr(dE), dptr(work), stream_ptr()), "oovqe_cas_energy_gradient_ws")
     return dict(c0=c0, c1=c1, c2=c2, E=E, fock=fock, gmat=gmat, gvec=gvec, dE=dE[:nrdm - 1])
 
 

@@ -202,6 +202,17 @@ int oovqe_cas_energy_gradient(const double* Gm, const double* hmo, const double*
                               int n_kappa, double* c0, double* c1, double* c2, double* E,
                               double* fock, double* gmat, double* gvec, double* dE,
                               oovqe_stream_t stream);
+/* The same stage spread over the CUs (a workgroup per (general index, RDM set), then one assembly
+ * launch) instead of one workgroup: same arguments plus work, oovqe_cas_energy_gradient_work_size()
+ * doubles of scratch (falls back to the one-workgroup kernel when the slices of g_mo[n] it gathers
+ * exceed 64 KB of LDS or n_occ + ncas > 64). */
+int oovqe_cas_energy_gradient_ws(const double* Gm, const double* hmo, const double* gamma,
+                                 const double* Gamma, int nrdm, double nuc, int N, int n_occ,
+                                 int ncas, const int32_t* kap_row, const int32_t* kap_col,
+                                 int n_kappa, double* c0, double* c1, double* c2, double* E,
+                                 double* fock, double* gmat, double* gvec, double* dE, double* work,
+                                 oovqe_stream_t stream);
+int64_t oovqe_cas_energy_gradient_work_size(int N, int n_occ, int ncas, int nrdm);
 
 /* The whole CAS path in one call: 4 launches (stage 1 [+ q->x inside the same persistent kernel
  * when the sweep is bandwidth-bound], contraction p->n, Fock-column kernel, final assembly); the

@@ -262,6 +262,11 @@ def test_cas_eval_fused_matches_staged_and_oracle(N, seed, nelec, ncas, nelecas,
     Gm, hmo = ops.cas_finish_transform(T2, hd, Cd, M)
     st = ops.cas_energy_gradient(Gm, hmo, gam.to(DEV).contiguous(), Gam.to(DEV).contiguous(),
                                  oo.nuc, no, ncas, rows_d, cols_d)
+    # the one-workgroup entry point of the same stage (oovqe_cas_energy_gradient, no scratch)
+    st1 = ops.cas_energy_gradient(Gm, hmo, gam.to(DEV).contiguous(), Gam.to(DEV).contiguous(),
+                                  oo.nuc, no, ncas, rows_d, cols_d, one_workgroup=True)
+    for key in ("c0", "c1", "c2", "E", "fock", "gmat", "gvec", "dE"):
+        assert (st1[key] - st[key]).abs().max() < 1e-11 * max(1.0, float(st[key].abs().max())), key
     g_mo = R.int2e_transform(oo.int2e_ao, C)
     h_mo = R.int1e_transform(oo.int1e_ao, C)
     assert (res["Gm"].cpu() - g_mo[:, :M, :M, :M]).abs().max() < 1e-11
