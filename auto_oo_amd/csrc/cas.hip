@@ -2490,6 +2490,7 @@ void cas_panel_kernel(const double* __restrict__ Gm_in, const double* __restrict
 // the one-workgroup fock_kernel inside oovqe_cas_eval: 481 -> ~15 us at N = 200, M = 26.
 // cas_final_kernel assembles the outputs.
 constexpr int FROW_THREADS = 256;
+constexpr size_t FROW_LDS_MAX = 150 * 1024;
 
 // doubles of LDS fock_rows_kernel needs for the slices of g_mo[n] it uses
 static size_t fock_rows_lds_elems(int no, int na)
@@ -3250,7 +3251,13 @@ static int cas_energy_gradient_rows(const double* Gm, const double* hmo, const d
     OOVQE_REQUIRE(M <= 64 && nrdm <= 65535, "cas_energy_gradient: n_occ + ncas = %d, nrdm = %d", M, nrdm);
     hipStream_t st = (hipStream_t)stream;
     const size_t lds_bytes = fock_rows_lds_elems(n_occ, ncas) * sizeof(double);
-    OOVQE_REQUIRE(lds_bytes <= 64 * 1024, "cas_energy_gradient: %zu B of LDS", lds_bytes);
+    OOVQE_REQUIRE(lds_bytes <= FROW_LDS_MAX, "cas_energy_gradient: %zu B of LDS", lds_bytes);
+    static bool attr_done = false;
+    if (!attr_done) {
+        OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)fock_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)FROW_LDS_MAX), "cas_energy_gradient");
+        attr_done = true;
+    }
     hipLaunchKernelGGL(fock_rows_kernel, dim3(N, nrdm), dim3(FROW_THREADS), lds_bytes, st, Gm, hmo, gamma, Gamma,
                        N, n_occ, ncas, Fcol, Epart, Cpart, c1, c2);
     OOVQE_CHECK_LAUNCH("cas_energy_gradient/rows");
@@ -3280,7 +3287,7 @@ extern "C" int oovqe_cas_energy_gradient_ws(const double* Gm, const double* hmo,
     OOVQE_REQUIRE(n_kappa == 0 || (kap_row && kap_col), "cas_energy_gradient: null index table");
     OOVQE_REQUIRE(nrdm == 1 || dE, "cas_energy_gradient: dE required when nrdm > 1");
     const size_t M = (size_t)n_occ + ncas;
-    if (M > 64 || fock_rows_lds_elems(n_occ, ncas) * sizeof(double) > 64 * 1024)   // one-workgroup kernel
+    if (M > 64 || fock_rows_lds_elems(n_occ, ncas) * sizeof(double) > FROW_LDS_MAX)   // one-workgroup kernel
         return cas_energy_gradient_impl(Gm, hmo, gamma, Gamma, nrdm, nuc, nullptr, N, n_occ, ncas, kap_row,
                                         kap_col, n_kappa, c0, c1, c2, E, fock, gmat, gvec, dE, stream);
     double* Fc = work;
@@ -3423,7 +3430,7 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
             double* Cp = Ep + (size_t)nrdm * N;
             const bool rows_fit = (size_t)N * m3 + (size_t)N * M + (size_t)nrdm * (M + 1) * N + N <=
                                   (size_t)N * N * m2 && M <= 64 &&
-                                  fock_rows_lds_elems(n_occ, ncas) * sizeof(double) <= 64 * 1024;
+                                  fock_rows_lds_elems(n_occ, ncas) * sizeof(double) <= FROW_LDS_MAX;
             if (rows_fit)
                 rc = cas_energy_gradient_rows(
                     Gmg, hmog, gamma + gi * nrdm * na2s, Gamma + gi * nrdm * na4s, nrdm, nuc,

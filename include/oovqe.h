@@ -205,7 +205,7 @@ int oovqe_cas_energy_gradient(const double* Gm, const double* hmo, const double*
 /* The same stage spread over the CUs (a workgroup per (general index, RDM set), then one assembly
  * launch) instead of one workgroup: same arguments plus work, oovqe_cas_energy_gradient_work_size()
  * doubles of scratch (falls back to the one-workgroup kernel when the slices of g_mo[n] it gathers
- * exceed 64 KB of LDS or n_occ + ncas > 64). */
+ * exceed 150 KB of LDS or n_occ + ncas > 64). */
 int oovqe_cas_energy_gradient_ws(const double* Gm, const double* hmo, const double* gamma,
                                  const double* Gamma, int nrdm, double nuc, int N, int n_occ,
                                  int ncas, const int32_t* kap_row, const int32_t* kap_col,
