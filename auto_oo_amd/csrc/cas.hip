@@ -1148,6 +1148,10 @@ void eri_pack_kernel(const double* __restrict__ g, double* __restrict__ out, int
 // the read stream costs far more than its bytes.
 // Algorithmic HBM bytes per geometry: 8 N^2 * N(N+1)/2 read + 8 M^2 * N(N+1)/2 written.
 // ------------------------------------------------------------------------------------------
+#ifdef OOVQE_TRI_PROBE
+__device__ long long g_tri_wg_end[4096];
+#endif
+
 template <int KCH, int NST, int RS>
 __global__ __launch_bounds__(HALF_WAVES * 64)
 void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
@@ -1392,6 +1396,10 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
         }
         __syncthreads();
     }
+#ifdef OOVQE_TRI_PROBE
+    // tools/half_standalone.hip: when does each workgroup finish (100 MHz wall clock)?
+    if (tid == 0) g_tri_wg_end[blockIdx.y * gridDim.x + blockIdx.x] = wall_clock64();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
