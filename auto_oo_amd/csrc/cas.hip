@@ -1150,13 +1150,18 @@ void eri_pack_kernel(const double* __restrict__ g, double* __restrict__ out, int
 // ------------------------------------------------------------------------------------------
 #ifdef OOVQE_TRI_PROBE
 __device__ long long g_tri_wg_end[4096];
+__device__ long long g_tri_cyc[16];      // workgroup (0,0): core cycles in the sweeps [wave], [8] the bursts, [9] all, [10] all in 100 MHz ticks
 #endif
 
-template <int KCH, int NST, int RS>
-__global__ __launch_bounds__(HALF_WAVES * 64)
+template <int KCH, int NST, int RS, int NWV = HALF_WAVES>
+__global__ __launch_bounds__(NWV * 64)
 void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
                      double* __restrict__ J, int N, int M, int phase_rounds, int tiled)
 {
+#ifdef OOVQE_TRI_PROBE
+    const long long pc_start = __builtin_readcyclecounter();
+    const long long pw_start = wall_clock64();
+#endif
     constexpr int NP = NST / 2, NS1 = NST % 2;
     constexpr int NPA = NP > 0 ? NP : 1;
     constexpr int NCF = NST * 4;
@@ -1171,12 +1176,17 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
     const size_t slab_elems = (size_t)N * N;
     double* dump = lds;             // [64] sink for lanes outside the M x M tile
     int* ctab = reinterpret_cast<int*>(lds + 64);   // [ncol <= 256] column -> position y*M + z in a tile
-    double* stg = lds + 64 + 128;   // [phase_rounds][HALF_WAVES][M2]
+    double* stg = lds + 64 + 128;   // [phase_rounds][NWV][M2]
     // RS == 2: g is the PACKED copy made by eri_pack_kernel: per slab t = (p <= q) the upper triangle
     // with the diagonal halved, row r = its columns (r & ~1) .. N-1, rows back to back
     constexpr bool rs = RS != 0, pk = RS == 2;
     const unsigned slab_pk = (unsigned)(eri_slab_pitch(N) * sizeof(double));
+#if defined(OOVQE_TRI_PROBE) && OOVQE_TRI_PROBE == 2
+    // tools/tri_spread.hip: every geometry reads geometry 0's integrals (cache-resident): the kernel
+    // without its HBM stream
+#else
     g += (size_t)blockIdx.y * (pk ? (size_t)tri * (slab_pk / sizeof(double)) : slab_elems * slab_elems);
+#endif
     C += (size_t)blockIdx.y * N * N;
     // tiled == 0: J[t][M2].  tiled == 1: J[ty][t][16], 16-wide tiles of the M2 (y z) columns
     // outermost (the layout sym_gm_kernel streams).  tiled == 2 (r <-> s symmetric integrals,
@@ -1223,11 +1233,14 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
 #pragma unroll
     for (int pp = 0; pp < NP; ++pp) {
         const int col = pp * 32 + 2 * lr;
-        const int cc = col + 1 < N ? col : (N >= 2 ? N - 2 : 0);
+        // the last column of an odd N: the full layout loads the pair (N-2, N-1) and takes .y; in the
+        // packed copy the pair (N-1, N) ends on the next row's first element or the slab's pad (finite,
+        // and column N meets a zero coefficient in the second product)
+        const int cc = (pk ? col < N : col + 1 < N) ? col : (N >= 2 ? N - 2 : 0);
         colp[pp] = col;
         offp[pp][0] = (unsigned)((lane_row + cc) * (int)sizeof(double));
         offp[pp][1] = (wts && lr < 8) ? total_bytes : offp[pp][0];   // first block's columns below the diagonal
-        last_even[pp] = col == N - 1;
+        last_even[pp] = !pk && col == N - 1;
     }
     const int col1 = NP * 32 + lr;
     const int col1c = col1 < N ? col1 : N - 1;
@@ -1248,8 +1261,8 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
         return drop ? total_bytes : vo - (unsigned)i * lstep;
     };
 
-    const int SW = gridDim.x * HALF_WAVES;                  // waves per geometry
-    const int gw = blockIdx.x * HALF_WAVES + wave;
+    const int SW = gridDim.x * NWV;                  // waves per geometry
+    const int gw = blockIdx.x * NWV + wave;
     const int n_rounds = (int)((tri + SW - 1) / SW);        // the same for every wave of the grid
     // round r of this wave: slab t = r*SW + gw of the triangle; past the end -> dropped loads
     auto slab_off = [&](int r) -> unsigned {
@@ -1260,6 +1273,17 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
         return __builtin_amdgcn_readfirstlane(t < tri ? (unsigned)(p * N + q) * slab_bytes : total_bytes);
     };
     auto issue = [&](int r, d2u (&ap)[NPA][KCH], double (&as)[KCH]) {
+#if defined(OOVQE_TRI_PROBE) && OOVQE_TRI_PROBE == 3
+        // tools/tri_spread.hip: the sweep without its loads (operands of the first slab for ever)
+        if (r > 1) {
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) {
+                asm volatile("" : "+v"(ap[0][i].x), "+v"(ap[0][i].y));
+                asm volatile("" : "+v"(as[i]));
+            }
+            return;
+        }
+#endif
         const unsigned sb = slab_off(r);
 #pragma unroll
         for (int pp = 0; pp < NP; ++pp)
@@ -1320,6 +1344,40 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
     }
     auto compute = [&](int r, int base, const d2u (&ap)[NPA][KCH], const double (&as)[KCH]) {
         d4 jt = d4{0.0, 0.0, 0.0, 0.0};
+        if constexpr (pk) {
+            // The packed copy carries its weights (halved diagonal): every first product is ONE
+            // accumulator chain, its result goes to the second product as it leaves the MFMA pipe.
+            // No VALU instruction in between: on gfx950 a VALU instruction does not run in the shadow
+            // of a v_mfma_f64 (tools/mfma_dep_probe.hip: 8 cycles of the pipe each).
+            d4 xs = d4{0.0, 0.0, 0.0, 0.0};
+            if constexpr (NS1) {
+#pragma unroll
+                for (int i = 0; i < KCH; ++i) xs = mfma_f64(as[i], cfr[i], xs);
+            }
+            d4 xh[NPA][2];
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int i = 0; i < KCH; ++i) {
+                        if (i / 4 > 2 * pp + 1) continue;      // rows below both blocks of the pair
+                        x = mfma_f64(half == 0 ? ap[pp][i].x : ap[pp][i].y, cfr[i], x);
+                    }
+                    xh[pp][half] = x;
+                }
+            if constexpr (NS1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) jt = mfma_f64(cfr[NP * 8 + i], xs[i], jt);
+            }
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+                for (int half = 0; half < 2; ++half)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) jt = mfma_f64(cpr[pp][half][i], xh[pp][half][i], jt);
+        } else {
 #pragma unroll
         for (int pp = 0; pp < NP; ++pp)
 #pragma unroll
@@ -1358,8 +1416,9 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
 #pragma unroll
             for (int i = 0; i < 4; ++i) jt = mfma_f64(cfr[NP * 8 + i], xt[i], jt);
         }
+        }
         if ((long)r * SW + gw >= tri) return;          // padding round
-        double* row = stg + ((size_t)(r - base) * HALF_WAVES + wave) * M2;
+        double* row = stg + ((size_t)(r - base) * NWV + wave) * M2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             double* dst = tile_off[i] >= 0 ? row + tile_off[i] : dump + lane;
@@ -1367,10 +1426,13 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
         }
     };
 
-    // phase_rounds is even: round `base` of every phase sits in register buffer 0.  Straight-line
-    // loop body, no VMEM store inside it (see half_transform_fused_kernel).
+    // phase_rounds is even (double-buffered form): round `base` of every phase sits in register buffer
+    // 0.  Straight-line loop body, no VMEM store inside it (see half_transform_fused_kernel).
     for (int base = 0; base < n_rounds; base += phase_rounds) {
         const int end = base + phase_rounds < n_rounds ? base + phase_rounds : n_rounds;
+#ifdef OOVQE_TRI_PROBE
+        const long long pc0 = __builtin_readcyclecounter();
+#endif
         for (int it = base; it < end; it += 2) {
             issue(it + 1, ap1, as1);
             __builtin_amdgcn_sched_barrier(0);
@@ -1381,22 +1443,38 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
             compute(it + 1, base, ap1, as1);
             __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef OOVQE_TRI_PROBE
+        const long long pc1 = __builtin_readcyclecounter();
+        if (lane == 0 && blockIdx.x == 0 && blockIdx.y == 0 && wave < 8) g_tri_cyc[wave] += pc1 - pc0;
+#endif
         __syncthreads();
-        const int nslot = (end - base) * HALF_WAVES;
-        for (int e = tid; e < nslot * ncol; e += HALF_WAVES * 64) {
-            const int slot = e / ncol, c = e - slot * ncol;
-            const long t = (long)(base + slot / HALF_WAVES) * SW + blockIdx.x * HALF_WAVES + slot % HALF_WAVES;
-            if (t < tri) {
-                const int cc2 = ctab[c];
-                double v = stg[(size_t)slot * M2 + (cc2 & 0xffff)];
-                if (rs) v += stg[(size_t)slot * M2 + (cc2 >> 16)];   // J = T + T^T
-                if (tiled) J[((size_t)(c >> 4) * tri + t) * 16 + (c & 15)] = v;
-                else J[(size_t)t * M2 + c] = v;
+        // every wave writes the tiles of its own slabs (lanes = columns: 128-byte runs in the tiled
+        // layouts), the rounds of the phase unrolled so that the LDS reads of several are in flight
+        for (int c = lane; c < ncol; c += 64) {
+            const int cc2 = ctab[c];
+            const int o1 = cc2 & 0xffff, o2 = cc2 >> 16;
+            double* dst = tiled ? J + ((size_t)(c >> 4) * tri) * 16 + (c & 15) : J + c;
+            const size_t tstep = tiled ? 16 : (size_t)M2;
+#pragma unroll 4
+            for (int k = 0; k < end - base; ++k) {
+                const long t = (long)(base + k) * SW + gw;
+                if (t >= tri) break;
+                const double* tile = stg + ((size_t)k * NWV + wave) * M2;
+                double v = tile[o1];
+                if (rs) v += tile[o2];                               // J = T + T^T
+                dst[(size_t)t * tstep] = v;
             }
         }
         __syncthreads();
+#ifdef OOVQE_TRI_PROBE
+        if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_tri_cyc[8] += __builtin_readcyclecounter() - pc1;
+#endif
     }
 #ifdef OOVQE_TRI_PROBE
+    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+        g_tri_cyc[9] += __builtin_readcyclecounter() - pc_start;
+        g_tri_cyc[10] += wall_clock64() - pw_start;      // 100 MHz
+    }
     // tools/half_standalone.hip: when does each workgroup finish (100 MHz wall clock)?
     if (tid == 0) g_tri_wg_end[blockIdx.y * gridDim.x + blockIdx.x] = wall_clock64();
 #endif

@@ -435,10 +435,11 @@ def test_in_place_edit_of_int2e_ao_reverifies_symmetry_flags():
 
 
 @pytest.mark.parametrize("N,G", [(43, 9), (13, 40), (30, 11), (47, 5)])
-def test_packed_stage1_realisations_agree_bitwise(N, G, lib_options):
+def test_packed_stage1_realisations_agree(N, G, lib_options):
     """The three realisations of stage 1 on the packed copy (operand-shaped HBM loads, LDS-DMA ring,
-    contiguous register loads with 3 / 4 slabs in flight; debug option tri_mode) form the same sums
-    in the same order: bit-identical energies and gradients, and equal to the oracle."""
+    contiguous register loads with 3 / 4 slabs in flight; debug option tri_mode) form the same sums:
+    energies and gradients agree (bit for bit among the modes that share a summation order), and
+    equal the oracle's."""
     from auto_oo_amd.synthetic import synthetic_problem
     ncas, nelecas, nelec = 3, 4, 16
     pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="ucc")
@@ -455,8 +456,11 @@ def test_packed_stage1_realisations_agree_bitwise(N, G, lib_options):
     for mode in (1, 2, 3, 4):
         lib_options(tri_mode=mode)
         outs.append(batch.energy_and_gradient(thetas).clone())
-    for o in outs[1:]:
-        assert torch.equal(o, outs[0])
+    # modes 2-4 weight the diagonal blocks after separate sums; mode 1 (the default) runs every first
+    # product as one accumulator chain (no VALU work between the MFMAs): same terms, another order
+    for o in outs[2:]:
+        assert torch.equal(o, outs[1])
+    assert (outs[1] - outs[0]).abs().max() < 1e-11
     omol = R.OracleMol(mols[0].int1e_ao, mols[0].int2e_ao, mols[0].overlap, mols[0].nuc, nelec)
     ooo = R.OracleOOPQC(R.OraclePQC(ncas, nelecas, "ucc"), omol, ncas, nelecas, coeffs[0])
     assert abs(outs[0][0, 0].item() - ooo.energy_from_parameters(thetas[0]).item()) < 1e-9

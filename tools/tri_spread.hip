@@ -1,6 +1,8 @@
 // When do the 256 workgroups of the packed stage-1 kernel finish (tools only)?  Builds cas.hip with
 // OOVQE_TRI_PROBE: every workgroup stores the 100 MHz wall clock at its end.
-#define OOVQE_TRI_PROBE 1
+#ifndef OOVQE_TRI_PROBE
+#define OOVQE_TRI_PROBE 1   // 2: every geometry reads geometry 0's integrals (no HBM stream)
+#endif
 #include "../auto_oo_amd/csrc/cas.hip"
 #include <vector>
 #include <algorithm>
@@ -22,6 +24,8 @@ int main()
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     for (int r = 0; r < 12; ++r) {
+        long long zero[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tri_cyc), zero, sizeof(zero));
         (void)hipEventRecord(e0, 0);
         int rc = half_tri_batched(gp, C, N, M, J, G, nullptr, 2, true);
         (void)hipEventRecord(e1, 0);
@@ -37,6 +41,14 @@ int main()
             printf("launch %.1f us; workgroup end times relative to the last one (us): first %.1f, 10%% %.1f, median %.1f, 90%% %.1f\n",
                    ms * 1e3, (v[0] - v[G - 1]) / 100.0, (v[G / 10] - v[G - 1]) / 100.0, (v[G / 2] - v[G - 1]) / 100.0,
                    (v[9 * G / 10] - v[G - 1]) / 100.0);
+        if (r == 11) {
+            long long c[16];
+            (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_tri_cyc), sizeof(c));
+            printf("workgroup (0,0): %.1f us on the 100 MHz clock = %.0f core cycles per us; core cycles: whole kernel %lld, bursts %lld, sweeps by wave",
+                   c[10] / 100.0, c[9] / (c[10] / 100.0), c[9], c[8]);
+            for (int w = 0; w < 8; ++w) printf(" %lld", c[w]);
+            printf("\n");
+        }
     }
     return 0;
 }
