@@ -28,6 +28,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #if defined(OOVQE_K1_PROBE) && (OOVQE_K1_PROBE & 64)
 // tools/k1_standalone.hip: clock marks of wave 0 of workgroup 0 from its 4th strip on
 __device__ long long g_k1p_marks[128];
+__device__ long long g_k1p_clk[2];     // workgroup 0: core cycles and 100 MHz ticks of the whole kernel
+#define K1P_CLK_START const long long k1p_c0 = clock64(), k1p_w0 = wall_clock64();
+#define K1P_CLK_END                                                                            \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                              \
+        g_k1p_clk[0] = clock64() - k1p_c0;                                                     \
+        g_k1p_clk[1] = wall_clock64() - k1p_w0;                                                \
+    }
 #define K1P_MARK(code)                                                                         \
     do {                                                                                       \
         if (k1_items >= 3 && k1_m < 64 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { \
@@ -38,6 +45,8 @@ __device__ long long g_k1p_marks[128];
     } while (0)
 #else
 #define K1P_MARK(code) do { } while (0)
+#define K1P_CLK_START
+#define K1P_CLK_END
 #endif
 
 namespace {
@@ -95,6 +104,7 @@ void contract_pair_kernel(const double* __restrict__ T, const double* __restrict
         return st;
     };
 
+    K1P_CLK_START
     d4 acc[2][NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[0][t] = acc[1][t] = d4{0.0, 0.0, 0.0, 0.0};
@@ -119,30 +129,40 @@ void contract_pair_kernel(const double* __restrict__ T, const double* __restrict
     int pf_kn = 0;
     unsigned pf_cso = 0, pf_rem = 0;
     __amdgpu_buffer_rsrc_t pf_tr = rsrc_c;
+    // start of a chunk's prefetch: the k offset of the Cm rows and the descriptor of the T rows
+    auto prefetch_begin = [&](const Strip& stn, int knext) {
+        pf_kn = knext;
+        asm volatile("" : "+s"(pf_kn));   // keeps the SALU arithmetic behind the MFMAs it follows
+        pf_cso = (unsigned)((long)pf_kn * ldc * sizeof(double));
+        const long e1 = stn.tb + (long)pf_kn * B;   // wave-uniform
+        long rem = (stn.te - e1) * (long)sizeof(double);
+        rem = rem < 0 ? 0 : (rem > 0xFFFFFFFFL ? 0xFFFFFFFFL : rem);
+        pf_rem = (unsigned)rem;
+        pf_tr = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(T) + e1, 0, (int)pf_rem, 0x00020000);
+    };
+    auto prefetch_c_part = [&](int part, int np) {
+        const int lo = part * CREG / np, hi = (part + 1) * CREG / np;
+#pragma unroll
+        for (int q = 0; q < CREG; ++q)
+            if (q >= lo && q < hi)
+                creg[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc_c, cvo[q], pf_cso, 0));
+    };
+    auto prefetch_t = [&](const Strip& stn, int s2, d2& dst) {
+        unsigned so = (unsigned)s2 * step_bytes;
+        so = so < pf_rem ? so : pf_rem;
+        dst = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(pf_tr, stn.vo, so, 0));
+    };
+    // Cm and T together in np parts (prologue and last chunk of a strip: T goes to tnext)
     auto prefetch_part = [&](const Strip& stn, int knext, int part, int np) {
         const int lo = part * NPF / np, hi = (part + 1) * NPF / np;
-        if (part == 0) {
-            pf_kn = knext;
-            asm volatile("" : "+s"(pf_kn));   // keeps the SALU arithmetic behind the MFMAs it follows
-            pf_cso = (unsigned)((long)pf_kn * ldc * sizeof(double));
-        }
+        if (part == 0) prefetch_begin(stn, knext);
 #pragma unroll
         for (int q = 0; q < NPF; ++q) {
             if (q < lo || q >= hi) continue;
             if (q < CREG) {
                 creg[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc_c, cvo[q], pf_cso, 0));
             } else {
-                const int s2 = q - CREG;
-                if (s2 == 0) {
-                    const long e1 = stn.tb + (long)pf_kn * B;   // wave-uniform
-                    long rem = (stn.te - e1) * (long)sizeof(double);
-                    rem = rem < 0 ? 0 : (rem > 0xFFFFFFFFL ? 0xFFFFFFFFL : rem);
-                    pf_rem = (unsigned)rem;
-                    pf_tr = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(T) + e1, 0, (int)pf_rem, 0x00020000);
-                }
-                unsigned so = (unsigned)s2 * step_bytes;
-                so = so < pf_rem ? so : pf_rem;
-                tnext[s2] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(pf_tr, stn.vo, so, 0));
+                prefetch_t(stn, q - CREG, tnext[q - CREG]);
             }
         }
     };
@@ -153,10 +173,16 @@ void contract_pair_kernel(const double* __restrict__ T, const double* __restrict
             if (i >= lo && i < hi) buf[tid + i * NTH] = creg[i];
     };
     int par = 0;
-    auto rotate = [&]() {
+    auto flip = [&]() {
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         par ^= 1;
+    };
+    // (last chunk of a strip only: its T prefetch cannot land in registers the chunk reads to its end.
+    // A VALU move costs MFMA time on gfx950, tools/mfma_dep_probe.hip: the other chunks reload tcur[s]
+    // in place as soon as k-step s is done.)
+    auto rotate = [&]() {
+        flip();
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             tcur[s] = tnext[s];
@@ -194,6 +220,11 @@ void contract_pair_kernel(const double* __restrict__ T, const double* __restrict
     while (group < n_groups) {
         const Strip nxt = decode(group + grid_x);
         // ---- all chunks but the last: k-step outer, tile inner -----------------------------------
+        // The next chunk's T operand of k-step s is loaded over tcur[s] once k-step s is done; the last
+        // NDB k-steps, whose loads would be issued too late for the next chunk's start (the last chunk
+        // of a strip runs tile-outer and needs every k-step at its first tile), go through tnext and
+        // are copied at the barrier.
+        constexpr int NDB = KSTEPS >= 4 ? 2 : 1;
         for (int c = 0; c + 1 < nchunks; ++c) {
             const int knext = (c + 1) * KC;
             K1P_MARK(c);
@@ -215,11 +246,24 @@ void contract_pair_kernel(const double* __restrict__ T, const double* __restrict
 #pragma unroll
                     for (int t = 2 * p2; t < 2 * p2 + 2 && t < NT; ++t)
                         if (s + 1 < KSTEPS) cv[(s + 1) & 1][t] = buf[(s + 1) * 4 * LDJ + t * 16];
-                    if (s == 0) prefetch_part(cur, knext, p2, NP);
+                    if (s == 0 && p2 == 0) prefetch_begin(cur, knext);
+                    if (s == 0) prefetch_c_part(p2, NP);
+                    if (p2 == NP - 1) {
+                        if (s < KSTEPS - NDB) prefetch_t(cur, s, tcur[s]);   // k-step s is done with tcur[s]
+                        if (s == 0) {
+#pragma unroll
+                            for (int s2 = KSTEPS - NDB; s2 < KSTEPS; ++s2) prefetch_t(cur, s2, tnext[s2]);
+                        }
+                    }
                     if (s == KSTEPS - 1) stage_store_part(lds + (par ^ 1) * BUF, p2, NP);
                 }
             }
-            rotate();
+            flip();
+#pragma unroll
+            for (int s = KSTEPS - NDB; s < KSTEPS; ++s) {
+                tcur[s] = tnext[s];
+                asm volatile("" : "+v"(tcur[s]));
+            }
         }
         // ---- last chunk of the strip: tile outer, k-step inner, stores between the MFMAs -------
         {
@@ -254,6 +298,7 @@ void contract_pair_kernel(const double* __restrict__ T, const double* __restrict
         cur = nxt;
         group += grid_x;
     }
+    K1P_CLK_END
 }
 
 template <int NT, int KS>

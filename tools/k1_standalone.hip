@@ -71,7 +71,12 @@ int main(int argc, char** argv)
         (void)hipMemcpyFromSymbol(marks, HIP_SYMBOL(g_k1_marks), sizeof(marks));
         if (step < 3 && !(argc > 2 && !strcmp(argv[2], "nopair")))
             (void)hipMemcpyFromSymbol(marks, HIP_SYMBOL(g_k1p_marks), sizeof(marks));
-        for (int m = 1; m < 64; ++m)
+        if (step < 3 && !(argc > 2 && !strcmp(argv[2], "nopair"))) {
+            long long clk[2];
+            (void)hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_k1p_clk), sizeof(clk));
+            printf("   workgroup 0: %lld core cycles in %.1f us = %.0f MHz\n", clk[0], clk[1] / 100.0, clk[0] / (clk[1] / 100.0));
+        }
+        for (int m = 1; m < (argc > 3 ? 64 : 14); ++m)
             printf("   mark %3lld -> %3lld : %7lld\n", marks[2 * m - 2], marks[2 * m], marks[2 * m + 1] - marks[2 * m - 1]);
 #endif
     }
