@@ -88,3 +88,13 @@ __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+
+// Byte count for a buffer descriptor: rem clamped to [0, 2^32 - 1] with 32-bit scalar compares (there
+// is no 64-bit scalar compare: the plain form runs on the VALU, and VALU instructions cost MFMA time).
+__device__ __forceinline__ long clamp_u32(long rem)
+{
+    int hi = (int)(rem >> 32);
+    const unsigned lo = (unsigned)rem;
+    asm("" : "+s"(hi));            // (keeps the optimiser from folding this back into a 64-bit compare)
+    return (long)(hi < 0 ? 0u : (hi != 0 ? 0xFFFFFFFFu : lo));
+}

@@ -206,7 +206,7 @@ void contract_body(const double* __restrict__ T, const double* __restrict__ Cm,
     auto load_t = [&](const Strip& st, int kbase, double* dst) {
         const long e0 = st.tb + (long)kbase * tstride;   // wave-uniform
         long rem = (st.te - e0) * (long)sizeof(double);
-        rem = rem < 0 ? 0 : (rem > 0xFFFFFFFFL ? 0xFFFFFFFFL : rem);
+        rem = clamp_u32(rem);
         if constexpr (!WIDE) {
             const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<double*>(T) + e0, 0, (int)(unsigned)rem, 0x00020000);
@@ -222,7 +222,7 @@ void contract_body(const double* __restrict__ T, const double* __restrict__ Cm,
             for (int s2 = 0; s2 < KSTEPS; ++s2) {
                 const long e1 = e0 + (long)(4 * s2) * tstride;
                 long rem1 = (st.te - e1) * (long)sizeof(double);
-                rem1 = rem1 < 0 ? 0 : (rem1 > 0xFFFFFFFFL ? 0xFFFFFFFFL : rem1);
+                rem1 = clamp_u32(rem1);
                 const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<double*>(T) + e1, 0, (int)(unsigned)rem1, 0x00020000);
                 dst[s2] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, st.tvo, 0, 0));
@@ -289,7 +289,7 @@ void contract_body(const double* __restrict__ T, const double* __restrict__ Cm,
                 if (s2 == 0 || WIDE) {
                     const long e1 = stn.tb + (long)(pf_kn + (WIDE ? 4 * s2 : 0)) * tstride;   // wave-uniform
                     long rem = (stn.te - e1) * (long)sizeof(double);
-                    rem = rem < 0 ? 0 : (rem > 0xFFFFFFFFL ? 0xFFFFFFFFL : rem);
+                    rem = clamp_u32(rem);
                     pf_rem = (unsigned)rem;
                     pf_tr = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(T) + e1, 0, (int)pf_rem, 0x00020000);
                 }
@@ -339,7 +339,7 @@ void contract_body(const double* __restrict__ T, const double* __restrict__ Cm,
 #endif
         const long e0 = st.ob + (long)t * (LAST ? 16 : 16 * B);   // wave-uniform
         long rem = (st.oe - e0) * (long)sizeof(double);
-        rem = rem < 0 ? 0 : (rem > 0xFFFFFFFFL ? 0xFFFFFFFFL : rem);
+        rem = clamp_u32(rem);
         const __amdgpu_buffer_rsrc_t r =
             __builtin_amdgcn_make_buffer_rsrc(out + e0, 0, (int)(unsigned)rem, 0x00020000);
         unsigned vo = st.ovo;

@@ -136,7 +136,7 @@ void contract_pair_kernel(const double* __restrict__ T, const double* __restrict
         pf_cso = (unsigned)((long)pf_kn * ldc * sizeof(double));
         const long e1 = stn.tb + (long)pf_kn * B;   // wave-uniform
         long rem = (stn.te - e1) * (long)sizeof(double);
-        rem = rem < 0 ? 0 : (rem > 0xFFFFFFFFL ? 0xFFFFFFFFL : rem);
+        rem = clamp_u32(rem);
         pf_rem = (unsigned)rem;
         pf_tr = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(T) + e1, 0, (int)pf_rem, 0x00020000);
     };
@@ -193,7 +193,7 @@ void contract_pair_kernel(const double* __restrict__ T, const double* __restrict
     auto store_tile = [&](const Strip& st, int t) {
         const long e0 = st.ob + (long)t * 16 * B;   // wave-uniform
         long rem = (st.oe - e0) * (long)sizeof(double);
-        rem = rem < 0 ? 0 : (rem > 0xFFFFFFFFL ? 0xFFFFFFFFL : rem);
+        rem = clamp_u32(rem);
         const __amdgpu_buffer_rsrc_t r =
             __builtin_amdgcn_make_buffer_rsrc(out + e0, 0, (int)(unsigned)rem, 0x00020000);
 #pragma unroll
