@@ -610,29 +610,41 @@ template <int KS, int WPE>
 __global__ __launch_bounds__(SMALL_THREADS, WPE)
 void sym_gm_kernel(const double* __restrict__ J, const double* __restrict__ C,
                    double* __restrict__ Gm, int N, int M, int packed, oovqe_circuit_job_t cj,
-                   int host_circuit)
+                   int host_circuit, int batch)
 {
+    // Workgroup -> (tile bx, geometry by).  1-D grid (gridDim.y == 1): workgroups are dealt to the 8
+    // XCDs round-robin by their linear index, so index v = xcd + 8 (nx k + bx) puts the nx workgroups
+    // of geometry by = xcd + 8 k on ONE XCD, next to each other in time: their partial writes of the
+    // same Gm lines meet in that XCD's L2 instead of going to memory from three of them.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (gridDim.y == 1 && batch > 1) {
+        const int nx = ((packed ? M * (M + 1) / 2 : M * M) + 15) / 16 + (host_circuit ? 1 : 0);
+        const int v = blockIdx.x, s = v >> 3;
+        bx = s % nx;
+        by = (v & 7) + 8 * (s / nx);
+        if (by >= batch) return;
+    }
     // packed: the columns of J are the pairs y <= z (half_tri_kernel, tiled == 2); each result goes
     // to Gm[n,x,y,z] and Gm[n,x,z,y]
     extern __shared__ double lds[];
     const int m2 = M * M;
     const int ncol = packed ? M * (M + 1) / 2 : m2;
     const int nty = (ncol + 15) / 16;
-    if ((int)blockIdx.x == nty) {
-        if (host_circuit && (int)blockIdx.y < cj.count)
+    if (bx == nty) {
+        if (host_circuit && by < cj.count)
             circuit_rdm_small_body(cj.theta, cj.n_theta, cj.gates, cj.n_gates, cj.n_qubits, cj.ncas,
                                    cj.init_index, cj.n_tan, nullptr, nullptr, cj.gamma, cj.Gamma,
-                                   (int)blockIdx.y, lds);
+                                   by, lds);
         return;
     }
     constexpr int NW = SMALL_THREADS / 64;
     constexpr int PW = (4 * KS + NW - 1) / NW;       // rows p per wave
-    const int ty = blockIdx.x;
+    const int ty = bx;
     const long tri = (long)N * (N + 1) / 2;
     // J is tile-major [ty][t][16] (half_tri_kernel, tiled): this workgroup's slice is contiguous
-    J += ((size_t)blockIdx.y * nty + ty) * tri * 16;
-    C += (size_t)blockIdx.y * N * N;
-    Gm += (size_t)blockIdx.y * N * M * m2;
+    J += ((size_t)by * nty + ty) * tri * 16;
+    C += (size_t)by * N * N;
+    Gm += (size_t)by * N * M * m2;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lq = lane >> 4, lr = lane & 15;
@@ -2941,6 +2953,9 @@ static int sym_gm_batched(const double* J, const double* C, double* Gm, int N, i
     oovqe_circuit_job_t job;
     memset(&job, 0, sizeof(job));
     if (cj) job = *cj;
+    const unsigned nx = nty + (cj ? 1 : 0);
+    const bool xcd_grid = batch > 1 && oovqe_opt(OOVQE_OPT_GM_PLAIN_GRID) == 0;
+    const dim3 grid = xcd_grid ? dim3(nx * (unsigned)((batch + 7) / 8 * 8)) : dim3(nx, batch);
 #define OOVQE_LAUNCH_GM2(KS_, WPE_)                                                               \
     do {                                                                                          \
         static size_t attr_bytes = 0;                                                             \
@@ -2950,9 +2965,8 @@ static int sym_gm_batched(const double* J, const double* C, double* Gm, int N, i
                                                 (int)lds_bytes), "cas_eval/sym_gm");              \
             attr_bytes = lds_bytes;                                                               \
         }                                                                                         \
-        hipLaunchKernelGGL((sym_gm_kernel<KS_, WPE_>), dim3(nty + (cj ? 1 : 0), batch),           \
-                           dim3(SMALL_THREADS), lds_bytes, st, J, C, Gm, N, M, packed ? 1 : 0,    \
-                           job, cj ? 1 : 0);                                                      \
+        hipLaunchKernelGGL((sym_gm_kernel<KS_, WPE_>), grid, dim3(SMALL_THREADS), lds_bytes, st,  \
+                           J, C, Gm, N, M, packed ? 1 : 0, job, cj ? 1 : 0, batch);               \
     } while (0)
     // (measurement hooks: OOVQE_GM_TWO_PER_CU / OOVQE_GM_ONE_PER_CU force a build; 128 geometries:
     // 45 -> 38 us with two per CU, 64 geometries: no difference)
