@@ -1242,17 +1242,32 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
     unsigned offp[NPA][2];              // pair pp: [0] rows of blocks <= 2pp, [1] rows of block 2pp+1 (full layout)
     int colp[NPA];
     bool last_even[NPA];
+    // Packed copy: the two operands of pair pp are the columns of its first block (32 pp + lr, in .x)
+    // and of its second block (32 pp + 16 + lr, in .y), one 8-byte load each: the first block's columns
+    // only have rows up to their own block, so its products stop there (the column-pair form of the
+    // full layout, .x = even and .y = odd columns from one 16-byte load, runs both over both blocks).
+    int colh[NPA][2];
 #pragma unroll
     for (int pp = 0; pp < NP; ++pp) {
-        const int col = pp * 32 + 2 * lr;
-        // the last column of an odd N: the full layout loads the pair (N-2, N-1) and takes .y; in the
-        // packed copy the pair (N-1, N) ends on the next row's first element or the slab's pad (finite,
-        // and column N meets a zero coefficient in the second product)
-        const int cc = (pk ? col < N : col + 1 < N) ? col : (N >= 2 ? N - 2 : 0);
-        colp[pp] = col;
-        offp[pp][0] = (unsigned)((lane_row + cc) * (int)sizeof(double));
-        offp[pp][1] = (wts && lr < 8) ? total_bytes : offp[pp][0];   // first block's columns below the diagonal
-        last_even[pp] = !pk && col == N - 1;
+        if constexpr (pk) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int col = pp * 32 + 16 * h + lr;
+                colh[pp][h] = col;
+                offp[pp][h] = (unsigned)((lane_row + (col < N ? col : N - 1)) * (int)sizeof(double));
+            }
+            colp[pp] = colh[pp][0];
+            last_even[pp] = false;
+        } else {
+            const int col = pp * 32 + 2 * lr;
+            // the last column of an odd N: the pair (N-2, N-1) is loaded and .y taken
+            const int cc = col + 1 < N ? col : (N >= 2 ? N - 2 : 0);
+            colp[pp] = col;
+            colh[pp][0] = colh[pp][1] = col;
+            offp[pp][0] = (unsigned)((lane_row + cc) * (int)sizeof(double));
+            offp[pp][1] = (wts && lr < 8) ? total_bytes : offp[pp][0];   // first block's columns below the diagonal
+            last_even[pp] = col == N - 1;
+        }
     }
     const int col1 = NP * 32 + lr;
     const int col1c = col1 < N ? col1 : N - 1;
@@ -1303,6 +1318,15 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
             for (int i = 0; i < KCH; ++i) {
                 const int blk = i / 4;                 // 16-row block of this k-step (compile time)
                 if (rs && blk > 2 * pp + 1) continue;  // rows below both blocks of the pair: lower blocks
+                if constexpr (pk) {
+                    if (blk <= 2 * pp) {
+                        const v2u v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff(offp[pp][0], colh[pp][0], i), soff(sb, i), AUX_NT);
+                        ap[pp][i].x = __builtin_bit_cast(double, v);
+                    }
+                    const v2u w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff(offp[pp][1], colh[pp][1], i), soff(sb, i), AUX_NT);
+                    ap[pp][i].y = __builtin_bit_cast(double, w);
+                    continue;
+                }
                 // (row blocks above the pair, blk < 2pp, only exist for NST > 3: not instantiated)
                 const unsigned vo = offp[pp][blk == 2 * pp + 1 ? 1 : 0];
                 const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff(vo, colp[pp], i), soff(sb, i), rs ? AUX_NT : AUX_PLAIN);
@@ -1334,7 +1358,7 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
         for (int half = 0; half < 2; ++half)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int col = pp * 32 + 2 * (lq + 4 * i) + half;
+                const int col = pk ? pp * 32 + 16 * half + lq + 4 * i : pp * 32 + 2 * (lq + 4 * i) + half;
                 cpr[pp][half][i] = C[(size_t)(col < N ? col : N - 1) * N + (lr < M ? lr : M - 1)];
             }
 #pragma unroll
@@ -1345,7 +1369,7 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
         for (int half = 0; half < 2; ++half)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                cpr[pp][half][i] *= ((pp * 32 + 2 * (lq + 4 * i) + half) < N && lr < M) ? 1.0 : 0.0;
+                cpr[pp][half][i] *= ((pk ? pp * 32 + 16 * half + lq + 4 * i : pp * 32 + 2 * (lq + 4 * i) + half) < N && lr < M) ? 1.0 : 0.0;
 
     // LDS destination of jt[i] = Jt[z = lq + 4i][y = lr] inside a staged tile: [y*M + z]
     int tile_off[4];
@@ -1374,14 +1398,16 @@ void half_tri_kernel(const double* __restrict__ g, const double* __restrict__ C,
                     d4 x = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int i = 0; i < KCH; ++i) {
-                        if (i / 4 > 2 * pp + 1) continue;      // rows below both blocks of the pair
+                        if (i / 4 > 2 * pp + half) continue;   // rows below the block of these columns
                         x = mfma_f64(half == 0 ? ap[pp][i].x : ap[pp][i].y, cfr[i], x);
                     }
                     xh[pp][half] = x;
                 }
             if constexpr (NS1) {
+                // columns of the last tile that exist for this KCH (rows and columns share the k-steps)
+                constexpr int KS1 = KCH - NP * 8 < 4 ? KCH - NP * 8 : 4;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) jt = mfma_f64(cfr[NP * 8 + i], xs[i], jt);
+                for (int i = 0; i < KS1; ++i) jt = mfma_f64(cfr[NP * 8 + i], xs[i], jt);
             }
 #pragma unroll
             for (int pp = 0; pp < NP; ++pp)
