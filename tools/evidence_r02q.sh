@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-2 evidence run (one gpurun call): dependency probe, stage-1 cycle accounting, clocks and power,
-# the bench on the driver's command and the same under rocprofv3 --kernel-trace --stats.
+# the bench on the driver's command, then tools/pmc_stage1_issue.sh (counters + rocprofv3 --kernel-trace --stats).
 set -o pipefail
 export TMPDIR=/tmp
 O=gpurun_out/q
@@ -13,7 +13,7 @@ timeout -k 10 200 python tools/clock_power_probe.py 256 > $O/clock_power.txt 2> 
 echo "clock probe done"
 timeout -k 10 600 python bench.py --gpus 1 > $O/bench_full.json 2> $O/bench_full.err || exit 1
 echo "bench done"
-timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $O/prof -o r02q -- python3 bench.py --steps 200 --no-transform --no-berry --no-kupccd --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/rocprof.err || exit 1
-find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/bench_kernel_stats.csv \;
-rm -rf $O/prof
+# issue counters, HBM bytes and the rocprofv3 --kernel-trace --stats summary (gpurun_out/s1_issue_counters.json,
+# s1i_kernel_stats.csv, s1i_bench_under_rocprof.json)
+bash tools/pmc_stage1_issue.sh || exit 1
 echo "rocprof done"
