@@ -2397,7 +2397,7 @@ void cas_panel_kernel(const double* __restrict__ Gm_in, const double* __restrict
                       double* __restrict__ Fcol, double* __restrict__ Epart,
                       double* __restrict__ Cpart, double* __restrict__ c1, double* __restrict__ c2,
                       double* __restrict__ Gm_out, double* __restrict__ hmo_out, size_t out_stride,
-                      int rdm_chunk)
+                      int rdm_chunk, int batch_1d)
 {
     extern __shared__ double lds[];
     const int M = no + na, M2 = M * M, M3 = M2 * M;
@@ -2412,10 +2412,20 @@ void cas_panel_kernel(const double* __restrict__ Gm_in, const double* __restrict
     double* gml = FIn + (size_t)npan * M;      // [rdm_chunk][na2]
     double* Gml = gml + (size_t)rdm_chunk * na2;   // [rdm_chunk][na4]
     const int tid = threadIdx.x;
-    const int n0 = blockIdx.x * npan;
+    // 1-D grid (batch_1d > 0): index v = xcd + 8 (npanels k + panel) keeps the panels of geometry
+    // xcd + 8 k on one XCD (see sym_gm_kernel): h_ao, C and the RDMs of a geometry enter one L2 only
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (batch_1d > 0) {
+        const int npanels = (N + npan - 1) / npan;
+        const int v = blockIdx.x, sidx = v >> 3;
+        bx = sidx % npanels;
+        by = (v & 7) + 8 * (sidx / npanels);
+        if (by >= batch_1d) return;
+    }
+    const int n0 = bx * npan;
     const int nn = (N - n0) < npan ? (N - n0) : npan;   // valid n in this panel
-    {   // blockIdx.y = geometry of a batch: every per-geometry array is stacked
-        const size_t gi = blockIdx.y;
+    {   // by = geometry of a batch: every per-geometry array is stacked
+        const size_t gi = by;
         Gm_in += gi * (size_t)N * M3;
         h_ao += gi * (size_t)N * N;
         C += gi * (size_t)N * N;
@@ -3618,9 +3628,13 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
             attr_done = true;
         }
         oovqe_profile_mark_start_l(st, 3);
-        hipLaunchKernelGGL(cas_panel_kernel, dim3((unsigned)((N + npan - 1) / npan), batch),
+        const unsigned npanels = (unsigned)((N + npan - 1) / npan);
+        const bool xcd_grid = batch > 1 && oovqe_opt(OOVQE_OPT_GM_PLAIN_GRID) == 0;
+        hipLaunchKernelGGL(cas_panel_kernel,
+                           xcd_grid ? dim3(npanels * (unsigned)((batch + 7) / 8 * 8)) : dim3(npanels, batch),
                            dim3(PAN_THREADS), lds_bytes, st, Gm_in, h_ao, C, gamma, Gamma, nrdm, N, n_occ,
-                           ncas, (int)npan, Fcol, Epart, Cpart, c1, c2, Gm, hmo, out_stride, rdm_chunk);
+                           ncas, (int)npan, Fcol, Epart, Cpart, c1, c2, Gm, hmo, out_stride, rdm_chunk,
+                           xcd_grid ? batch : 0);
         oovqe_profile_mark_stop(st);
         OOVQE_CHECK_LAUNCH("cas_eval/panel");
     } else {
