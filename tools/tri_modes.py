@@ -8,7 +8,7 @@ G = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 pqc, batch, single, thetas = bench.build_geometries([g % 16 for g in range(G)])
 lib = _lib.load()
 ref = None
-for mode in (1, 3, 1):
+for mode in (1, 2, 3, 4, 1):
     lib.oovqe_debug_set_option(b"tri_mode", mode)
     out = batch.energy_and_gradient(thetas)
     torch.cuda.synchronize()
