@@ -350,6 +350,9 @@ void half_transform_kernel(const double* __restrict__ g, const double* __restric
 //     the s_waitcnt counts in the loop stay exact;
 //   * KCH is chosen per N so that nkc * KCH wastes at most a few k-steps (half_stream_plan).
 // ------------------------------------------------------------------------------------------
+#ifdef OOVQE_STREAM_PROBE
+__device__ long long g_stream_cyc[16];   // workgroup 0: [0] core cycles, [1] 100 MHz ticks, [2] MFMAs of wave 0
+#endif
 template <int ZT, int KCH, int DEPTH, bool RS>
 __global__ __launch_bounds__(HALF_WAVES * 64)
 void half_stream_kernel(const double* __restrict__ g, const double* __restrict__ C,
@@ -369,6 +372,10 @@ void half_stream_kernel(const double* __restrict__ g, const double* __restrict__
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane >> 4, lr = lane & 15;
+#ifdef OOVQE_STREAM_PROBE
+    const long long pc0 = __builtin_readcyclecounter(), pw0 = wall_clock64();
+    long long n_mfma = 0;
+#endif
     double* patch = lds + (((size_t)RT16 * LDM + 511) / 512) * 512 + (size_t)wave * (16 * 17);   // (RS)
     g += (size_t)blockIdx.y * N * N * N * N;
     C += (size_t)blockIdx.y * N * N;
@@ -399,6 +406,18 @@ void half_stream_kernel(const double* __restrict__ g, const double* __restrict__
     };
     int lk = 0, lst = 0, lkc = 0;
     auto issue = [&](double (&dst)[KCH]) {
+#if defined(OOVQE_STREAM_PROBE) && OOVQE_STREAM_PROBE == 3
+        // tools/stream_probe.hip: the stream without its loads (the first chunks' operands for ever)
+        if (lk > 0) {
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) asm volatile("" : "+v"(dst[i]));
+            if (++lkc == tile_chunks(lst)) {
+                lkc = 0;
+                if (++lst == nst) { lst = 0; ++lk; }
+            }
+            return;
+        }
+#endif
         long sl = lk < n_mine ? slab0 + (long)lk * stride : 0;
         if (sym != SYM_FULL) {
             int p, q;
@@ -546,6 +565,13 @@ void half_stream_kernel(const double* __restrict__ g, const double* __restrict__
             compute(ab[d]);
         }
     }
+#ifdef OOVQE_STREAM_PROBE
+    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+        g_stream_cyc[0] = __builtin_readcyclecounter() - pc0;
+        g_stream_cyc[1] = wall_clock64() - pw0;
+        g_stream_cyc[2] = (long long)rounds * DEPTH * KCH * ZT + (long long)n_mine * nst * 4 * ZT * ZT;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
