@@ -70,7 +70,7 @@ constexpr int AUX_PLAIN = 0, AUX_NT = 2;
 // upper triangle, t = p(2N - p + 1)/2 + (q - p); the result goes to T2[p,q] AND T2[q,p] (sym == 1)
 // or to the packed triangle J[t] (sym == 2).
 constexpr int SYM_FULL = 0, SYM_MIRROR = 1, SYM_PACKED = 2;
-constexpr int OOVQE_TRI_MODE_DEFAULT = 1;      // realisation of the packed-triangle stage 1 (half_tri_batched)
+constexpr int OOVQE_TRI_MODE_DEFAULT = 3;      // realisation of the packed-triangle stage 1 (half_tri_batched)
 __device__ __forceinline__ void tri_decode(long t, int N, int& p, int& q)
 {
     const double b = 2.0 * N + 1.0;
@@ -1868,29 +1868,32 @@ void half_tri_reg_kernel(const double* __restrict__ g, const double* __restrict_
 #pragma unroll
     for (int b = 0; b < R; ++b) load(b, buf[b]);
 
-    int colp[NPA];
-    bool last_even[NPA];
-    int offp[NPA][KCH];             // < 0: zero
+    // Operand positions inside the wave's slot, in doubles relative to my_slot: pair pp = the columns
+    // of its first block (32 pp + lr, k-steps of that block's rows only) and of its second block
+    // (32 pp + 16 + lr); elements outside the stored triangle point at a zero word of LDS -- no select
+    // between the ds_read and the MFMA (VALU instructions cost MFMA time on gfx950).
+    double* zero_word = lds + 64 + 126;                     // (inside the unused tail of ctab's 256 ints)
+    if (tid == 0) *zero_word = 0.0;
+    const int zoff = (int)(zero_word - my_slot);
+    int offp[NPA][2][KCH < 8 ? KCH : 8];
     int offs[KCH];
 #pragma unroll
-    for (int pp = 0; pp < NP; ++pp) {
-        const int col = pp * 32 + 2 * lr;
-        const int cc = col + 1 < N ? col : (N >= 2 ? N - 2 : 0);
-        colp[pp] = col;
-        last_even[pp] = col == N - 1;
+    for (int pp = 0; pp < NP; ++pp)
 #pragma unroll
-        for (int i = 0; i < KCH; ++i) {
-            const int r = 4 * i + lq, e = r & ~1;
-            offp[pp][i] = (r < N && col >= e && col < N) ? (int)eri_tri_row_start(r, N) + cc - e : -1;
+        for (int h = 0; h < 2; ++h) {
+            const int col = pp * 32 + 16 * h + lr;
+#pragma unroll
+            for (int i = 0; i < (KCH < 8 ? KCH : 8); ++i) {
+                const int r = 4 * i + lq, e = r & ~1;
+                offp[pp][h][i] = (r < N && col >= e && col < N) ? (int)eri_tri_row_start(r, N) + col - e : zoff;
+            }
         }
-    }
     {
         const int col1 = NP * 32 + lr;
-        const int col1c = col1 < N ? col1 : N - 1;
 #pragma unroll
         for (int i = 0; i < KCH; ++i) {
             const int r = 4 * i + lq, e = r & ~1;
-            offs[i] = (r < N && col1 < N && col1c >= e) ? (int)eri_tri_row_start(r, N) + col1c - e : -1;
+            offs[i] = (r < N && col1 < N && col1 >= e) ? (int)eri_tri_row_start(r, N) + col1 - e : zoff;
         }
     }
 
@@ -1907,7 +1910,7 @@ void half_tri_reg_kernel(const double* __restrict__ g, const double* __restrict_
         for (int half = 0; half < 2; ++half)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int col = pp * 32 + 2 * (lq + 4 * i) + half;
+                const int col = pp * 32 + 16 * half + lq + 4 * i;
                 cpr[pp][half][i] = C[(size_t)(col < N ? col : N - 1) * N + (lr < M ? lr : M - 1)];
             }
 #pragma unroll
@@ -1918,7 +1921,7 @@ void half_tri_reg_kernel(const double* __restrict__ g, const double* __restrict_
         for (int half = 0; half < 2; ++half)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                cpr[pp][half][i] *= ((pp * 32 + 2 * (lq + 4 * i) + half) < N && lr < M) ? 1.0 : 0.0;
+                cpr[pp][half][i] *= ((pp * 32 + 16 * half + lq + 4 * i) < N && lr < M) ? 1.0 : 0.0;
 
     int tile_off[4];
 #pragma unroll
@@ -1935,58 +1938,38 @@ void half_tri_reg_kernel(const double* __restrict__ g, const double* __restrict_
         __builtin_amdgcn_sched_barrier(0);
         load(r + R, b);
         __builtin_amdgcn_sched_barrier(0);
+        // every first product one accumulator chain, its result straight into the second product
+        // (half_tri_kernel<.,.,2>); operands read from the slot as they are needed
         d4 jt = d4{0.0, 0.0, 0.0, 0.0};
+        d4 xs = d4{0.0, 0.0, 0.0, 0.0};
+        if constexpr (NS1) {
 #pragma unroll
-        for (int pp = 0; pp < NP; ++pp) {
-            d2u ap[KCH];
+            for (int i = 0; i < KCH; ++i) xs = mfma_f64(my_slot[offs[i]], cfr[i], xs);
+        }
+        d4 xh[NPA][2];
 #pragma unroll
-            for (int i = 0; i < KCH; ++i) {
-                if (i / 4 > 2 * pp + 1) continue;
-                const int o = offp[pp][i];
-                d2u v = *reinterpret_cast<const d2u*>(my_slot + (o >= 0 ? o : 0));
-                if (o < 0) v = d2u{0.0, 0.0};
-                ap[i] = v;
-            }
+        for (int pp = 0; pp < NP; ++pp)
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                d4 xu = d4{0.0, 0.0, 0.0, 0.0}, xa = xu, xb = xu;
+                d4 x = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int i = 0; i < KCH; ++i) {
-                    const int blk = i / 4;
-                    if (blk > 2 * pp + 1) continue;
-                    const double ev = last_even[pp] ? ap[i].y : ap[i].x;
-                    const double av = half == 0 ? ev : ap[i].y;
-                    if (blk < 2 * pp) xu = mfma_f64(av, cfr[i], xu);
-                    else if (blk == 2 * pp) xa = mfma_f64(av, cfr[i], xa);
-                    else xb = mfma_f64(av, cfr[i], xb);
+                for (int i = 0; i < (KCH < 8 ? KCH : 8); ++i) {
+                    if (i / 4 > 2 * pp + half) continue;       // rows below the block of these columns
+                    x = mfma_f64(my_slot[offp[pp][half][i]], cfr[i], x);
                 }
-                d4 xt;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) xt[e] = xu[e] + xa[e] + xb[e];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) jt = mfma_f64(cpr[pp][half][i], xt[i], jt);
+                xh[pp][half] = x;
             }
-        }
         if constexpr (NS1) {
-            double as[KCH];
+            constexpr int KS1 = KCH - NP * 8 < 4 ? KCH - NP * 8 : 4;
 #pragma unroll
-            for (int i = 0; i < KCH; ++i) {
-                const int o = offs[i];
-                const double v = my_slot[o >= 0 ? o : 0];
-                as[i] = o >= 0 ? v : 0.0;
-            }
-            d4 xu = d4{0.0, 0.0, 0.0, 0.0}, xd = xu;
-#pragma unroll
-            for (int i = 0; i < KCH; ++i) {
-                if (i / 4 < NST - 1) xu = mfma_f64(as[i], cfr[i], xu);
-                else xd = mfma_f64(as[i], cfr[i], xd);
-            }
-            d4 xt;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) xt[e] = xu[e] + xd[e];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) jt = mfma_f64(cfr[NP * 8 + i], xt[i], jt);
+            for (int i = 0; i < KS1; ++i) jt = mfma_f64(cfr[NP * 8 + i], xs[i], jt);
         }
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) jt = mfma_f64(cpr[pp][half][i], xh[pp][half][i], jt);
         if ((long)r * SW + gw < tri) {
             double* row = stg + ((size_t)(r - base) * HALF_WAVES + wave) * M2;
 #pragma unroll
@@ -1999,6 +1982,7 @@ void half_tri_reg_kernel(const double* __restrict__ g, const double* __restrict_
         // the same slot are issued: same wave, LDS operations execute in order
     };
 
+    __syncthreads();                                   // zero word, ctab
     // phase_rounds is a multiple of R: round `base` of every phase sits in register buffer 0
     for (int base = 0; base < n_rounds; base += phase_rounds) {
         const int end = base + phase_rounds < n_rounds ? base + phase_rounds : n_rounds;
@@ -2010,14 +1994,16 @@ void half_tri_reg_kernel(const double* __restrict__ g, const double* __restrict_
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // loads stay in flight
-        const int nslot = (end - base) * HALF_WAVES;
-        for (int e = tid; e < nslot * ncol; e += HALF_WAVES * 64) {
-            const int slot = e / ncol, c = e - slot * ncol;
-            const long t = (long)(base + slot / HALF_WAVES) * SW + blockIdx.x * HALF_WAVES + slot % HALF_WAVES;
-            if (t < tri) {
-                const int cc2 = ctab[c];
-                const double v = stg[(size_t)slot * M2 + (cc2 & 0xffff)] + stg[(size_t)slot * M2 + (cc2 >> 16)];
-                J[((size_t)(c >> 4) * tri + t) * 16 + (c & 15)] = v;
+        for (int c = lane; c < ncol; c += 64) {
+            const int cc2 = ctab[c];
+            const int o1 = cc2 & 0xffff, o2 = cc2 >> 16;
+            double* dst = J + ((size_t)(c >> 4) * tri) * 16 + (c & 15);
+#pragma unroll 4
+            for (int kk = 0; kk < end - base; ++kk) {
+                const long t = (long)(base + kk) * SW + gw;
+                if (t >= tri) break;
+                const double* tile = stg + ((size_t)kk * HALF_WAVES + wave) * M2;
+                dst[(size_t)t * 16] = tile[o1] + tile[o2];
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

@@ -542,7 +542,8 @@ def main():
             # the columns y <= z of its result are written
             slab_elems = sum(NAO - (r & ~1) for r in range(NAO))   # upper triangle, even row starts
             bytes_per_eval = 8.0 * slab_elems * tri + 8.0 * tri * (M * (M + 1) // 2)
-        kernel_name = ("half_tri_kernel<11,3," + ("2" if rs_sym else "0") + ",8> (J[p<=q,y,z] = sum_rs C[r,y] g[p,q,r,s] C[s,z] over the "
+        kernel_name = (("half_tri_reg_kernel<11,3,8,3>" if rs_sym else "half_tri_kernel<11,3,0,8>")
+                       + " (J[p<=q,y,z] = sum_rs C[r,y] g[p,q,r,s] C[s,z] over the "
                        "upper triangle of slabs"
                        + (", streaming the packed copy (upper triangle of each slab)"
                           if rs_sym else "")

@@ -1,12 +1,12 @@
 """Means per dispatch of the counters in one rocprofv3 --pmc output directory for the packed stage-1
-kernel (half_tri_kernel, full-batch launches); appends to gpurun_out/s1_pmc_summary.json."""
+kernel (half_tri_kernel / half_tri_reg_kernel, full-batch launches); appends to gpurun_out/s1_pmc_summary.json."""
 import csv, glob, json, os, sys
 d = sys.argv[1]
 out_path = os.path.join(os.path.dirname(d.rstrip("/")), "s1_pmc_summary.json")
 acc = {}
 for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
     with open(path) as fh:
-        rows = [r for r in csv.DictReader(fh) if "half_tri_kernel" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(fh) if "half_tri_kernel" in r["Kernel_Name"] or "half_tri_reg_kernel" in r["Kernel_Name"]]
     if not rows:
         continue
     top = max(int(r["Grid_Size"]) for r in rows)
