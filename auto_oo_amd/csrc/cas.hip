@@ -1797,6 +1797,12 @@ void half_tri_dma_kernel(const double* __restrict__ g, const double* __restrict_
     }
 }
 
+typedef __attribute__((address_space(3))) double lds_double_t;
+__device__ __forceinline__ unsigned lds_address(const double* p)     // p points into LDS
+{
+    return (unsigned)(unsigned long)(lds_double_t*)p;
+}
+
 // ------------------------------------------------------------------------------------------
 // Stage 1 on the packed copy, slabs fetched as CONTIGUOUS 16-byte-per-lane register loads.
 //
@@ -1858,8 +1864,8 @@ void half_tri_reg_kernel(const double* __restrict__ g, const double* __restrict_
     const unsigned lane_off = (unsigned)lane * 16u;
     // round r of this wave: slab t = r*SW + gw; past the end of the triangle -> out of range, dropped
     auto load = [&](int r, v4u (&b)[NPC]) {
-        const long t = (long)r * SW + gw;
-        const unsigned sb = __builtin_amdgcn_readfirstlane(t < tri ? (unsigned)t * slab_bytes : total_bytes);
+        const int t = r * SW + gw;                      // (32-bit: scalar compare; tri <= 1 176)
+        const unsigned sb = __builtin_amdgcn_readfirstlane(t < (int)tri ? (unsigned)t * slab_bytes : total_bytes);
 #pragma unroll
         for (int p = 0; p < NPC; ++p)
             b[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off + (unsigned)p * 1024u, sb, AUX_NT);
@@ -1923,11 +1929,16 @@ void half_tri_reg_kernel(const double* __restrict__ g, const double* __restrict_
             for (int i = 0; i < 4; ++i)
                 cpr[pp][half][i] *= ((pp * 32 + 16 * half + lq + 4 * i) < N && lr < M) ? 1.0 : 0.0;
 
-    int tile_off[4];
+    // LDS destination of jt[i] = Jt[z = lq + 4i][y = lr] inside a staged tile ([y*M + z]): the 32-bit LDS
+    // address of the position in the phase's first row; lanes outside the M x M tile go to the dump
+    unsigned st_mul[4], st_off[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int zz = lq + 4 * i;
-        tile_off[i] = (lr < M && zz < M) ? lr * M + zz : -1;
+        const bool ok = lr < M && zz < M;
+        st_mul[i] = ok ? 1u : 0u;
+        st_off[i] = ok ? lds_address(stg) + (unsigned)((lr * M + zz) * (int)sizeof(double))
+                       : lds_address(dump + lane);
     }
 
     // one round: slab in `b` -> LDS slot -> (registers reloaded R rounds ahead) -> fragments -> MFMA
@@ -1970,12 +1981,14 @@ void half_tri_reg_kernel(const double* __restrict__ g, const double* __restrict_
             for (int half = 0; half < 2; ++half)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) jt = mfma_f64(cpr[pp][half][i], xh[pp][half][i], jt);
-        if ((long)r * SW + gw < tri) {
-            double* row = stg + ((size_t)(r - base) * HALF_WAVES + wave) * M2;
+        if (r * SW + gw < (int)tri) {
+            // byte address = row * (1 | 0) + (tile position | dump): one v_mad per store, no select
+            const unsigned row_b = (unsigned)(((r - base) * HALF_WAVES + wave) * M2) * (unsigned)sizeof(double);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                double* dst = tile_off[i] >= 0 ? row + tile_off[i] : dump + lane;
-                *dst = jt[i];
+                unsigned a;        // (as asm: the optimiser turns the 0/1 product back into a select)
+                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(a) : "s"(row_b), "v"(st_mul[i]), "v"(st_off[i]));
+                *reinterpret_cast<lds_double_t*>((unsigned long)a) = jt[i];
             }
         }
         // the fragment reads of this round retire (lgkmcnt) before the next round's ds_writes to
