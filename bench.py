@@ -624,6 +624,18 @@ def main():
             "launches_timed": kern_count,
         },
     }
+    if pq_sym and rs_sym and t3_path and NAO == 43 and M == 9:
+        # The same launch against the fp64 matrix pipe (informational; DESIGN.md "What bounds stage 1": the
+        # kernel is bound by MFMA issue at a power-limited clock, not by HBM).  34 v_mfma_f64_16x16x4 per
+        # slab (11 + 4 + 8 first products, 3 + 4 + 4 second), 2 048 flop each, padding included.
+        mfma_flops = 34 * 2048.0 * tri * evals_per_launch
+        out["roofline"]["mfma_view"] = {
+            "mfma_instructions_per_slab": 34,
+            "achieved_TFLOPs_incl_tile_padding": mfma_flops / kern_s / 1e12,
+            "peak_TFLOPs": 78.6,
+            "frac_of_peak_at_2.4GHz": mfma_flops / kern_s / 1e12 / 78.6,
+            "note": "the core clock under this kernel is 1.6-1.8 GHz (tools/tri_spread.hip)",
+        }
     if rank == 0 and world == 1:
         # latency of ONE un-batched evaluation through the drop-in API (not the headline)
         th0 = thetas[0].contiguous()
