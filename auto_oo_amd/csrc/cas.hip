@@ -1830,6 +1830,10 @@ void half_tri_reg_kernel(const double* __restrict__ g, const double* __restrict_
     static_assert(KCH <= NCF, "C fragments must cover every k-step");
     static_assert(NP <= 1, "row blocks above a pair are not handled by the offsets below");
     extern __shared__ double lds[];
+#ifdef OOVQE_TRI_PROBE
+    const long long pc_start = __builtin_readcyclecounter();
+    const long long pw_start = wall_clock64();
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane >> 4, lr = lane & 15;
@@ -1842,7 +1846,11 @@ void half_tri_reg_kernel(const double* __restrict__ g, const double* __restrict_
     int* ctab = reinterpret_cast<int*>(lds + 64);   // [ncol <= 256] column -> position y*M + z in a tile
     double* slots = lds + 64 + 128; // [HALF_WAVES][SLOT_D]
     double* stg = slots + (size_t)HALF_WAVES * SLOT_D;      // [phase_rounds][HALF_WAVES][M2]
+#if defined(OOVQE_TRI_PROBE) && OOVQE_TRI_PROBE == 2
+    // tools/tri_spread.hip: every geometry reads geometry 0's integrals (cache-resident)
+#else
     g += (size_t)blockIdx.y * (size_t)tri * slab_d;
+#endif
     C += (size_t)blockIdx.y * N * N;
     const int ncol = M * (M + 1) / 2;                                // columns y <= z of J
     const int nty = (ncol + 15) / 16;
@@ -1864,6 +1872,13 @@ void half_tri_reg_kernel(const double* __restrict__ g, const double* __restrict_
     const unsigned lane_off = (unsigned)lane * 16u;
     // round r of this wave: slab t = r*SW + gw; past the end of the triangle -> out of range, dropped
     auto load = [&](int r, v4u (&b)[NPC]) {
+#if defined(OOVQE_TRI_PROBE) && OOVQE_TRI_PROBE == 3
+        if (r > 2) {                                    // tools/tri_spread.hip: the sweep without its loads
+#pragma unroll
+            for (int p = 0; p < NPC; ++p) asm volatile("" : "+v"(b[p]));
+            return;
+        }
+#endif
         const int t = r * SW + gw;                      // (32-bit: scalar compare; tri <= 1 176)
         const unsigned sb = __builtin_amdgcn_readfirstlane(t < (int)tri ? (unsigned)t * slab_bytes : total_bytes);
 #pragma unroll
@@ -2021,6 +2036,13 @@ void half_tri_reg_kernel(const double* __restrict__ g, const double* __restrict_
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+#ifdef OOVQE_TRI_PROBE
+    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+        g_tri_cyc[9] += __builtin_readcyclecounter() - pc_start;
+        g_tri_cyc[10] += wall_clock64() - pw_start;      // 100 MHz
+    }
+    if (tid == 0) g_tri_wg_end[blockIdx.y * gridDim.x + blockIdx.x] = wall_clock64();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -634,7 +634,7 @@ def main():
             "achieved_TFLOPs_incl_tile_padding": mfma_flops / kern_s / 1e12,
             "peak_TFLOPs": 78.6,
             "frac_of_peak_at_2.4GHz": mfma_flops / kern_s / 1e12 / 78.6,
-            "note": "the core clock under this kernel is 1.6-1.8 GHz (tools/tri_spread.hip)",
+            "note": "the core clock under this kernel is ~1.75 GHz (tools/tri_spread.hip, profiles/r02_t_stage1_cycles.txt)",
         }
     if rank == 0 and world == 1:
         # latency of ONE un-batched evaluation through the drop-in API (not the headline)

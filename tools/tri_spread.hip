@@ -1,4 +1,5 @@
-// When do the 256 workgroups of the packed stage-1 kernel finish (tools only)?  Builds cas.hip with
+// When do the 256 workgroups of the packed stage-1 kernel finish (tools only)?  (the default realisation;
+// run with an argument to select another tri_mode, e.g. 1 = the operand-load kernel with its sweep / burst counters)  Builds cas.hip with
 // OOVQE_TRI_PROBE: every workgroup stores the 100 MHz wall clock at its end.
 #ifndef OOVQE_TRI_PROBE
 #define OOVQE_TRI_PROBE 1   // 2: every geometry reads geometry 0's integrals (no HBM stream)
@@ -6,8 +7,9 @@
 #include "../auto_oo_amd/csrc/cas.hip"
 #include <vector>
 #include <algorithm>
-int main()
+int main(int argc, char** argv)
 {
+    if (argc > 1) oovqe_debug_set_option("tri_mode", atoi(argv[1]));
     const int N = 43, M = 9, G = 256;
     const size_t psz = (size_t)oovqe_eri_packed_size(N);
     const size_t nc = (size_t)G * N * N, nj = (size_t)G * (N * (N + 1) / 2) * 48;
