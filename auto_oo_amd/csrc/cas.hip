@@ -1586,8 +1586,9 @@ void half_tri_dma_kernel(const double* __restrict__ g, const double* __restrict_
     const int npiece = (int)((slab_bytes + 1023u) / 1024u);          // 1 KB DMA pieces per slab
     double* dump = lds;             // [64] sink for lanes outside the M x M tile
     int* ctab = reinterpret_cast<int*>(lds + 64);   // [ncol <= 256] column -> position y*M + z in a tile
-    double* ring = lds + 64 + 128;  // [HALF_WAVES][2][slab_d]: two slots per wave
-    double* stg = ring + (size_t)HALF_WAVES * 2 * slab_d;   // [phase_rounds][HALF_WAVES][M2]
+    const unsigned slot_d = slab_d + 2;                              // + a zero word the DMA never writes
+    double* ring = lds + 64 + 128;  // [HALF_WAVES][2][slot_d]: two slots per wave
+    double* stg = ring + (size_t)HALF_WAVES * 2 * slot_d;   // [phase_rounds][HALF_WAVES][M2]
     g += (size_t)blockIdx.y * (size_t)tri * slab_d;
     C += (size_t)blockIdx.y * N * N;
     const int ncol = M * (M + 1) / 2;                                // columns y <= z of J
@@ -1603,11 +1604,12 @@ void half_tri_dma_kernel(const double* __restrict__ g, const double* __restrict_
     const int gw = blockIdx.x * HALF_WAVES + wave;
     const int n_rounds = (int)((tri + SW - 1) / SW);        // the same for every wave of the grid
     const int my_rounds = gw < tri ? (int)((tri - 1 - gw) / SW) + 1 : 0;   // rounds with a slab for this wave
-    double* my_ring = ring + (size_t)wave * 2 * slab_d;
+    double* my_ring = ring + (size_t)wave * 2 * slot_d;
+    if (lane < 2) my_ring[(size_t)lane * slot_d + slab_d] = 0.0;
     // round r of this wave: slab t = r*SW + gw, into slot r & 1
     auto dma = [&](int r) {
         const char* src = reinterpret_cast<const char*>(g + ((size_t)r * SW + gw) * slab_d) + lane * 16;
-        char* dst = reinterpret_cast<char*>(my_ring + (size_t)(r & 1) * slab_d);
+        char* dst = reinterpret_cast<char*>(my_ring + (size_t)(r & 1) * slot_d);
         for (int p = 0; p < npiece; ++p) {
             if ((unsigned)(p * 1024 + lane * 16) < slab_bytes)
                 __builtin_amdgcn_global_load_lds((oovqe_glob_void*)(src + p * 1024),
@@ -1620,29 +1622,29 @@ void half_tri_dma_kernel(const double* __restrict__ g, const double* __restrict_
     // Offsets (in doubles) of this lane's operands inside a packed slab: row r = 4i + lq starts
     // 2k(N-k+1) + (r&1)(N-2k) doubles in, k = r/2, and holds the columns (r & ~1) .. N-1.
     // A position below the diagonal (or a row past N) reads as zero.
-    int colp[NPA];
-    bool last_even[NPA];
-    int offp[NPA][KCH];             // < 0: zero
+    // (elements outside the stored triangle point at the zero word behind the slot; pair pp = the
+    // columns of its first block, k-steps of that block's rows only, and of its second block: see
+    // half_tri_reg_kernel)
+    const int zoff = (int)slab_d;
+    int offp[NPA][2][KCH < 8 ? KCH : 8];
     int offs[KCH];
 #pragma unroll
-    for (int pp = 0; pp < NP; ++pp) {
-        const int col = pp * 32 + 2 * lr;
-        const int cc = col + 1 < N ? col : (N >= 2 ? N - 2 : 0);
-        colp[pp] = col;
-        last_even[pp] = col == N - 1;
+    for (int pp = 0; pp < NP; ++pp)
 #pragma unroll
-        for (int i = 0; i < KCH; ++i) {
-            const int r = 4 * i + lq, e = r & ~1;
-            offp[pp][i] = (r < N && col >= e && col < N) ? (int)eri_tri_row_start(r, N) + cc - e : -1;
+        for (int h = 0; h < 2; ++h) {
+            const int col = pp * 32 + 16 * h + lr;
+#pragma unroll
+            for (int i = 0; i < (KCH < 8 ? KCH : 8); ++i) {
+                const int r = 4 * i + lq, e = r & ~1;
+                offp[pp][h][i] = (r < N && col >= e && col < N) ? (int)eri_tri_row_start(r, N) + col - e : zoff;
+            }
         }
-    }
     {
         const int col1 = NP * 32 + lr;
-        const int col1c = col1 < N ? col1 : N - 1;
 #pragma unroll
         for (int i = 0; i < KCH; ++i) {
             const int r = 4 * i + lq, e = r & ~1;
-            offs[i] = (r < N && col1 < N && col1c >= e) ? (int)eri_tri_row_start(r, N) + col1c - e : -1;
+            offs[i] = (r < N && col1 < N && col1 >= e) ? (int)eri_tri_row_start(r, N) + col1 - e : zoff;
         }
     }
 
@@ -1660,7 +1662,7 @@ void half_tri_dma_kernel(const double* __restrict__ g, const double* __restrict_
         for (int half = 0; half < 2; ++half)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int col = pp * 32 + 2 * (lq + 4 * i) + half;
+                const int col = pp * 32 + 16 * half + lq + 4 * i;
                 cpr[pp][half][i] = C[(size_t)(col < N ? col : N - 1) * N + (lr < M ? lr : M - 1)];
             }
 #pragma unroll
@@ -1671,7 +1673,7 @@ void half_tri_dma_kernel(const double* __restrict__ g, const double* __restrict_
         for (int half = 0; half < 2; ++half)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                cpr[pp][half][i] *= ((pp * 32 + 2 * (lq + 4 * i) + half) < N && lr < M) ? 1.0 : 0.0;
+                cpr[pp][half][i] *= ((pp * 32 + 16 * half + lq + 4 * i) < N && lr < M) ? 1.0 : 0.0;
 
     // LDS destination of jt[i] = Jt[z = lq + 4i][y = lr] inside a staged tile: [y*M + z]
     int tile_off[4];
@@ -1681,67 +1683,61 @@ void half_tri_dma_kernel(const double* __restrict__ g, const double* __restrict_
         tile_off[i] = (lr < M && zz < M) ? lr * M + zz : -1;
     }
 
-    d2u ap[NPA][KCH];
+    double a0[NPA][4], a1[NPA][KCH < 8 ? KCH : 8];
     double as[KCH];
-    // operands of the slab in slot `slot` out of LDS (the rows of the lower blocks of a column pair
-    // are below the diagonal altogether: skipped at compile time, as in half_tri_kernel)
+    // operands of the slab in slot `slot` out of LDS into registers (the slot is then free for the DMA
+    // of the slab two rounds ahead)
     auto fetch = [&](int slot) {
-        const double* sl = my_ring + (size_t)slot * slab_d;
-#pragma unroll
-        for (int pp = 0; pp < NP; ++pp)
-#pragma unroll
-            for (int i = 0; i < KCH; ++i) {
-                if (i / 4 > 2 * pp + 1) continue;
-                const int o = offp[pp][i];
-                d2u v = *reinterpret_cast<const d2u*>(sl + (o >= 0 ? o : 0));
-                if (o < 0) v = d2u{0.0, 0.0};
-                ap[pp][i] = v;
-            }
+        const double* sl = my_ring + (size_t)slot * slot_d;
         if constexpr (NS1) {
 #pragma unroll
-            for (int i = 0; i < KCH; ++i) {
-                const int o = offs[i];
-                const double v = sl[o >= 0 ? o : 0];
-                as[i] = o >= 0 ? v : 0.0;
-            }
+            for (int i = 0; i < KCH; ++i) as[i] = sl[offs[i]];
+        }
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) {
+#pragma unroll
+            for (int i = 0; i < 4 && i < KCH; ++i) a0[pp][i] = sl[offp[pp][0][i]];
+#pragma unroll
+            for (int i = 0; i < (KCH < 8 ? KCH : 8); ++i) a1[pp][i] = sl[offp[pp][1][i]];
         }
     };
+    // every first product one accumulator chain, its result straight into the second product
     auto compute = [&](int r, int base) {
         d4 jt = d4{0.0, 0.0, 0.0, 0.0};
+        d4 xs = d4{0.0, 0.0, 0.0, 0.0};
+        if constexpr (NS1) {
+#pragma unroll
+            for (int i = 0; i < KCH; ++i) xs = mfma_f64(as[i], cfr[i], xs);
+        }
+        d4 xh[NPA][2];
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) {
+            d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < 4 && i < KCH; ++i) {
+                if (i / 4 > 2 * pp) continue;
+                x = mfma_f64(a0[pp][i], cfr[i], x);
+            }
+            xh[pp][0] = x;
+            x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < (KCH < 8 ? KCH : 8); ++i) {
+                if (i / 4 > 2 * pp + 1) continue;
+                x = mfma_f64(a1[pp][i], cfr[i], x);
+            }
+            xh[pp][1] = x;
+        }
+        if constexpr (NS1) {
+            constexpr int KS1 = KCH - NP * 8 < 4 ? KCH - NP * 8 : 4;
+#pragma unroll
+            for (int i = 0; i < KS1; ++i) jt = mfma_f64(cfr[NP * 8 + i], xs[i], jt);
+        }
 #pragma unroll
         for (int pp = 0; pp < NP; ++pp)
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                d4 xu = d4{0.0, 0.0, 0.0, 0.0}, xa = xu, xb = xu;
+            for (int half = 0; half < 2; ++half)
 #pragma unroll
-                for (int i = 0; i < KCH; ++i) {
-                    const double ev = last_even[pp] ? ap[pp][i].y : ap[pp][i].x;
-                    const double av = half == 0 ? ev : ap[pp][i].y;
-                    const int blk = i / 4;
-                    if (blk > 2 * pp + 1) continue;
-                    if (blk < 2 * pp) xu = mfma_f64(av, cfr[i], xu);
-                    else if (blk == 2 * pp) xa = mfma_f64(av, cfr[i], xa);
-                    else xb = mfma_f64(av, cfr[i], xb);
-                }
-                d4 xt;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) xt[e] = xu[e] + xa[e] + xb[e];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) jt = mfma_f64(cpr[pp][half][i], xt[i], jt);
-            }
-        if constexpr (NS1) {
-            d4 xu = d4{0.0, 0.0, 0.0, 0.0}, xd = xu;
-#pragma unroll
-            for (int i = 0; i < KCH; ++i) {
-                if (i / 4 < NST - 1) xu = mfma_f64(as[i], cfr[i], xu);
-                else xd = mfma_f64(as[i], cfr[i], xd);
-            }
-            d4 xt;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) xt[e] = xu[e] + xd[e];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) jt = mfma_f64(cfr[NP * 8 + i], xt[i], jt);
-        }
+                for (int i = 0; i < 4; ++i) jt = mfma_f64(cpr[pp][half][i], xh[pp][half][i], jt);
         double* row = stg + ((size_t)(r - base) * HALF_WAVES + wave) * M2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -3235,7 +3231,7 @@ static int half_tri_batched(const double* g_ao, const double* C, int N, int M, d
     //   2 half_tri_dma_kernel      LDS-DMA ring, two slots per wave
     //   3 / 4 half_tri_reg_kernel  contiguous register loads, R = 3 / 4 slabs per wave in flight
     const int tri_mode = oovqe_opt(OOVQE_OPT_TRI_MODE) ? oovqe_opt(OOVQE_OPT_TRI_MODE) : OOVQE_TRI_MODE_DEFAULT;
-    const size_t ring_bytes = (size_t)HALF_WAVES * 2 * eri_slab_packed_elems(N) * sizeof(double);
+    const size_t ring_bytes = (size_t)HALF_WAVES * 2 * (eri_slab_packed_elems(N) + 2) * sizeof(double);
     if (packed_src && tiled == 2 && tri_mode == 2 && fixed_bytes + ring_bytes + round_bytes <= 160 * 1024) {
         long ph = (long)((160 * 1024 - fixed_bytes - ring_bytes) / round_bytes);
         if (ph > n_rounds) ph = n_rounds;
