@@ -5,16 +5,19 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ d4 mf(double a, double b, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
 template <int MODE>
-__global__ __launch_bounds__(768) void probe(double* out, long long* cyc, long long* wcyc, int iters)
+__global__ __launch_bounds__(768) void probe(double* out, long long* cyc, long long* wcyc, int iters, double* gbuf_all = nullptr)
 {
     double a = threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-4, a1 = a + 0.5, a2 = a - 0.25;
     d4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
     unsigned k0 = threadIdx.x, k1 = 77;
     double f0 = a, f1 = b;
     __shared__ double lds[2 * 768];
+    double* gbuf = gbuf_all ? gbuf_all + (size_t)blockIdx.x * 64 * 16 * 4096 : nullptr;
+    d2v ld_acc = {0.0, 0.0};
     __syncthreads();
     const long long w0 = __builtin_amdgcn_s_memrealtime();
     const long long t0 = __builtin_readcyclecounter();
@@ -78,6 +81,20 @@ __global__ __launch_bounds__(768) void probe(double* out, long long* cyc, long l
                 if (i % 4 == 0) c0 = mf(a, b, c0); else if (i % 4 == 1) c1 = mf(a, b, c1); else if (i % 4 == 2) c2 = mf(a, b, c2); else c3 = mf(a, b, c3);
                 lds[threadIdx.x] = a1; lds[threadIdx.x + 768] = a2;
             }
+        } else if constexpr (MODE == 10) {  // one 16-byte-per-lane global store (4 rows of 256 B) per MFMA
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i % 4 == 0) c0 = mf(a, b, c0); else if (i % 4 == 1) c1 = mf(a, b, c1); else if (i % 4 == 2) c2 = mf(a, b, c2); else c3 = mf(a, b, c3);
+                d2v* dst = reinterpret_cast<d2v*>(gbuf + ((size_t)(it & 63) * 16 + i) * 4096 + (threadIdx.x >> 4) * 256 + (threadIdx.x & 15) * 2);
+                __builtin_nontemporal_store(d2v{a1, a2}, dst);
+            }
+        } else if constexpr (MODE == 11) {  // one 16-byte-per-lane global load per MFMA (consumed at the end)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i % 4 == 0) c0 = mf(a, b, c0); else if (i % 4 == 1) c1 = mf(a, b, c1); else if (i % 4 == 2) c2 = mf(a, b, c2); else c3 = mf(a, b, c3);
+                const d2v v = *reinterpret_cast<const d2v*>(gbuf + ((size_t)(it & 63) * 16 + i) * 4096 + (threadIdx.x >> 4) * 256 + (threadIdx.x & 15) * 2);
+                ld_acc.x += v.x; ld_acc.y += v.y;
+            }
         } else if constexpr (MODE == 5) {   // MFMA result straight into a VALU op and back, one at a time
 #pragma unroll
             for (int i = 0; i < 16; ++i) { c0 = mf(a, b, c0); b += c0[0]; }
@@ -88,21 +105,22 @@ __global__ __launch_bounds__(768) void probe(double* out, long long* cyc, long l
     const long long w1 = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0) wcyc[blockIdx.x * 12 + 11] = w1 - w0;     // 100 MHz
     d4 s = c0 + c1 + c2 + c3;
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s[0] + s[1] + s[2] + s[3] + k0 + f0 + f1 + lds[(threadIdx.x * 7) % 1536];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s[0] + s[1] + s[2] + s[3] + k0 + f0 + f1 + lds[(threadIdx.x * 7) % 1536] + ld_acc.x + ld_acc.y;
     // the last wave to finish counts (the oldest wave of a SIMD wins the pipe whenever it is ready)
     if ((threadIdx.x & 63) == 0) atomicMax((unsigned long long*)&cyc[blockIdx.x], (unsigned long long)(t1 - t0));
     if ((threadIdx.x & 63) == 0) wcyc[blockIdx.x * 12 + threadIdx.x / 64] = t1 - t0;
 }
 
 template <int MODE>
-static void run(const char* what, double* out, long long* cyc, long long* wcyc)
+static void run(const char* what, double* out, long long* cyc, long long* wcyc, double* gbuf = nullptr)
 {
     const int iters = 2000;
     for (int wps = 1; wps <= 3; ++wps)
         for (int grid : {1, 256}) {
-            hipLaunchKernelGGL(probe<MODE>, dim3(grid), dim3(256 * wps), 0, 0, out, cyc, wcyc, iters);
+            if (gbuf && wps > 1) continue;                // (the store / load patterns are written for 256 threads)
+            hipLaunchKernelGGL(probe<MODE>, dim3(grid), dim3(256 * wps), 0, 0, out, cyc, wcyc, iters, gbuf);
             (void)hipMemset(cyc, 0, 256 * sizeof(long long));
-            hipLaunchKernelGGL(probe<MODE>, dim3(grid), dim3(256 * wps), 0, 0, out, cyc, wcyc, iters);
+            hipLaunchKernelGGL(probe<MODE>, dim3(grid), dim3(256 * wps), 0, 0, out, cyc, wcyc, iters, gbuf);
             (void)hipDeviceSynchronize();
             long long h[256], w[12];
             (void)hipMemcpy(w, wcyc, sizeof(w), hipMemcpyDeviceToHost);
@@ -148,5 +166,10 @@ int main()
     run<8>("four independent integer VALU ops after each MFMA", out, cyc, wcyc);
     run<7>("two independent v_add_f64 after each MFMA", out, cyc, wcyc);
     run<9>("two LDS stores after each MFMA", out, cyc, wcyc);
+    double* gbuf;
+    (void)hipMalloc(&gbuf, (size_t)256 * 64 * 16 * 4096 * sizeof(double));
+    (void)hipMemset(gbuf, 0, (size_t)256 * 64 * 16 * 4096 * sizeof(double));
+    run<10>("one global store (16 B per lane, 4 rows of 256 B) per MFMA", out, cyc, wcyc, gbuf);
+    run<11>("one global load (16 B per lane) per MFMA", out, cyc, wcyc, gbuf);
     return 0;
 }
