@@ -16,7 +16,7 @@ __global__ __launch_bounds__(768) void probe(double* out, long long* cyc, long l
     unsigned k0 = threadIdx.x, k1 = 77;
     double f0 = a, f1 = b;
     __shared__ double lds[2 * 768];
-    double* gbuf = gbuf_all ? gbuf_all + (size_t)blockIdx.x * 64 * 16 * 4096 : nullptr;
+    double* gbuf = gbuf_all ? gbuf_all + (size_t)blockIdx.x * 3 * 64 * 16 * 4096 : nullptr;   // [3 groups of 256 threads][64][16][4096]
     d2v ld_acc = {0.0, 0.0};
     __syncthreads();
     const long long w0 = __builtin_amdgcn_s_memrealtime();
@@ -85,14 +85,14 @@ __global__ __launch_bounds__(768) void probe(double* out, long long* cyc, long l
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 if (i % 4 == 0) c0 = mf(a, b, c0); else if (i % 4 == 1) c1 = mf(a, b, c1); else if (i % 4 == 2) c2 = mf(a, b, c2); else c3 = mf(a, b, c3);
-                d2v* dst = reinterpret_cast<d2v*>(gbuf + ((size_t)(it & 63) * 16 + i) * 4096 + (threadIdx.x >> 4) * 256 + (threadIdx.x & 15) * 2);
+                d2v* dst = reinterpret_cast<d2v*>(gbuf + ((size_t)(threadIdx.x >> 8) * 1024 + (size_t)(it & 63) * 16 + i) * 4096 + ((threadIdx.x & 255) >> 4) * 256 + (threadIdx.x & 15) * 2);
                 __builtin_nontemporal_store(d2v{a1, a2}, dst);
             }
         } else if constexpr (MODE == 11) {  // one 16-byte-per-lane global load per MFMA (consumed at the end)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 if (i % 4 == 0) c0 = mf(a, b, c0); else if (i % 4 == 1) c1 = mf(a, b, c1); else if (i % 4 == 2) c2 = mf(a, b, c2); else c3 = mf(a, b, c3);
-                const d2v v = *reinterpret_cast<const d2v*>(gbuf + ((size_t)(it & 63) * 16 + i) * 4096 + (threadIdx.x >> 4) * 256 + (threadIdx.x & 15) * 2);
+                const d2v v = *reinterpret_cast<const d2v*>(gbuf + ((size_t)(threadIdx.x >> 8) * 1024 + (size_t)(it & 63) * 16 + i) * 4096 + ((threadIdx.x & 255) >> 4) * 256 + (threadIdx.x & 15) * 2);
                 ld_acc.x += v.x; ld_acc.y += v.y;
             }
         } else if constexpr (MODE == 5) {   // MFMA result straight into a VALU op and back, one at a time
@@ -117,7 +117,6 @@ static void run(const char* what, double* out, long long* cyc, long long* wcyc, 
     const int iters = 2000;
     for (int wps = 1; wps <= 3; ++wps)
         for (int grid : {1, 256}) {
-            if (gbuf && wps > 1) continue;                // (the store / load patterns are written for 256 threads)
             hipLaunchKernelGGL(probe<MODE>, dim3(grid), dim3(256 * wps), 0, 0, out, cyc, wcyc, iters, gbuf);
             (void)hipMemset(cyc, 0, 256 * sizeof(long long));
             hipLaunchKernelGGL(probe<MODE>, dim3(grid), dim3(256 * wps), 0, 0, out, cyc, wcyc, iters, gbuf);
@@ -167,8 +166,8 @@ int main()
     run<7>("two independent v_add_f64 after each MFMA", out, cyc, wcyc);
     run<9>("two LDS stores after each MFMA", out, cyc, wcyc);
     double* gbuf;
-    (void)hipMalloc(&gbuf, (size_t)256 * 64 * 16 * 4096 * sizeof(double));
-    (void)hipMemset(gbuf, 0, (size_t)256 * 64 * 16 * 4096 * sizeof(double));
+    (void)hipMalloc(&gbuf, (size_t)256 * 3 * 64 * 16 * 4096 * sizeof(double));
+    (void)hipMemset(gbuf, 0, (size_t)256 * 3 * 64 * 16 * 4096 * sizeof(double));
     run<10>("one global store (16 B per lane, 4 rows of 256 B) per MFMA", out, cyc, wcyc, gbuf);
     run<11>("one global load (16 B per lane) per MFMA", out, cyc, wcyc, gbuf);
     return 0;
