@@ -149,6 +149,24 @@ SIGNATURES = {
                                               c_double_p, c_stream]),
     "oovqe_newton_direction_work_size": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int]),
     "oovqe_newton_direction_max_n": (ctypes.c_int, []),
+    "oovqe_orbital_hessian_batch": (ctypes.c_int, [c_double_p] * 6 + [ctypes.c_int, ctypes.c_int,
+                                                                     ctypes.c_int, c_int32_p, c_int32_p,
+                                                                     ctypes.c_int, ctypes.c_int, c_double_p,
+                                                                     c_double_p, ctypes.c_uint, c_stream]),
+    "oovqe_circuit_hessian_batch": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                                   ctypes.c_int, ctypes.c_int, ctypes.c_uint32, c_double_p,
+                                                   c_double_p, c_int32_p, ctypes.c_int, ctypes.c_int,
+                                                   c_double_p, c_double_p, c_stream]),
+    "oovqe_oo_hessian_batch": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_uint32, c_double_p, c_double_p,
+                                              c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, c_int32_p, c_int32_p, ctypes.c_int, c_int32_p,
+                                              ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p,
+                                              ctypes.c_uint, c_double_p, c_stream]),
+    "oovqe_oo_hessian_work_size": (ctypes.c_int64, [ctypes.c_int] * 7),
+    "oovqe_rotate_orbitals_batch": (ctypes.c_int, [c_double_p, c_int32_p, c_int32_p, ctypes.c_int,
+                                                   ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
+                                                   c_double_p, c_double_p, c_stream]),
 }
 
 _lib = None

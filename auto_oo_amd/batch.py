@@ -143,13 +143,15 @@ class OO_pqc_batch:
             self._plans[key] = (work, int(osz))
         return self._plans[key]
 
-    def evaluate(self, thetas, derivatives=True, count=None, slot=0):
+    def evaluate(self, thetas, derivatives=True, count=None, slot=0, mo_coeff=None):
         """thetas [G, n_theta] (device, fp64) -> packed outputs [G, out_size]
         ([c0 | E | dE/dtheta | gvec rows | c1 | c2] per geometry, include/oovqe.h).
         ``count``: evaluate only the first ``count`` geometries of the batch.
         ``slot``: workspace slot -- calls issued on different HIP streams must use different slots
         (their kernels then overlap: the HBM-bound N^4 sweep of one call runs beside the
-        latency-bound tail kernels of the other)."""
+        latency-bound tail kernels of the other).
+        ``mo_coeff``: [G, N, N] orbitals to evaluate at instead of ``self.mo_coeff`` (rotated trial
+        orbitals of a line search)."""
         G = self.G if count is None else int(count)
         if not 1 <= G <= self.G:
             raise ValueError(f"count must be in 1..{self.G}")
@@ -160,7 +162,8 @@ class OO_pqc_batch:
         check(self.lib.oovqe_oo_eval_batch(
             dptr(thetas), self.n_theta, dptr(pqc._gates_dev, torch.uint8), pqc._n_gates,
             pqc.n_qubits, ctypes.c_uint32(pqc._init_index), dptr(self.int2e_ao),
-            dptr(self.int1e_ao), dptr(self.mo_coeff), dptr(self.nuc), self.nao, self._n_occ,
+            dptr(self.int1e_ao), dptr(self.mo_coeff if mo_coeff is None else mo_coeff), dptr(self.nuc),
+            self.nao, self._n_occ,
             self.ncas, dptr(self._kap_row, torch.int32), dptr(self._kap_col, torch.int32),
             self.n_kappa, int(bool(derivatives)), G, dptr(work), dptr(out), int(self.eri_flags),
             dptr(self._eri_packed) if self.eri_flags == 3 else None, stream_ptr()),
@@ -172,6 +175,93 @@ class OO_pqc_batch:
         out = self.evaluate(thetas, derivatives=True, count=count, slot=slot)
         return out[:, 1:2 + self.n_theta + self.n_kappa]
 
-    def energy(self, thetas):
-        """-> [G] energies (OO_pqc.energy_from_parameters per geometry)."""
-        return self.evaluate(thetas, derivatives=False)[:, 1]
+    def energy(self, thetas, kappas=None):
+        """-> [G] energies (OO_pqc.energy_from_parameters(theta, kappa) per geometry, oo_pqc.py:64-84).
+        ``kappas`` [G, n_kappa]: evaluate at the rotated orbitals mo_coeff[g] expm(-K(kappa[g])) --
+        one extra launch for all geometries (oovqe_rotate_orbitals_batch)."""
+        if kappas is None:
+            return self.evaluate(thetas, derivatives=False)[:, 1]
+        return self.evaluate(thetas, derivatives=False, mo_coeff=self.rotated_mo_coeff(kappas))[:, 1]
+
+    # ---- orbital rotations of the whole stack -------------------------------------------------------
+    def _rotate(self, C, kappas, out):
+        kappas = ops.as_device(kappas, self.device).reshape(self.G, self.n_kappa)
+        N = self.nao
+        work = None
+        if N > 48:
+            work = torch.empty((self.G + 7) * N * N, dtype=F64, device=self.device)
+        check(self.lib.oovqe_rotate_orbitals_batch(
+            dptr(kappas), dptr(self._kap_row, torch.int32), dptr(self._kap_col, torch.int32),
+            self.n_kappa, N, self.G, dptr(C), dptr(out), None, dptr(work), stream_ptr()),
+            "oovqe_rotate_orbitals_batch")
+        return out
+
+    def rotated_mo_coeff(self, kappas):
+        """[G, N, N]: mo_coeff[g] @ expm(-K(kappas[g])) (OO_energy.get_transformed_mo per geometry)."""
+        return self._rotate(self.mo_coeff, kappas, torch.empty_like(self.mo_coeff))
+
+    def rotate_(self, kappas):
+        """oao_mo_coeff[g] <- oao_mo_coeff[g] @ expm(-K(kappas[g])) for every geometry (the update of
+        oo_pqc.py:191) and mo_coeff = S^-1/2 C_oao refreshed."""
+        new = self._rotate(self.oao_mo_coeff, kappas, torch.empty_like(self.oao_mo_coeff))
+        self.oao_mo_coeff.copy_(new)
+        torch.bmm(self.oao_coeff, self.oao_mo_coeff, out=self.mo_coeff)
+
+    # ---- configs[3]'s unit of work, batched -----------------------------------------------------------
+    def energy_gradient_hessian(self, thetas):
+        """E [G], full gradient [G, n] and full Hessian [G, n, n] (n = n_theta + n_kappa) of every
+        geometry from ONE library call (``oovqe_oo_hessian_batch``): OO_pqc.full_gradient +
+        OO_pqc.full_hessian (oo_pqc.py:132-148) with the geometry index as a grid dimension of every
+        launch.  Block layout of the Hessian as the reference's: [[tt, (kt)^T], [kt, kk]]."""
+        G, nt, nk = self.G, self.n_theta, self.n_kappa
+        n = nt + nk
+        thetas = ops.as_device(thetas, self.device).reshape(G, nt)
+        pqc = self.pqc
+        pairs_dev, _, _ = ops._hessian_pair_tables(nt, self.device)
+        n_pairs = pairs_dev.shape[0]
+        key = ("hessian", 0)
+        if key not in self._plans:
+            wsz = self.lib.oovqe_oo_hessian_work_size(nt, pqc._n_gates, pqc.n_qubits, self.nao, self._n_occ,
+                                                      self.ncas, n_pairs)
+            osz = self.lib.oovqe_oo_eval_out_size(nt, nk, self.ncas, 1)
+            self._plans[key] = (torch.empty(G * wsz, dtype=F64, device=self.device), int(osz))
+        work, osz = self._plans[key]
+        out = torch.empty((G, osz), dtype=F64, device=self.device)
+        H = torch.empty((G, n, n), dtype=F64, device=self.device)
+        check(self.lib.oovqe_oo_hessian_batch(
+            dptr(thetas), nt, dptr(pqc._gates_dev, torch.uint8), pqc._n_gates, pqc.n_qubits,
+            ctypes.c_uint32(pqc._init_index), dptr(self.int2e_ao), dptr(self.int1e_ao), dptr(self.mo_coeff),
+            dptr(self.nuc), self.nao, self._n_occ, self.ncas, dptr(self._kap_row, torch.int32),
+            dptr(self._kap_col, torch.int32), nk, dptr(pairs_dev, torch.int32), n_pairs, G, dptr(work),
+            dptr(out), dptr(H), int(self.eri_flags),
+            dptr(self._eri_packed) if self.eri_flags == 3 else None, stream_ptr()), "oovqe_oo_hessian_batch")
+        return out[:, 1], out[:, 2:2 + n], H
+
+    def full_gradient(self, thetas):
+        """-> [G, n_theta + n_kappa] (OO_pqc.full_gradient per geometry, oo_pqc.py:132-134)."""
+        return self.energy_and_gradient(thetas)[:, 1:]
+
+    def full_hessian(self, thetas):
+        """-> [G, n, n] (OO_pqc.full_hessian per geometry, oo_pqc.py:136-148)."""
+        return self.energy_gradient_hessian(thetas)[2]
+
+    def damped_newton_step(self, thetas, opt=None):
+        """One damped Newton step on (theta, kappa) of EVERY geometry in lockstep -- the body of
+        OO_pqc.full_optimization / of the Berry-phase loop (oo_pqc.py:172-196), per geometry the
+        arithmetic of NewtonStep.damped_newton_step: gradient + Hessian (one call), the G directions
+        (one launch), a line search whose trials evaluate all geometries at once, then the orbitals
+        of every geometry rotated in place.  Returns (new thetas [G, n_theta], energies at the new
+        parameters [G], lowest Hessian eigenvalues [G])."""
+        from .newton_raphson import BatchedNewtonStep
+        if opt is None:
+            opt = BatchedNewtonStep(verbose=0)
+        nt = self.n_theta
+        thetas = ops.as_device(thetas, self.device).reshape(self.G, nt)
+        E, grad, H = self.energy_gradient_hessian(thetas)
+        flat = torch.cat((thetas, torch.zeros((self.G, self.n_kappa), dtype=F64, device=self.device)), dim=1)
+        new, low = opt.damped_newton_steps_flat(
+            lambda pts: self.energy(pts[:, :nt].contiguous(), pts[:, nt:].contiguous()), flat, grad, H,
+            energy0=E)
+        self.rotate_(new[:, nt:].contiguous())
+        new_thetas = new[:, :nt].contiguous()
+        return new_thetas, self.energy(new_thetas), low

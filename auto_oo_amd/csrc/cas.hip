@@ -3762,7 +3762,8 @@ static int oo_eval_batched(const double* theta, int n_theta, const oovqe_gate_t*
                            const double* C, double nuc, const double* nuc_arr, int N, int n_occ,
                            int ncas, const int32_t* kap_row, const int32_t* kap_col, int n_kappa,
                            int derivatives, int batch, double* work, double* out,
-                           unsigned eri_flags, oovqe_stream_t stream, const double* g_packed = nullptr)
+                           unsigned eri_flags, oovqe_stream_t stream, const double* g_packed = nullptr,
+                           double* fock = nullptr)
 {
     OOVQE_REQUIRE(theta && gates && g_ao && h_ao && C && work && out, "oo_eval: null pointer");
     OOVQE_REQUIRE(n_qubits == 2 * ncas, "oo_eval: n_qubits != 2*ncas");
@@ -3826,9 +3827,34 @@ static int oo_eval_batched(const double* theta, int n_theta, const oovqe_gate_t*
     double* c1 = gvec + (size_t)nvec * n_kappa;
     double* c2 = c1 + na2;
     return cas_eval_batched(g_ao, h_ao, C, gamma, Gamma, nvec, nuc, nuc_arr, N, n_occ, ncas, kap_row,
-                            kap_col, n_kappa, cas_work, c0, c1, c2, E, gvec, dE, nullptr, nullptr,
+                            kap_col, n_kappa, cas_work, c0, c1, c2, E, gvec, dE, fock, nullptr,
                             nullptr, nullptr, batch, out_stride, stream, ride ? &cj : nullptr, eri_flags,
                             g_packed);
+}
+
+// hessian.hip (oovqe_oo_hessian_batch): the batched evaluation with the generalized Fock matrices
+// [G][N][N] as an extra output; the RDM sets stay at the head of `work` (gamma [G][nvec][a^2], then
+// Gamma [G][nvec][a^4]) for the orbital-Hessian stage that follows.
+int oovqe_oo_eval_batched_impl(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
+                               int n_qubits, uint32_t init_index, const double* g_ao, const double* h_ao,
+                               const double* C, const double* nuc_arr, int N, int n_occ, int ncas,
+                               const int32_t* kap_row, const int32_t* kap_col, int n_kappa, int derivatives,
+                               int batch, double* work, double* out, unsigned eri_flags,
+                               oovqe_stream_t stream, const double* g_packed, double* fock)
+{
+    return oo_eval_batched(theta, n_theta, gates, n_gates, n_qubits, init_index, g_ao, h_ao, C, 0.0, nuc_arr,
+                           N, n_occ, ncas, kap_row, kap_col, n_kappa, derivatives, batch, work, out,
+                           eri_flags, stream, g_packed, fock);
+}
+
+// hessian.hip: stage 1 (T2[p,q,y,z]) for a stack of geometries, reading only the slabs p <= q when the
+// caller vouches for the p<->q symmetry
+int oovqe_half_transform_batched_impl(const double* g_ao, const double* C, int N, int M, double* T2,
+                                      int batch, unsigned eri_flags, oovqe_stream_t stream)
+{
+    const bool pq = (eri_flags & OOVQE_ERI_PQ_SYMMETRIC) != 0;
+    const bool rs = (eri_flags & OOVQE_ERI_RS_SYMMETRIC) != 0 && oovqe_opt(OOVQE_OPT_SYM_NO_RS) == 0;
+    return half_transform_batched(g_ao, C, N, M, T2, batch, stream, pq ? SYM_MIRROR : SYM_FULL, rs);
 }
 
 extern "C" int oovqe_oo_eval(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,

@@ -354,15 +354,17 @@ __device__ void apply_gate_mode(double* st, uint32_t D, const oovqe_gate_t& g, d
 // grid = npairs; pair (j,k): out[pair] = sum over gates g1 driven by theta_j, g2 driven by theta_k
 // of the circuit with g1 and g2 differentiated (g1 == g2: second derivative of that gate).
 __global__ __launch_bounds__(CIRC_THREADS)
-void circuit_second_tangent_kernel(const double* __restrict__ theta,
+void circuit_second_tangent_kernel(const double* __restrict__ theta, int n_theta,
                                    const oovqe_gate_t* __restrict__ gates, int n_gates, int n_qubits,
                                    uint32_t init_index, const int32_t* __restrict__ pairs,
                                    double* __restrict__ out, double* __restrict__ scratch)
 {
     const uint32_t D = 1u << n_qubits;
     const int j = pairs[2 * blockIdx.x], k = pairs[2 * blockIdx.x + 1];
-    double* dst = out + (size_t)blockIdx.x * D;
-    double* w = scratch + (size_t)blockIdx.x * D;
+    // blockIdx.y = element of a batch: theta [batch][n_theta], out / scratch [batch][n_pairs][D]
+    theta += (size_t)blockIdx.y * n_theta;
+    double* dst = out + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * D;
+    double* w = scratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * D;
     for (uint32_t x = threadIdx.x; x < D; x += CIRC_THREADS) dst[x] = 0.0;
     __syncthreads();
     for (int g1 = 0; g1 < n_gates; ++g1) {
@@ -390,15 +392,21 @@ void circuit_second_tangent_kernel(const double* __restrict__ theta,
 __global__ __launch_bounds__(256)
 void circuit_hessian_kernel(const double* __restrict__ gamma, const double* __restrict__ Gamma,
                             const double* __restrict__ c1, const double* __restrict__ c2, int ncas,
-                            const int32_t* __restrict__ pairs, int n_theta, double* __restrict__ H)
+                            const int32_t* __restrict__ pairs, int n_theta, double* __restrict__ H,
+                            long c1_bs, long c2_bs, long ldh, long h_bs)
 {
     __shared__ double red[256];
     const int na2 = ncas * ncas, na4 = na2 * na2;
     const int pr = blockIdx.x, tid = threadIdx.x;
+    // blockIdx.y = element of a batch: RDM sets [batch][n_pairs][4], c1 / c2 / H with batch strides
+    const size_t prb = (size_t)blockIdx.y * gridDim.x + pr;
+    c1 += (size_t)blockIdx.y * c1_bs;
+    c2 += (size_t)blockIdx.y * c2_bs;
+    H += (size_t)blockIdx.y * h_bs;
     double acc = 0.0;
     for (int set = 0; set < 4; ++set) {
-        const double* g1 = gamma + ((size_t)pr * 4 + set) * na2;
-        const double* g2 = Gamma + ((size_t)pr * 4 + set) * na4;
+        const double* g1 = gamma + (prb * 4 + set) * na2;
+        const double* g2 = Gamma + (prb * 4 + set) * na4;
         for (int i = tid; i < na2; i += 256) acc += c1[i] * g1[i];
         for (int i = tid; i < na4; i += 256) acc += c2[i] * g2[i];
     }
@@ -410,8 +418,8 @@ void circuit_hessian_kernel(const double* __restrict__ gamma, const double* __re
     }
     if (tid == 0) {
         const int j = pairs[2 * pr], k = pairs[2 * pr + 1];
-        H[(size_t)j * n_theta + k] = red[0];
-        H[(size_t)k * n_theta + j] = red[0];
+        H[(size_t)j * ldh + k] = red[0];
+        H[(size_t)k * ldh + j] = red[0];
     }
 }
 
@@ -420,16 +428,21 @@ void circuit_hessian_kernel(const double* __restrict__ gamma, const double* __re
 __global__ __launch_bounds__(256)
 void hessian_operands_kernel(const double* __restrict__ psi, const double* __restrict__ dpsi,
                              const double* __restrict__ psi2, const int32_t* __restrict__ pairs,
-                             unsigned D, double* __restrict__ bra, double* __restrict__ ket)
+                             unsigned D, int n_theta, double* __restrict__ bra, double* __restrict__ ket)
 {
     const unsigned x = blockIdx.x * 256 + threadIdx.x;
     if (x >= D) return;
     const int row = blockIdx.y, pr = row >> 2, set = row & 3;
+    // blockIdx.z = element of a batch: psi [batch][D], dpsi [batch][n_theta][D], psi2 [batch][n_pairs][D]
+    const size_t b = blockIdx.z, n_rows = gridDim.y;
+    psi += b * D;
+    dpsi += b * n_theta * D;
+    psi2 += b * (n_rows >> 2) * D;
     const int j = pairs[2 * pr], k = pairs[2 * pr + 1];
     const double p0 = psi[x], p2 = psi2[(size_t)pr * D + x];
     const double pj = dpsi[(size_t)j * D + x], pk = dpsi[(size_t)k * D + x];
-    bra[(size_t)row * D + x] = set == 0 ? p2 : set == 1 ? pj : set == 2 ? pk : p0;
-    ket[(size_t)row * D + x] = set == 0 ? p0 : set == 1 ? pk : set == 2 ? pj : p2;
+    bra[(b * n_rows + row) * D + x] = set == 0 ? p2 : set == 1 ? pj : set == 2 ? pk : p0;
+    ket[(b * n_rows + row) * D + x] = set == 0 ? p0 : set == 1 ? pk : set == 2 ? pj : p2;
 }
 
 }  // namespace
@@ -565,7 +578,7 @@ extern "C" int oovqe_circuit_second_tangents(const double* theta, int n_theta,
     OOVQE_REQUIRE(n_qubits >= 2 && n_qubits <= 26 && n_pairs >= 1 && n_gates >= 1 && n_theta >= 1,
                   "second_tangents: bad sizes");
     hipLaunchKernelGGL(circuit_second_tangent_kernel, dim3(n_pairs), dim3(CIRC_THREADS), 0,
-                       (hipStream_t)stream, theta, gates, n_gates, n_qubits, init_index, pairs, out,
+                       (hipStream_t)stream, theta, n_theta, gates, n_gates, n_qubits, init_index, pairs, out,
                        scratch);
     OOVQE_CHECK_LAUNCH("second_tangents");
     return 0;
@@ -578,7 +591,7 @@ extern "C" int oovqe_circuit_hessian_assemble(const double* gamma, const double*
 {
     OOVQE_REQUIRE(gamma && Gamma && c1 && c2 && pairs && H, "circuit_hessian: null pointer");
     hipLaunchKernelGGL(circuit_hessian_kernel, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream,
-                       gamma, Gamma, c1, c2, ncas, pairs, n_theta, H);
+                       gamma, Gamma, c1, c2, ncas, pairs, n_theta, H, 0L, 0L, (long)n_theta, 0L);
     OOVQE_CHECK_LAUNCH("circuit_hessian");
     return 0;
 }
@@ -596,32 +609,63 @@ extern "C" int64_t oovqe_circuit_hessian_work_size(int n_theta, int n_qubits, in
            4 * n_pairs * 2 * na2 * D;
 }
 
+// batch elements stacked: theta [batch][n_theta]; c1 / c2 of element b at c1 + b * c1_bs, c2 + b * c2_bs;
+// H element (j,k) of b at H[b * h_bs + j * ldh + k]; work: batch * oovqe_circuit_hessian_work_size()
+int oovqe_circuit_hessian_batched_impl(const double* theta, int n_theta, const oovqe_gate_t* gates,
+                                       int n_gates, int n_qubits, int ncas, uint32_t init_index,
+                                       const double* c1, const double* c2, long c1_bs, long c2_bs,
+                                       const int32_t* pairs, int n_pairs, int batch, double* work, double* H,
+                                       long ldh, long h_bs, oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(theta && gates && c1 && c2 && pairs && work && H, "circuit_hessian: null pointer");
+    OOVQE_REQUIRE(n_pairs >= 1 && 4 * n_pairs <= 65535, "circuit_hessian: n_pairs=%d", n_pairs);
+    OOVQE_REQUIRE(batch >= 1 && (long)batch * 4 * n_pairs <= 65535, "circuit_hessian: batch=%d", batch);
+    const size_t D = (size_t)1 << n_qubits, na2 = (size_t)ncas * ncas, nb = (size_t)batch;
+    double* psi = work;                                       // [G][D]
+    double* dpsi = psi + nb * D;                              // [G][n_theta][D]
+    double* psi2 = dpsi + nb * n_theta * D;                   // [G][n_pairs][D]
+    double* scratch = psi2 + nb * n_pairs * D;                // [G][n_pairs][D]
+    double* bra = scratch + nb * n_pairs * D;                 // [G][4 n_pairs][D]
+    double* ket = bra + 4 * nb * n_pairs * D;
+    double* g1 = ket + 4 * nb * n_pairs * D;                  // [G][4 n_pairs][a^2]
+    double* g2 = g1 + 4 * nb * n_pairs * na2;                 // [G][4 n_pairs][a^4]
+    double* rwork = g2 + 4 * nb * n_pairs * na2 * na2;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = oovqe_circuit_state(theta, n_theta, gates, n_gates, n_qubits, init_index, batch, psi, dpsi, stream)))
+        return rc;
+    OOVQE_REQUIRE(n_qubits >= 2 && n_qubits <= 26 && n_gates >= 1 && n_theta >= 1, "circuit_hessian: bad sizes");
+    hipLaunchKernelGGL(circuit_second_tangent_kernel, dim3(n_pairs, batch), dim3(CIRC_THREADS), 0, st, theta,
+                       n_theta, gates, n_gates, n_qubits, init_index, pairs, psi2, scratch);
+    OOVQE_CHECK_LAUNCH("circuit_hessian/second_tangents");
+    hipLaunchKernelGGL(hessian_operands_kernel,
+                       dim3((unsigned)((D + 255) / 256), (unsigned)(4 * n_pairs), (unsigned)batch), dim3(256), 0,
+                       st, psi, dpsi, psi2, pairs, (unsigned)D, n_theta, bra, ket);
+    OOVQE_CHECK_LAUNCH("circuit_hessian/operands");
+    if ((rc = oovqe_rdms(bra, ket, n_qubits, ncas, 4 * n_pairs * batch, g1, g2, rwork, stream))) return rc;
+    hipLaunchKernelGGL(circuit_hessian_kernel, dim3(n_pairs, batch), dim3(256), 0, st, g1, g2, c1, c2, ncas,
+                       pairs, n_theta, H, c1_bs, c2_bs, ldh, h_bs);
+    OOVQE_CHECK_LAUNCH("circuit_hessian");
+    return 0;
+}
+
 extern "C" int oovqe_circuit_hessian(const double* theta, int n_theta, const oovqe_gate_t* gates,
                                      int n_gates, int n_qubits, int ncas, uint32_t init_index,
                                      const double* c1, const double* c2, const int32_t* pairs,
                                      int n_pairs, double* work, double* H, oovqe_stream_t stream)
 {
-    OOVQE_REQUIRE(theta && gates && c1 && c2 && pairs && work && H, "circuit_hessian: null pointer");
-    OOVQE_REQUIRE(n_pairs >= 1 && 4 * n_pairs <= 65535, "circuit_hessian: n_pairs=%d", n_pairs);
-    const size_t D = (size_t)1 << n_qubits, na2 = (size_t)ncas * ncas;
-    double* psi = work;
-    double* dpsi = psi + D;
-    double* psi2 = dpsi + (size_t)n_theta * D;
-    double* scratch = psi2 + (size_t)n_pairs * D;
-    double* bra = scratch + (size_t)n_pairs * D;
-    double* ket = bra + 4 * (size_t)n_pairs * D;
-    double* g1 = ket + 4 * (size_t)n_pairs * D;
-    double* g2 = g1 + 4 * (size_t)n_pairs * na2;
-    double* rwork = g2 + 4 * (size_t)n_pairs * na2 * na2;
-    int rc;
-    if ((rc = oovqe_circuit_state(theta, n_theta, gates, n_gates, n_qubits, init_index, 1, psi, dpsi, stream)))
-        return rc;
-    if ((rc = oovqe_circuit_second_tangents(theta, n_theta, gates, n_gates, n_qubits, init_index, pairs,
-                                            n_pairs, psi2, scratch, stream)))
-        return rc;
-    hipLaunchKernelGGL(hessian_operands_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)(4 * n_pairs)),
-                       dim3(256), 0, (hipStream_t)stream, psi, dpsi, psi2, pairs, (unsigned)D, bra, ket);
-    OOVQE_CHECK_LAUNCH("circuit_hessian/operands");
-    if ((rc = oovqe_rdms(bra, ket, n_qubits, ncas, 4 * n_pairs, g1, g2, rwork, stream))) return rc;
-    return oovqe_circuit_hessian_assemble(g1, g2, c1, c2, ncas, pairs, n_pairs, n_theta, H, stream);
+    return oovqe_circuit_hessian_batched_impl(theta, n_theta, gates, n_gates, n_qubits, ncas, init_index, c1, c2,
+                                              0, 0, pairs, n_pairs, 1, work, H, n_theta, 0, stream);
+}
+
+extern "C" int oovqe_circuit_hessian_batch(const double* theta, int n_theta, const oovqe_gate_t* gates,
+                                           int n_gates, int n_qubits, int ncas, uint32_t init_index,
+                                           const double* c1, const double* c2, const int32_t* pairs,
+                                           int n_pairs, int batch, double* work, double* H,
+                                           oovqe_stream_t stream)
+{
+    const long na2 = (long)ncas * ncas;
+    return oovqe_circuit_hessian_batched_impl(theta, n_theta, gates, n_gates, n_qubits, ncas, init_index, c1, c2,
+                                              na2, na2 * na2, pairs, n_pairs, batch, work, H, n_theta,
+                                              (long)n_theta * n_theta, stream);
 }

@@ -73,8 +73,18 @@ __global__ __launch_bounds__(EX_THREADS)
 void expm_small_kernel(const double* __restrict__ X, const double* __restrict__ kappa,
                        const int32_t* __restrict__ kap_row, const int32_t* __restrict__ kap_col,
                        int n_kappa, double sign, int N, double* __restrict__ Kout,
-                       double* __restrict__ U)
+                       double* __restrict__ U, const double* __restrict__ Cin, double* __restrict__ Cout)
 {
+    // blockIdx.x = element of a batch: every array advances by its own size
+    {
+        const size_t b = blockIdx.x, n2 = (size_t)N * N;
+        if (X) X += b * n2;
+        if (kappa) kappa += b * n_kappa;
+        if (Kout) Kout += b * n2;
+        if (U) U += b * n2;
+        if (Cin) Cin += b * n2;
+        if (Cout) Cout += b * n2;
+    }
     extern __shared__ double lds[];
     __shared__ double colsum[SMALL_MAX];
     __shared__ int s_shared, m_shared;
@@ -152,9 +162,23 @@ void expm_small_kernel(const double* __restrict__ X, const double* __restrict__ 
         lds_matmul(cur, cur, oth, nt, ksteps, LD);
         double* tmp = cur; cur = oth; oth = tmp;
     }
-    for (int idx = tid; idx < N * N; idx += EX_THREADS) {
-        const int r = idx / N, c = idx - r * N;
-        U[idx] = cur[r * LD + c];
+    if (U)
+        for (int idx = tid; idx < N * N; idx += EX_THREADS) {
+            const int r = idx / N, c = idx - r * N;
+            U[idx] = cur[r * LD + c];
+        }
+    if (Cout) {
+        // rotated orbitals Cout = Cin expm(sign X) (oo_energy.py:232-236) without leaving LDS
+        for (int idx = tid; idx < N * N; idx += EX_THREADS) {
+            const int r = idx / N, c = idx - r * N;
+            A[r * LD + c] = Cin[idx];
+        }
+        __syncthreads();
+        lds_matmul(A, cur, oth, nt, ksteps, LD);
+        for (int idx = tid; idx < N * N; idx += EX_THREADS) {
+            const int r = idx / N, c = idx - r * N;
+            Cout[idx] = oth[r * LD + c];
+        }
     }
 }
 
@@ -288,7 +312,8 @@ int expm_large(const double* X, double sign, int N, double* U, double* work, hip
 }
 
 int expm_small(const double* X, const double* kappa, const int32_t* kap_row, const int32_t* kap_col,
-               int n_kappa, double sign, int N, double* Kout, double* U, hipStream_t st)
+               int n_kappa, double sign, int N, double* Kout, double* U, hipStream_t st, int batch = 1,
+               const double* Cin = nullptr, double* Cout = nullptr)
 {
     const int nt = (N + 15) / 16, NP = nt * 16, LD = NP + 2;
     const size_t lds_bytes = (size_t)6 * NP * LD * sizeof(double);
@@ -302,8 +327,8 @@ int expm_small(const double* X, const double* kappa, const int32_t* kap_row, con
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL(expm_small_kernel, dim3(1), dim3(EX_THREADS), lds_bytes, st, X, kappa,
-                       kap_row, kap_col, n_kappa, sign, N, Kout, U);
+    hipLaunchKernelGGL(expm_small_kernel, dim3(batch), dim3(EX_THREADS), lds_bytes, st, X, kappa,
+                       kap_row, kap_col, n_kappa, sign, N, Kout, U, Cin, Cout);
     OOVQE_CHECK_LAUNCH("expm_small");
     return 0;
 }
@@ -343,4 +368,38 @@ extern "C" int oovqe_expm_skew(const double* kappa, const int32_t* kap_row, cons
         scatter_skew_kernel<<<(n_kappa + 255) / 256, 256, 0, st>>>(kappa, kap_row, kap_col, n_kappa,
                                                                   N, Kbuf);
     return expm_large(Kbuf, -1.0, N, U, work, st);
+}
+
+// Orbital rotation of a stack of geometries in ONE launch (OO_energy.get_transformed_mo,
+// src/auto_oo/oo_energy.py:213-236, per geometry): C_out[b] = C[b] expm(-K(kappa[b])).
+// kappa [batch][n_kappa], C / C_out [batch][N][N] (C_out may alias C), U [batch][N][N] or NULL.
+// N <= 48: one workgroup per geometry, everything in LDS.
+int oovqe_mode_contract_batched(const double* T, const double* Cm, double* out, long A, int K, int J,
+                                long B, int ldc, int last, int batch, long t_bs, long c_bs, long o_bs,
+                                hipStream_t st);
+
+extern "C" int oovqe_rotate_orbitals_batch(const double* kappa, const int32_t* kap_row,
+                                           const int32_t* kap_col, int n_kappa, int N, int batch,
+                                           const double* C, double* C_out, double* U, double* work,
+                                           oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(kappa && kap_row && kap_col && C && C_out, "rotate_orbitals_batch: null pointer");
+    OOVQE_REQUIRE(N >= 1 && N <= 4096 && n_kappa >= 0 && batch >= 1 && batch <= 65535,
+                  "rotate_orbitals_batch: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= SMALL_MAX)
+        return expm_small(nullptr, kappa, kap_row, kap_col, n_kappa, -1.0, N, nullptr, U, st, batch, C, C_out);
+    // larger orbital spaces: one expm per geometry through the multi-launch path, then one batched product
+    OOVQE_REQUIRE(work, "rotate_orbitals_batch: work (batch*N*N + 7*N*N doubles) required for N > %d", SMALL_MAX);
+    OOVQE_REQUIRE(C_out != C, "rotate_orbitals_batch: C_out must not alias C for N > %d", SMALL_MAX);
+    const size_t n2 = (size_t)N * N;
+    double* Ub = U ? U : work;                 // [batch][N][N]
+    double* ew = work + (size_t)batch * n2;    // 7 N^2 scratch of oovqe_expm_skew
+    int rc;
+    for (int b = 0; b < batch; ++b)
+        if ((rc = oovqe_expm_skew(kappa + (size_t)b * n_kappa, kap_row, kap_col, n_kappa, N, nullptr,
+                                  Ub + (size_t)b * n2, ew, stream)))
+            return rc;
+    // C_out[b] = C[b] U[b]  (LAST-mode contraction: T = C [N,N], Cm = U)
+    return oovqe_mode_contract_batched(C, Ub, C_out, N, N, N, 1, N, 1, batch, (long)n2, (long)n2, (long)n2, st);
 }

@@ -36,11 +36,17 @@ __device__ __forceinline__ double gamma2_full(int p, int m, int r, int n, int no
 }
 
 // At[(m,n),(p,r)] = Gam_pmrn + Gam_pmnr ;  Bt[(m,n),(p,r)] = Gam_prmn      (all indices < M)
+// blockIdx.y = geometry of a batch (gam / Gam / At / Bt advance by their batch strides)
 __global__ void hess_ab_kernel(const double* __restrict__ gam, const double* __restrict__ Gam,
-                               int no, int na, double* __restrict__ At, double* __restrict__ Bt)
+                               int no, int na, double* __restrict__ At, double* __restrict__ Bt,
+                               long gam_bs, long Gam_bs)
 {
     const int M = no + na;
     const long total = (long)M * M * M * M;
+    gam += (size_t)blockIdx.y * gam_bs;
+    Gam += (size_t)blockIdx.y * Gam_bs;
+    At += (size_t)blockIdx.y * total;
+    Bt += (size_t)blockIdx.y * total;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long)gridDim.x * blockDim.x) {
         long t = idx;
@@ -60,7 +66,19 @@ struct HessArgs {
     const double* fock;   // [N][N] generalized Fock (rows >= M are zero)
     const double* gam;    // [na][na]
     int N, no, na;
+    // batch strides (doubles) of the five arrays above; geometry = blockIdx.y
+    long y_bs, h_bs, f_bs, g_bs;
 };
+
+__device__ __forceinline__ HessArgs hess_batch_slice(HessArgs a, unsigned b)
+{
+    a.YkT += (size_t)b * a.y_bs;
+    a.YjT += (size_t)b * a.y_bs;
+    a.hmo += (size_t)b * a.h_bs;
+    a.fock += (size_t)b * a.f_bs;
+    a.gam += (size_t)b * a.g_bs;
+    return a;
+}
 
 __device__ __forceinline__ double hess_x(const HessArgs& a, int p, int q, int r, int s)
 {
@@ -79,18 +97,21 @@ __device__ __forceinline__ double hess_x(const HessArgs& a, int p, int q, int r,
     return x;
 }
 
-// H[t1,t2] on the non-redundant (row>col) pairs
-__global__ void hess_matrix_kernel(HessArgs a, const int32_t* __restrict__ kap_row,
+// H[t1,t2] on the non-redundant (row>col) pairs; element (t1,t2) of geometry b goes to
+// H[b * h_out_bs + t1 * ldh + t2] (a block of a larger matrix when ldh > n_kappa)
+__global__ void hess_matrix_kernel(HessArgs a0, const int32_t* __restrict__ kap_row,
                                    const int32_t* __restrict__ kap_col, int n_kappa,
-                                   double* __restrict__ H)
+                                   double* __restrict__ H, long ldh, long h_out_bs)
 {
+    const HessArgs a = hess_batch_slice(a0, blockIdx.y);
+    H += (size_t)blockIdx.y * h_out_bs;
     const long total = (long)n_kappa * n_kappa;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long)gridDim.x * blockDim.x) {
         const int t1 = (int)(idx / n_kappa), t2 = (int)(idx - (long)t1 * n_kappa);
         const int p = kap_row[t1], q = kap_col[t1], r = kap_row[t2], s = kap_col[t2];
-        H[idx] = hess_x(a, p, q, r, s) - hess_x(a, p, q, s, r) - hess_x(a, q, p, r, s) +
-                 hess_x(a, q, p, s, r);
+        H[(size_t)t1 * ldh + t2] = hess_x(a, p, q, r, s) - hess_x(a, p, q, s, r) - hess_x(a, q, p, r, s) +
+                                   hess_x(a, q, p, s, r);
     }
 }
 
@@ -111,6 +132,23 @@ __global__ void hess_full_kernel(HessArgs a, double* __restrict__ H)
     }
 }
 
+// kappa-theta block of the full Hessian from the packed evaluation output (gvec rows k >= 1 =
+// d G_kappa / d theta_k, oo_pqc.py:113-125,141-148): H[nt + i][k] = H[k][nt + i] = gvec[1 + k][i]
+__global__ void hess_cross_block_kernel(const double* __restrict__ gvec, long gvec_bs, int n_theta,
+                                        int n_kappa, double* __restrict__ H, long ldh, long h_bs)
+{
+    gvec += (size_t)blockIdx.y * gvec_bs;
+    H += (size_t)blockIdx.y * h_bs;
+    const long total = (long)n_theta * n_kappa;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx / n_kappa), i = (int)(idx - (long)k * n_kappa);
+        const double v = gvec[(size_t)(1 + k) * n_kappa + i];
+        H[(size_t)(n_theta + i) * ldh + k] = v;
+        H[(size_t)k * ldh + n_theta + i] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t oovqe_orbital_hessian_work_size(int N, int n_occ, int ncas)
@@ -121,8 +159,84 @@ extern "C" int64_t oovqe_orbital_hessian_work_size(int N, int n_occ, int ncas)
     return 8 * n * n * M * M + n * n * n * M + 2 * n * n + 2 * M * M * M * M;
 }
 
-extern "C" int oovqe_cas_half_transform(const double* g_ao, const double* C, int N, int M, double* T2,
-                                        oovqe_stream_t stream);
+// cas.hip: stage 1 for a stack of geometries (slabs p <= q only when the flags allow it)
+int oovqe_half_transform_batched_impl(const double* g_ao, const double* C, int N, int M, double* T2,
+                                      int batch, unsigned eri_flags, oovqe_stream_t stream);
+int oovqe_mode_contract_batched(const double* T, const double* Cm, double* out, long A, int K, int J,
+                                long B, int ldc, int last, int batch, long t_bs, long c_bs, long o_bs,
+                                hipStream_t st);
+
+// The orbital-orbital Hessian for `batch` geometries of identical shape: every input stacked along a
+// leading batch axis with the given strides (doubles), every intermediate stacked in `work`
+// (batch * oovqe_orbital_hessian_work_size() doubles); the geometry index is a grid dimension of
+// every launch.  H_matrix element (t1,t2) of geometry b -> H_matrix[b * h_bs + t1 * ldh + t2].
+static int orbital_hessian_batched(const double* g_ao, const double* h_ao, const double* C,
+                                   const double* gamma, long gamma_bs, const double* Gamma, long Gamma_bs,
+                                   const double* fock, int N, int n_occ, int ncas, const int32_t* kap_row,
+                                   const int32_t* kap_col, int n_kappa, int batch, double* work,
+                                   double* H_matrix, long ldh, long h_bs, double* H_full,
+                                   unsigned eri_flags, oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(g_ao && h_ao && C && gamma && Gamma && fock && work, "orbital_hessian: null pointer");
+    OOVQE_REQUIRE(H_matrix || H_full, "orbital_hessian: no output requested");
+    OOVQE_REQUIRE(!H_matrix || (kap_row && kap_col && n_kappa > 0), "orbital_hessian: index tables");
+    OOVQE_REQUIRE(N >= 1 && n_occ >= 0 && ncas >= 1 && n_occ + ncas <= N, "orbital_hessian: sizes");
+    OOVQE_REQUIRE(batch >= 1 && batch <= 65535 && (batch == 1 || !H_full), "orbital_hessian: batch=%d", batch);
+    hipStream_t st = (hipStream_t)stream;
+    const int M = n_occ + ncas;
+    const long n = N, m2 = (long)M * M, n2 = n * n;
+    const size_t nb = (size_t)batch;
+    // every block stacked over the batch
+    double* T2 = work;                      // [G][N][N][M][M]
+    double* Uj = T2 + nb * n2 * m2;         // [G][N][N][M*M]
+    double* Jint = Uj + nb * n2 * m2;       // [G][N][N][M*M]      g_mo[q,s,m,n]
+    double* Vk = Jint + nb * n2 * m2;       // [G][N][N][M][N]
+    double* T2K = Vk + nb * n2 * n * M;     // [G][N][M][M][N]
+    double* W = T2K + nb * n2 * m2;         // [G][N][M][M][N]
+    double* Kint = W + nb * n2 * m2;        // [G][N][M][M][N]     g_mo[q,m,n,s]
+    double* X1 = Kint + nb * n2 * m2;       // [G][N][N]
+    double* hmo = X1 + nb * n2;             // [G][N][N]
+    double* At = hmo + nb * n2;             // [G][M*M][M*M]
+    double* Bt = At + nb * m2 * m2;         // [G][M*M][M*M]
+    double* YkT = Bt + nb * m2 * m2;        // [G][N][M*M][N]
+    double* YjT = YkT + nb * n2 * m2;       // [G][N][N][M*M]
+    int rc;
+    const long t4 = n2 * n2, y = n2 * m2;
+#define MC(T_, tb, C_, cb, O_, ob, ...) \
+    if ((rc = oovqe_mode_contract_batched(T_, C_, O_, __VA_ARGS__, batch, tb, cb, ob, st))) return rc
+    // ---- J-type integrals: g_mo[q,s,m,n] ---------------------------------------------------------
+    if ((rc = oovqe_half_transform_batched_impl(g_ao, C, N, M, T2, batch, eri_flags, stream))) return rc;
+    MC(T2, y, C, n2, Uj, y, 1, N, N, n * m2, N, 0);          // Uj[q',q,yz]  = sum_p C[p,q'] T2[p,q,yz]
+    MC(Uj, y, C, n2, Jint, y, n, N, N, m2, N, 0);            // Jint[q',s',yz] = sum_q C[q,s'] Uj[q',q,yz]
+    // ---- K-type integrals: g_mo[q,m,n,s] ---------------------------------------------------------
+    MC(g_ao, t4, C, n2, Vk, n2 * n * M, n2, N, M, n, N, 0);  // Vk[p,q,n,s]  = sum_r C[r,n] g[p,q,r,s]
+    MC(Vk, n2 * n * M, C, n2, T2K, y, n, N, M, (long)M * n, N, 0);   // T2K[p,m,n,s] = sum_q C[q,m] Vk[p,q,n,s]
+    MC(T2K, y, C, n2, W, y, n * m2, N, N, 1, N, 1);          // W[p,m,n,s']  = sum_s T2K[p,m,n,s] C[s,s']
+    MC(W, y, C, n2, Kint, y, 1, N, N, m2 * n, N, 0);         // Kint[q',m,n,s'] = sum_p C[p,q'] W[p,m,n,s']
+    // ---- one-electron integrals ------------------------------------------------------------------
+    MC(h_ao, n2, C, n2, X1, n2, 1, N, N, n, N, 0);           // X1 = C^T h
+    MC(X1, n2, C, n2, hmo, n2, n, N, N, 1, N, 1);            // hmo = X1 C
+    // ---- Y ------------------------------------------------------------------------------------------
+    hess_ab_kernel<<<dim3(64, batch), 256, 0, st>>>(gamma, Gamma, n_occ, ncas, At, Bt, gamma_bs, Gamma_bs);
+    // YkT[q,(pr),s] = sum_(mn) At[(mn),(pr)] Kint[q,(mn),s]
+    MC(Kint, y, At, m2 * m2, YkT, y, n, (int)m2, (int)m2, n, (int)m2, 0);
+    // YjT[(qs),(pr)] = sum_(mn) Jint[(qs),(mn)] Bt[(mn),(pr)]
+    MC(Jint, y, Bt, m2 * m2, YjT, y, n2, (int)m2, (int)m2, 1, (int)m2, 1);
+#undef MC
+    HessArgs a{YkT, YjT, hmo, fock, gamma, N, n_occ, ncas, y, n2, n2, gamma_bs};
+    if (H_matrix) {
+        const long total = (long)n_kappa * n_kappa;
+        const unsigned nbk = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hess_matrix_kernel<<<dim3(nbk, batch), 256, 0, st>>>(a, kap_row, kap_col, n_kappa, H_matrix, ldh, h_bs);
+    }
+    if (H_full) {
+        const long total = n2 * n2;
+        const unsigned nbk = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        hess_full_kernel<<<nbk, 256, 0, st>>>(a, H_full);
+    }
+    OOVQE_CHECK_LAUNCH("orbital_hessian");
+    return 0;
+}
 
 extern "C" int oovqe_orbital_hessian(const double* g_ao, const double* h_ao, const double* C,
                                      const double* gamma, const double* Gamma, const double* fock,
@@ -130,58 +244,96 @@ extern "C" int oovqe_orbital_hessian(const double* g_ao, const double* h_ao, con
                                      const int32_t* kap_col, int n_kappa, double* work,
                                      double* H_matrix, double* H_full, oovqe_stream_t stream)
 {
-    OOVQE_REQUIRE(g_ao && h_ao && C && gamma && Gamma && fock && work, "orbital_hessian: null pointer");
-    OOVQE_REQUIRE(H_matrix || H_full, "orbital_hessian: no output requested");
-    OOVQE_REQUIRE(!H_matrix || (kap_row && kap_col && n_kappa > 0), "orbital_hessian: index tables");
-    OOVQE_REQUIRE(N >= 1 && n_occ >= 0 && ncas >= 1 && n_occ + ncas <= N, "orbital_hessian: sizes");
-    hipStream_t st = (hipStream_t)stream;
-    const int M = n_occ + ncas;
-    const long n = N, m2 = (long)M * M, n2 = n * n;
-    double* T2 = work;                 // [N][N][M][M]
-    double* Uj = T2 + n2 * m2;         // [N][N][M*M]
-    double* Jint = Uj + n2 * m2;       // [N][N][M*M]      g_mo[q,s,m,n]
-    double* Vk = Jint + n2 * m2;       // [N][N][M][N]
-    double* T2K = Vk + n2 * n * M;     // [N][M][M][N]
-    double* W = T2K + n2 * m2;         // [N][M][M][N]
-    double* Kint = W + n2 * m2;        // [N][M][M][N]     g_mo[q,m,n,s]
-    double* X1 = Kint + n2 * m2;       // [N][N]
-    double* hmo = X1 + n2;             // [N][N]
-    double* At = hmo + n2;             // [M*M][M*M]
-    double* Bt = At + m2 * m2;         // [M*M][M*M]
-    double* YkT = Bt + m2 * m2;        // [N][M*M][N]
-    double* YjT = YkT + n2 * m2;       // [N][N][M*M]
+    return orbital_hessian_batched(g_ao, h_ao, C, gamma, 0, Gamma, 0, fock, N, n_occ, ncas, kap_row, kap_col,
+                                   n_kappa, 1, work, H_matrix, n_kappa, 0, H_full, 0, stream);
+}
+
+extern "C" int oovqe_orbital_hessian_batch(const double* g_ao, const double* h_ao, const double* C,
+                                           const double* gamma, const double* Gamma, const double* fock,
+                                           int N, int n_occ, int ncas, const int32_t* kap_row,
+                                           const int32_t* kap_col, int n_kappa, int batch, double* work,
+                                           double* H_matrix, unsigned eri_flags, oovqe_stream_t stream)
+{
+    const long na2 = (long)ncas * ncas;
+    return orbital_hessian_batched(g_ao, h_ao, C, gamma, na2, Gamma, na2 * na2, fock, N, n_occ, ncas, kap_row,
+                                   kap_col, n_kappa, batch, work, H_matrix, n_kappa,
+                                   (long)n_kappa * n_kappa, nullptr, eri_flags, stream);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// configs[3]'s unit of work for a batch of geometries in ONE call: energy, full gradient and the full
+// (n_theta + n_kappa)^2 Hessian of every geometry (OO_pqc.full_gradient + full_hessian,
+// oo_pqc.py:132-148), the geometry index being a grid dimension of every launch.
+// ------------------------------------------------------------------------------------------------------
+int oovqe_oo_eval_batched_impl(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
+                               int n_qubits, uint32_t init_index, const double* g_ao, const double* h_ao,
+                               const double* C, const double* nuc_arr, int N, int n_occ, int ncas,
+                               const int32_t* kap_row, const int32_t* kap_col, int n_kappa, int derivatives,
+                               int batch, double* work, double* out, unsigned eri_flags,
+                               oovqe_stream_t stream, const double* g_packed, double* fock);
+int oovqe_circuit_hessian_batched_impl(const double* theta, int n_theta, const oovqe_gate_t* gates,
+                                       int n_gates, int n_qubits, int ncas, uint32_t init_index,
+                                       const double* c1, const double* c2, long c1_bs, long c2_bs,
+                                       const int32_t* pairs, int n_pairs, int batch, double* work, double* H,
+                                       long ldh, long h_bs, oovqe_stream_t stream);
+
+extern "C" int64_t oovqe_oo_hessian_work_size(int n_theta, int n_gates, int n_qubits, int N, int n_occ,
+                                              int ncas, int n_pairs)
+{
+    // per geometry: evaluation workspace | fock | max(circuit-Hessian, orbital-Hessian) workspace
+    const int64_t ev = oovqe_oo_eval_work_size(n_theta, n_gates, n_qubits, N, n_occ, ncas, 1);
+    const int64_t ch = oovqe_circuit_hessian_work_size(n_theta, n_qubits, ncas, n_pairs);
+    const int64_t oh = oovqe_orbital_hessian_work_size(N, n_occ, ncas);
+    return ev + (int64_t)N * N + (ch > oh ? ch : oh);
+}
+
+extern "C" int oovqe_oo_hessian_batch(const double* theta, int n_theta, const oovqe_gate_t* gates,
+                                      int n_gates, int n_qubits, uint32_t init_index, const double* g_ao,
+                                      const double* h_ao, const double* C, const double* nuc, int N,
+                                      int n_occ, int ncas, const int32_t* kap_row, const int32_t* kap_col,
+                                      int n_kappa, const int32_t* pairs, int n_pairs, int batch,
+                                      double* work, double* out, double* hessian, unsigned eri_flags,
+                                      const double* g_packed, oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(theta && gates && g_ao && h_ao && C && nuc && work && out && hessian && pairs,
+                  "oo_hessian_batch: null pointer");
+    OOVQE_REQUIRE(batch >= 1 && batch <= 65535 && n_theta >= 1 && n_kappa >= 1, "oo_hessian_batch: sizes");
+    OOVQE_REQUIRE(n_pairs == n_theta * (n_theta + 1) / 2, "oo_hessian_batch: pairs must list every j <= k");
+    const size_t nb = (size_t)batch;
+    const long na2 = (long)ncas * ncas, na4 = na2 * na2;
+    const int nvec = 1 + n_theta;
+    const int64_t ev = oovqe_oo_eval_work_size(n_theta, n_gates, n_qubits, N, n_occ, ncas, 1);
+    double* ev_work = work;                              // [G * ev]: starts with gamma [G][nvec][a^2], Gamma [G][nvec][a^4]
+    double* fock = ev_work + nb * ev;                    // [G][N][N]
+    double* hs_work = fock + nb * N * N;                 // circuit / orbital Hessian scratch, one after the other
     int rc;
-#define MC(...) if ((rc = oovqe_mode_contract_impl(__VA_ARGS__, st))) return rc
-    // ---- J-type integrals: g_mo[q,s,m,n] ---------------------------------------------------------
-    if ((rc = oovqe_cas_half_transform(g_ao, C, N, M, T2, stream))) return rc;   // T2[p,q,y,z]
-    MC(T2, C, Uj, 1, N, N, n * m2, N, 0);          // Uj[q',q,yz]  = sum_p C[p,q'] T2[p,q,yz]
-    MC(Uj, C, Jint, n, N, N, m2, N, 0);            // Jint[q',s',yz] = sum_q C[q,s'] Uj[q',q,yz]
-    // ---- K-type integrals: g_mo[q,m,n,s] ---------------------------------------------------------
-    MC(g_ao, C, Vk, n2, N, M, n, N, 0);            // Vk[p,q,n,s]  = sum_r C[r,n] g[p,q,r,s]
-    MC(Vk, C, T2K, n, N, M, (long)M * n, N, 0);    // T2K[p,m,n,s] = sum_q C[q,m] Vk[p,q,n,s]
-    MC(T2K, C, W, n * m2, N, N, 1, N, 1);          // W[p,m,n,s']  = sum_s T2K[p,m,n,s] C[s,s']
-    MC(W, C, Kint, 1, N, N, m2 * n, N, 0);         // Kint[q',m,n,s'] = sum_p C[p,q'] W[p,m,n,s']
-    // ---- one-electron integrals ------------------------------------------------------------------
-    MC(h_ao, C, X1, 1, N, N, n, N, 0);             // X1 = C^T h
-    MC(X1, C, hmo, n, N, N, 1, N, 1);              // hmo = X1 C
-    // ---- Y ------------------------------------------------------------------------------------------
-    hess_ab_kernel<<<64, 256, 0, st>>>(gamma, Gamma, n_occ, ncas, At, Bt);
-    // YkT[q,(pr),s] = sum_(mn) At[(mn),(pr)] Kint[q,(mn),s]
-    MC(Kint, At, YkT, n, (int)m2, (int)m2, n, (int)m2, 0);
-    // YjT[(qs),(pr)] = sum_(mn) Jint[(qs),(mn)] Bt[(mn),(pr)]
-    MC(Jint, Bt, YjT, n2, (int)m2, (int)m2, 1, (int)m2, 1);
-#undef MC
-    HessArgs a{YkT, YjT, hmo, fock, gamma, N, n_occ, ncas};
-    if (H_matrix) {
-        const long total = (long)n_kappa * n_kappa;
-        const unsigned nb = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hess_matrix_kernel<<<nb, 256, 0, st>>>(a, kap_row, kap_col, n_kappa, H_matrix);
+    // 1. circuit + tangents -> RDM sets -> CAS path: E, dE/dtheta, dE/dkappa, d^2E/dkappa dtheta, c1, c2, F
+    if ((rc = oovqe_oo_eval_batched_impl(theta, n_theta, gates, n_gates, n_qubits, init_index, g_ao, h_ao, C, nuc,
+                                         N, n_occ, ncas, kap_row, kap_col, n_kappa, 1, batch, ev_work, out,
+                                         eri_flags, stream, g_packed, fock)))
+        return rc;
+    const long out_stride = (long)oovqe_oo_eval_out_size(n_theta, n_kappa, ncas, 1);
+    const long n = (long)n_theta + n_kappa;
+    const double* gvec = out + 2 + n_theta;
+    const double* c1 = gvec + (size_t)nvec * n_kappa;
+    const double* c2 = c1 + na2;
+    // 2. theta-theta block (top left)
+    if ((rc = oovqe_circuit_hessian_batched_impl(theta, n_theta, gates, n_gates, n_qubits, ncas, init_index, c1,
+                                                 c2, out_stride, out_stride, pairs, n_pairs, batch, hs_work,
+                                                 hessian, n, n * n, stream)))
+        return rc;
+    // 3. kappa-theta blocks
+    {
+        const long total = (long)n_theta * n_kappa;
+        const unsigned nbk = (unsigned)((total + 255) / 256);
+        hess_cross_block_kernel<<<dim3(nbk, batch), 256, 0, (hipStream_t)stream>>>(gvec, out_stride, n_theta,
+                                                                                  n_kappa, hessian, n, n * n);
+        OOVQE_CHECK_LAUNCH("oo_hessian_batch/cross");
     }
-    if (H_full) {
-        const long total = n2 * n2;
-        const unsigned nb = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-        hess_full_kernel<<<nb, 256, 0, st>>>(a, H_full);
-    }
-    OOVQE_CHECK_LAUNCH("orbital_hessian");
-    return 0;
+    // 4. kappa-kappa block (bottom right) from RDM set 0 of every geometry and its Fock matrix
+    const double* gamma = ev_work;
+    const double* Gamma = gamma + nb * nvec * na2;
+    return orbital_hessian_batched(g_ao, h_ao, C, gamma, (long)nvec * na2, Gamma, (long)nvec * na4, fock, N,
+                                   n_occ, ncas, kap_row, kap_col, n_kappa, batch, hs_work,
+                                   hessian + (size_t)n_theta * n + n_theta, n, n * n, nullptr, eri_flags, stream);
 }

@@ -169,7 +169,6 @@ class BatchedNewtonStep(NewtonStep):
         """objective_fns[g](*parameters[g]) -> 0-d tensor; parameters[g] = tuple of tensors.
         Returns (list of new parameter tuples, lowest Hessian eigenvalues [G])."""
         G = len(objective_fns)
-        dp, low = self.newton_steps(gradients, hessians)
         shapes = [[tuple(p.shape) for p in ps] for ps in parameters]
         flat = torch.stack([torch.cat([p.flatten() for p in ps]) for ps in parameters])
 
@@ -177,7 +176,18 @@ class BatchedNewtonStep(NewtonStep):
             return torch.stack([objective_fns[g](*split_list_shapes(points[g], shapes[g])).reshape(())
                                 for g in range(G)])
 
-        energy = evaluate(flat)
+        newp, low = self.damped_newton_steps_flat(evaluate, flat, gradients, hessians)
+        return [tuple(split_list_shapes(newp[g], shapes[g])) for g in range(G)], low
+
+    def damped_newton_steps_flat(self, objective, flat, gradients, hessians, energy0=None):
+        """The same with ONE objective for all problems: objective(points [G, n]) -> energies [G]
+        (e.g. ``OO_pqc_batch.energy``: every line-search trial is one batched evaluation).
+        flat [G, n] = the current parameters; energy0 [G] = objective(flat) when the caller has it.
+        Returns (new parameters [G, n], lowest Hessian eigenvalues [G])."""
+        dp, low = self.newton_steps(gradients, hessians)
+        G = flat.shape[0]
+        evaluate = objective
+        energy = evaluate(flat) if energy0 is None else energy0
         slope = self.alpha * (ops.as_device(gradients, flat.device) * dp).sum(dim=1)   # wolfe(t) = t * slope
         t = torch.ones(G, dtype=flat.dtype, device=flat.device)
         test = evaluate(flat + t[:, None] * dp)
@@ -197,5 +207,4 @@ class BatchedNewtonStep(NewtonStep):
                 break
             test = torch.where(active, trial, test)
             active = active & (test > energy + t * slope)
-        newp = flat + t[:, None] * dp
-        return [tuple(split_list_shapes(newp[g], shapes[g])) for g in range(G)], low
+        return flat + t[:, None] * dp, low

@@ -65,7 +65,7 @@ typedef struct {
 /* Test / measurement switches between realisations that compute the same numbers (which kernel
  * variant a call takes): "half_stream_old", "gm_two_per_cu", "gm_one_per_cu", "fused_chunks" (int),
  * "tri_plain_w", "cas_unfused", "sym_no_rs", "sym_mirror", "sym_simple", "sym_two_step", "no_ride",
- * "tri_mode" (int).
+ * "tri_mode" (int), "k1_no_pair", "k1_force_wide", "gm_plain_grid".
  * All 0 by default; the library never reads environment variables.  tests/ and tools/ only. */
 int oovqe_debug_set_option(const char* name, int value);
 int oovqe_debug_get_option(const char* name);
@@ -247,6 +247,16 @@ int oovqe_orbital_hessian(const double* g_ao, const double* h_ao, const double* 
                           double* H_matrix, double* H_full, oovqe_stream_t stream);
 int64_t oovqe_orbital_hessian_work_size(int N, int n_occ, int ncas);
 
+/* The same for a stack of `batch` geometries of identical shape in one call (the geometry index is a
+ * grid dimension of every launch): g_ao [batch][N^4], h_ao / C / fock [batch][N^2], gamma [batch][a^2],
+ * Gamma [batch][a^4], H_matrix [batch][n_kappa][n_kappa]; work: batch * oovqe_orbital_hessian_work_size()
+ * doubles; eri_flags as for oovqe_cas_eval (OOVQE_ERI_PQ_SYMMETRIC: the J-type half transform reads the
+ * slabs p <= q only). */
+int oovqe_orbital_hessian_batch(const double* g_ao, const double* h_ao, const double* C, const double* gamma,
+                                const double* Gamma, const double* fock, int N, int n_occ, int ncas,
+                                const int32_t* kap_row, const int32_t* kap_col, int n_kappa, int batch,
+                                double* work, double* H_matrix, unsigned eri_flags, oovqe_stream_t stream);
+
 /* ---- a16: circuit-circuit Hessian pieces (oo_pqc.py:103-111) ------------------------------------
  * second tangents d^2 psi/d theta_j d theta_k for the listed (j,k) pairs: out [n_pairs, D],
  * scratch [n_pairs, D]; pairs int32 [n_pairs, 2]. */
@@ -284,6 +294,13 @@ int oovqe_circuit_hessian(const double* theta, int n_theta, const oovqe_gate_t* 
                           const double* c2, const int32_t* pairs, int n_pairs, double* work,
                           double* H, oovqe_stream_t stream);
 int64_t oovqe_circuit_hessian_work_size(int n_theta, int n_qubits, int ncas, int n_pairs);
+/* The same for `batch` parameter sets in one call: theta [batch][n_theta], c1 [batch][a^2],
+ * c2 [batch][a^4], H [batch][n_theta][n_theta]; work: batch * oovqe_circuit_hessian_work_size();
+ * batch * 4 * n_pairs <= 65535. */
+int oovqe_circuit_hessian_batch(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
+                                int n_qubits, int ncas, uint32_t init_index, const double* c1,
+                                const double* c2, const int32_t* pairs, int n_pairs, int batch,
+                                double* work, double* H, oovqe_stream_t stream);
 
 /* ---- a10/a11/a13 at scale: particle-number-sector engine with reverse-mode gradients -------------
  * For circuits that conserve (N_alpha, N_beta) -- UCCD, UCCSD, kUpCCD -- the state lives in a
@@ -340,6 +357,33 @@ int oovqe_oo_eval_batch(const double* theta, int n_theta, const oovqe_gate_t* ga
                         const int32_t* kap_row, const int32_t* kap_col, int n_kappa, int derivatives,
                         int batch, double* work, double* out, unsigned eri_flags,
                         const double* g_packed, oovqe_stream_t stream);
+/* ---- configs[3]'s unit of work for a batch of geometries: energy + full gradient + full Hessian ----
+ * OO_pqc.full_gradient + OO_pqc.full_hessian (src/auto_oo/oo_pqc.py:132-148) of every geometry of a
+ * stack in ONE call: the batched evaluation above with derivatives (E, dE/dtheta, dE/dkappa, the
+ * orbital-circuit block, c1, c2, generalized Fock matrices), the circuit-circuit block from second
+ * tangent states (oo_pqc.py:103-111) and the orbital-orbital block (oo_energy.py:311-402) -- every
+ * launch carries the geometry index as a grid dimension.  Arguments as oovqe_oo_eval_batch; pairs
+ * [n_pairs][2] = every (j <= k) of the theta indices; out [batch][oovqe_oo_eval_out_size(.., 1)] (the
+ * packed evaluation result: [E | full gradient] is out[b][1 : 2 + n_theta + n_kappa]); hessian
+ * [batch][n][n], n = n_theta + n_kappa, laid out [[theta-theta, (kappa-theta)^T], [kappa-theta,
+ * kappa-kappa]] as the reference's full_hessian; work: batch * oovqe_oo_hessian_work_size(). */
+int oovqe_oo_hessian_batch(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
+                           int n_qubits, uint32_t init_index, const double* g_ao, const double* h_ao,
+                           const double* C, const double* nuc, int N, int n_occ, int ncas,
+                           const int32_t* kap_row, const int32_t* kap_col, int n_kappa,
+                           const int32_t* pairs, int n_pairs, int batch, double* work, double* out,
+                           double* hessian, unsigned eri_flags, const double* g_packed,
+                           oovqe_stream_t stream);
+int64_t oovqe_oo_hessian_work_size(int n_theta, int n_gates, int n_qubits, int N, int n_occ, int ncas,
+                                   int n_pairs);
+/* Orbital rotation of a stack of geometries in one launch (OO_energy.get_transformed_mo,
+ * src/auto_oo/oo_energy.py:213-236, per geometry): C_out[b] = C[b] expm(-K(kappa[b])); kappa
+ * [batch][n_kappa], C / C_out [batch][N][N] (C_out may alias C when N <= 48), U [batch][N][N] or NULL
+ * (the rotation matrices).  work: NULL for N <= 48 (one workgroup per geometry, all in LDS), else
+ * (batch + 7) * N * N doubles. */
+int oovqe_rotate_orbitals_batch(const double* kappa, const int32_t* kap_row, const int32_t* kap_col,
+                                int n_kappa, int N, int batch, const double* C, double* C_out, double* U,
+                                double* work, oovqe_stream_t stream);
 /* 1 when oovqe_circuit_rdms takes its one-workgroup LDS path for these sizes */
 int oovqe_circuit_rdms_is_small(int n_qubits, int ncas, int nvec, int n_gates);
 
