@@ -590,14 +590,753 @@ void newton_direction_kernel(const double* __restrict__ H, const double* __restr
     }
 }
 
+
+// =====================================================================================================
+// Round 3: the same direction from SEVERAL workgroups per problem, in two stages.
+//
+//   stage 1  H = Q1 Bnd Q1^T, Bnd symmetric with half-bandwidth BW = 8: blocked two-sided Householder
+//            reduction, panels of BW columns.  Everything that touches the n x n trailing matrix is a
+//            matrix-matrix product on the fp64 matrix cores, spread over the W workgroups of the problem
+//            by 16-row tiles (tile t belongs to workgroup t mod W and stays there):
+//              P  (the tile owner of the panel's rows)  QR of the (m x BW) panel in LDS, one wave per
+//                 column -> V, T (compact WY), the band entries of these BW columns;
+//              X  (all)  X0 = A22 V for the own row tiles (reads only rows this workgroup wrote itself);
+//              U  (all)  W = X0 T - 1/2 V (T^T V^T X0 T), own rows of A22 -= V W^T + W V^T.
+//            Two hand-offs per panel (V | T from the panel owner to all, X0 rows from all to all).  The
+//            exchanged doubles validate themselves: their buffers start as an all-ones NaN pattern no
+//            computation produces, every location is written once (write-through, `sc1`) and read with
+//            L1-bypassing `sc1` loads until no lane sees the pattern -- no flags, no fences, no ordering.
+//   stage 2  (workgroup 0 of the problem) lambda_min(Bnd) by multisection on the test "Bnd - x I is
+//            positive definite" = band LDL^T without pivoting, ONE SHIFT PER LANE (the 9 x 9 active
+//            window of the factorisation lives in 45 registers, ring-indexed so that nothing moves; 256
+//            shifts per round, 8 bits per round); nu as before; (Bnd + nu I) y = Q1^T (-g) by the same
+//            LDL^T (positive definite by construction when aug != 0); dp = Q1 y.
+// Per column nothing is left that synchronises more than one workgroup; per panel two hand-offs of
+// ~1.5 us.  n <= NEWTON2_NMAX (LDS of the panel operands).
+// =====================================================================================================
+#ifdef OOVQE_NEWTON_TIMING
+// tools/newton2_probe.hip: cycles per phase of the two-stage kernels, thread 0 of problem 0's workgroup 0
+__device__ long long g_newton2_cycles[16];
+#define N2_MARK(k)                                                                     \
+    do {                                                                               \
+        if (threadIdx.x == 0 && blockIdx.x == 0) {                                     \
+            const long long now__ = clock64();                                         \
+            g_newton2_cycles[k] += now__ - t_mark;                                     \
+            t_mark = now__;                                                            \
+        }                                                                              \
+    } while (0)
+#else
+#define N2_MARK(k) do {} while (0)
+#endif
+
+constexpr int BW = 8;                 // band half-width = panel width
+constexpr int RW = BW + 1;            // rows / columns of the LDL^T window
+constexpr int NEWTON2_NMAX = 672;
+constexpr int N2_SPIN_LIMIT = 1 << 17;
+constexpr int N2_SHIFTS = 256;        // shifts per multisection round (4 waves, one per SIMD)
+
+typedef unsigned n2_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned n2_v2u __attribute__((ext_vector_type(2)));
+constexpr int N2_SC1 = 16;            // gfx950 buffer aux bit: sc1 (bypass L1 on loads, write through on stores)
+
+struct N2Global {                     // workspace of a call: [Aw of every problem | exchange block of every problem | status words]
+    int npv, npan, ntile;
+    size_t aw_size;                   // doubles per problem in the first block (the working copy, [npv][npv])
+    size_t Vst, Tst, X0, Band, ex_size;   // offsets inside a problem's exchange block, and its size
+};
+
+__host__ __device__ inline N2Global n2_global(int n)
+{
+    N2Global L;
+    L.ntile = (n + 15) / 16;
+    L.npv = 16 * L.ntile;
+    L.npan = n >= 2 ? (n - 2) / BW : 0;
+    L.aw_size = (size_t)L.npv * L.npv;
+    size_t o = 0;
+    L.Vst = o; o += (size_t)L.npan * BW * L.npv;
+    L.Tst = o; o += (size_t)L.npan * BW * BW;
+    L.X0 = o; o += (size_t)L.npan * L.npv * BW;
+    L.Band = o; o += (size_t)L.npv * RW;
+    L.ex_size = (o + 1) & ~(size_t)1;
+    return L;
+}
+// doubles of workspace for `batch` problems (2 status doubles per problem at the end)
+__host__ __device__ inline size_t n2_work_total(const N2Global& L, int batch)
+{
+    return (size_t)batch * (L.aw_size + L.ex_size + 2);
+}
+
+struct N2Lds {                        // dynamic LDS, offsets in doubles
+    int VW, Xc, part, Tm, Gm, Ym, S0, tau, x1, x2, red, bb, total;
+    // stage-2 aliases (inside VW | Xc)
+    int rb, Lst, dst, zst;
+};
+
+__host__ __device__ inline N2Lds n2_lds(int n)
+{
+    const int npv = 16 * ((n + 15) / 16);
+    N2Lds L;
+    int o = 0;
+    L.VW = o; o += 16 * npv;          // rows 0..7 = V, 8..15 = W
+    L.Xc = o; o += 8 * npv;           // X0 [j][r]; the panel during its QR
+    L.part = o; o += 16 * 128;        // K-split partial tiles of X0 / partial sums of V^T X0
+    L.Tm = o; o += 64;
+    L.Gm = o; o += 64;
+    L.Ym = o; o += 64;
+    L.S0 = o; o += 64;
+    L.tau = o; o += 16;
+    L.x1 = o; o += 16;
+    L.x2 = o; o += 16;
+    L.red = o; o += 4 * 2 * NW + 2;
+    L.bb = o; o += npv + 16;
+    L.total = o;
+    L.rb = L.VW;                      // [(n + RW + 1)][RW]
+    L.Lst = L.rb + (n + RW + 1) * RW; // [n][BW]
+    L.dst = L.Lst + n * BW;           // [n]
+    L.zst = L.dst + n;                // [n]     (in all 19 n + 90 <= 24 npv)
+    return L;
+}
+
+__device__ __forceinline__ bool n2_is_sent(double x)
+{
+    return (unsigned long long)__double_as_longlong(x) == ~0ull;
+}
+
+__device__ __forceinline__ d2 n2_ld2(__amdgpu_buffer_rsrc_t r, size_t elem)
+{
+    return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)(elem * 8), 0, N2_SC1));
+}
+__device__ __forceinline__ double n2_ld1(__amdgpu_buffer_rsrc_t r, size_t elem)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (unsigned)(elem * 8), 0, N2_SC1));
+}
+__device__ __forceinline__ void n2_st2(__amdgpu_buffer_rsrc_t r, size_t elem, d2 v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(n2_v4u, v), r, (unsigned)(elem * 8), 0, N2_SC1);
+}
+__device__ __forceinline__ void n2_st1(__amdgpu_buffer_rsrc_t r, size_t elem, double v)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(n2_v2u, v), r, (unsigned)(elem * 8), 0, N2_SC1);
+}
+
+// index of the ring pair (a, b), 0 <= a, b < RW, in the 45-element triangle
+__device__ __forceinline__ constexpr int n2_tri(int a, int b)
+{
+    return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a;
+}
+
+// Band LDL^T of (Bnd - sigma I) without pivoting, run by ONE LANE: rb[r][t] = Bnd[r][r - BW + t] (row r of
+// the band, t = BW the diagonal; rows >= n are zero).  Returns false as soon as a pivot is not positive
+// (the matrix is not positive definite: an eigenvalue <= sigma exists).  SOLVE: also carries the right-hand
+// side through the elimination and leaves the solution of (Bnd - sigma I) y = rhs in rhs (LDS); only used
+// on positive definite matrices.  The window of the factorisation is ring-indexed (row r lives in ring slot
+// r mod 9), the k loop is unrolled by 9, so every register index is static and no entry ever moves.
+template <bool SOLVE>
+__device__ bool n2_band_ldlt(const double* __restrict__ rb, int n, double sigma, double pivmin,
+                             double* __restrict__ rhs, double* __restrict__ Lst, double* __restrict__ dst,
+                             double* __restrict__ zst)
+{
+    double E[RW * (RW + 1) / 2];
+    double cw[RW];
+#pragma unroll
+    for (int a = 0; a < RW; ++a) {
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            // rows a >= b (both < RW): A[a][b] = rb[a][BW - (a - b)]
+            double v = rb[a * RW + BW - (a - b)];
+            if (a == b) v -= sigma;
+            E[n2_tri(a, b)] = v;
+        }
+        if (SOLVE) cw[a] = a < n ? rhs[a] : 0.0;
+    }
+    bool ok = true;
+    for (int k0 = 0; k0 < n; k0 += RW) {
+#pragma unroll
+        for (int s = 0; s < RW; ++s) {
+            const int k = k0 + s;
+            if (k < n) {
+                const double d = E[n2_tri(s, s)];
+                ok = ok && (d > pivmin);
+                const double rinv = fast_rcp(d);
+                double col[RW], l[RW];
+#pragma unroll
+                for (int i = 1; i < RW; ++i) {
+                    col[i] = E[n2_tri((s + i) % RW, s)];
+                    l[i] = col[i] * rinv;
+                }
+#pragma unroll
+                for (int i = 1; i < RW; ++i)
+#pragma unroll
+                    for (int j = 1; j <= i; ++j)
+                        E[n2_tri((s + i) % RW, (s + j) % RW)] -= l[i] * col[j];
+                if (SOLVE) {
+                    const double zk = cw[s];
+#pragma unroll
+                    for (int i = 1; i < RW; ++i) {
+                        cw[(s + i) % RW] -= l[i] * zk;
+                        Lst[k * BW + i - 1] = l[i];
+                    }
+                    dst[k] = rinv;
+                    zst[k] = zk;
+                    cw[s] = (k + RW < n) ? rhs[k + RW] : 0.0;
+                }
+                // ring slot s now holds row k + RW
+                const double* rn = rb + (size_t)(k + RW) * RW;
+#pragma unroll
+                for (int t = 0; t < BW; ++t) E[n2_tri(s, (s + 1 + t) % RW)] = rn[t];
+                E[n2_tri(s, s)] = rn[BW] - sigma;
+            }
+        }
+    }
+    if (SOLVE) {
+        // L^T y = D^-1 z from the last row up; y overwrites rhs (rows >= n read as 0)
+        for (int k = n - 1; k >= 0; --k) {
+            double acc = zst[k] * dst[k];
+#pragma unroll
+            for (int i = 1; i < RW; ++i)
+                if (k + i < n) acc -= Lst[k * BW + i - 1] * rhs[k + i];
+            rhs[k] = acc;
+        }
+    }
+    return ok;
+}
+
+__global__ __launch_bounds__(NT)
+void newton_band_kernel(const double* __restrict__ H, int n, double* __restrict__ work, int W, int batch)
+{
+    extern __shared__ double sm[];
+    const N2Global GL = n2_global(n);
+    const N2Lds L = n2_lds(n);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane >> 4, lr = lane & 15;
+    const int prob = blockIdx.x % batch, slot = blockIdx.x / batch;
+    const int npv = GL.npv, lda = GL.npv, npan = GL.npan, ntile = GL.ntile;
+    double* Aw = work + (size_t)prob * GL.aw_size;
+    double* ex = work + (size_t)batch * GL.aw_size + (size_t)prob * GL.ex_size;
+    // ra: the working copy (own rows are re-read past the L1); rs: the exchange block
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(Aw, 0, (int)(GL.aw_size * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ex, 0, (int)(GL.ex_size * 8), 0x00020000);
+    const double* Hb = H + (size_t)prob * n * n;
+    double* VW = sm + L.VW;
+    double* Xc = sm + L.Xc;
+    double* part = sm + L.part;
+    double* Tm = sm + L.Tm;
+    double* Gm = sm + L.Gm;
+    double* Ym = sm + L.Ym;
+    double* S0 = sm + L.S0;
+    double* taus = sm + L.tau;
+    bool dead = false;                // a hand-off timed out (never on a healthy run): give up loudly
+    // status word of the problem: all ones (the memset) = healthy, 1 = a hand-off timed out
+    int* status = reinterpret_cast<int*>(work + (size_t)batch * (GL.aw_size + GL.ex_size) + 2 * (size_t)prob);
+#ifdef OOVQE_NEWTON_TIMING
+    long long t_mark = clock64();
+#endif
+
+    // ---- working copy of the own row tiles, rows and columns padded with zeros to whole tiles
+    for (int t = slot; t < ntile; t += W)
+        for (int idx = tid; idx < 16 * npv; idx += NT) {
+            const int r = 16 * t + idx / npv, c = idx % npv;
+            Aw[(size_t)r * lda + c] = (r < n && c < n) ? Hb[(size_t)r * n + c] : 0.0;
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    N2_MARK(0);
+
+    for (int p = 0; p < npan && !dead; ++p) {
+        const int k = p * BW, r0 = k + BW, m = n - r0;
+        const int leader = (k >> 4) % W;
+        const size_t vst_p = GL.Vst + (size_t)p * BW * npv, tst_p = GL.Tst + (size_t)p * BW * BW;
+        const size_t x0_p = GL.X0 + (size_t)p * npv * BW;
+        // =============== P: QR of the panel, by the owner of rows k .. k+7 ===============
+        if (slot == leader) {
+            double* Pn = Xc;                                  // Pn[j][c] = A[k+j][c] = A[c][k+j]
+            for (int idx = tid; idx < BW * (npv / 2); idx += NT) {
+                const int j = idx / (npv / 2), c2 = idx - j * (npv / 2);
+                const d2 v = n2_ld2(ra, (size_t)(k + j) * lda + 2 * c2);
+                *reinterpret_cast<d2*>(Pn + j * npv + 2 * c2) = v;
+            }
+            for (int idx = tid; idx < BW * npv; idx += NT) VW[idx] = 0.0;
+            if (tid < 64) { Tm[tid] = 0.0; Gm[tid] = 0.0; }
+            if (tid < 16) taus[tid] = 0.0;
+            __syncthreads();
+            N2_MARK(1);
+            // band: the part of columns k .. k+7 inside the diagonal block
+            if (tid < BW * BW) {
+                const int j = tid >> 3, d = tid & 7;
+                if (d < BW - j) n2_st1(rs, GL.Band + (size_t)(k + j) * RW + d, Pn[j * npv + k + j + d]);
+            }
+            const int jb = (m - 1) < BW ? (m - 1) : BW;
+            for (int j = 0; j < jb; ++j) {
+                if (wave == j) {
+                    const double* x = Pn + j * npv + r0;      // x[i], i = j .. m-1
+                    double s2 = 0.0;
+                    for (int i2 = j + 1 + lane; i2 < m; i2 += 64) s2 += x[i2] * x[i2];
+                    s2 = wave_sum(s2);
+                    const double al = x[j];
+                    double beta, tau, scale;
+                    if (s2 == 0.0) { beta = al; tau = 0.0; scale = 0.0; }
+                    else {
+                        beta = -copysign(sqrt(al * al + s2), al);
+                        tau = (beta - al) / beta;
+                        scale = 1.0 / (al - beta);
+                    }
+                    for (int i2 = j + 1 + lane; i2 < m; i2 += 64) {
+                        VW[j * npv + r0 + i2] = x[i2] * scale;
+                        Pn[j * npv + r0 + i2] = 0.0;
+                    }
+                    if (lane == 0) {
+                        VW[j * npv + r0 + j] = 1.0;
+                        Pn[j * npv + r0 + j] = beta;
+                        taus[j] = tau;
+                    }
+                }
+                lds_barrier();
+                if (wave > j && wave < BW) {
+                    const double* v = VW + j * npv + r0;
+                    double* y = Pn + wave * npv + r0;
+                    double dot = 0.0;
+                    for (int i2 = j + lane; i2 < m; i2 += 64) dot += v[i2] * y[i2];
+                    dot = wave_sum(dot);
+                    const double f = taus[j] * dot;
+                    for (int i2 = j + lane; i2 < m; i2 += 64) y[i2] -= f * v[i2];
+                } else if (wave < j) {
+                    const double* v = VW + j * npv + r0;
+                    const double* u = VW + wave * npv + r0;
+                    double dot = 0.0;
+                    for (int i2 = j + lane; i2 < m; i2 += 64) dot += v[i2] * u[i2];
+                    dot = wave_sum(dot);
+                    if (lane == 0) Gm[wave * BW + j] = dot;
+                }
+                lds_barrier();
+            }
+            N2_MARK(2);
+            // band: the R part (row r0 + i of column k + j, i <= j)
+            if (tid < BW * BW) {
+                const int j = tid >> 3, i2 = tid & 7;
+                if (i2 <= j && i2 < m) n2_st1(rs, GL.Band + (size_t)(k + j) * RW + BW + i2 - j, Pn[j * npv + r0 + i2]);
+            }
+            // compact WY factor: row l of T by thread l (upper triangular)
+            if (tid < BW) {
+                for (int jj = 0; jj < jb; ++jj) {
+                    const double tj = taus[jj];
+                    double val = 0.0;
+                    if (tid == jj) val = tj;
+                    else if (tid < jj) {
+                        double sacc = 0.0;
+                        for (int mm = tid; mm < jj; ++mm) sacc += Tm[tid * BW + mm] * Gm[mm * BW + jj];
+                        val = -tj * sacc;
+                    }
+                    Tm[tid * BW + jj] = val;
+                }
+            }
+            __syncthreads();
+            for (int idx = tid; idx < BW * (npv / 2); idx += NT)
+                n2_st2(rs, vst_p + 2 * (size_t)idx, *reinterpret_cast<const d2*>(VW + 2 * idx));
+            if (tid < 32) n2_st2(rs, tst_p + 2 * (size_t)tid, *reinterpret_cast<const d2*>(Tm + 2 * tid));
+            __syncthreads();      // (the hand-off loop below refills VW | Tm: not before every wave has published)
+            N2_MARK(3);
+        }
+        // =============== X: V | T from the panel owner, X0 = A22 V on the own row tiles ===============
+        {
+            int spins = 0;
+            while (true) {
+                int bad = 0;
+                for (int idx = tid; idx < BW * (npv / 2); idx += NT) {
+                    const d2 v = n2_ld2(rs, vst_p + 2 * (size_t)idx);
+                    bad |= (int)n2_is_sent(v.x) | (int)n2_is_sent(v.y);
+                    *reinterpret_cast<d2*>(VW + 2 * idx) = v;
+                }
+                if (tid < 32) {
+                    const d2 v = n2_ld2(rs, tst_p + 2 * (size_t)tid);
+                    bad |= (int)n2_is_sent(v.x) | (int)n2_is_sent(v.y);
+                    *reinterpret_cast<d2*>(Tm + 2 * tid) = v;
+                }
+                if (!__syncthreads_or(bad)) break;
+                ++spins;
+                int st = -1;
+                if ((spins & 63) == 0) st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__syncthreads_or(st == 1 || spins > N2_SPIN_LIMIT)) { dead = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (dead) break;
+        }
+        N2_MARK(4);
+        const int cg0 = r0 >> 4;                 // first 16-column group / row tile that reaches into A22
+        int q0 = 0;                              // own tiles t = slot + W q, q >= q0, reach into A22
+        while (slot + W * q0 < cg0) ++q0;
+        int n_own = 0;
+        for (int t = slot + W * q0; t < ntile; t += W) ++n_own;
+        {
+            const int KS = n_own > 0 && n_own < NW ? NW / n_own : 1;     // K split over the waves
+            for (int item = wave; item < n_own * KS; item += NW) {
+                const int qi = item / KS, ks = item - qi * KS;
+                const int t = slot + W * (q0 + qi);
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+                const size_t arow = (size_t)(16 * t + lr) * lda + 4 * lq;
+                for (int gq = cg0 + ks; gq < ntile; gq += KS) {
+                    const d2 a01 = n2_ld2(ra, arow + 16 * gq);
+                    const d2 a23 = n2_ld2(ra, arow + 16 * gq + 2);
+                    const double* vb = VW + lr * npv + 16 * gq + 4 * lq;
+                    acc = mfma_f64(a01.x, vb[0], acc);
+                    acc = mfma_f64(a01.y, vb[1], acc);
+                    acc = mfma_f64(a23.x, vb[2], acc);
+                    acc = mfma_f64(a23.y, vb[3], acc);
+                }
+                if (KS == 1) {
+                    if (lr < BW)
+#pragma unroll
+                        for (int i2 = 0; i2 < 4; ++i2)
+                            n2_st1(rs, x0_p + (size_t)(16 * t + lq + 4 * i2) * BW + lr, acc[i2]);
+                } else if (lr < BW) {
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; ++i2) part[item * 128 + (lq + 4 * i2) * BW + lr] = acc[i2];
+                }
+            }
+            N2_MARK(5);
+            if (KS > 1) {
+                __syncthreads();
+                for (int idx = tid; idx < n_own * 128; idx += NT) {
+                    const int qi = idx >> 7, e = idx & 127;
+                    double sacc = 0.0;
+                    for (int ks = 0; ks < KS; ++ks) sacc += part[(qi * KS + ks) * 128 + e];
+                    const int t = slot + W * (q0 + qi);
+                    n2_st1(rs, x0_p + (size_t)(16 * t) * BW + e, sacc);
+                }
+            }
+        }
+        N2_MARK(6);
+        // =============== U: all of X0, W, own rows of A22 -= V W^T + W V^T ===============
+        {
+            int spins = 0;
+            while (true) {
+                int bad = 0;
+                for (int idx = tid; idx < (n - r0) * (BW / 2); idx += NT) {
+                    const int r = r0 + idx / (BW / 2), j2 = (idx % (BW / 2)) * 2;
+                    const d2 v = n2_ld2(rs, x0_p + (size_t)r * BW + j2);
+                    bad |= (int)n2_is_sent(v.x) | (int)n2_is_sent(v.y);
+                    Xc[j2 * npv + r] = v.x;
+                    Xc[(j2 + 1) * npv + r] = v.y;
+                }
+                if (!__syncthreads_or(bad)) break;
+                ++spins;
+                int st = -1;
+                if ((spins & 63) == 0) st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__syncthreads_or(st == 1 || spins > N2_SPIN_LIMIT)) { dead = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (dead) break;
+        }
+        N2_MARK(7);
+        {   // S0 = V^T X0 (8 x 8): 16 row classes x 64 (m, n) pairs, then a fixed-order sum
+            const int pair = tid & 63, cls = tid >> 6;
+            const double* vv = VW + (pair >> 3) * npv;
+            const double* xx = Xc + (pair & 7) * npv;
+            double sacc = 0.0;
+            for (int r = r0 + cls; r < n; r += NW) sacc += vv[r] * xx[r];
+            part[cls * 64 + pair] = sacc;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int c = 0; c < NW; ++c) sacc += part[c * 64 + tid];
+            S0[tid] = sacc;
+        }
+        __syncthreads();
+        if (tid < 64) {                           // Y = T^T S0 T
+            const int a = tid >> 3, b = tid & 7;
+            double sacc = 0.0;
+            for (int l = 0; l < BW; ++l) {
+                double inner = 0.0;
+                for (int q = 0; q < BW; ++q) inner += S0[l * BW + q] * Tm[q * BW + b];
+                sacc += Tm[l * BW + a] * inner;
+            }
+            Ym[tid] = sacc;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * npv; idx += NT) {      // W = X0 T - 1/2 V Y, four columns per thread
+            const int r = idx % npv, jh = idx / npv;
+            double xr[BW], vr[BW];
+            const bool in = r >= r0 && r < n;
+#pragma unroll
+            for (int l = 0; l < BW; ++l) { xr[l] = in ? Xc[l * npv + r] : 0.0; vr[l] = in ? VW[l * npv + r] : 0.0; }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = 4 * jh + jj;
+                double sacc = 0.0;
+#pragma unroll
+                for (int l = 0; l < BW; ++l) sacc += xr[l] * Tm[l * BW + j] - 0.5 * vr[l] * Ym[l * BW + j];
+                VW[(BW + j) * npv + r] = sacc;
+            }
+        }
+        __syncthreads();
+        N2_MARK(8);
+        {
+            const int ng = ntile - cg0;
+            for (int item = wave; item < n_own * ng; item += NW) {
+                const int qi = item / ng, ct = cg0 + item - qi * ng;
+                const int t = slot + W * (q0 + qi);
+                double old[4];
+                const size_t base = (size_t)(16 * t + lq) * lda + 16 * ct + lr;
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) old[i2] = n2_ld1(ra, base + (size_t)(4 * i2) * lda);
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int sx = 0; sx < 4; ++sx) {
+                    const int kk = 4 * sx + lq;
+                    acc = mfma_f64(VW[kk * npv + 16 * t + lr], VW[((kk + BW) & 15) * npv + 16 * ct + lr], acc);
+                }
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2)
+                    Aw[(size_t)(16 * t + lq + 4 * i2) * lda + 16 * ct + lr] = old[i2] - acc[i2];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        N2_MARK(9);
+    }
+    // ---- band: the dense remainder behind the last panel (rows >= kend), by the owners of those rows
+    if (!dead) {
+        const int kend = npan * BW;
+        for (int idx = tid; idx < (n - kend) * RW; idx += NT) {
+            const int r = kend + idx / RW, c = r - (idx % RW);
+            if (c >= kend && ((r >> 4) % W) == slot)
+                n2_st1(rs, GL.Band + (size_t)c * RW + (r - c), n2_ld1(ra, (size_t)r * lda + c));
+        }
+    }
+    // a hand-off that timed out leaves its mark for the solve kernel (which then answers with NaNs)
+    if (dead && tid == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// =============== stage 2: one workgroup of 256 threads per problem, launched behind stage 1 ===============
+// (a kernel of its own: one wave per SIMD, so the one-shift-per-lane LDL^T has the whole register file --
+// inside the 1024-thread stage-1 kernel it would be capped at 128 VGPRs and spill its window)
+constexpr int NT2 = 256;
+constexpr int NW2 = NT2 / 64;
+
+struct N2Lds2 { int rb, Lst, dst, zst, Vp, Tm, x1, x2, red, bb, total; };
+
+__host__ __device__ inline N2Lds2 n2_lds2(int n)
+{
+    const int npv = 16 * ((n + 15) / 16);
+    N2Lds2 L;
+    int o = 0;
+    L.rb = o; o += (n + RW + 1) * RW;
+    o = (o + 1) & ~1;
+    L.Lst = o; o += n * BW;
+    L.dst = o; o += n;
+    L.zst = o; o += n;
+    o = (o + 1) & ~1;
+    L.Vp = o; o += BW * npv;
+    L.Tm = o; o += 64;
+    L.x1 = o; o += 16;
+    L.x2 = o; o += 16;
+    L.red = o; o += 4 * 2 * NW + 2;
+    L.bb = o; o += npv + 16;
+    L.total = o;
+    return L;
+}
+
+__device__ __forceinline__ void block_min2_w4(double& a, double& b, double* red, int& parity, int lane, int wave)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a = fmin(a, __shfl_xor(a, o, 64));
+        b = fmin(b, __shfl_xor(b, o, 64));
+    }
+    double* r = red + parity * 2 * NW;
+    if (lane == 0) { r[2 * wave] = a; r[2 * wave + 1] = b; }
+    __syncthreads();
+    double sa = r[0], sb = r[1];
+#pragma unroll
+    for (int w = 1; w < NW2; ++w) { sa = fmin(sa, r[2 * w]); sb = fmin(sb, r[2 * w + 1]); }
+    a = sa; b = sb;
+    parity ^= 1;
+}
+
+__global__ __launch_bounds__(NT2)
+void newton_band_solve_kernel(const double* __restrict__ g, int n, double lam_threshold, double mu, double rho,
+                              int aug, const double* __restrict__ work, double* __restrict__ dp,
+                              double* __restrict__ lowest, double* __restrict__ shift_out)
+{
+    extern __shared__ double sm[];
+    const N2Global GL = n2_global(n);
+    const N2Lds2 L = n2_lds2(n);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int prob = blockIdx.x;
+    const int npv = GL.npv, npan = GL.npan;
+    const int batch = gridDim.x;
+    const double* wk = work + (size_t)batch * GL.aw_size + (size_t)prob * GL.ex_size;     // the exchange block
+    double* rb = sm + L.rb;
+    double* Lst = sm + L.Lst;
+    double* dst = sm + L.dst;
+    double* zst = sm + L.zst;
+    double* Vp = sm + L.Vp;
+    double* Tm = sm + L.Tm;
+    double* x1 = sm + L.x1;
+    double* x2 = sm + L.x2;
+    double* red = sm + L.red;
+    double* bb = sm + L.bb;
+    int parity = 0;
+    const int dead = *reinterpret_cast<const int*>(work + (size_t)batch * (GL.aw_size + GL.ex_size) + 2 * (size_t)prob) == 1;
+#ifdef OOVQE_NEWTON_TIMING
+    long long t_mark = clock64();
+#endif
+    for (int idx = tid; idx < (n + RW + 1) * RW; idx += NT2) rb[idx] = 0.0;
+    __syncthreads();
+    int bad = dead;
+    {
+        const double* Band = wk + GL.Band;
+        for (int idx = tid; idx < n * RW; idx += NT2) {
+            const int c = idx / RW, d = idx - c * RW;
+            if (c + d < n) {
+                const double v = Band[idx];
+                bad |= (int)n2_is_sent(v);          // (an entry stage 1 never wrote: cannot happen on a healthy run)
+                rb[(c + d) * RW + BW - d] = v;
+            }
+        }
+    }
+    if (__syncthreads_or(bad)) {
+        const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+        for (int i2 = tid; i2 < n; i2 += NT2) dp[(size_t)prob * n + i2] = qnan;
+        if (tid == 0) {
+            lowest[prob] = qnan;
+            if (shift_out) shift_out[prob] = qnan;
+        }
+        return;
+    }
+    // Gershgorin lower bound and the smallest diagonal element bracket lambda_min
+    double lo, hi, amax;
+    {
+        double glo = INFINITY, dmin = INFINITY, nam = 0.0, dum = INFINITY;
+        for (int r = tid; r < n; r += NT2) {
+            const double dg = rb[r * RW + BW];
+            double off = 0.0;
+#pragma unroll
+            for (int t = 0; t < BW; ++t) off += fabs(rb[r * RW + t]);
+#pragma unroll
+            for (int d = 1; d <= BW; ++d) off += fabs(rb[(r + d) * RW + BW - d]);
+            glo = fmin(glo, dg - off);
+            dmin = fmin(dmin, dg);
+            nam = fmin(nam, -(off + fabs(dg)));
+        }
+        block_min2_w4(glo, dmin, red, parity, lane, wave);
+        block_min2_w4(nam, dum, red, parity, lane, wave);
+        lo = glo; hi = dmin; amax = -nam;
+    }
+    N2_MARK(11);
+    const double pivmin = 2.2250738585072014e-308 * fmax(1.0, amax * amax);
+    {
+        const double span = fmax(fabs(lo), fabs(hi));
+        lo -= 2.0 * 2.220446049250313e-16 * span + 2.0 * pivmin;
+        hi += 2.0 * 2.220446049250313e-16 * span + 2.0 * pivmin;
+    }
+    for (int round = 0; round < 12; ++round) {
+        const double width = hi - lo;
+        if (!(width > 4.0 * 2.220446049250313e-16 * fmax(fabs(lo), fabs(hi)) + 4.0 * pivmin)) break;
+        double first = (double)N2_SHIFTS, dum = 0.0;
+        if (tid < N2_SHIFTS) {
+            const double x = lo + width * ((double)(tid + 1) / (double)(N2_SHIFTS + 1));
+            const bool pd = n2_band_ldlt<false>(rb, n, x, pivmin, nullptr, nullptr, nullptr, nullptr);
+            if (!pd) first = (double)tid;
+        }
+        block_min2_w4(first, dum, red, parity, lane, wave);
+        const int t0 = (int)first;            // first shift that is not below every eigenvalue
+        const double nlo = t0 > 0 ? lo + width * ((double)t0 / (double)(N2_SHIFTS + 1)) : lo;
+        const double nhi = t0 < N2_SHIFTS ? lo + width * ((double)(t0 + 1) / (double)(N2_SHIFTS + 1)) : hi;
+        lo = nlo; hi = nhi;
+    }
+    const double lam = 0.5 * (lo + hi);
+    const double nu = (aug && lam < lam_threshold) ? mu + rho * fabs(lam) : 0.0;
+    N2_MARK(12);
+
+    // ---- b = Q1^T (-g): panel by panel, b -= V T^T (V^T b)
+    const double* gb = g + (size_t)prob * n;
+    for (int i2 = tid; i2 < npv + 16; i2 += NT2) bb[i2] = i2 < n ? -gb[i2] : 0.0;
+    __syncthreads();
+    for (int dir = 0; dir < 2; ++dir) {
+        if (dir == 1) {
+            N2_MARK(13);
+            // ---- (Bnd + nu I) y = b by the same LDL^T, one lane
+            if (tid == 0) n2_band_ldlt<true>(rb, n, -nu, 0.0, bb, Lst, dst, zst);
+            __syncthreads();
+            N2_MARK(14);
+        }
+        for (int pp = 0; pp < npan; ++pp) {
+            const int p = dir == 0 ? pp : npan - 1 - pp;
+            const size_t vst_p = GL.Vst + (size_t)p * BW * npv, tst_p = GL.Tst + (size_t)p * BW * BW;
+            for (int idx = tid; idx < BW * (npv / 2); idx += NT2)
+                *reinterpret_cast<d2*>(Vp + 2 * idx) = *reinterpret_cast<const d2*>(wk + vst_p + 2 * (size_t)idx);
+            if (tid < 32) *reinterpret_cast<d2*>(Tm + 2 * tid) = *reinterpret_cast<const d2*>(wk + tst_p + 2 * (size_t)tid);
+            __syncthreads();
+            for (int col = wave; col < BW; col += NW2) {
+                double a = 0.0;
+                for (int r = lane; r < n; r += 64) a += Vp[col * npv + r] * bb[r];
+                a = wave_sum(a);
+                if (lane == 0) x1[col] = a;
+            }
+            __syncthreads();
+            if (tid < BW) {
+                double sacc = 0.0;
+                for (int mm = 0; mm < BW; ++mm)
+                    sacc += (dir == 0 ? Tm[mm * BW + tid] : Tm[tid * BW + mm]) * x1[mm];
+                x2[tid] = sacc;
+            }
+            __syncthreads();
+            for (int r = tid; r < n; r += NT2) {
+                double sacc = bb[r];
+#pragma unroll
+                for (int l = 0; l < BW; ++l) sacc -= Vp[l * npv + r] * x2[l];
+                bb[r] = sacc;
+            }
+            __syncthreads();
+        }
+    }
+    N2_MARK(15);
+    for (int i2 = tid; i2 < n; i2 += NT2) dp[(size_t)prob * n + i2] = bb[i2];
+    if (tid == 0) {
+        lowest[prob] = lam;
+        if (shift_out) shift_out[prob] = nu;
+    }
+}
+
 }  // namespace
 
-extern "C" int oovqe_newton_direction_max_n(void) { return NEWTON_NMAX; }
+static int n2_cu_count()
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            cus = v;
+        else
+            cus = 1;
+    }
+    return cus;
+}
+
+// which kernel serves (n, aug): the two-stage multi-workgroup one whenever the level shift is on (then the
+// system it solves is positive definite by construction); without the shift (aug == 0: the reference then
+// inverts an indefinite Hessian as it stands) the one-workgroup kernel with its pivoted tridiagonal solve
+static bool n2_use_band(int n, int aug)
+{
+    if (oovqe_opt(OOVQE_OPT_NEWTON_ONE_WG)) return false;
+    if (n > NEWTON2_NMAX) return false;
+    if (!aug && n <= NEWTON_NMAX) return false;
+    return true;
+}
+
+extern "C" int oovqe_newton_direction_max_n(void) { return NEWTON2_NMAX; }
 
 extern "C" int64_t oovqe_newton_direction_work_size(int n, int batch)
 {
-    if (n < 1 || n > NEWTON_NMAX || batch < 1) return 0;
-    return (int64_t)newton_work_per_problem(n) * batch;
+    if (n < 1 || n > NEWTON2_NMAX || batch < 1) return 0;
+    const size_t a = n <= NEWTON_NMAX ? newton_work_per_problem(n) : 0;
+    const size_t b = n2_work_total(n2_global(n), 1);
+    return (int64_t)(a > b ? a : b) * batch;
 }
 
 extern "C" int oovqe_newton_direction(const double* hessian, const double* gradient, int n, int batch,
@@ -606,15 +1345,48 @@ extern "C" int oovqe_newton_direction(const double* hessian, const double* gradi
                                       oovqe_stream_t stream)
 {
     OOVQE_REQUIRE(hessian && gradient && work && dp && lowest_eigenvalue, "oovqe_newton_direction: null pointer");
-    OOVQE_REQUIRE(n >= 1 && n <= NEWTON_NMAX, "oovqe_newton_direction: n = %d outside 1..%d", n, NEWTON_NMAX);
+    OOVQE_REQUIRE(n >= 1 && n <= NEWTON2_NMAX, "oovqe_newton_direction: n = %d outside 1..%d", n, NEWTON2_NMAX);
     OOVQE_REQUIRE(batch >= 1 && batch <= 65535, "oovqe_newton_direction: batch = %d", batch);
+    hipStream_t st = (hipStream_t)stream;
+    if (n2_use_band(n, aug)) {
+        const N2Global GL = n2_global(n);
+        const N2Lds L = n2_lds(n);
+        const size_t lds = (size_t)L.total * sizeof(double);
+        const size_t lds2 = (size_t)n2_lds2(n).total * sizeof(double);
+        OOVQE_REQUIRE(lds <= 159 * 1024 && lds2 <= 159 * 1024, "oovqe_newton_direction: %zu bytes of LDS needed",
+                      lds > lds2 ? lds : lds2);
+        OOVQE_REQUIRE(GL.aw_size * 8 < 0x7FFFFFFFull && GL.ex_size * 8 < 0x7FFFFFFFull,
+                      "oovqe_newton_direction: workspace per problem too large");
+        // workgroups per problem: all of them must be resident together (they wait for each other), one per CU
+        const int cus = n2_cu_count();
+        int W = 1;
+        while (2 * W * batch <= cus && 2 * W <= 32 && 2 * W <= GL.ntile) W *= 2;
+        OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)newton_band_kernel,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                        "oovqe_newton_direction: hipFuncSetAttribute");
+        OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)newton_band_solve_kernel,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2),
+                        "oovqe_newton_direction: hipFuncSetAttribute");
+        // exchange blocks and status words start as all ones: the pattern the hand-offs wait to see replaced
+        OOVQE_CHECK_HIP(hipMemsetAsync(work + (size_t)batch * GL.aw_size, 0xFF,
+                                       (size_t)batch * (GL.ex_size + 2) * sizeof(double), st),
+                        "oovqe_newton_direction: memset");
+        hipLaunchKernelGGL(newton_band_kernel, dim3(batch * W), dim3(NT), lds, st, hessian, n, work, W, batch);
+        OOVQE_CHECK_LAUNCH("oovqe_newton_direction/band");
+        hipLaunchKernelGGL(newton_band_solve_kernel, dim3(batch), dim3(NT2), lds2, st, gradient, n, lambda_min, mu,
+                           rho, aug, work, dp, lowest_eigenvalue, shift);
+        OOVQE_CHECK_LAUNCH("oovqe_newton_direction/solve");
+        return 0;
+    }
+    OOVQE_REQUIRE(n <= NEWTON_NMAX, "oovqe_newton_direction: n = %d > %d needs the level shift (aug != 0)", n,
+                  NEWTON_NMAX);
     const Layout L = make_layout(n);
     const size_t lds = (size_t)L.total * sizeof(double);
     OOVQE_REQUIRE(lds <= 160 * 1024, "oovqe_newton_direction: %zu bytes of LDS needed", lds);
     OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)newton_direction_kernel,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                     "oovqe_newton_direction: hipFuncSetAttribute");
-    hipLaunchKernelGGL(newton_direction_kernel, dim3(batch), dim3(NT), lds, (hipStream_t)stream, hessian,
+    hipLaunchKernelGGL(newton_direction_kernel, dim3(batch), dim3(NT), lds, st, hessian,
                        gradient, n, lambda_min, mu, rho, aug, work, dp, lowest_eigenvalue, shift);
     OOVQE_CHECK_LAUNCH("oovqe_newton_direction");
     return 0;

@@ -37,7 +37,7 @@ def _sym(rng, n, kind):
     return 0.5 * (S + S.T)
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 5, 16, 17, 18, 33, 100, 331, 480])
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 9, 10, 11, 16, 17, 18, 33, 100, 331, 480, 601, 672])
 @pytest.mark.parametrize("kind", ["indefinite", "pd", "near_singular", "diagonal"])
 def test_newton_direction_vs_eigh(n, kind):
     rng = np.random.default_rng(1000 * n + len(kind))
@@ -65,7 +65,8 @@ def test_newton_direction_batch_and_no_augmentation():
     gs = torch.tensor(rng.standard_normal((G, n)))
     dp, low, nu = ops.newton_direction(Hs.cuda(), gs.cuda())
     dp_na, low_na, nu_na = ops.newton_direction(Hs.cuda(), gs.cuda(), aug=False)
-    assert torch.equal(low, low_na) and float(nu_na.abs().max()) == 0.0
+    # (aug=False runs on the one-workgroup kernel with its pivoted solve: same eigenvalues to rounding)
+    assert (low - low_na).abs().max() < 1e-12 and float(nu_na.abs().max()) == 0.0
     for k in range(G):
         d1, l1, _ = ops.newton_direction(Hs[k].cuda(), gs[k].cuda())
         assert torch.equal(d1, dp[k]) and torch.equal(l1, low[k])      # batch == one by one, bitwise
@@ -74,9 +75,37 @@ def test_newton_direction_batch_and_no_augmentation():
         assert (dp[k].cpu() - dr).abs().max() < 1e-8 * (1 + dr.abs().max())
         dr_na, _ = _reference_direction(Hs[k], gs[k], aug=False)      # plain H^-1 g, indefinite or not
         assert (dp_na[k].cpu() - dr_na).abs().max() < 1e-8 * (1 + dr_na.abs().max())
+    nmax = aoo._lib.load().oovqe_newton_direction_max_n()
     with pytest.raises(aoo._lib.OovqeError):
-        ops.newton_direction(torch.eye(481, dtype=torch.float64, device="cuda"),
-                             torch.ones(481, dtype=torch.float64, device="cuda"))
+        ops.newton_direction(torch.eye(nmax + 1, dtype=torch.float64, device="cuda"),
+                             torch.ones(nmax + 1, dtype=torch.float64, device="cuda"))
+
+
+@pytest.mark.parametrize("n,G", [(331, 1), (331, 5), (331, 64), (58, 19), (100, 300), (9, 3)])
+def test_newton_direction_two_stage_equals_one_workgroup_kernel(n, G):
+    """The default kernel (two stages, several workgroups per problem: band reduction on the matrix
+    cores + band LDL^T multisection) against the round-2 one-workgroup tridiagonalisation kernel
+    (debug option newton_one_wg) on the same Hessians: same lowest eigenvalues, same shifts, same
+    directions (as residuals), whatever the number of workgroups a problem gets (1 ... 32)."""
+    rng = np.random.default_rng(31 * n + G)
+    Hs = torch.tensor(np.stack([_sym(rng, n, ("indefinite", "pd", "near_singular")[k % 3]) for k in range(G)])).cuda()
+    gs = torch.tensor(rng.standard_normal((G, n))).cuda()
+    dp, low, nu = ops.newton_direction(Hs, gs)
+    with aoo._lib.debug_options(newton_one_wg=1):
+        dp1, low1, nu1 = ops.newton_direction(Hs, gs)
+    scale = float(Hs.abs().amax())
+    assert (low - low1).abs().max() < 1e-12 * max(1.0, scale) * n
+    assert (nu - nu1).abs().max() < 1e-11 * max(1.0, scale) * n
+    eye = torch.eye(n, dtype=torch.float64, device="cuda")
+    for k in range(0, G, max(1, G // 8)):
+        Hk = Hs[k] + nu[k] * eye
+        res = (Hk @ dp[k] + gs[k]).abs().max() / (1.0 + gs[k].abs().max())
+        assert res < 1e-9, (k, float(res))
+        cond = float(torch.linalg.cond(Hk))
+        assert (dp[k] - dp1[k]).abs().max() <= 1e-13 * cond * (1.0 + dp1[k].abs().max()) * n
+    # a batch is the same arithmetic problem by problem, bitwise, however many workgroups share one
+    d0, l0, _ = ops.newton_direction(Hs[0], gs[0])
+    assert torch.equal(d0, dp[0]) and torch.equal(l0, low[0])
 
 
 def _quartic_problems(G, n, seed):
