@@ -642,7 +642,7 @@ constexpr int N2_SC1 = 16;            // gfx950 buffer aux bit: sc1 (bypass L1 o
 struct N2Global {                     // workspace of a call: [Aw of every problem | exchange block of every problem | status words]
     int npv, npan, ntile;
     size_t aw_size;                   // doubles per problem in the first block (the working copy, [npv][npv])
-    size_t Vst, Tst, X0, Band, ex_size;   // offsets inside a problem's exchange block, and its size
+    size_t Vst, Tst, X0, Band, bvec, ex_size;   // offsets inside a problem's exchange block, and its size
 };
 
 __host__ __device__ inline N2Global n2_global(int n)
@@ -657,6 +657,7 @@ __host__ __device__ inline N2Global n2_global(int n)
     L.Tst = o; o += (size_t)L.npan * BW * BW;
     L.X0 = o; o += (size_t)L.npan * L.npv * BW;
     L.Band = o; o += (size_t)L.npv * RW;
+    L.bvec = o; o += (size_t)L.npv;              // Q1^T (-g), from stage 1 to the solve kernel
     L.ex_size = (o + 1) & ~(size_t)1;
     return L;
 }
@@ -666,34 +667,33 @@ __host__ __device__ inline size_t n2_work_total(const N2Global& L, int batch)
     return (size_t)batch * (L.aw_size + L.ex_size + 2);
 }
 
-struct N2Lds {                        // dynamic LDS, offsets in doubles
-    int VW, Xc, part, Tm, Gm, Ym, S0, tau, x1, x2, red, bb, total;
-    // stage-2 aliases (inside VW | Xc)
-    int rb, Lst, dst, zst;
+constexpr int RQ_SMALL = 6, RQ_LARGE = (NEWTON2_NMAX - BW + 63) / 64;   // panel-column elements per lane of the owning wave
+
+struct N2Lds {                        // dynamic LDS of stage 1, offsets in doubles
+    int ldp;                          // pitch of the VW / Xc rows: npv + 4 (rows 8 banks apart)
+    int VW, Xc, part, Tm, Gm, Ym, Zm, S0, TQ, tau, x1, x2, bb, total;
 };
 
 __host__ __device__ inline N2Lds n2_lds(int n)
 {
     const int npv = 16 * ((n + 15) / 16);
     N2Lds L;
+    L.ldp = npv + 4;
     int o = 0;
-    L.VW = o; o += 16 * npv;          // rows 0..7 = V, 8..15 = W
-    L.Xc = o; o += 8 * npv;           // X0 [j][r]; the panel during its QR
-    L.part = o; o += 16 * 128;        // K-split partial tiles of X0 / partial sums of V^T X0
+    L.VW = o; o += 16 * L.ldp;        // rows 0..7 = V, 8..15 = W
+    L.Xc = o; o += 8 * L.ldp;         // X0 [j][r]
+    L.part = o; o += 16 * 128;        // K-split partial tiles of X0 / of V^T X0; the panel column during the QR (2 x 64 RQ_LARGE <= 2048)
     L.Tm = o; o += 64;
     L.Gm = o; o += 64;
     L.Ym = o; o += 64;
+    L.Zm = o; o += 64;
     L.S0 = o; o += 64;
+    L.TQ = o; o += 128;               // [T ; -1/2 Y] (16 x 8)
     L.tau = o; o += 16;
     L.x1 = o; o += 16;
     L.x2 = o; o += 16;
-    L.red = o; o += 4 * 2 * NW + 2;
     L.bb = o; o += npv + 16;
     L.total = o;
-    L.rb = L.VW;                      // [(n + RW + 1)][RW]
-    L.Lst = L.rb + (n + RW + 1) * RW; // [n][BW]
-    L.dst = L.Lst + n * BW;           // [n]
-    L.zst = L.dst + n;                // [n]     (in all 19 n + 90 <= 24 npv)
     return L;
 }
 
@@ -719,6 +719,12 @@ __device__ __forceinline__ void n2_st1(__amdgpu_buffer_rsrc_t r, size_t elem, do
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(n2_v2u, v), r, (unsigned)(elem * 8), 0, N2_SC1);
 }
 
+__device__ __forceinline__ double n2_lane(double x, int src)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), src),
+                            __builtin_amdgcn_readlane(__double2loint(x), src));
+}
+
 // index of the ring pair (a, b), 0 <= a, b < RW, in the 45-element triangle
 __device__ __forceinline__ constexpr int n2_tri(int a, int b)
 {
@@ -726,11 +732,14 @@ __device__ __forceinline__ constexpr int n2_tri(int a, int b)
 }
 
 // Band LDL^T of (Bnd - sigma I) without pivoting, run by ONE LANE: rb[r][t] = Bnd[r][r - BW + t] (row r of
-// the band, t = BW the diagonal; rows >= n are zero).  Returns false as soon as a pivot is not positive
+// the band, t = BW the diagonal; rows n .. n + 2 RW are zero).  Returns false when a pivot is not positive
 // (the matrix is not positive definite: an eigenvalue <= sigma exists).  SOLVE: also carries the right-hand
 // side through the elimination and leaves the solution of (Bnd - sigma I) y = rhs in rhs (LDS); only used
 // on positive definite matrices.  The window of the factorisation is ring-indexed (row r lives in ring slot
-// r mod 9), the k loop is unrolled by 9, so every register index is static and no entry ever moves.
+// r mod 9) and the k loop unrolled by 9: every register index is static, no entry ever moves.  The loop
+// runs over whole rounds of 9 (the rows behind n are zero rows: their pivots are ignored); the band row
+// that enters the window is fetched a step ahead, and the pivot of the next step -- and its reciprocal --
+// is formed before the other 35 updates of a step, which then run in the shadow of that dependent chain.
 template <bool SOLVE>
 __device__ bool n2_band_ldlt(const double* __restrict__ rb, int n, double sigma, double pivmin,
                              double* __restrict__ rhs, double* __restrict__ Lst, double* __restrict__ dst,
@@ -742,67 +751,81 @@ __device__ bool n2_band_ldlt(const double* __restrict__ rb, int n, double sigma,
     for (int a = 0; a < RW; ++a) {
 #pragma unroll
         for (int b = 0; b <= a; ++b) {
-            // rows a >= b (both < RW): A[a][b] = rb[a][BW - (a - b)]
-            double v = rb[a * RW + BW - (a - b)];
+            double v = rb[a * RW + BW - (a - b)];      // A[a][b], a >= b
             if (a == b) v -= sigma;
             E[n2_tri(a, b)] = v;
         }
-        if (SOLVE) cw[a] = a < n ? rhs[a] : 0.0;
+        if (SOLVE) cw[a] = rhs[a];                     // (rhs is zero behind n)
     }
     bool ok = true;
+    double rn[RW];                                     // band row k + RW, fetched one step ahead
+#pragma unroll
+    for (int t = 0; t < RW; ++t) rn[t] = rb[RW * RW + t];
+    double rinv = fast_rcp(E[n2_tri(0, 0)]);
     for (int k0 = 0; k0 < n; k0 += RW) {
 #pragma unroll
         for (int s = 0; s < RW; ++s) {
             const int k = k0 + s;
-            if (k < n) {
-                const double d = E[n2_tri(s, s)];
-                ok = ok && (d > pivmin);
-                const double rinv = fast_rcp(d);
-                double col[RW], l[RW];
+            const int s1 = (s + 1) % RW;
+            double rnn[RW];
+            const double* rnp = rb + (size_t)(k + RW + 1) * RW;
+#pragma unroll
+            for (int t = 0; t < RW; ++t) rnn[t] = rnp[t];
+            ok = ok && (E[n2_tri(s, s)] > pivmin || k >= n);
+            double col[RW], l[RW];
+#pragma unroll
+            for (int i = 1; i < RW; ++i) col[i] = E[n2_tri((s + i) % RW, s)];
+            // the next pivot first, its reciprocal in flight while the rest of the window is updated
+            l[1] = col[1] * rinv;
+            E[n2_tri(s1, s1)] -= l[1] * col[1];
+            const double rinv_next = fast_rcp(E[n2_tri(s1, s1)]);
+#pragma unroll
+            for (int i = 2; i < RW; ++i) {
+                l[i] = col[i] * rinv;
+                E[n2_tri((s + i) % RW, s1)] -= l[i] * col[1];
+            }
+#pragma unroll
+            for (int i = 2; i < RW; ++i)
+#pragma unroll
+                for (int j = 2; j <= i; ++j)
+                    E[n2_tri((s + i) % RW, (s + j) % RW)] -= l[i] * col[j];
+            if (SOLVE) {
+                const double zk = cw[s];
 #pragma unroll
                 for (int i = 1; i < RW; ++i) {
-                    col[i] = E[n2_tri((s + i) % RW, s)];
-                    l[i] = col[i] * rinv;
+                    cw[(s + i) % RW] -= l[i] * zk;
+                    Lst[k * BW + i - 1] = l[i];
                 }
-#pragma unroll
-                for (int i = 1; i < RW; ++i)
-#pragma unroll
-                    for (int j = 1; j <= i; ++j)
-                        E[n2_tri((s + i) % RW, (s + j) % RW)] -= l[i] * col[j];
-                if (SOLVE) {
-                    const double zk = cw[s];
-#pragma unroll
-                    for (int i = 1; i < RW; ++i) {
-                        cw[(s + i) % RW] -= l[i] * zk;
-                        Lst[k * BW + i - 1] = l[i];
-                    }
-                    dst[k] = rinv;
-                    zst[k] = zk;
-                    cw[s] = (k + RW < n) ? rhs[k + RW] : 0.0;
-                }
-                // ring slot s now holds row k + RW
-                const double* rn = rb + (size_t)(k + RW) * RW;
-#pragma unroll
-                for (int t = 0; t < BW; ++t) E[n2_tri(s, (s + 1 + t) % RW)] = rn[t];
-                E[n2_tri(s, s)] = rn[BW] - sigma;
+                dst[k] = rinv;
+                zst[k] = zk;
+                cw[s] = rhs[k + RW];
             }
+            // ring slot s now holds row k + RW
+#pragma unroll
+            for (int t = 0; t < BW; ++t) E[n2_tri(s, (s + 1 + t) % RW)] = rn[t];
+            E[n2_tri(s, s)] = rn[BW] - sigma;
+#pragma unroll
+            for (int t = 0; t < RW; ++t) rn[t] = rnn[t];
+            rinv = rinv_next;
         }
     }
     if (SOLVE) {
-        // L^T y = D^-1 z from the last row up; y overwrites rhs (rows >= n read as 0)
+        // L^T y = D^-1 z from the last row up; y overwrites rhs (rows >= n stay 0: their L entries are 0)
         for (int k = n - 1; k >= 0; --k) {
             double acc = zst[k] * dst[k];
 #pragma unroll
-            for (int i = 1; i < RW; ++i)
-                if (k + i < n) acc -= Lst[k * BW + i - 1] * rhs[k + i];
+            for (int i = 1; i < RW; ++i) acc -= Lst[k * BW + i - 1] * rhs[k + i];
             rhs[k] = acc;
         }
     }
     return ok;
 }
 
+// RQMAX: panel-column elements a lane holds during the QR (n - 8 <= 64 RQMAX)
+template <int RQMAX>
 __global__ __launch_bounds__(NT)
-void newton_band_kernel(const double* __restrict__ H, int n, double* __restrict__ work, int W, int batch)
+void newton_band_kernel(const double* __restrict__ H, const double* __restrict__ g, int n,
+                        double* __restrict__ work, int W, int batch)
 {
     extern __shared__ double sm[];
     const N2Global GL = n2_global(n);
@@ -811,7 +834,7 @@ void newton_band_kernel(const double* __restrict__ H, int n, double* __restrict_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane >> 4, lr = lane & 15;
     const int prob = blockIdx.x % batch, slot = blockIdx.x / batch;
-    const int npv = GL.npv, lda = GL.npv, npan = GL.npan, ntile = GL.ntile;
+    const int npv = GL.npv, lda = GL.npv, npan = GL.npan, ntile = GL.ntile, ldp = L.ldp;
     double* Aw = work + (size_t)prob * GL.aw_size;
     double* ex = work + (size_t)batch * GL.aw_size + (size_t)prob * GL.ex_size;
     // ra: the working copy (own rows are re-read past the L1); rs: the exchange block
@@ -824,8 +847,13 @@ void newton_band_kernel(const double* __restrict__ H, int n, double* __restrict_
     double* Tm = sm + L.Tm;
     double* Gm = sm + L.Gm;
     double* Ym = sm + L.Ym;
+    double* Zm = sm + L.Zm;
     double* S0 = sm + L.S0;
+    double* TQ = sm + L.TQ;
     double* taus = sm + L.tau;
+    double* x1 = sm + L.x1;
+    double* x2 = sm + L.x2;
+    double* bb = sm + L.bb;
     bool dead = false;                // a hand-off timed out (never on a healthy run): give up loudly
     // status word of the problem: all ones (the memset) = healthy, 1 = a hand-off timed out
     int* status = reinterpret_cast<int*>(work + (size_t)batch * (GL.aw_size + GL.ex_size) + 2 * (size_t)prob);
@@ -839,8 +867,14 @@ void newton_band_kernel(const double* __restrict__ H, int n, double* __restrict_
             const int r = 16 * t + idx / npv, c = idx % npv;
             Aw[(size_t)r * lda + c] = (r < n && c < n) ? Hb[(size_t)r * n + c] : 0.0;
         }
+    // (no stale bits of LDS may ever meet a zero operand as a NaN)
+    for (int idx = tid; idx < L.total; idx += NT) sm[idx] = 0.0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (slot == 0) {                  // b = -g, carried through the panels' Q^T by workgroup 0
+        const double* gb = g + (size_t)prob * n;
+        for (int i2 = tid; i2 < n; i2 += NT) bb[i2] = -gb[i2];
+    }
     N2_MARK(0);
 
     for (int p = 0; p < npan && !dead; ++p) {
@@ -849,73 +883,89 @@ void newton_band_kernel(const double* __restrict__ H, int n, double* __restrict_
         const size_t vst_p = GL.Vst + (size_t)p * BW * npv, tst_p = GL.Tst + (size_t)p * BW * BW;
         const size_t x0_p = GL.X0 + (size_t)p * npv * BW;
         // =============== P: QR of the panel, by the owner of rows k .. k+7 ===============
+        // Column c of the panel = row k + c of the (symmetric) working copy, columns r0 .. n-1: wave c keeps
+        // it in registers, element i in lane i % 64.  A step j costs ONE barrier: wave j drops its column
+        // into LDS, and then every wave forms the reflector for itself from that copy (norm, beta, tau,
+        // scale: redundant and cheap) next to its own dot product with it -- nothing waits for wave j.
         if (slot == leader) {
-            double* Pn = Xc;                                  // Pn[j][c] = A[k+j][c] = A[c][k+j]
-            for (int idx = tid; idx < BW * (npv / 2); idx += NT) {
-                const int j = idx / (npv / 2), c2 = idx - j * (npv / 2);
-                const d2 v = n2_ld2(ra, (size_t)(k + j) * lda + 2 * c2);
-                *reinterpret_cast<d2*>(Pn + j * npv + 2 * c2) = v;
-            }
-            for (int idx = tid; idx < BW * npv; idx += NT) VW[idx] = 0.0;
+            for (int idx = tid; idx < BW * ldp; idx += NT) VW[idx] = 0.0;
             if (tid < 64) { Tm[tid] = 0.0; Gm[tid] = 0.0; }
             if (tid < 16) taus[tid] = 0.0;
-            __syncthreads();
-            N2_MARK(1);
-            // band: the part of columns k .. k+7 inside the diagonal block
-            if (tid < BW * BW) {
-                const int j = tid >> 3, d = tid & 7;
-                if (d < BW - j) n2_st1(rs, GL.Band + (size_t)(k + j) * RW + d, Pn[j * npv + k + j + d]);
-            }
+            // y: the wave's panel column; once its own step is done, its reflector (for the T factor)
+            double y[RQMAX];
+            double rcol = 0.0;                                // lanes i <= c: R[i][c] of the wave's column c
             const int jb = (m - 1) < BW ? (m - 1) : BW;
+            if (wave < BW) {
+#pragma unroll
+                for (int q = 0; q < RQMAX; ++q) {
+                    const int i2 = lane + 64 * q;
+                    // (rows behind the matrix are zero rows of the working copy: in range for q < RQMAX)
+                    y[q] = i2 < m ? n2_ld1(ra, (size_t)(k + wave) * lda + r0 + (i2 < m ? i2 : 0)) : 0.0;
+                }
+                // band: the part of column k + wave inside the diagonal block
+                if (lane < BW - wave)
+                    n2_st1(rs, GL.Band + (size_t)(k + wave) * RW + lane,
+                           n2_ld1(ra, (size_t)(k + wave) * lda + k + wave + lane));
+            }
+            N2_MARK(1);
             for (int j = 0; j < jb; ++j) {
+                double* colb = part + (j & 1) * (64 * RQMAX);
                 if (wave == j) {
-                    const double* x = Pn + j * npv + r0;      // x[i], i = j .. m-1
-                    double s2 = 0.0;
-                    for (int i2 = j + 1 + lane; i2 < m; i2 += 64) s2 += x[i2] * x[i2];
+#pragma unroll
+                    for (int q = 0; q < RQMAX; ++q) colb[lane + 64 * q] = y[q];
+                }
+                lds_barrier();
+                if (wave < BW) {
+                    // (only the first 64 elements of a column can sit at or above the step's row j < 8: the
+                    // others take part in everything without a select)
+                    double x[RQMAX];
+                    x[0] = colb[lane];
+                    const double xb0 = lane > j ? x[0] : 0.0;                    // elements i > j
+                    double s2 = xb0 * xb0, dc = xb0 * y[0];
+#pragma unroll
+                    for (int q = 1; q < RQMAX; ++q) {
+                        x[q] = colb[lane + 64 * q];
+                        s2 = fma(x[q], x[q], s2);
+                        dc = fma(x[q], y[q], dc);
+                    }
                     s2 = wave_sum(s2);
-                    const double al = x[j];
-                    double beta, tau, scale;
-                    if (s2 == 0.0) { beta = al; tau = 0.0; scale = 0.0; }
-                    else {
-                        beta = -copysign(sqrt(al * al + s2), al);
-                        tau = (beta - al) / beta;
-                        scale = 1.0 / (al - beta);
-                    }
-                    for (int i2 = j + 1 + lane; i2 < m; i2 += 64) {
-                        VW[j * npv + r0 + i2] = x[i2] * scale;
-                        Pn[j * npv + r0 + i2] = 0.0;
-                    }
-                    if (lane == 0) {
-                        VW[j * npv + r0 + j] = 1.0;
-                        Pn[j * npv + r0 + j] = beta;
-                        taus[j] = tau;
+                    dc = wave_sum(dc);
+                    const double al = n2_lane(x[0], j), yj = n2_lane(y[0], j);
+                    const bool nz = s2 != 0.0;
+                    const double beta = nz ? -copysign(sqrt(fma(al, al, s2)), al) : al;
+                    const double tau = nz ? (beta - al) * fast_rcp(beta) : 0.0;
+                    const double scale = nz ? fast_rcp(al - beta) : 0.0;
+                    const double v0 = lane > j ? x[0] * scale : (lane == j ? 1.0 : 0.0);
+                    if (wave > j) {
+                        const double f = tau * fma(scale, dc, yj), fs = f * scale;
+                        y[0] = fma(-f, v0, y[0]);
+#pragma unroll
+                        for (int q = 1; q < RQMAX; ++q) y[q] = fma(-fs, x[q], y[q]);
+                    } else if (wave == j) {
+                        rcol = lane == j ? beta : y[0];
+                        y[0] = v0;
+                        VW[j * ldp + r0 + (lane < m ? lane : m)] = lane < m ? v0 : 0.0;
+#pragma unroll
+                        for (int q = 1; q < RQMAX; ++q) {
+                            const int i2 = lane + 64 * q;
+                            y[q] = x[q] * scale;
+                            // (lanes behind the panel all drop a zero just behind the matrix: inside the row's pad)
+                            VW[j * ldp + r0 + (i2 < m ? i2 : m)] = y[q];
+                        }
+                        if (lane == 0) taus[j] = tau;
+                    } else {
+                        // an earlier reflector (now in y): (V^T v_j)[wave] = v_wave[j] + scale * sum_{i > j} v_wave[i] x[i]
+                        const double gv = fma(scale, dc, yj);
+                        if (lane == 0) Gm[wave * BW + j] = gv;
                     }
                 }
-                lds_barrier();
-                if (wave > j && wave < BW) {
-                    const double* v = VW + j * npv + r0;
-                    double* y = Pn + wave * npv + r0;
-                    double dot = 0.0;
-                    for (int i2 = j + lane; i2 < m; i2 += 64) dot += v[i2] * y[i2];
-                    dot = wave_sum(dot);
-                    const double f = taus[j] * dot;
-                    for (int i2 = j + lane; i2 < m; i2 += 64) y[i2] -= f * v[i2];
-                } else if (wave < j) {
-                    const double* v = VW + j * npv + r0;
-                    const double* u = VW + wave * npv + r0;
-                    double dot = 0.0;
-                    for (int i2 = j + lane; i2 < m; i2 += 64) dot += v[i2] * u[i2];
-                    dot = wave_sum(dot);
-                    if (lane == 0) Gm[wave * BW + j] = dot;
-                }
-                lds_barrier();
             }
             N2_MARK(2);
-            // band: the R part (row r0 + i of column k + j, i <= j)
-            if (tid < BW * BW) {
-                const int j = tid >> 3, i2 = tid & 7;
-                if (i2 <= j && i2 < m) n2_st1(rs, GL.Band + (size_t)(k + j) * RW + BW + i2 - j, Pn[j * npv + r0 + i2]);
-            }
+            // band: the R part (row r0 + i of column k + wave, i <= wave)
+            if (wave < BW && wave >= jb) rcol = y[0];
+            if (wave < BW && lane <= wave && lane < m)
+                n2_st1(rs, GL.Band + (size_t)(k + wave) * RW + BW + lane - wave, rcol);
+            __syncthreads();
             // compact WY factor: row l of T by thread l (upper triangular)
             if (tid < BW) {
                 for (int jj = 0; jj < jb; ++jj) {
@@ -931,21 +981,22 @@ void newton_band_kernel(const double* __restrict__ H, int n, double* __restrict_
                 }
             }
             __syncthreads();
-            for (int idx = tid; idx < BW * (npv / 2); idx += NT)
-                n2_st2(rs, vst_p + 2 * (size_t)idx, *reinterpret_cast<const d2*>(VW + 2 * idx));
+            for (int idx = tid; idx < BW * (npv / 2); idx += NT) {
+                const int j = idx / (npv / 2), c2 = idx - j * (npv / 2);
+                n2_st2(rs, vst_p + (size_t)j * npv + 2 * c2, *reinterpret_cast<const d2*>(VW + j * ldp + 2 * c2));
+            }
             if (tid < 32) n2_st2(rs, tst_p + 2 * (size_t)tid, *reinterpret_cast<const d2*>(Tm + 2 * tid));
-            __syncthreads();      // (the hand-off loop below refills VW | Tm: not before every wave has published)
             N2_MARK(3);
-        }
-        // =============== X: V | T from the panel owner, X0 = A22 V on the own row tiles ===============
-        {
+        } else {
+            // =============== X (1): V | T from the panel owner ===============
             int spins = 0;
             while (true) {
                 int bad = 0;
                 for (int idx = tid; idx < BW * (npv / 2); idx += NT) {
-                    const d2 v = n2_ld2(rs, vst_p + 2 * (size_t)idx);
+                    const int j = idx / (npv / 2), c2 = idx - j * (npv / 2);
+                    const d2 v = n2_ld2(rs, vst_p + (size_t)j * npv + 2 * c2);
                     bad |= (int)n2_is_sent(v.x) | (int)n2_is_sent(v.y);
-                    *reinterpret_cast<d2*>(VW + 2 * idx) = v;
+                    *reinterpret_cast<d2*>(VW + j * ldp + 2 * c2) = v;
                 }
                 if (tid < 32) {
                     const d2 v = n2_ld2(rs, tst_p + 2 * (size_t)tid);
@@ -960,8 +1011,9 @@ void newton_band_kernel(const double* __restrict__ H, int n, double* __restrict_
                 __builtin_amdgcn_s_sleep(1);
             }
             if (dead) break;
+            N2_MARK(4);
         }
-        N2_MARK(4);
+        // =============== X (2): X0 = A22 V on the own row tiles ===============
         const int cg0 = r0 >> 4;                 // first 16-column group / row tile that reaches into A22
         int q0 = 0;                              // own tiles t = slot + W q, q >= q0, reach into A22
         while (slot + W * q0 < cg0) ++q0;
@@ -977,7 +1029,7 @@ void newton_band_kernel(const double* __restrict__ H, int n, double* __restrict_
                 for (int gq = cg0 + ks; gq < ntile; gq += KS) {
                     const d2 a01 = n2_ld2(ra, arow + 16 * gq);
                     const d2 a23 = n2_ld2(ra, arow + 16 * gq + 2);
-                    const double* vb = VW + lr * npv + 16 * gq + 4 * lq;
+                    const double* vb = VW + (lr & 7) * ldp + 16 * gq + 4 * lq;
                     acc = mfma_f64(a01.x, vb[0], acc);
                     acc = mfma_f64(a01.y, vb[1], acc);
                     acc = mfma_f64(a23.x, vb[2], acc);
@@ -1005,6 +1057,29 @@ void newton_band_kernel(const double* __restrict__ H, int n, double* __restrict_
                 }
             }
         }
+        if (slot == 0) {
+            // b <- Q_p^T b = b - V T^T (V^T b), while the other workgroups' X0 rows are on their way
+            __syncthreads();
+            if (wave < BW) {
+                double a = 0.0;
+                for (int r = r0 + lane; r < n; r += 64) a += VW[wave * ldp + r] * bb[r];
+                a = wave_sum(a);
+                if (lane == 0) x1[wave] = a;
+            }
+            __syncthreads();
+            if (tid < BW) {
+                double sacc = 0.0;
+                for (int mm = 0; mm < BW; ++mm) sacc += Tm[mm * BW + tid] * x1[mm];
+                x2[tid] = sacc;
+            }
+            __syncthreads();
+            for (int r = r0 + tid; r < n; r += NT) {
+                double sacc = bb[r];
+#pragma unroll
+                for (int l = 0; l < BW; ++l) sacc -= VW[l * ldp + r] * x2[l];
+                bb[r] = sacc;
+            }
+        }
         N2_MARK(6);
         // =============== U: all of X0, W, own rows of A22 -= V W^T + W V^T ===============
         {
@@ -1015,8 +1090,13 @@ void newton_band_kernel(const double* __restrict__ H, int n, double* __restrict_
                     const int r = r0 + idx / (BW / 2), j2 = (idx % (BW / 2)) * 2;
                     const d2 v = n2_ld2(rs, x0_p + (size_t)r * BW + j2);
                     bad |= (int)n2_is_sent(v.x) | (int)n2_is_sent(v.y);
-                    Xc[j2 * npv + r] = v.x;
-                    Xc[(j2 + 1) * npv + r] = v.y;
+                    Xc[j2 * ldp + r] = v.x;
+                    Xc[(j2 + 1) * ldp + r] = v.y;
+                }
+                // the rows of the first tile above the panel carry no X0
+                if (tid < BW * 16) {
+                    const int r = 16 * cg0 + (tid & 15);
+                    if (r < r0) Xc[(tid >> 4) * ldp + r] = 0.0;
                 }
                 if (!__syncthreads_or(bad)) break;
                 ++spins;
@@ -1028,13 +1108,15 @@ void newton_band_kernel(const double* __restrict__ H, int n, double* __restrict_
             if (dead) break;
         }
         N2_MARK(7);
-        {   // S0 = V^T X0 (8 x 8): 16 row classes x 64 (m, n) pairs, then a fixed-order sum
-            const int pair = tid & 63, cls = tid >> 6;
-            const double* vv = VW + (pair >> 3) * npv;
-            const double* xx = Xc + (pair & 7) * npv;
-            double sacc = 0.0;
-            for (int r = r0 + cls; r < n; r += NW) sacc += vv[r] * xx[r];
-            part[cls * 64 + pair] = sacc;
+        {   // S0 = V^T X0 (8 x 8) on the matrix cores, the rows dealt to the waves four at a time
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            const double* va = VW + (lr & 7) * ldp + lq;
+            const double* xb = Xc + (lr & 7) * ldp + lq;
+            for (int r = r0 + 4 * wave; r < n; r += 4 * NW) acc = mfma_f64(va[r], xb[r], acc);
+            if (lr < BW) {
+                part[wave * 64 + lq * BW + lr] = acc[0];            // rows lq, lq + 4 of the 8 x 8 block
+                part[wave * 64 + (lq + 4) * BW + lr] = acc[1];
+            }
         }
         __syncthreads();
         if (tid < 64) {
@@ -1044,31 +1126,36 @@ void newton_band_kernel(const double* __restrict__ H, int n, double* __restrict_
             S0[tid] = sacc;
         }
         __syncthreads();
-        if (tid < 64) {                           // Y = T^T S0 T
+        if (tid < 64) {                           // Z = S0 T
             const int a = tid >> 3, b = tid & 7;
             double sacc = 0.0;
-            for (int l = 0; l < BW; ++l) {
-                double inner = 0.0;
-                for (int q = 0; q < BW; ++q) inner += S0[l * BW + q] * Tm[q * BW + b];
-                sacc += Tm[l * BW + a] * inner;
-            }
-            Ym[tid] = sacc;
+#pragma unroll
+            for (int q = 0; q < BW; ++q) sacc += S0[a * BW + q] * Tm[q * BW + b];
+            Zm[tid] = sacc;
         }
         __syncthreads();
-        for (int idx = tid; idx < 2 * npv; idx += NT) {      // W = X0 T - 1/2 V Y, four columns per thread
-            const int r = idx % npv, jh = idx / npv;
-            double xr[BW], vr[BW];
-            const bool in = r >= r0 && r < n;
+        if (tid < 64) {                           // Y = T^T Z;  TQ = [T ; -1/2 Y]
+            const int a = tid >> 3, b = tid & 7;
+            double sacc = 0.0;
 #pragma unroll
-            for (int l = 0; l < BW; ++l) { xr[l] = in ? Xc[l * npv + r] : 0.0; vr[l] = in ? VW[l * npv + r] : 0.0; }
+            for (int l = 0; l < BW; ++l) sacc += Tm[l * BW + a] * Zm[l * BW + b];
+            Ym[tid] = sacc;
+            TQ[tid] = Tm[tid];
+            TQ[64 + tid] = -0.5 * sacc;
+        }
+        __syncthreads();
+        // W = [X0 | V] [T ; -1/2 Y]: one 16 x 16 x 16 product per row tile (rows outside r0 .. n-1 come out 0)
+        for (int t = cg0 + wave; t < ntile; t += NW) {
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int j = 4 * jh + jj;
-                double sacc = 0.0;
-#pragma unroll
-                for (int l = 0; l < BW; ++l) sacc += xr[l] * Tm[l * BW + j] - 0.5 * vr[l] * Ym[l * BW + j];
-                VW[(BW + j) * npv + r] = sacc;
+            for (int sx = 0; sx < 4; ++sx) {
+                const int kk = 4 * sx + lq;
+                const double av = kk < BW ? Xc[kk * ldp + 16 * t + lr] : VW[(kk - BW) * ldp + 16 * t + lr];
+                acc = mfma_f64(av, TQ[kk * BW + (lr & 7)], acc);
             }
+            if (lr < BW)
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) VW[(BW + lr) * ldp + 16 * t + lq + 4 * i2] = acc[i2];
         }
         __syncthreads();
         N2_MARK(8);
@@ -1085,7 +1172,7 @@ void newton_band_kernel(const double* __restrict__ H, int n, double* __restrict_
 #pragma unroll
                 for (int sx = 0; sx < 4; ++sx) {
                     const int kk = 4 * sx + lq;
-                    acc = mfma_f64(VW[kk * npv + 16 * t + lr], VW[((kk + BW) & 15) * npv + 16 * ct + lr], acc);
+                    acc = mfma_f64(VW[kk * ldp + 16 * t + lr], VW[((kk + BW) & 15) * ldp + 16 * ct + lr], acc);
                 }
 #pragma unroll
                 for (int i2 = 0; i2 < 4; ++i2)
@@ -1103,6 +1190,11 @@ void newton_band_kernel(const double* __restrict__ H, int n, double* __restrict_
             const int r = kend + idx / RW, c = r - (idx % RW);
             if (c >= kend && ((r >> 4) % W) == slot)
                 n2_st1(rs, GL.Band + (size_t)c * RW + (r - c), n2_ld1(ra, (size_t)r * lda + c));
+        }
+        // b = Q1^T (-g) for the solve kernel
+        if (slot == 0) {
+            __syncthreads();
+            for (int i2 = tid; i2 < n; i2 += NT) ex[GL.bvec + i2] = bb[i2];
         }
     }
     // a hand-off that timed out leaves its mark for the solve kernel (which then answers with NaNs)
@@ -1122,18 +1214,18 @@ __host__ __device__ inline N2Lds2 n2_lds2(int n)
     const int npv = 16 * ((n + 15) / 16);
     N2Lds2 L;
     int o = 0;
-    L.rb = o; o += (n + RW + 1) * RW;
+    L.rb = o; o += (n + 2 * RW + 2) * RW;
     o = (o + 1) & ~1;
-    L.Lst = o; o += n * BW;
-    L.dst = o; o += n;
-    L.zst = o; o += n;
+    L.Lst = o; o += (n + RW) * BW;
+    L.dst = o; o += n + RW;
+    L.zst = o; o += n + RW;
     o = (o + 1) & ~1;
     L.Vp = o; o += BW * npv;
     L.Tm = o; o += 64;
     L.x1 = o; o += 16;
     L.x2 = o; o += 16;
     L.red = o; o += 4 * 2 * NW + 2;
-    L.bb = o; o += npv + 16;
+    L.bb = o; o += npv + 2 * RW + 16;
     L.total = o;
     return L;
 }
@@ -1156,8 +1248,8 @@ __device__ __forceinline__ void block_min2_w4(double& a, double& b, double* red,
 }
 
 __global__ __launch_bounds__(NT2)
-void newton_band_solve_kernel(const double* __restrict__ g, int n, double lam_threshold, double mu, double rho,
-                              int aug, const double* __restrict__ work, double* __restrict__ dp,
+void newton_band_solve_kernel(int n, double lam_threshold, double mu, double rho, int aug,
+                              const double* __restrict__ work, double* __restrict__ dp,
                               double* __restrict__ lowest, double* __restrict__ shift_out)
 {
     extern __shared__ double sm[];
@@ -1184,7 +1276,8 @@ void newton_band_solve_kernel(const double* __restrict__ g, int n, double lam_th
 #ifdef OOVQE_NEWTON_TIMING
     long long t_mark = clock64();
 #endif
-    for (int idx = tid; idx < (n + RW + 1) * RW; idx += NT2) rb[idx] = 0.0;
+    for (int idx = tid; idx < (n + 2 * RW + 2) * RW; idx += NT2) rb[idx] = 0.0;
+    for (int i2 = tid; i2 < npv + 2 * RW + 16; i2 += NT2) bb[i2] = i2 < n ? wk[GL.bvec + i2] : 0.0;
     __syncthreads();
     int bad = dead;
     {
@@ -1224,7 +1317,7 @@ void newton_band_solve_kernel(const double* __restrict__ g, int n, double lam_th
         }
         block_min2_w4(glo, dmin, red, parity, lane, wave);
         block_min2_w4(nam, dum, red, parity, lane, wave);
-        lo = glo; hi = dmin; amax = -nam;
+        lo = glo; hi = dmin; amax = -nam;            // amax = the infinity norm of the band matrix
     }
     N2_MARK(11);
     const double pivmin = 2.2250738585072014e-308 * fmax(1.0, amax * amax);
@@ -1233,11 +1326,12 @@ void newton_band_solve_kernel(const double* __restrict__ g, int n, double lam_th
         lo -= 2.0 * 2.220446049250313e-16 * span + 2.0 * pivmin;
         hi += 2.0 * 2.220446049250313e-16 * span + 2.0 * pivmin;
     }
+    // bracket down to a rounding error of the matrix norm (what eigh delivers for an eigenvalue)
     for (int round = 0; round < 12; ++round) {
         const double width = hi - lo;
-        if (!(width > 4.0 * 2.220446049250313e-16 * fmax(fabs(lo), fabs(hi)) + 4.0 * pivmin)) break;
+        if (!(width > 2.220446049250313e-16 * amax + 4.0 * pivmin)) break;
         double first = (double)N2_SHIFTS, dum = 0.0;
-        if (tid < N2_SHIFTS) {
+        {
             const double x = lo + width * ((double)(tid + 1) / (double)(N2_SHIFTS + 1));
             const bool pd = n2_band_ldlt<false>(rb, n, x, pivmin, nullptr, nullptr, nullptr, nullptr);
             if (!pd) first = (double)tid;
@@ -1251,48 +1345,53 @@ void newton_band_solve_kernel(const double* __restrict__ g, int n, double lam_th
     const double lam = 0.5 * (lo + hi);
     const double nu = (aug && lam < lam_threshold) ? mu + rho * fabs(lam) : 0.0;
     N2_MARK(12);
-
-    // ---- b = Q1^T (-g): panel by panel, b -= V T^T (V^T b)
-    const double* gb = g + (size_t)prob * n;
-    for (int i2 = tid; i2 < npv + 16; i2 += NT2) bb[i2] = i2 < n ? -gb[i2] : 0.0;
+    // ---- (Bnd + nu I) y = b = Q1^T (-g) (carried through the panels by stage 1) by the same LDL^T, one lane
+    if (tid == 0) n2_band_ldlt<true>(rb, n, -nu, 0.0, bb, Lst, dst, zst);
     __syncthreads();
-    for (int dir = 0; dir < 2; ++dir) {
-        if (dir == 1) {
-            N2_MARK(13);
-            // ---- (Bnd + nu I) y = b by the same LDL^T, one lane
-            if (tid == 0) n2_band_ldlt<true>(rb, n, -nu, 0.0, bb, Lst, dst, zst);
-            __syncthreads();
-            N2_MARK(14);
-        }
-        for (int pp = 0; pp < npan; ++pp) {
-            const int p = dir == 0 ? pp : npan - 1 - pp;
-            const size_t vst_p = GL.Vst + (size_t)p * BW * npv, tst_p = GL.Tst + (size_t)p * BW * BW;
-            for (int idx = tid; idx < BW * (npv / 2); idx += NT2)
-                *reinterpret_cast<d2*>(Vp + 2 * idx) = *reinterpret_cast<const d2*>(wk + vst_p + 2 * (size_t)idx);
-            if (tid < 32) *reinterpret_cast<d2*>(Tm + 2 * tid) = *reinterpret_cast<const d2*>(wk + tst_p + 2 * (size_t)tid);
-            __syncthreads();
-            for (int col = wave; col < BW; col += NW2) {
-                double a = 0.0;
-                for (int r = lane; r < n; r += 64) a += Vp[col * npv + r] * bb[r];
-                a = wave_sum(a);
-                if (lane == 0) x1[col] = a;
-            }
-            __syncthreads();
-            if (tid < BW) {
-                double sacc = 0.0;
-                for (int mm = 0; mm < BW; ++mm)
-                    sacc += (dir == 0 ? Tm[mm * BW + tid] : Tm[tid * BW + mm]) * x1[mm];
-                x2[tid] = sacc;
-            }
-            __syncthreads();
-            for (int r = tid; r < n; r += NT2) {
-                double sacc = bb[r];
+    N2_MARK(14);
+    // ---- dp = Q1 y: panels in reverse, y -= V T (V^T y); the next panel's V | T are fetched into registers
+    // while the current one is applied
+    constexpr int VREG = (BW * (16 * ((NEWTON2_NMAX + 15) / 16)) / 2 + NT2 - 1) / NT2;
+    d2 vnext[VREG], tnext = {0.0, 0.0};
+    auto fetch = [&](int p) {
+        const double* vsrc = wk + GL.Vst + (size_t)p * BW * npv;
 #pragma unroll
-                for (int l = 0; l < BW; ++l) sacc -= Vp[l * npv + r] * x2[l];
-                bb[r] = sacc;
-            }
-            __syncthreads();
+        for (int u = 0; u < VREG; ++u) {
+            const int idx = tid + u * NT2;
+            if (idx < BW * (npv / 2)) vnext[u] = *reinterpret_cast<const d2*>(vsrc + 2 * (size_t)idx);
         }
+        if (tid < 32) tnext = *reinterpret_cast<const d2*>(wk + GL.Tst + (size_t)p * BW * BW + 2 * tid);
+    };
+    if (npan > 0) fetch(npan - 1);
+    for (int p = npan - 1; p >= 0; --p) {
+#pragma unroll
+        for (int u = 0; u < VREG; ++u) {
+            const int idx = tid + u * NT2;
+            if (idx < BW * (npv / 2)) *reinterpret_cast<d2*>(Vp + 2 * idx) = vnext[u];
+        }
+        if (tid < 32) *reinterpret_cast<d2*>(Tm + 2 * tid) = tnext;
+        __syncthreads();
+        if (p > 0) fetch(p - 1);
+        for (int col = wave; col < BW; col += NW2) {
+            double a = 0.0;
+            for (int r = lane; r < n; r += 64) a += Vp[col * npv + r] * bb[r];
+            a = wave_sum(a);
+            if (lane == 0) x1[col] = a;
+        }
+        __syncthreads();
+        if (tid < BW) {
+            double sacc = 0.0;
+            for (int mm = 0; mm < BW; ++mm) sacc += Tm[tid * BW + mm] * x1[mm];
+            x2[tid] = sacc;
+        }
+        __syncthreads();
+        for (int r = tid; r < n; r += NT2) {
+            double sacc = bb[r];
+#pragma unroll
+            for (int l = 0; l < BW; ++l) sacc -= Vp[l * npv + r] * x2[l];
+            bb[r] = sacc;
+        }
+        __syncthreads();
     }
     N2_MARK(15);
     for (int i2 = tid; i2 < n; i2 += NT2) dp[(size_t)prob * n + i2] = bb[i2];
@@ -1361,7 +1460,9 @@ extern "C" int oovqe_newton_direction(const double* hessian, const double* gradi
         const int cus = n2_cu_count();
         int W = 1;
         while (2 * W * batch <= cus && 2 * W <= 32 && 2 * W <= GL.ntile) W *= 2;
-        OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)newton_band_kernel,
+        const bool small_q = n - BW <= 64 * RQ_SMALL;
+        OOVQE_CHECK_HIP(hipFuncSetAttribute(small_q ? (const void*)newton_band_kernel<RQ_SMALL>
+                                                    : (const void*)newton_band_kernel<RQ_LARGE>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                         "oovqe_newton_direction: hipFuncSetAttribute");
         OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)newton_band_solve_kernel,
@@ -1371,10 +1472,15 @@ extern "C" int oovqe_newton_direction(const double* hessian, const double* gradi
         OOVQE_CHECK_HIP(hipMemsetAsync(work + (size_t)batch * GL.aw_size, 0xFF,
                                        (size_t)batch * (GL.ex_size + 2) * sizeof(double), st),
                         "oovqe_newton_direction: memset");
-        hipLaunchKernelGGL(newton_band_kernel, dim3(batch * W), dim3(NT), lds, st, hessian, n, work, W, batch);
+        if (small_q)
+            hipLaunchKernelGGL(newton_band_kernel<RQ_SMALL>, dim3(batch * W), dim3(NT), lds, st, hessian, gradient, n,
+                               work, W, batch);
+        else
+            hipLaunchKernelGGL(newton_band_kernel<RQ_LARGE>, dim3(batch * W), dim3(NT), lds, st, hessian, gradient, n,
+                               work, W, batch);
         OOVQE_CHECK_LAUNCH("oovqe_newton_direction/band");
-        hipLaunchKernelGGL(newton_band_solve_kernel, dim3(batch), dim3(NT2), lds2, st, gradient, n, lambda_min, mu,
-                           rho, aug, work, dp, lowest_eigenvalue, shift);
+        hipLaunchKernelGGL(newton_band_solve_kernel, dim3(batch), dim3(NT2), lds2, st, n, lambda_min, mu, rho, aug,
+                           work, dp, lowest_eigenvalue, shift);
         OOVQE_CHECK_LAUNCH("oovqe_newton_direction/solve");
         return 0;
     }

@@ -103,9 +103,14 @@ def test_newton_direction_two_stage_equals_one_workgroup_kernel(n, G):
         assert res < 1e-9, (k, float(res))
         cond = float(torch.linalg.cond(Hk))
         assert (dp[k] - dp1[k]).abs().max() <= 1e-13 * cond * (1.0 + dp1[k].abs().max()) * n
-    # a batch is the same arithmetic problem by problem, bitwise, however many workgroups share one
+    # a problem alone gets more workgroups than inside a batch: other summation orders, same numbers
     d0, l0, _ = ops.newton_direction(Hs[0], gs[0])
-    assert torch.equal(d0, dp[0]) and torch.equal(l0, low[0])
+    cond0 = float(torch.linalg.cond(Hs[0] + nu[0] * eye))
+    assert (d0 - dp[0]).abs().max() <= 1e-13 * cond0 * (1.0 + dp[0].abs().max()) * n
+    assert abs(l0.item() - low[0].item()) < 1e-12 * max(1.0, scale) * n
+    # and the same call twice gives the same bits
+    dp_again, low_again, _ = ops.newton_direction(Hs, gs)
+    assert torch.equal(dp_again, dp) and torch.equal(low_again, low)
 
 
 def _quartic_problems(G, n, seed):
