@@ -449,6 +449,183 @@ void sector_gram_rows_kernel(const double* __restrict__ psi_c, const double* __r
     }
 }
 
+// ---- round 3: the E_pq vectors never leave the chip --------------------------------------------------
+// V = (E_pq psi) is 64 x 4 900 doubles per CAS(8e,8o) state: written once and read once it was 1.28 GB of the
+// RDM stage's traffic at batch 256 (and as much again for the adjoint).  But both consumers are LOCAL in the
+// determinant index -- the Gram sums over it, W = Ms^T V acts on the (p,q) index -- so a workgroup that holds
+// psi (39 KB) in LDS can form V for a chunk of SEC_CH determinants in LDS (a^2 x SEC_CH doubles), use it and
+// drop it.  Both kernels below: grid (batch, nsplit), 512 threads, the chunks of a state dealt to the
+// nsplit workgroups; four threads per determinant build the chunk (a^2 / 4 operators each).
+constexpr int SEC_CH = 128;                  // determinants per chunk
+constexpr int SEC_CHP = SEC_CH + 4;          // LDS pitch of a V row (rows 8 banks apart)
+
+__host__ __device__ inline size_t sec_fused_lds_bytes(int na, int nb, int ncas)
+{
+    const size_t Dc = (size_t)na * nb, na2 = (size_t)ncas * ncas;
+    return (Dc + (Dc & 1) + na2 * SEC_CHP) * sizeof(double) + 2 * ((size_t)1 << ncas) * sizeof(int32_t);
+}
+
+// fills Vc[pq][0 .. SEC_CH) for the determinants c0 .. c0 + SEC_CH - 1 (zeros behind the sector)
+__device__ __forceinline__ void sec_build_chunk(const double* __restrict__ src, const Sector& sl, const Sector& sg,
+                                                int c0, double* __restrict__ Vc)
+{
+    const int Dc = sl.na * sl.nb, n = 2 * sl.ncas, a = sl.ncas, na2 = a * a;
+    const int cl = threadIdx.x & (SEC_CH - 1), part = threadIdx.x / SEC_CH;       // 512 / 128 = 4 parts
+    const int c = c0 + cl;
+    const bool in = c < Dc;
+    const uint32_t x = in ? sec_full(sg, c) : 0u;
+    for (int pq = part; pq < na2; pq += 512 / SEC_CH) {
+        const int p = pq / a, q = pq - p * a;
+        Vc[pq * SEC_CHP + cl] = in ? sec_epq(src, sl, n, p, q, x, c) : 0.0;
+    }
+}
+
+// RDM Gram without V in memory: R as sector_gram_rows_kernel writes it (same finish kernel).
+// a^2 a multiple of 16 (a = 4, 8): MT = NT = a^2 / 16, the <psi| V_rs> row on the vector ALUs.
+template <int NT>
+__global__ __launch_bounds__(512)
+void sector_rdm_fused_kernel(const double* __restrict__ psi_c, Sector s, int batch, int MTR, double* __restrict__ R)
+{
+    extern __shared__ double lds[];
+    __shared__ double red[8][256];
+    const int Dc = s.na * s.nb, a = s.ncas, na2 = a * a, ns = 1 << a;
+    double* src = lds;                                            // [Dc]
+    double* Vc = src + Dc + (Dc & 1);                             // [a^2][SEC_CHP]
+    int32_t* ra = reinterpret_cast<int32_t*>(Vc + (size_t)na2 * SEC_CHP);
+    int32_t* rb = ra + ns;
+    const size_t b = blockIdx.x;
+    const int split = blockIdx.y, nsplit = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane >> 4, lr = lane & 15;
+    for (int i = tid; i < Dc; i += 512) src[i] = psi_c[b * Dc + i];
+    for (int i = tid; i < ns; i += 512) { ra[i] = s.rank_a[i]; rb[i] = s.rank_b[i]; }
+    const Sector sg = s;
+    Sector sl = s;
+    sl.rank_a = ra;
+    sl.rank_b = rb;
+    // A rows m = (p,q) read V[(q,p)]; B rows n read V[n]
+    int arow[NT];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        const int m = mt * 16 + lr, p = m / a, q = m - p * a;
+        arow[mt] = (q * a + p) * SEC_CHP;
+    }
+    d4 acc[NT][NT];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = d4{0.0, 0.0, 0.0, 0.0};
+    double gpart[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) gpart[nt] = 0.0;
+    const int nchunk = (Dc + SEC_CH - 1) / SEC_CH;
+    __syncthreads();
+    for (int ch = split; ch < nchunk; ch += nsplit) {
+        const int c0 = ch * SEC_CH;
+        sec_build_chunk(src, sl, sg, c0, Vc);
+        __syncthreads();
+        // the 32 k-steps of the chunk dealt to the 8 waves; k-step ks covers determinants 4 ks .. 4 ks + 3
+#pragma unroll
+        for (int u = 0; u < SEC_CH / 4 / 8; ++u) {
+            const int cc = 4 * (wave + 8 * u) + lq;
+            double bv[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = Vc[(nt * 16 + lr) * SEC_CHP + cc];
+            const double pv = c0 + cc < Dc ? src[c0 + cc] : 0.0;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) gpart[nt] += pv * bv[nt];
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) {
+                const double av = Vc[arow[mt] + cc];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_f64(av, bv[nt], acc[mt][nt]);
+            }
+        }
+        __syncthreads();
+    }
+    // the 8 waves' partial tiles are summed through LDS in fixed order, tile by tile
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[wave][(lq + 4 * i) * 16 + lr] = acc[mt][nt][i];
+            __syncthreads();
+            if (tid < 256) {
+                double v = red[0][tid];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) v += red[w][tid];
+                const int row = mt * 16 + tid / 16, col = nt * 16 + (tid & 15);
+                R[(((size_t)split * batch + b) * (MTR * 16) + row) * (NT * 16) + col] = v;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        red[wave][lq * 16 + lr] = gpart[nt];
+        __syncthreads();
+        if (tid < 16) {
+            double v = 0.0;
+            for (int w = 0; w < 8; ++w)
+                for (int gq = 0; gq < 4; ++gq) v += red[w][gq * 16 + tid];
+            R[(((size_t)split * batch + b) * (MTR * 16) + na2) * (NT * 16) + nt * 16 + tid] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// W[b][j][c] = sum_k Ms[k][j] (E_k psi_b)[c] without V in memory.  Wave w forms the 16 x 16 tiles of W rows
+// 16 (w % NT) .. for the c-tiles (w / NT), (w / NT) + 8 / NT, ... of every chunk, its Ms fragments in registers.
+template <int NT>
+__global__ __launch_bounds__(512)
+void sector_w_fused_kernel(const double* __restrict__ psi_c, const double* __restrict__ Ms, Sector s,
+                           double* __restrict__ W)
+{
+    extern __shared__ double lds[];
+    const int Dc = s.na * s.nb, a = s.ncas, na2 = a * a, ns = 1 << a;
+    double* src = lds;
+    double* Vc = src + Dc + (Dc & 1);
+    int32_t* ra = reinterpret_cast<int32_t*>(Vc + (size_t)na2 * SEC_CHP);
+    int32_t* rb = ra + ns;
+    const size_t b = blockIdx.x;
+    const int split = blockIdx.y, nsplit = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane >> 4, lr = lane & 15;
+    for (int i = tid; i < Dc; i += 512) src[i] = psi_c[b * Dc + i];
+    for (int i = tid; i < ns; i += 512) { ra[i] = s.rank_a[i]; rb[i] = s.rank_b[i]; }
+    const Sector sg = s;
+    Sector sl = s;
+    sl.rank_a = ra;
+    sl.rank_b = rb;
+    constexpr int KS = NT * 4;                           // k-steps over the a^2 = 16 NT rows of V
+    const int jt = wave % NT, ct0 = wave / NT;           // this wave's W row tile, its first c-tile
+    constexpr int CSTEP = 8 / NT;                        // c-tiles a wave skips (8 waves, NT row tiles)
+    double af[KS];                                       // A[m = j][k] = Ms[k][16 jt + lr], k = 4 ks + lq
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) af[ks] = Ms[(size_t)(4 * ks + lq) * na2 + 16 * jt + lr];
+    double* Wb = W + b * (size_t)na2 * Dc;
+    const int nchunk = (Dc + SEC_CH - 1) / SEC_CH;
+    __syncthreads();
+    for (int ch = split; ch < nchunk; ch += nsplit) {
+        const int c0 = ch * SEC_CH;
+        sec_build_chunk(src, sl, sg, c0, Vc);
+        __syncthreads();
+        for (int ct = ct0; ct < SEC_CH / 16; ct += CSTEP) {
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                acc = mfma_f64(af[ks], Vc[(4 * ks + lq) * SEC_CHP + 16 * ct + lr], acc);
+            const int c = c0 + 16 * ct + lr;
+            if (c < Dc)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Wb[(size_t)(16 * jt + lq + 4 * i) * Dc + c] = acc[i];
+        }
+        __syncthreads();
+    }
+}
+
 // gamma[rs] = R[a^2][rs];  Gamma[pq,rs] = R[pq][rs] - delta_qr gamma[ps]
 __global__ void sector_rdm_finish_kernel(const double* __restrict__ R, int ncas, int batch, int nsplit,
                                          double* __restrict__ gamma, double* __restrict__ Gamma)
@@ -478,43 +655,42 @@ __global__ void sector_rdm_finish_kernel(const double* __restrict__ R, int ncas,
 }
 
 // ---- lambda = (Hop + Hop^T) psi -------------------------------------------------------------------
-// coefficient matrices for the two GEMMs:  M1[(rs),(pq)] = c2[pq,rs]  (W_pq  = sum_rs c2 V_rs)
-//                                           M2[(k),(rs)]  = c2[swap(k),rs], swap(q*a+p) = p*a+q
-//                                                            (W'_rs = sum_pq c2[pq,rs] V_qp)
-// c1e[ps] = c1[ps] - sum_q c2[p,q,q,s]
+// E = psi^T Hop psi with Hop = sum c1e_pq E_pq + sum c2_pqrs E_pq E_rs, c1e[ps] = c1[ps] - sum_q c2[p,q,q,s].
+// (E_pq E_rs)^T = E_sr E_qp, so  Hop + Hop^T = sum (c1e_pq + c1e_qp) E_pq + sum (c2[pq,rs] + c2[sr,qp]) E_pq E_rs
+// and  lambda = sum_pq E_pq W_pq,  W_pq = sum_rs Ms[rs][pq] V_rs  with ONE symmetrised coefficient matrix
+// (round 2 carried the transposed half as a second set of a^2 vectors W': twice the bytes written and read).
 __global__ void sector_coeff_kernel(const double* __restrict__ c1, const double* __restrict__ c2,
                                     int ncas, const uint32_t* __restrict__ unrank_a,
-                                    const uint32_t* __restrict__ unrank_b, double* __restrict__ M12)
+                                    const uint32_t* __restrict__ unrank_b, double* __restrict__ Ms)
 {
-    // M12 [a^2][2 a^2] = [M1 | M2]: W and W' come out of ONE contraction over V (J = 2 a^2).  The
-    // one-body term u = sum_k s_k V_k rides in M1: on the sector sum_p E_pp = N (the electron
-    // number), so adding s_k / N to the columns (p,p) of row k adds sum_p E_pp (s_k / N) V_k = s_k V_k
-    // to lambda = sum_j E_j W_j -- no extra column (129 -> 128: eight full 16-wide tiles), no extra
-    // row of W to write and read.   s_k = c1e[k] + c1e[swap k],  c1e[ps] = c1[ps] - sum_q c2[p,q,q,s]
-    const int na2 = ncas * ncas, ldm = 2 * na2;
+    // Ms [a^2][a^2]: row k = (r,s) of V, column j = (p,q) of W.  The one-body term u = sum_k s_k V_k rides
+    // along: on the sector sum_p E_pp = N (the electron number), so adding s_k / N to the columns (p,p) of
+    // row k adds sum_p E_pp (s_k / N) V_k = s_k V_k to lambda = sum_j E_j W_j -- no extra row of W to write
+    // and read.   s_k = c1e[k] + c1e[swap k]
+    const int na2 = ncas * ncas;
     const int nel = __popc(unrank_a[0]) + __popc(unrank_b[0]);
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < na2 * na2;
          idx += gridDim.x * blockDim.x) {
         const int k = idx / na2, j = idx - k * na2;
-        const int kq = k / ncas, kp = k - kq * ncas;          // k = q*a + p  ->  pq = p*a + q
-        double m1 = c2[(size_t)j * na2 + k];
-        if (j / ncas == j % ncas && nel > 0) {
+        const int kr = k / ncas, ks = k - kr * ncas;          // V row k = E_rs psi
+        const int jp = j / ncas, jq = j - jp * ncas;          // W row j = (p,q)
+        double m = c2[(size_t)j * na2 + k] + c2[(size_t)(ks * ncas + kr) * na2 + (jq * ncas + jp)];
+        if (jp == jq && nel > 0) {
             auto c1e = [&](int p, int s2) {
                 double v = c1[p * ncas + s2];
                 for (int q = 0; q < ncas; ++q) v -= c2[((size_t)(p * ncas + q) * ncas + q) * ncas + s2];
                 return v;
             };
-            m1 += (c1e(kq, kp) + c1e(kp, kq)) / nel;
+            m += (c1e(kr, ks) + c1e(ks, kr)) / nel;
         }
-        M12[(size_t)k * ldm + j] = m1;
-        M12[(size_t)k * ldm + na2 + j] = c2[(size_t)(kp * ncas + kq) * na2 + j];
+        Ms[(size_t)k * na2 + j] = m;
     }
 }
 
 // grid: (ceil(Dc/64), batch); block = 64 determinants x 4 slices of the (p,q) loop, summed in LDS
 // in fixed order; string tables staged in LDS.
 __global__ __launch_bounds__(256)
-void sector_lambda_kernel(const double* __restrict__ W12, Sector s, double* __restrict__ lam)
+void sector_lambda_kernel(const double* __restrict__ W, Sector s, double* __restrict__ lam)
 {
     extern __shared__ double lds[];
     double* part = lds;                                         // [4][64]
@@ -533,13 +709,11 @@ void sector_lambda_kernel(const double* __restrict__ W12, Sector s, double* __re
     const size_t b = blockIdx.y;
     double acc = 0.0;
     if (c < Dc) {
-        const double* W1b = W12 + b * (size_t)(2 * na2) * Dc;        // [2 a^2][Dc]: W rows, W' rows
-        const double* W2b = W1b + (size_t)na2 * Dc;
+        const double* Wb = W + b * (size_t)na2 * Dc;                 // [a^2][Dc]
         const uint32_t x = sec_full(sg, c);
         for (int pq = slice; pq < na2; pq += 4) {
             const int p = pq / a, q = pq - p * a;
-            acc += sec_epq(W1b + (size_t)pq * Dc, s, n, p, q, x, c);      // E_pq W_pq
-            acc += sec_epq(W2b + (size_t)pq * Dc, s, n, q, p, x, c);      // E_sr W'_rs (r=p, s=q)
+            acc += sec_epq(Wb + (size_t)pq * Dc, s, n, p, q, x, c);       // E_pq W_pq
         }
     }
     part[slice * 64 + cl] = acc;
@@ -733,6 +907,36 @@ extern "C" int oovqe_sector_rdms(const double* psi_c, int ncas, const uint32_t* 
     Sector s = make_sector(unrank_a, unrank_b, rank_a, rank_b, na, nb, ncas);
     double* V = work;                                              // [batch][a^2][Dc]
     double* R = work + (size_t)batch * (3 * (size_t)na2 * Dc + 2 * (size_t)Dc); // [splits][batch][MT*16][NT*16]
+    // a^2 a multiple of 16 and the sector vector + one chunk of E_pq vectors within a workgroup's LDS: the
+    // fused kernel (V never written); nsplit workgroups per state share its chunks when the batch is small
+    const size_t fused_lds = sec_fused_lds_bytes(na, nb, ncas);
+    if (na2 % 16 == 0 && na2 <= 64 && fused_lds <= 150 * 1024 && oovqe_opt(OOVQE_OPT_SECTOR_UNFUSED) == 0) {
+        const int nchunk = (Dc + SEC_CH - 1) / SEC_CH;
+        int nsplit = batch >= 128 ? 1 : (batch >= 64 ? 2 : (batch >= 16 ? 4 : 8));
+        if (nsplit > nchunk) nsplit = nchunk;
+#define OOVQE_SEC_RDMF(NT_)                                                                        \
+        do {                                                                                       \
+            static bool attr_done = false;                                                         \
+            if (!attr_done) {                                                                      \
+                OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)sector_rdm_fused_kernel<NT_>,     \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                                    150 * 1024), "sector_rdms: hipFuncSetAttribute"); \
+                attr_done = true;                                                                  \
+            }                                                                                      \
+            hipLaunchKernelGGL(sector_rdm_fused_kernel<NT_>, dim3(batch, nsplit), dim3(512), fused_lds, st, \
+                               psi_c, s, batch, MT, R);                                            \
+        } while (0)
+        if (NT == 4) OOVQE_SEC_RDMF(4);
+        else if (NT == 2) OOVQE_SEC_RDMF(2);
+        else if (NT == 3) OOVQE_SEC_RDMF(3);
+        else OOVQE_SEC_RDMF(1);
+#undef OOVQE_SEC_RDMF
+        OOVQE_CHECK_LAUNCH("sector_rdms/fused");
+        hipLaunchKernelGGL(sector_rdm_finish_kernel, dim3((na2 * na2 + na2 + 255) / 256, batch), dim3(256),
+                           0, st, R, ncas, batch, nsplit, gamma, Gamma);
+        OOVQE_CHECK_LAUNCH("sector_rdms/finish");
+        return 0;
+    }
     {
         const size_t epq_lds = ((size_t)Dc + (Dc & 1)) * sizeof(double) + 2 * ((size_t)1 << ncas) * sizeof(int32_t);
         // (few states: the one-element-per-thread grid has 64 x more workgroups to fill the chip with)
@@ -797,12 +1001,47 @@ extern "C" int oovqe_sector_adjoint(const double* theta, int n_theta, const oovq
                        unrank_a, unrank_b, M12);
     OOVQE_CHECK_LAUNCH("sector_adjoint/coeff");
     int rc;
-    // W12[b][j][c] = sum_k M12[k][j] V[b][k][c]: rows j < a^2: W_pq = sum_rs c2[pq,rs] V_rs (+ the
-    // one-body term on the rows (p,p)), rows a^2 <= j < 2 a^2: W'_rs = sum_pq c2[pq,rs] V_qp -- one
-    // pass over V for all of them
-    if ((rc = oovqe_mode_contract_batched(V, M12, W12, 1, na2, 2 * na2, Dc, 2 * na2, 0, batch,
-                                          (long)na2 * Dc, 0, (long)(2 * na2) * Dc, st)))
+    const size_t fused_lds = sec_fused_lds_bytes(na, nb, ncas);
+    const bool fused = na2 % 16 == 0 && na2 <= 64 && fused_lds <= 150 * 1024 &&
+                       oovqe_opt(OOVQE_OPT_SECTOR_UNFUSED) == 0;
+    if (fused) {
+        // W straight from psi: the E_pq vectors are formed chunk by chunk in LDS and contracted there
+        const int nchunk = (Dc + SEC_CH - 1) / SEC_CH;
+        int nsplit = batch >= 128 ? 1 : (batch >= 64 ? 2 : (batch >= 16 ? 4 : 8));
+        if (nsplit > nchunk) nsplit = nchunk;
+#define OOVQE_SEC_WF(NT_)                                                                          \
+        do {                                                                                       \
+            static bool attr_done = false;                                                         \
+            if (!attr_done) {                                                                      \
+                OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)sector_w_fused_kernel<NT_>,       \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                                    150 * 1024), "sector_adjoint: hipFuncSetAttribute"); \
+                attr_done = true;                                                                  \
+            }                                                                                      \
+            hipLaunchKernelGGL(sector_w_fused_kernel<NT_>, dim3(batch, nsplit), dim3(512), fused_lds, st, \
+                               psi_c, M12, s, W12);                                                \
+        } while (0)
+        if (NT == 4) OOVQE_SEC_WF(4);
+        else if (NT == 2) OOVQE_SEC_WF(2);
+        else OOVQE_SEC_WF(1);
+#undef OOVQE_SEC_WF
+        OOVQE_CHECK_LAUNCH("sector_adjoint/w_fused");
+    } else {
+        // (the unfused path needs V: the caller's oovqe_sector_rdms on the same work left it there only when
+        // it took the unfused path too -- form it here)
+        const size_t epq_lds = ((size_t)Dc + (Dc & 1)) * sizeof(double) + 2 * ((size_t)1 << ncas) * sizeof(int32_t);
+        if (epq_lds <= 64 * 1024 && batch >= 8)
+            hipLaunchKernelGGL(sector_epq_rows_kernel, dim3((Dc + 255) / 256, batch), dim3(256), epq_lds, st, psi_c,
+                               s, V);
+        else
+            hipLaunchKernelGGL(sector_epq_kernel, dim3((Dc + 255) / 256, na2, batch), dim3(256), 0, st, psi_c, s, V);
+        OOVQE_CHECK_LAUNCH("sector_adjoint/epq");
+    // W[b][j][c] = sum_k Ms[k][j] V[b][k][c]: W_pq = sum_rs (c2[pq,rs] + c2[sr,qp]) V_rs (+ the one-body
+    // term on the rows (p,p)) -- one pass over V, a^2 vectors out
+    if ((rc = oovqe_mode_contract_batched(V, M12, W12, 1, na2, na2, Dc, na2, 0, batch,
+                                          (long)na2 * Dc, 0, (long)na2 * Dc, st)))
         return rc;
+    }
     hipLaunchKernelGGL(sector_lambda_kernel, dim3((Dc + 63) / 64, batch), dim3(256),
                        256 * sizeof(double) + 2 * ((size_t)1 << ncas) * sizeof(int32_t), st, W12, s, lam);
     OOVQE_CHECK_LAUNCH("sector_adjoint/lambda");

@@ -93,6 +93,18 @@ def _matvec(H, v):
     return None if v is None else torch.matmul(H, v.reshape(-1))
 
 
+def _apply_rows(fn, v, shape):
+    """fn on a direction v, or row by row on a stack of directions (torch.func's vmap over the
+    cotangents of a Hessian hands a batched tangent to a derivative rule)."""
+    if torch._C._functorch.is_functorch_wrapped_tensor(v) and torch._C._functorch.is_batchedtensor(v):
+        raw = v
+        while torch._C._functorch.is_functorch_wrapped_tensor(raw):
+            raw = torch._C._functorch.get_unwrapped(raw)
+        raise NotImplementedError("batched tangents at kappa != 0: use torch.autograd.functional.hessian "
+                                  "(or vectorize=False)")
+    return fn(unwrap(v).reshape(-1)).reshape(shape)
+
+
 class _OrbitalRotationRule:
     """Shared chain rule through C(kappa) = C0 expm(-K(kappa)) (oo_energy.py:226-236).
 
@@ -112,6 +124,86 @@ class _OrbitalRotationRule:
             return oo.mo_coeff, None, None
         U, K = ops.expm_skew(oo._t(kappa).reshape(-1), oo._kap_row, oo._kap_col, oo.nao, want_K=True)
         return ops.matmul_nn(oo.mo_coeff, U), U, K
+
+    # ---- second order at kappa != 0 -------------------------------------------------------------
+    # E(theta, kappa_bar + d) = e(theta, x(d)) with e the energy in the LOCAL rotation parameters of the
+    # rotated orbitals C_bar = C0 U_bar (all N(N-1)/2 pairs: x = 0 is C_bar itself) and
+    # exp(-K_full(x(d))) = U_bar^T exp(-K(kappa_bar + d)).  Every second derivative the kernels know is
+    # local (analytic Hessian blocks at C_bar, oo_energy.py:311-402, oo_pqc.py:103-148); what is left is the
+    # small-matrix map d -> x(d), through the first and second Frechet derivatives of the exponential:
+    #   J v      = pairs( U_bar^T L(-K_bar; K(v)) )
+    #   J^T w    = pairs_kappa( 1/2 L(K_bar; U_bar W) )                       W = skew(w)
+    #   sum_i g_i d^2 x_i [., v] = pairs_kappa( 1/2 L2(K_bar; U_bar G, K(v)) + 1/4 L(K_bar; U_bar (G B^T + B^T G)) )
+    #                              G = skew(g), B = U_bar^T L(-K_bar; K(v))
+    # L(X; A) = upper right block of expm([[X, A], [0, X]]); L2(X; A, B) = the (1,3) blocks of
+    # expm([[X, A, 0], [0, X, B], [0, 0, X]]) for (A, B) and (B, A); the adjoint of L(X; .) is L(X^T; .), that
+    # of L2(X; ., V) is L2(X^T; ., V^T) (checked against torch autograd of the same map to 1e-14).
+    def _full_pairs(self):
+        oo = self.oo
+        tabs = oo.__dict__.get("_full_pair_tables")
+        if tabs is None:
+            tr, tc = np.tril_indices(oo.nao, -1)
+            tabs = (torch.as_tensor(tr.astype(np.int32)).to(oo.device),
+                    torch.as_tensor(tc.astype(np.int32)).to(oo.device))
+            oo.__dict__["_full_pair_tables"] = tabs
+        return tabs
+
+    def _frechet(self, X, A):
+        N = X.shape[0]
+        blk = torch.zeros((2 * N, 2 * N), dtype=F64, device=X.device)
+        blk[:N, :N] = X
+        blk[N:, N:] = X
+        blk[:N, N:] = A
+        return ops.expm(blk, 1.0)[:N, N:]
+
+    def _frechet2(self, X, A, B):
+        N = X.shape[0]
+
+        def ordered(P, Q):
+            blk = torch.zeros((3 * N, 3 * N), dtype=F64, device=X.device)
+            for i in range(3):
+                blk[i * N:(i + 1) * N, i * N:(i + 1) * N] = X
+            blk[:N, N:2 * N] = P
+            blk[N:2 * N, 2 * N:] = Q
+            return ops.expm(blk, 1.0)[:N, 2 * N:]
+        return ordered(A, B) + ordered(B, A)
+
+    def _kmat(self, v):
+        oo = self.oo
+        r, c = oo._kap_row.long(), oo._kap_col.long()
+        Km = torch.zeros((oo.nao, oo.nao), dtype=F64, device=oo.device)
+        Km[r, c] = v.reshape(-1)
+        Km[c, r] = -v.reshape(-1)
+        return Km
+
+    def _skew_full(self, w):
+        oo = self.oo
+        tr, tc = self._full_pairs()
+        Wm = torch.zeros((oo.nao, oo.nao), dtype=F64, device=oo.device)
+        Wm[tr.long(), tc.long()] = w
+        Wm[tc.long(), tr.long()] = -w
+        return Wm
+
+    def local_push(self, U, K, v):
+        """J v (all pairs) and B = U^T L(-K; K(v))."""
+        tr, tc = self._full_pairs()
+        B = ops.matmul_tn(U, self._frechet(-K, self._kmat(v)).contiguous())
+        return B[tr.long(), tc.long()], B
+
+    def local_pull(self, U, K, w):
+        """J^T w on the non-redundant kappa pairs (w over all pairs)."""
+        oo = self.oo
+        Y = 0.5 * self._frechet(K.contiguous(), ops.matmul_nn(U, self._skew_full(w)))
+        r, c = oo._kap_row.long(), oo._kap_col.long()
+        return Y[r, c] - Y[c, r]
+
+    def local_curvature(self, U, K, Gm, v, B):
+        """sum_i g_i d^2 x_i / d kappa d kappa . v  for the local gradient G (skew matrix)."""
+        oo = self.oo
+        Z = 0.5 * self._frechet2(K.contiguous(), ops.matmul_nn(U, Gm.contiguous()), self._kmat(v)) \
+            + 0.25 * self._frechet(K.contiguous(), ops.matmul_nn(U, (Gm @ B.T + B.T @ Gm).contiguous()))
+        r, c = oo._kap_row.long(), oo._kap_col.long()
+        return Z[r, c] - Z[c, r]
 
     def kappa_gradient(self, fock, gvec0, U, K):
         """dE/dkappa from the Fock matrix at C0 U (gvec0: its value when kappa = 0)."""
@@ -149,19 +241,37 @@ class _KappaEnergyModel(_OrbitalRotationRule):
 
     def hvp(self, xs, vs, needs=None):
         kappa, one_rdm, two_rdm = (unwrap(x) for x in xs)
-        if not _is_zero(kappa):
-            raise NotImplementedError("second derivatives of energy_from_kappa are available at "
-                                      "kappa = 0 (where the reference's tests take them)")
         if (not is_zero_tangent(vs[1]) or not is_zero_tangent(vs[2])
                 or (needs is not None and (needs[1] or needs[2]))):
             raise NotImplementedError("second derivatives of energy_from_kappa involving the RDMs "
                                       "are not built")
-        H = getattr(self, "_H", None)
-        if H is None:
+        if vs[0] is None:
+            return None, None, None
+        oo = self.oo
+        if _is_zero(kappa):
+            H = getattr(self, "_H", None)
+            if H is None:
+                with kernel_scope():
+                    H = self._H = oo.analytic_hessian_matrix(one_rdm, two_rdm)
+            return _matvec(H, vs[0]).reshape(kappa.shape), None, None
+        # kappa != 0: the analytic Hessian over ALL rotation pairs at the rotated orbitals, pulled back
+        cache = getattr(self, "_rot", None)
+        if cache is None:
             with kernel_scope():
-                H = self._H = self.oo.analytic_hessian_matrix(one_rdm, two_rdm)
-        out = _matvec(H, vs[0])
-        return (None if out is None else out.reshape(kappa.shape)), None, None
+                C, U, K = self.rotated(kappa)
+                g1, g2 = oo._rdm_stack(one_rdm, two_rdm)
+                res = oo._cas_eval(C, g1, g2, want_matrices=True)
+                tr, tc = self._full_pairs()
+                Hm = ops.orbital_hessian(oo.int2e_ao, oo.int1e_ao, oo._t(C), g1[0].contiguous(), g2[0].contiguous(),
+                                         res["fock"], oo._n_occ, oo.ncas, tr, tc, want_matrix=True)[0]
+                cache = self._rot = (U, K, res["gmat"], Hm)
+        U, K, Gm, Hm = cache
+
+        def one(v):
+            with kernel_scope():
+                xv, B = self.local_push(U, K, v)
+                return self.local_pull(U, K, Hm @ xv) + self.local_curvature(U, K, Gm, v, B)
+        return _apply_rows(one, vs[0], kappa.shape), None, None
 
 
 class _MoCoeffEnergyModel:

@@ -45,9 +45,7 @@ class _ParametersEnergyModel(_OrbitalRotationRule):
     def hvp(self, xs, vs, needs=None):
         theta, kappa = (unwrap(x) for x in xs)
         if not _is_zero(kappa):
-            raise NotImplementedError("second derivatives of energy_from_parameters are available at "
-                                      "kappa = 0 (where the reference's tests take them); move the "
-                                      "rotation into oao_mo_coeff and differentiate at kappa = 0")
+            return self._hvp_rotated(theta, kappa, vs)
         H = getattr(self, "_H", None)
         if H is None:
             with kernel_scope():
@@ -61,6 +59,59 @@ class _ParametersEnergyModel(_OrbitalRotationRule):
             bt, bk = _matvec(H[:nt, nt:], vk), _matvec(H[nt:, nt:], vk)
             out_t = bt if out_t is None else out_t + bt
             out_k = bk if out_k is None else out_k + bk
+        return (None if out_t is None else out_t.reshape(theta.shape),
+                None if out_k is None else out_k.reshape(kappa.shape))
+
+
+    def _hvp_rotated(self, theta, kappa, vs):
+        """Second derivatives at kappa != 0 (oo_pqc.py:103-125 differentiates at any point): the three
+        analytic blocks at the rotated orbitals over ALL rotation pairs, pulled back through the map
+        between kappa and the local rotation parameters (_OrbitalRotationRule)."""
+        oo = self.oo
+        pqc = oo.pqc
+        if getattr(pqc, "_use_sector", False):
+            raise NotImplementedError("second derivatives at kappa != 0 are built for the dense-register "
+                                      "circuits (n_qubits <= 10)")
+        cache = getattr(self, "_rot", None)
+        if cache is None:
+            with kernel_scope():
+                C, U, K = self.rotated(kappa)
+                C = oo._t(C)
+                tr, tc = self._full_pairs()
+                gamma, Gamma = pqc.rdms_with_derivatives(theta)
+                res = ops.cas_eval(oo.int2e_ao, oo.int1e_ao, C, gamma, Gamma, oo.nuc, oo._n_occ, oo.ncas, tr, tc,
+                                   want_matrices=True, eri_flags=oo._eri_flags())
+                Hxt = res["gvec"][1:].T.contiguous()                       # [P, n_theta]
+                nt = oo._n_theta()
+                Htt = ops.circuit_hessian(pqc._theta2d(theta).reshape(-1), pqc._gates_dev, pqc._n_gates,
+                                          pqc.n_qubits, oo.ncas, pqc._init_index, res["c1"], res["c2"]).reshape(nt, nt)
+                Hxx = ops.orbital_hessian(oo.int2e_ao, oo.int1e_ao, C, gamma[0].contiguous(), Gamma[0].contiguous(),
+                                          res["fock"], oo._n_occ, oo.ncas, tr, tc, want_matrix=True)[0]
+                cache = self._rot = (U, K, res["gmat"], Hxx, Hxt, Htt)
+        U, K, Gm, Hxx, Hxt, Htt = cache
+        vt, vk = vs
+        for v in (vt, vk):
+            if (v is not None and torch._C._functorch.is_functorch_wrapped_tensor(v)
+                    and torch._C._functorch.is_batchedtensor(v)):
+                raise NotImplementedError("batched tangents at kappa != 0: use "
+                                          "torch.autograd.functional.hessian (vectorize=False)")
+        with kernel_scope():
+            out_t = out_x = curv = None
+            if vt is not None:
+                t = unwrap(vt).reshape(-1)
+                out_t, out_x = Htt @ t, Hxt @ t
+            if vk is not None:
+                v = unwrap(vk).reshape(-1)
+                xv, B = self.local_push(U, K, v)
+                bt, bx = Hxt.T @ xv, Hxx @ xv
+                out_t = bt if out_t is None else out_t + bt
+                out_x = bx if out_x is None else out_x + bx
+                curv = self.local_curvature(U, K, Gm, v, B)
+            out_k = None
+            if out_x is not None:
+                out_k = self.local_pull(U, K, out_x)
+                if curv is not None:
+                    out_k = out_k + curv
         return (None if out_t is None else out_t.reshape(theta.shape),
                 None if out_k is None else out_k.reshape(kappa.shape))
 

@@ -23,7 +23,7 @@ def gather_results(local, my_geoms, n_geom, dist=None):
 
     One all_gather of equally sized, zero-padded blocks (ranks may own one geometry more or less)."""
     n_out = local.shape[1]
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         full = torch.zeros((n_geom, n_out), dtype=local.dtype, device=local.device)
         full[torch.as_tensor(my_geoms, device=local.device)] = local
         return full

@@ -296,8 +296,9 @@ def kupccd_extra():
     """BASELINE.json configs[4]: kUpCCD CAS(8e,8o), k = 1 and 2 layers (56 / 112 thetas,
     ansatze/kUpCCD.py:16-33), 16-qubit register simulated in its 4900-determinant (N_alpha, N_beta)
     sector: state, state + RDMs + reverse-mode theta-gradient per second, and one full OO evaluation
-    (E + full gradient) on a synthetic N=43 geometry.  The sector state lives in LDS, so the gate-apply
-    figure is LDS traffic (batch x gates x 2 x sector_dim x 8 B), not HBM bytes."""
+    (E + full gradient) on a synthetic N=43 geometry; the RDM stage against the fp64 matrix peak (its Gram
+    is 2 a^4 Dc flop per state, its HBM traffic a few KB) and the adjoint stage against HBM (W written once,
+    read once)."""
     import auto_oo_amd as aoo
     from auto_oo_amd.synthetic import synthetic_problem
     ncas, nelecas = 8, 8
@@ -336,11 +337,27 @@ def kupccd_extra():
                 eng.rdms(psi_c)
                 return eng.adjoint(th, psi_c, c1, c2)
             t_full = timed(full, warm=2, reps=5)
+            psi_c = eng.state(th)
+            t_rdm = timed(lambda: eng.rdms(psi_c), warm=2, reps=5)
+            t_adj = timed(lambda: eng.adjoint(th, psi_c, c1, c2), warm=2, reps=5)
+            a2 = ncas * ncas
+            gram_flops = 2.0 * a2 * a2 * eng.Dc * batch              # Gamma = Gram of the a^2 vectors E_pq psi
+            w_bytes = 2.0 * a2 * eng.Dc * 8 * batch                  # W = Ms^T V written once, read once
             rec["batches"].append({
                 "batch": batch, "state_us": t_state * 1e6,
-                "gate_apply_lds_GBs": batch * pqc._n_gates * 2.0 * eng.Dc * 8 / t_state / 1e9,
                 "state_rdm_grad_us": t_full * 1e6,
-                "state_rdm_grad_evals_per_s": batch / t_full})
+                "state_rdm_grad_evals_per_s": batch / t_full,
+                "rdm_stage": {"us": t_rdm * 1e6, "bound": "mfma", "flops": gram_flops,
+                              "achieved": gram_flops / t_rdm / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": gram_flops / t_rdm / 1e12 / FP64_PEAK_TFLOPS,
+                              "hbm_bytes_algorithmic": batch * (eng.Dc + a2 + a2 * a2) * 8.0,
+                              "note": "psi read, gamma / Gamma written; the a^2 vectors E_pq psi live in LDS only"},
+                "adjoint_stage": {"us": t_adj * 1e6, "bound": "hbm", "bytes": w_bytes,
+                                  "achieved": w_bytes / t_adj / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": w_bytes / t_adj / 1e9 / HBM_PEAK_GBS,
+                                  "mfma_flops": gram_flops,
+                                  "note": "W = Ms^T (E psi) written once and gathered once by the lambda kernel "
+                                          "(+ the same 2 a^4 Dc flop as the Gram to form it, + the reverse sweep)"}})
         oo = aoo.OO_pqc(pqc, mol, ncas, nelecas, oao_mo_coeff=P["oao_mo_coeff"])
         th1 = torch.tensor(rng.uniform(0, 2 * np.pi, n_theta), device="cuda")
         rec["oo_eval_us"] = timed(lambda: oo.energy_and_gradient(th1), warm=3, reps=20) * 1e6
@@ -665,6 +682,9 @@ def main():
             "frac_of_peak_at_2.4GHz": mfma_flops / kern_s / 1e12 / 78.6,
             "note": "the core clock under this kernel is ~1.75 GHz (tools/tri_spread.hip, profiles/r02_t_stage1_cycles.txt)",
         }
+    if n_geom_total <= 64:
+        # small jobs (tests): the gathered energies bit for bit, geometry by geometry
+        out["gathered_energies_hex"] = [float(e).hex() for e in gathered[:, 0].tolist()]
     if rank == 0 and world == 1:
         # latency of ONE un-batched evaluation through the drop-in API (not the headline)
         th0 = thetas[0].contiguous()

@@ -65,7 +65,7 @@ typedef struct {
 /* Test / measurement switches between realisations that compute the same numbers (which kernel
  * variant a call takes): "half_stream_old", "gm_two_per_cu", "gm_one_per_cu", "fused_chunks" (int),
  * "tri_plain_w", "cas_unfused", "sym_no_rs", "sym_mirror", "sym_simple", "sym_two_step", "no_ride",
- * "tri_mode" (int), "k1_no_pair", "k1_force_wide", "gm_plain_grid", "newton_one_wg".
+ * "tri_mode" (int), "k1_no_pair", "k1_force_wide", "gm_plain_grid", "newton_one_wg", "sector_unfused".
  * All 0 by default; the library never reads environment variables.  tests/ and tools/ only. */
 int oovqe_debug_set_option(const char* name, int value);
 int oovqe_debug_get_option(const char* name);
@@ -313,7 +313,8 @@ int oovqe_circuit_hessian_batch(const double* theta, int n_theta, const oovqe_ga
  *   oovqe_sector_rdms    : gamma [batch,a,a], Gamma [batch,a,a,a,a] (pqc.py:192-221); MFMA Gram
  *   oovqe_sector_adjoint : dtheta [batch,n_theta] = d/dtheta (c1.gamma + c2.Gamma): the reverse
  *                          sweep torch autograd performs for the reference (oo_pqc.py:86-95);
- *                          must follow oovqe_sector_rdms on the same `work` (reuses E_pq psi)
+ *                          (round 3: independent of oovqe_sector_rdms -- the E_pq psi vectors are formed
+ *                          again, chunk by chunk in LDS, never in memory)
  * work: oovqe_sector_work_size() doubles. */
 int oovqe_sector_state(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
                        int ncas, uint32_t init_index, const uint32_t* unrank_a, const uint32_t* unrank_b,

@@ -67,9 +67,15 @@ def test_first_derivatives_at_nonzero_kappa_vs_oracle_autograd(N, seed):
     assert abs(E.item() - ooo.energy_from_parameters(theta, kappa).item()) < 1e-9
     E.backward()
     assert (th.grad.cpu() - gr[0]).abs().max() < TOL and (ka.grad.cpu() - gr[1]).abs().max() < TOL
-    # second derivatives away from kappa = 0 are not built: loud, not silent zeros
-    with pytest.raises(NotImplementedError):
-        thessian(oo.energy_from_parameters, (theta, kappa))
+    # second derivatives away from kappa = 0 (oo_pqc.py:103-125 works at any point): all four blocks
+    # against autograd through the oracle (1e-7: round 3)
+    if N == 13:
+        ha = thessian(oo.energy_from_parameters, (theta, kappa))
+        hr = thessian(ooo.energy_from_parameters, (theta, kappa))
+        for i in range(2):
+            for j in range(2):
+                assert ha[i][j].shape == hr[i][j].shape
+                assert (ha[i][j] - hr[i][j]).abs().max() < 1e-7, (i, j)
 
 
 @pytest.mark.parametrize("freeze", [False, True])
@@ -94,6 +100,13 @@ def test_energy_from_kappa_jacrev_and_hessian(freeze):
     jr = tjacobian(ooo.energy_from_kappa, (kappa, one_rdm, two_rdm))
     for a, r in zip(ja, jr):
         assert (a - r).abs().max() < TOL
+    # the kappa-kappa Hessian at kappa != 0: the analytic Hessian over all rotation pairs at the rotated
+    # orbitals pulled back through the first and second Frechet derivatives of expm
+    kappa2 = torch.tensor(np.random.default_rng(6).normal(0, 0.1, oo.n_kappa))
+    ha = thessian(lambda k: oo.energy_from_kappa(k, one_rdm, two_rdm), kappa2)
+    hr = thessian(lambda k: ooo.energy_from_kappa(k, one_rdm, two_rdm), kappa2)
+    assert (ha - hr).abs().max() < 1e-7
+    assert (ha - ha.T).abs().max() < 1e-9
     # energy_from_mo_coeff with respect to the orbital matrix itself
     C = ooo.mo_coeff.clone()
     wa = tjacobian(lambda c: oo.energy_from_mo_coeff(c, one_rdm, two_rdm), C)

@@ -676,3 +676,32 @@ def test_mode_contract_random_shapes():
         ref = torch.einsum("kj,akb->ajb", C, T)
         err = float((out - ref).abs().max())
         assert err < 1e-11 * max(1.0, float(ref.abs().max())), (trial, last, A, K, J, B, err)
+
+
+@pytest.mark.parametrize("ncas,nelecas,batch", [(4, 4, 5), (8, 8, 3), (8, 8, 130)])
+def test_sector_fused_kernels_equal_the_unfused_ones(ncas, nelecas, batch):
+    """Round 3: RDMs and adjoint gradient with the E_pq vectors formed chunk by chunk in LDS
+    (sector_rdm_fused_kernel / sector_w_fused_kernel, the default for a^2 = 16, 64) against the round-2
+    kernels that write and re-read them (debug option sector_unfused) -- same sums in another order."""
+    from auto_oo_amd.sector import SectorEngine
+    n = 2 * ncas
+    gates, n_theta = X.kupccd_gates(ncas, 1)
+    hf = X.hf_state(nelecas, n)
+    gd = _gates_dev(gates)
+    eng = SectorEngine(ncas, hf, gd, len(gates), n_theta, X.basis_index(hf), torch.device(DEV))
+    rng = np.random.default_rng(77 + ncas + batch)
+    th = torch.tensor(rng.uniform(0, 2 * np.pi, (batch, n_theta))).to(DEV)
+    c1 = torch.tensor(rng.standard_normal((ncas, ncas))).to(DEV)
+    c2 = torch.tensor(rng.standard_normal((ncas,) * 4)).to(DEV)
+    psi_c = eng.state(th)
+    g1, g2 = eng.rdms(psi_c)
+    dth = eng.adjoint(th, psi_c, c1, c2)
+    from auto_oo_amd._lib import debug_options
+    with debug_options(sector_unfused=1):
+        h1, h2 = eng.rdms(psi_c)
+        dth_u = eng.adjoint(th, psi_c, c1, c2)
+    assert (g1 - h1).abs().max() < 1e-12 and (g2 - h2).abs().max() < 1e-12
+    assert (dth - dth_u).abs().max() < 1e-11 * max(1.0, float(dth_u.abs().max()))
+    # the adjoint no longer depends on a preceding RDM call on the same workspace
+    eng2 = SectorEngine(ncas, hf, gd, len(gates), n_theta, X.basis_index(hf), torch.device(DEV))
+    assert torch.equal(eng2.adjoint(th, psi_c, c1, c2), dth)
