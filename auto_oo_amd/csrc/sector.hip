@@ -457,26 +457,103 @@ void sector_gram_rows_kernel(const double* __restrict__ psi_c, const double* __r
 // drop it.  Both kernels below: grid (batch, nsplit), 512 threads, the chunks of a state dealt to the
 // nsplit workgroups; four threads per determinant build the chunk (a^2 / 4 operators each).
 constexpr int SEC_CH = 128;                  // determinants per chunk
-constexpr int SEC_CHP = SEC_CH + 4;          // LDS pitch of a V row (rows 8 banks apart)
+// LDS pitch of a V row, chosen per kernel for its MFMA operand reads (64 banks of 4 bytes, 32 lanes per pass):
+//   Gram: a lane reads V[row = tile row lr][column cc + lq]: rows 4 banks apart  -> 128 + 2 doubles
+//   W:    a lane reads V[row = k-step row lq][column 16 ct + lr]: rows 32 banks apart -> 128 + 16 doubles
+constexpr int SEC_CHP_GRAM = SEC_CH + 2;
+constexpr int SEC_CHP_W = SEC_CH + 16;
+constexpr int SEC_CHP_MAX = SEC_CHP_W;
+
+// Excitation tables of the strings (built by every workgroup at its start, a few hundred entries per thread
+// once): E_pq = E^alpha_pq + E^beta_pq, and on the determinant (ia, ib)
+//   (E^alpha_pq v)[ia, ib] = (-1)^(own_a(ia) + cross_b(ib)) v[src_a(ia), ib]     if valid_a(ia)
+// where src_a = the alpha string with the electron moved back from p to q, own_a the parity of the alpha
+// electrons strictly between p and q, cross_b the parity of the beta electrons the Jordan-Wigner string of an
+// alpha excitation crosses (orbitals min(p,q) .. max(p,q) - 1; for a beta excitation the alpha electrons in
+// min + 1 .. max) -- spin orbital 2p = alpha_p, 2p + 1 = beta_p, utils/active_space.py:29-83.  One 16-bit word
+// per (string, pq): source index (11 bits) | valid | own parity | cross parity.  The per-determinant bit
+// arithmetic of sec_epq (two rank look-ups, two popcounts, four branches per operator) becomes two table
+// reads: the chunk build went from 60 % of the fused kernels' time to a tenth.
+constexpr int SEC_TAB_MAXSTR = 2048;
 
 __host__ __device__ inline size_t sec_fused_lds_bytes(int na, int nb, int ncas)
 {
     const size_t Dc = (size_t)na * nb, na2 = (size_t)ncas * ncas;
-    return (Dc + (Dc & 1) + na2 * SEC_CHP) * sizeof(double) + 2 * ((size_t)1 << ncas) * sizeof(int32_t);
+    size_t bytes = (Dc + (Dc & 1) + na2 * SEC_CHP_MAX) * sizeof(double);
+    bytes += (((size_t)na + nb) * na2 * sizeof(uint16_t) + 7) & ~(size_t)7;
+    return bytes;
+}
+
+__device__ __forceinline__ uint32_t sec_orb_mask(int a, int r1, int r2)     // orbitals r1 .. r2 of a string
+{
+    return r2 < r1 ? 0u : (((1u << (r2 - r1 + 1)) - 1u) << (a - 1 - r2));
+}
+
+// tab[pq * nstr + (string index)]; is_alpha selects which cross range the string serves
+__device__ void sec_build_table(const uint32_t* __restrict__ unrank, const int32_t* __restrict__ rank, int nstr,
+                                int a, bool is_alpha, uint16_t* __restrict__ tab, int nthreads)
+{
+    const int na2 = a * a;
+    for (int idx = threadIdx.x; idx < nstr * na2; idx += nthreads) {
+        const int is = idx / na2, pq = idx - is * na2, p = pq / a, q = pq - p * a;
+        const uint32_t st = unrank[is];
+        const uint32_t bp = 1u << (a - 1 - p), bq = 1u << (a - 1 - q);
+        const int lo = p < q ? p : q, hi = p < q ? q : p;
+        uint32_t valid, src;
+        if (p == q) { valid = (st & bp) ? 1u : 0u; src = (uint32_t)is; }
+        else {
+            valid = ((st & bp) && !(st & bq)) ? 1u : 0u;
+            src = valid ? (uint32_t)rank[(st & ~bp) | bq] : 0u;
+        }
+        const uint32_t own = __popc(st & sec_orb_mask(a, lo + 1, hi - 1)) & 1u;
+        // the range of THIS spin's electrons that an excitation of the OTHER spin crosses
+        const uint32_t cross = is_alpha ? (__popc(st & sec_orb_mask(a, lo + 1, hi)) & 1u)
+                                        : (__popc(st & sec_orb_mask(a, lo, hi - 1)) & 1u);
+        // operator-major: the lanes of a wave hold consecutive beta strings and read one operator's word each
+        // (string-major, 128 bytes apart, all 64 reads fell on two LDS banks)
+        tab[pq * nstr + is] = (uint16_t)(src | (valid << 11) | (own << 12) | (cross << 13));
+    }
 }
 
 // fills Vc[pq][0 .. SEC_CH) for the determinants c0 .. c0 + SEC_CH - 1 (zeros behind the sector)
-__device__ __forceinline__ void sec_build_chunk(const double* __restrict__ src, const Sector& sl, const Sector& sg,
-                                                int c0, double* __restrict__ Vc)
+template <int SEC_CHP>
+__device__ __forceinline__ void sec_build_chunk(const double* __restrict__ src, int na, int nb, int a,
+                                                const uint16_t* __restrict__ tabA,
+                                                const uint16_t* __restrict__ tabB, int c0,
+                                                double* __restrict__ Vc)
 {
-    const int Dc = sl.na * sl.nb, n = 2 * sl.ncas, a = sl.ncas, na2 = a * a;
+    const int Dc = na * nb, na2 = a * a;
     const int cl = threadIdx.x & (SEC_CH - 1), part = threadIdx.x / SEC_CH;       // 512 / 128 = 4 parts
     const int c = c0 + cl;
     const bool in = c < Dc;
-    const uint32_t x = in ? sec_full(sg, c) : 0u;
-    for (int pq = part; pq < na2; pq += 512 / SEC_CH) {
-        const int p = pq / a, q = pq - p * a;
-        Vc[pq * SEC_CHP + cl] = in ? sec_epq(src, sl, n, p, q, x, c) : 0.0;
+    const int ia = in ? c / nb : 0, ib = in ? c - ia * nb : 0;
+    const uint16_t* ta = tabA + ia;
+    const uint16_t* tb = tabB + ib;
+    const double* rowa = src + ia * nb;
+    // eight operators at a time: the table reads, then the amplitude reads, then the stores (one operator
+    // after the other is a chain of four dependent LDS round trips each)
+    for (int pq0 = part; pq0 < na2; pq0 += 8 * (512 / SEC_CH)) {
+        uint32_t ea[8], eb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int pq = pq0 + u * (512 / SEC_CH);
+            ea[u] = pq < na2 ? ta[pq * na] : 0u;
+            eb[u] = pq < na2 ? tb[pq * nb] : 0u;
+        }
+        double va[8], vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            va[u] = src[__umul24(ea[u] & 2047u, (unsigned)nb) + ib];      // (24-bit multiply: full rate)
+            vb[u] = rowa[eb[u] & 2047u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int pq = pq0 + u * (512 / SEC_CH);
+            const bool sa = ((ea[u] >> 12) ^ (eb[u] >> 13)) & 1u, sb = ((eb[u] >> 12) ^ (ea[u] >> 13)) & 1u;
+            const double xa = (ea[u] & 2048u) ? (sa ? -va[u] : va[u]) : 0.0;
+            const double xb = (eb[u] & 2048u) ? (sb ? -vb[u] : vb[u]) : 0.0;
+            if (pq < na2) Vc[pq * SEC_CHP + cl] = in ? xa + xb : 0.0;
+        }
     }
 }
 
@@ -484,33 +561,29 @@ __device__ __forceinline__ void sec_build_chunk(const double* __restrict__ src, 
 // a^2 a multiple of 16 (a = 4, 8): MT = NT = a^2 / 16, the <psi| V_rs> row on the vector ALUs.
 template <int NT>
 __global__ __launch_bounds__(512)
-void sector_rdm_fused_kernel(const double* __restrict__ psi_c, Sector s, int batch, int MTR, double* __restrict__ R)
+void sector_rdm_fused_kernel(const double* __restrict__ psi_c, Sector s, int batch, int MTR, double* __restrict__ R,
+                             int probe)
 {
     extern __shared__ double lds[];
     __shared__ double red[8][256];
-    const int Dc = s.na * s.nb, a = s.ncas, na2 = a * a, ns = 1 << a;
+    const int Dc = s.na * s.nb, a = s.ncas, na2 = a * a;
     double* src = lds;                                            // [Dc]
     double* Vc = src + Dc + (Dc & 1);                             // [a^2][SEC_CHP]
-    int32_t* ra = reinterpret_cast<int32_t*>(Vc + (size_t)na2 * SEC_CHP);
-    int32_t* rb = ra + ns;
+    constexpr int SEC_CHP = SEC_CHP_GRAM;
+    uint16_t* tabA = reinterpret_cast<uint16_t*>(Vc + (size_t)na2 * SEC_CHP_MAX);
+    uint16_t* tabB = tabA + (size_t)s.na * na2;
     const size_t b = blockIdx.x;
     const int split = blockIdx.y, nsplit = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane >> 4, lr = lane & 15;
     for (int i = tid; i < Dc; i += 512) src[i] = psi_c[b * Dc + i];
-    for (int i = tid; i < ns; i += 512) { ra[i] = s.rank_a[i]; rb[i] = s.rank_b[i]; }
-    const Sector sg = s;
-    Sector sl = s;
-    sl.rank_a = ra;
-    sl.rank_b = rb;
-    // A rows m = (p,q) read V[(q,p)]; B rows n read V[n]
-    int arow[NT];
-#pragma unroll
-    for (int mt = 0; mt < NT; ++mt) {
-        const int m = mt * 16 + lr, p = m / a, q = m - p * a;
-        arow[mt] = (q * a + p) * SEC_CHP;
-    }
+    sec_build_table(s.unrank_a, s.rank_a, s.na, a, true, tabA, 512);
+    sec_build_table(s.unrank_b, s.rank_b, s.nb, a, false, tabB, 512);
+    // A row m' of the product is V[m'] as well (the same conflict-free operand reads as B); it stands for
+    // the pair (p,q) = (m' % a, m' / a), i.e. V[(q,p)] is row pq of the Gram: the rows are permuted when R
+    // is written
+
     d4 acc[NT][NT];
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt)
@@ -523,9 +596,10 @@ void sector_rdm_fused_kernel(const double* __restrict__ psi_c, Sector s, int bat
     __syncthreads();
     for (int ch = split; ch < nchunk; ch += nsplit) {
         const int c0 = ch * SEC_CH;
-        sec_build_chunk(src, sl, sg, c0, Vc);
+        if (!(probe == 1 && ch != split)) sec_build_chunk<SEC_CHP>(src, s.na, s.nb, a, tabA, tabB, c0, Vc);
         __syncthreads();
         // the 32 k-steps of the chunk dealt to the 8 waves; k-step ks covers determinants 4 ks .. 4 ks + 3
+        if (probe != 2)
 #pragma unroll
         for (int u = 0; u < SEC_CH / 4 / 8; ++u) {
             const int cc = 4 * (wave + 8 * u) + lq;
@@ -536,11 +610,9 @@ void sector_rdm_fused_kernel(const double* __restrict__ psi_c, Sector s, int bat
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) gpart[nt] += pv * bv[nt];
 #pragma unroll
-            for (int mt = 0; mt < NT; ++mt) {
-                const double av = Vc[arow[mt] + cc];
+            for (int mt = 0; mt < NT; ++mt)              // (A row tile mt holds the same V rows as B tile mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_f64(av, bv[nt], acc[mt][nt]);
-            }
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_f64(bv[mt], bv[nt], acc[mt][nt]);
         }
         __syncthreads();
     }
@@ -556,7 +628,8 @@ void sector_rdm_fused_kernel(const double* __restrict__ psi_c, Sector s, int bat
                 double v = red[0][tid];
 #pragma unroll
                 for (int w = 1; w < 8; ++w) v += red[w][tid];
-                const int row = mt * 16 + tid / 16, col = nt * 16 + (tid & 15);
+                const int mrow = mt * 16 + tid / 16, col = nt * 16 + (tid & 15);
+                const int row = (mrow % a) * a + mrow / a;            // product row (q,p) -> Gram row (p,q)
                 R[(((size_t)split * batch + b) * (MTR * 16) + row) * (NT * 16) + col] = v;
             }
             __syncthreads();
@@ -580,25 +653,28 @@ void sector_rdm_fused_kernel(const double* __restrict__ psi_c, Sector s, int bat
 template <int NT>
 __global__ __launch_bounds__(512)
 void sector_w_fused_kernel(const double* __restrict__ psi_c, const double* __restrict__ Ms, Sector s,
-                           double* __restrict__ W)
+                           double* __restrict__ W, uint16_t* __restrict__ tab_out)
 {
     extern __shared__ double lds[];
-    const int Dc = s.na * s.nb, a = s.ncas, na2 = a * a, ns = 1 << a;
+    const int Dc = s.na * s.nb, a = s.ncas, na2 = a * a;
     double* src = lds;
     double* Vc = src + Dc + (Dc & 1);
-    int32_t* ra = reinterpret_cast<int32_t*>(Vc + (size_t)na2 * SEC_CHP);
-    int32_t* rb = ra + ns;
+    constexpr int SEC_CHP = SEC_CHP_W;
+    uint16_t* tabA = reinterpret_cast<uint16_t*>(Vc + (size_t)na2 * SEC_CHP_MAX);
+    uint16_t* tabB = tabA + (size_t)s.na * na2;
     const size_t b = blockIdx.x;
     const int split = blockIdx.y, nsplit = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane >> 4, lr = lane & 15;
     for (int i = tid; i < Dc; i += 512) src[i] = psi_c[b * Dc + i];
-    for (int i = tid; i < ns; i += 512) { ra[i] = s.rank_a[i]; rb[i] = s.rank_b[i]; }
-    const Sector sg = s;
-    Sector sl = s;
-    sl.rank_a = ra;
-    sl.rank_b = rb;
+    sec_build_table(s.unrank_a, s.rank_a, s.na, a, true, tabA, 512);
+    sec_build_table(s.unrank_b, s.rank_b, s.nb, a, false, tabB, 512);
+    if (tab_out && blockIdx.x == 0 && blockIdx.y == 0) {
+        // the excitation tables for the lambda kernel that follows this launch ([a^2][na] | [a^2][nb])
+        __syncthreads();
+        for (int i = tid; i < (s.na + s.nb) * na2; i += 512) tab_out[i] = tabA[i];
+    }
     constexpr int KS = NT * 4;                           // k-steps over the a^2 = 16 NT rows of V
     const int jt = wave % NT, ct0 = wave / NT;           // this wave's W row tile, its first c-tile
     constexpr int CSTEP = 8 / NT;                        // c-tiles a wave skips (8 waves, NT row tiles)
@@ -610,7 +686,7 @@ void sector_w_fused_kernel(const double* __restrict__ psi_c, const double* __res
     __syncthreads();
     for (int ch = split; ch < nchunk; ch += nsplit) {
         const int c0 = ch * SEC_CH;
-        sec_build_chunk(src, sl, sg, c0, Vc);
+        sec_build_chunk<SEC_CHP>(src, s.na, s.nb, a, tabA, tabB, c0, Vc);
         __syncthreads();
         for (int ct = ct0; ct < SEC_CH / 16; ct += CSTEP) {
             d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -720,6 +796,52 @@ void sector_lambda_kernel(const double* __restrict__ W, Sector s, double* __rest
     __syncthreads();
     if (slice == 0 && c < Dc)
         lam[b * Dc + c] = part[cl] + part[64 + cl] + part[128 + cl] + part[192 + cl];
+}
+
+// The same with the excitation tables of the fused kernels (global, L1-resident): per (determinant, operator)
+// two 16-bit table reads and two gathers from the row W_pq instead of the bit arithmetic of sec_epq.
+// grid: (ceil(Dc/64), batch); block = 64 determinants x 4 slices of the (p,q) loop, summed in fixed order.
+__global__ __launch_bounds__(256)
+void sector_lambda_tab_kernel(const double* __restrict__ W, const uint16_t* __restrict__ tabA,
+                              const uint16_t* __restrict__ tabB, int na, int nb, int ncas,
+                              double* __restrict__ lam)
+{
+    __shared__ double part[4][64];
+    const int Dc = na * nb, na2 = ncas * ncas;
+    const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const size_t b = blockIdx.y;
+    double acc = 0.0;
+    if (c < Dc) {
+        const double* Wb = W + b * (size_t)na2 * Dc;
+        const int ia = c / nb, ib = c - ia * nb;
+        for (int pq0 = slice; pq0 < na2; pq0 += 16) {
+            uint32_t ea[4], eb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pq = pq0 + 4 * u;
+                ea[u] = pq < na2 ? tabA[pq * na + ia] : 0u;
+                eb[u] = pq < na2 ? tabB[pq * nb + ib] : 0u;
+            }
+            double va[4], vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pq = pq0 + 4 * u < na2 ? pq0 + 4 * u : 0;
+                const double* row = Wb + (size_t)pq * Dc;
+                va[u] = row[__umul24(ea[u] & 2047u, (unsigned)nb) + ib];
+                vb[u] = row[ia * nb + (eb[u] & 2047u)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool sa = ((ea[u] >> 12) ^ (eb[u] >> 13)) & 1u, sb = ((eb[u] >> 12) ^ (ea[u] >> 13)) & 1u;
+                if (ea[u] & 2048u) acc += sa ? -va[u] : va[u];
+                if (eb[u] & 2048u) acc += sb ? -vb[u] : vb[u];
+            }
+        }
+    }
+    part[slice][cl] = acc;
+    __syncthreads();
+    if (slice == 0 && c < Dc) lam[b * Dc + c] = part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl];
 }
 
 // ---- adjoint sweep: grid = batch --------------------------------------------------------------------
@@ -910,21 +1032,18 @@ extern "C" int oovqe_sector_rdms(const double* psi_c, int ncas, const uint32_t* 
     // a^2 a multiple of 16 and the sector vector + one chunk of E_pq vectors within a workgroup's LDS: the
     // fused kernel (V never written); nsplit workgroups per state share its chunks when the batch is small
     const size_t fused_lds = sec_fused_lds_bytes(na, nb, ncas);
-    if (na2 % 16 == 0 && na2 <= 64 && fused_lds <= 150 * 1024 && oovqe_opt(OOVQE_OPT_SECTOR_UNFUSED) == 0) {
+    if (na2 % 16 == 0 && na2 <= 64 && fused_lds <= 140 * 1024 && na < SEC_TAB_MAXSTR && nb < SEC_TAB_MAXSTR &&
+        oovqe_opt(OOVQE_OPT_SECTOR_UNFUSED) == 0) {
         const int nchunk = (Dc + SEC_CH - 1) / SEC_CH;
         int nsplit = batch >= 128 ? 1 : (batch >= 64 ? 2 : (batch >= 16 ? 4 : 8));
         if (nsplit > nchunk) nsplit = nchunk;
 #define OOVQE_SEC_RDMF(NT_)                                                                        \
         do {                                                                                       \
-            static bool attr_done = false;                                                         \
-            if (!attr_done) {                                                                      \
-                OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)sector_rdm_fused_kernel<NT_>,     \
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                                    150 * 1024), "sector_rdms: hipFuncSetAttribute"); \
-                attr_done = true;                                                                  \
-            }                                                                                      \
+            OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)sector_rdm_fused_kernel<NT_>,         \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                                (int)fused_lds), "sector_rdms: hipFuncSetAttribute"); \
             hipLaunchKernelGGL(sector_rdm_fused_kernel<NT_>, dim3(batch, nsplit), dim3(512), fused_lds, st, \
-                               psi_c, s, batch, MT, R);                                            \
+                               psi_c, s, batch, MT, R, oovqe_opt(OOVQE_OPT_SECTOR_PROBE));         \
         } while (0)
         if (NT == 4) OOVQE_SEC_RDMF(4);
         else if (NT == 2) OOVQE_SEC_RDMF(2);
@@ -1001,8 +1120,10 @@ extern "C" int oovqe_sector_adjoint(const double* theta, int n_theta, const oovq
                        unrank_a, unrank_b, M12);
     OOVQE_CHECK_LAUNCH("sector_adjoint/coeff");
     int rc;
+    uint16_t* tabs = reinterpret_cast<uint16_t*>(M12 + (size_t)na2 * na2);   // [a^2][na] | [a^2][nb], 16-bit
     const size_t fused_lds = sec_fused_lds_bytes(na, nb, ncas);
-    const bool fused = na2 % 16 == 0 && na2 <= 64 && fused_lds <= 150 * 1024 &&
+    const bool fused = na2 % 16 == 0 && na2 <= 64 && fused_lds <= 140 * 1024 && na < SEC_TAB_MAXSTR &&
+                       nb < SEC_TAB_MAXSTR &&
                        oovqe_opt(OOVQE_OPT_SECTOR_UNFUSED) == 0;
     if (fused) {
         // W straight from psi: the E_pq vectors are formed chunk by chunk in LDS and contracted there
@@ -1011,15 +1132,11 @@ extern "C" int oovqe_sector_adjoint(const double* theta, int n_theta, const oovq
         if (nsplit > nchunk) nsplit = nchunk;
 #define OOVQE_SEC_WF(NT_)                                                                          \
         do {                                                                                       \
-            static bool attr_done = false;                                                         \
-            if (!attr_done) {                                                                      \
-                OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)sector_w_fused_kernel<NT_>,       \
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                                    150 * 1024), "sector_adjoint: hipFuncSetAttribute"); \
-                attr_done = true;                                                                  \
-            }                                                                                      \
+            OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)sector_w_fused_kernel<NT_>,           \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                                (int)fused_lds), "sector_adjoint: hipFuncSetAttribute"); \
             hipLaunchKernelGGL(sector_w_fused_kernel<NT_>, dim3(batch, nsplit), dim3(512), fused_lds, st, \
-                               psi_c, M12, s, W12);                                                \
+                               psi_c, M12, s, W12, tabs);                                          \
         } while (0)
         if (NT == 4) OOVQE_SEC_WF(4);
         else if (NT == 2) OOVQE_SEC_WF(2);
@@ -1042,8 +1159,12 @@ extern "C" int oovqe_sector_adjoint(const double* theta, int n_theta, const oovq
                                           (long)na2 * Dc, 0, (long)na2 * Dc, st)))
         return rc;
     }
-    hipLaunchKernelGGL(sector_lambda_kernel, dim3((Dc + 63) / 64, batch), dim3(256),
-                       256 * sizeof(double) + 2 * ((size_t)1 << ncas) * sizeof(int32_t), st, W12, s, lam);
+    if (fused && (size_t)(na + nb) * na2 * sizeof(uint16_t) <= ((size_t)na2 * na2 + na2) * sizeof(double))
+        hipLaunchKernelGGL(sector_lambda_tab_kernel, dim3((Dc + 63) / 64, batch), dim3(256), 0, st, W12, tabs,
+                           tabs + (size_t)na * na2, na, nb, ncas, lam);
+    else
+        hipLaunchKernelGGL(sector_lambda_kernel, dim3((Dc + 63) / 64, batch), dim3(256),
+                           256 * sizeof(double) + 2 * ((size_t)1 << ncas) * sizeof(int32_t), st, W12, s, lam);
     OOVQE_CHECK_LAUNCH("sector_adjoint/lambda");
     const int nit = (Dc + SEC_THREADS - 1) / SEC_THREADS;
 #define OOVQE_SEC_ADJ(MI)                                                                          \
