@@ -37,6 +37,7 @@ SIGNATURES = {
     "oovqe_version": (ctypes.c_int, []),
     "oovqe_last_error": (ctypes.c_char_p, []),
     "oovqe_device_count": (ctypes.c_int, []),
+    "oovqe_last_stage1_kernel": (ctypes.c_char_p, []),
     "oovqe_profile_begin": (ctypes.c_int, []),
     "oovqe_profile_begin_detail": (ctypes.c_int, []),
     "oovqe_profile_end": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double),

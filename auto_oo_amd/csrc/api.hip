@@ -39,6 +39,18 @@ static_assert(sizeof(g_opt_names) / sizeof(g_opt_names[0]) == OOVQE_OPT_COUNT, "
 
 int oovqe_opt(int id) { return (id >= 0 && id < OOVQE_OPT_COUNT) ? g_opts[id] : 0; }
 
+// name (with template arguments) of the stage-1 kernel the last evaluation dispatched: bench.py quotes the
+// kernel that ran, not a literal
+static char g_stage1[160] = "";
+void oovqe_note_stage1(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_stage1, sizeof(g_stage1), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* oovqe_last_stage1_kernel(void) { return g_stage1; }
+
 extern "C" int oovqe_debug_set_option(const char* name, int value)
 {
     for (int i = 0; name && i < OOVQE_OPT_COUNT; ++i)

@@ -2886,6 +2886,7 @@ static int half_transform_batched(const double* g_ao, const double* C, int N, in
             }                                                                                     \
             attr_done = true;                                                                     \
         }                                                                                         \
+        oovqe_note_stage1("half_transform_kernel<%d,%d,%d>%s", Z, KC_, NS_, sym ? " (slabs p <= q)" : ""); \
         hipLaunchKernelGGL((half_transform_kernel<Z, KC_, NS_>), dim3(grid, batch),               \
                            dim3(HALF_WAVES * 64),                                                 \
                            lds_bytes, st, g_ao, C, T2, N, M, nrb, nkc, nslabs, sym);              \
@@ -2939,6 +2940,7 @@ static int half_transform_batched(const double* g_ao, const double* C, int N, in
         long per = ((long)occ * device_cu_count()) / batch;                                       \
         if (per < 1) per = 1;                                                                     \
         if (per > want) per = want;                                                               \
+        oovqe_note_stage1("half_stream_kernel<%d,%d,%d,%s>", Z, KC_, D_, RS_ ? "true" : "false"); \
         hipLaunchKernelGGL((half_stream_kernel<Z, KC_, D_, RS_>), dim3((unsigned)per, batch),     \
                            dim3(HALF_WAVES * 64), lds_bytes, st, g_ao, C, T2, N, M, nrb, snkc,    \
                            nslabs, sym);                                                          \
@@ -3157,6 +3159,7 @@ static int half_transform_fused_batched(const double* g_ao, const double* C, int
             }                                                                                     \
             attr_done = true;                                                                     \
         }                                                                                         \
+        oovqe_note_stage1("half_transform_fused_kernel<%d,%d>", KC_, NS_);                        \
         hipLaunchKernelGGL((half_transform_fused_kernel<KC_, NS_>), dim3(fp.wpg, batch),          \
                            dim3(HALF_WAVES * 64), fp.lds_bytes, st, g_ao, C, T3, Cdup, N, M,      \
                            fp.nchunk, fp.qc, fp.nbuf, fp.ldb);                                    \
@@ -3245,6 +3248,7 @@ static int half_tri_batched(const double* g_ao, const double* C, int N, int M, d
                                                 160 * 1024), "cas_eval/half_tri_dma");            \
             attr_done = true;                                                                     \
         }                                                                                         \
+        oovqe_note_stage1("half_tri_dma_kernel<%d,%d>", KC_, NS_);                                \
         hipLaunchKernelGGL((half_tri_dma_kernel<KC_, NS_>), dim3((unsigned)W, batch),             \
                            dim3(HALF_WAVES * 64), lds_dma, st, g_ao, C, J, N, M, (int)ph);        \
     } while (0)
@@ -3283,6 +3287,7 @@ static int half_tri_batched(const double* g_ao, const double* C, int N, int M, d
                                                 160 * 1024), "cas_eval/half_tri_reg");            \
             attr_done = true;                                                                     \
         }                                                                                         \
+        oovqe_note_stage1("half_tri_reg_kernel<%d,%d,%d,%d>", KC_, NS_, NPC_, R_);                \
         hipLaunchKernelGGL((half_tri_reg_kernel<KC_, NS_, NPC_, R_>), dim3((unsigned)W, batch),   \
                            dim3(HALF_WAVES * 64), lds_reg, st, g_ao, C, J, N, M, (int)ph);        \
     } while (0)
@@ -3319,6 +3324,7 @@ static int half_tri_batched(const double* g_ao, const double* C, int N, int M, d
                                                 160 * 1024), "cas_eval/half_tri");                \
             attr_done = true;                                                                     \
         }                                                                                         \
+        oovqe_note_stage1("half_tri_kernel<%d,%d,%d>", KC_, NS_, RS_);                            \
         hipLaunchKernelGGL((half_tri_kernel<KC_, NS_, RS_>), dim3((unsigned)W, batch),            \
                            dim3(HALF_WAVES * 64), lds_bytes, st, g_ao, C, J, N, M, (int)phase,    \
                            tiled);                                                                \

@@ -46,6 +46,7 @@ enum oovqe_option_t {
     OOVQE_OPT_COUNT
 };
 int oovqe_opt(int id);
+void oovqe_note_stage1(const char* fmt, ...);
 
 #define OOVQE_CHECK_LAUNCH(name)                                                          \
     do {                                                                                  \

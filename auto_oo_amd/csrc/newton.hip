@@ -1247,32 +1247,37 @@ __device__ __forceinline__ void block_min2_w4(double& a, double& b, double* red,
     parity ^= 1;
 }
 
+// BIG (n > NEWTON2_NMAX, the host-orchestrated stage 1 below): the band rows and the factor of the solve do
+// not fit LDS; they live in `scratch` (global, (n + 2 RW + 2) RW + (n + RW)(BW + 2) doubles per problem), V is
+// applied straight from memory, and `work` is that problem's exchange block (status = `*big_status`).
+template <bool BIG>
 __global__ __launch_bounds__(NT2)
 void newton_band_solve_kernel(int n, double lam_threshold, double mu, double rho, int aug,
                               const double* __restrict__ work, double* __restrict__ dp,
-                              double* __restrict__ lowest, double* __restrict__ shift_out)
+                              double* __restrict__ lowest, double* __restrict__ shift_out,
+                              double* __restrict__ scratch)
 {
     extern __shared__ double sm[];
     const N2Global GL = n2_global(n);
-    const N2Lds2 L = n2_lds2(n);
+    const N2Lds2 L = n2_lds2(BIG ? 16 : n);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int prob = blockIdx.x;
     const int npv = GL.npv, npan = GL.npan;
     const int batch = gridDim.x;
-    const double* wk = work + (size_t)batch * GL.aw_size + (size_t)prob * GL.ex_size;     // the exchange block
-    double* rb = sm + L.rb;
-    double* Lst = sm + L.Lst;
-    double* dst = sm + L.dst;
-    double* zst = sm + L.zst;
+    const double* wk = BIG ? work : work + (size_t)batch * GL.aw_size + (size_t)prob * GL.ex_size;     // the exchange block
+    double* rb = BIG ? scratch : sm + L.rb;
+    double* Lst = BIG ? rb + (size_t)(n + 2 * RW + 2) * RW : sm + L.Lst;
+    double* dst = BIG ? Lst + (size_t)(n + RW) * BW : sm + L.dst;
+    double* zst = BIG ? dst + (n + RW) : sm + L.zst;
     double* Vp = sm + L.Vp;
     double* Tm = sm + L.Tm;
     double* x1 = sm + L.x1;
     double* x2 = sm + L.x2;
     double* red = sm + L.red;
-    double* bb = sm + L.bb;
+    double* bb = BIG ? sm + L.total : sm + L.bb;            // (BIG: behind the small arrays, npv + 2 RW + 16 doubles)
     int parity = 0;
-    const int dead = *reinterpret_cast<const int*>(work + (size_t)batch * (GL.aw_size + GL.ex_size) + 2 * (size_t)prob) == 1;
+    const int dead = BIG ? 0 : *reinterpret_cast<const int*>(work + (size_t)batch * (GL.aw_size + GL.ex_size) + 2 * (size_t)prob) == 1;
 #ifdef OOVQE_NEWTON_TIMING
     long long t_mark = clock64();
 #endif
@@ -1362,8 +1367,34 @@ void newton_band_solve_kernel(int n, double lam_threshold, double mu, double rho
         }
         if (tid < 32) tnext = *reinterpret_cast<const d2*>(wk + GL.Tst + (size_t)p * BW * BW + 2 * tid);
     };
-    if (npan > 0) fetch(npan - 1);
-    for (int p = npan - 1; p >= 0; --p) {
+    if (BIG) {
+        for (int p = npan - 1; p >= 0; --p) {
+            const double* vsrc = wk + GL.Vst + (size_t)p * BW * npv;
+            const double* tsrc = wk + GL.Tst + (size_t)p * BW * BW;
+            for (int col = wave; col < BW; col += NW2) {
+                double a = 0.0;
+                for (int r = lane; r < n; r += 64) a += vsrc[(size_t)col * npv + r] * bb[r];
+                a = wave_sum(a);
+                if (lane == 0) x1[col] = a;
+            }
+            __syncthreads();
+            if (tid < BW) {
+                double sacc = 0.0;
+                for (int mm = 0; mm < BW; ++mm) sacc += tsrc[tid * BW + mm] * x1[mm];
+                x2[tid] = sacc;
+            }
+            __syncthreads();
+            for (int r = tid; r < n; r += NT2) {
+                double sacc = bb[r];
+#pragma unroll
+                for (int l = 0; l < BW; ++l) sacc -= vsrc[(size_t)l * npv + r] * x2[l];
+                bb[r] = sacc;
+            }
+            __syncthreads();
+        }
+    }
+    if (!BIG && npan > 0) fetch(npan - 1);
+    for (int p = BIG ? -1 : npan - 1; p >= 0; --p) {
 #pragma unroll
         for (int u = 0; u < VREG; ++u) {
             const int idx = tid + u * NT2;
@@ -1401,6 +1432,300 @@ void newton_band_solve_kernel(int n, double lam_threshold, double mu, double rho
     }
 }
 
+// =====================================================================================================
+// n > NEWTON2_NMAX (the panel operands no longer fit LDS; orbital spaces of N = 200: n ~ 4 700): the same
+// band reduction, one launch per phase of a panel instead of in-kernel hand-offs (the phases are large
+// enough to fill the chip by themselves, ~4 launches x n / 8 panels):
+//   n2l_panel_kernel   QR of the panel (one workgroup; the columns in registers, 64 x RQ elements each)
+//   n2l_x0_kernel      X0 = A22 V, a workgroup per 16-row tile, the four waves split K
+//   n2l_w_kernel       S0, Y, W = X0 T - 1/2 V Y; b <- Q_p^T b
+//   n2l_update_kernel  A22 -= V W^T + W V^T, a wave per 16 x 16 tile
+// then the same solve kernel with its band rows and factor in global scratch.  n <= NEWTON3_NMAX.
+// =====================================================================================================
+constexpr int NEWTON3_NMAX = 5128;
+constexpr int RQ_HUGE = (NEWTON3_NMAX - BW + 63) / 64;          // 80
+constexpr int RQ_MID = 24;                                      // n - 8 <= 1536
+
+struct N3Global {          // per problem, doubles: [Aw | Vst | Tst | Vt | X0 | Wt | Band | bvec | scratch]
+    int npv, npan, ntile;
+    size_t Aw, Vt, X0, Wt, scratch, total;
+    N2Global ex;           // Vst / Tst / Band / bvec offsets are those of the exchange block (at `exoff`)
+    size_t exoff;
+};
+
+__host__ __device__ inline N3Global n3_global(int n)
+{
+    N3Global L;
+    L.ex = n2_global(n);
+    L.npv = L.ex.npv; L.npan = L.ex.npan; L.ntile = L.ex.ntile;
+    size_t o = 0;
+    L.Aw = o; o += (size_t)L.npv * L.npv;
+    L.exoff = o; o += L.ex.ex_size;
+    L.Vt = o; o += (size_t)L.npv * BW;
+    L.X0 = o; o += (size_t)L.npv * BW;
+    L.Wt = o; o += (size_t)L.npv * BW;
+    L.scratch = o; o += (size_t)(n + 2 * RW + 2) * RW + (size_t)(n + RW) * (BW + 2) + 16;
+    L.total = (o + 1) & ~(size_t)1;
+    return L;
+}
+
+__global__ void n2l_copy_kernel(const double* __restrict__ H, const double* __restrict__ g, int n, int npv,
+                                double* __restrict__ Aw, double* __restrict__ bvec)
+{
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (size_t)npv * npv;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(idx / npv), c = (int)(idx - (size_t)r * npv);
+        Aw[idx] = (r < n && c < n) ? H[(size_t)r * n + c] : 0.0;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npv; i += gridDim.x * blockDim.x) bvec[i] = i < n ? -g[i] : 0.0;
+}
+
+// one workgroup of 8 waves: wave c owns panel column c (= row k + c of the working copy)
+template <int RQMAX>
+__global__ __launch_bounds__(512)
+void n2l_panel_kernel(int n, int p, double* __restrict__ wk)
+{
+    extern __shared__ double sm[];
+    const N3Global GL = n3_global(n);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int npv = GL.npv, lda = GL.npv;
+    const int k = p * BW, r0 = k + BW, m = n - r0;
+    const double* Aw = wk + GL.Aw;
+    double* ex = wk + GL.exoff;
+    double* Vst = ex + GL.ex.Vst + (size_t)p * BW * npv;
+    double* Tst = ex + GL.ex.Tst + (size_t)p * BW * BW;
+    double* Band = ex + GL.ex.Band;
+    double* Vt = wk + GL.Vt;
+    double* colbuf = sm;                          // [2][64 RQMAX]
+    double* Tm = colbuf + 2 * 64 * RQMAX;         // [64]
+    double* Gm = Tm + 64;
+    double* taus = Gm + 64;
+    if (tid < 64) { Tm[tid] = 0.0; Gm[tid] = 0.0; }
+    if (tid < 16) taus[tid] = 0.0;
+    for (int idx = tid; idx < BW * npv; idx += 512) Vst[idx] = 0.0;
+    for (int idx = tid; idx < npv * BW; idx += 512) Vt[idx] = 0.0;
+    double y[RQMAX];
+    double rcol = 0.0;
+    const int jb = (m - 1) < BW ? (m - 1) : BW;
+#pragma unroll
+    for (int q = 0; q < RQMAX; ++q) {
+        const int i2 = lane + 64 * q;
+        y[q] = i2 < m ? Aw[(size_t)(k + wave) * lda + r0 + i2] : 0.0;
+    }
+    if (lane < BW - wave) Band[(size_t)(k + wave) * RW + lane] = Aw[(size_t)(k + wave) * lda + k + wave + lane];
+    __syncthreads();
+    for (int j = 0; j < jb; ++j) {
+        double* colb = colbuf + (j & 1) * (64 * RQMAX);
+        if (wave == j) {
+#pragma unroll
+            for (int q = 0; q < RQMAX; ++q) colb[lane + 64 * q] = y[q];
+        }
+        lds_barrier();
+        const double x0 = colb[lane];
+        const double xb0 = lane > j ? x0 : 0.0;
+        double s2 = xb0 * xb0, dc = xb0 * y[0];
+#pragma unroll
+        for (int q = 1; q < RQMAX; ++q) {
+            const double xq = colb[lane + 64 * q];
+            s2 = fma(xq, xq, s2);
+            dc = fma(xq, y[q], dc);
+        }
+        s2 = wave_sum(s2);
+        dc = wave_sum(dc);
+        const double al = n2_lane(x0, j), yj = n2_lane(y[0], j);
+        const bool nz = s2 != 0.0;
+        const double beta = nz ? -copysign(sqrt(fma(al, al, s2)), al) : al;
+        const double tau = nz ? (beta - al) * fast_rcp(beta) : 0.0;
+        const double scale = nz ? fast_rcp(al - beta) : 0.0;
+        const double v0 = lane > j ? x0 * scale : (lane == j ? 1.0 : 0.0);
+        if (wave > j) {
+            const double f = tau * fma(scale, dc, yj), fs = f * scale;
+            y[0] = fma(-f, v0, y[0]);
+#pragma unroll
+            for (int q = 1; q < RQMAX; ++q) y[q] = fma(-fs, colb[lane + 64 * q], y[q]);
+        } else if (wave == j) {
+            rcol = lane == j ? beta : y[0];
+            y[0] = v0;
+            if (lane < m) { Vst[(size_t)j * npv + r0 + lane] = v0; Vt[(size_t)(r0 + lane) * BW + j] = v0; }
+#pragma unroll
+            for (int q = 1; q < RQMAX; ++q) {
+                const int i2 = lane + 64 * q;
+                y[q] = colb[i2] * scale;
+                if (i2 < m) { Vst[(size_t)j * npv + r0 + i2] = y[q]; Vt[(size_t)(r0 + i2) * BW + j] = y[q]; }
+            }
+            if (lane == 0) taus[j] = tau;
+        } else {
+            const double gv = fma(scale, dc, yj);
+            if (lane == 0) Gm[wave * BW + j] = gv;
+        }
+    }
+    if (wave >= jb) rcol = y[0];
+    if (lane <= wave && lane < m) Band[(size_t)(k + wave) * RW + BW + lane - wave] = rcol;
+    __syncthreads();
+    if (tid < BW) {
+        for (int jj = 0; jj < jb; ++jj) {
+            const double tj = taus[jj];
+            double val = 0.0;
+            if (tid == jj) val = tj;
+            else if (tid < jj) {
+                double sacc = 0.0;
+                for (int mm = tid; mm < jj; ++mm) sacc += Tm[tid * BW + mm] * Gm[mm * BW + jj];
+                val = -tj * sacc;
+            }
+            Tm[tid * BW + jj] = val;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) Tst[tid] = Tm[tid];
+}
+
+// X0[r][0..7] = sum_c A[r][c] V[c][0..7] for the rows of tile blockIdx.x + cg0; 4 waves split the columns
+__global__ __launch_bounds__(256)
+void n2l_x0_kernel(int n, int p, double* __restrict__ wk)
+{
+    __shared__ double part[4][128];
+    const N3Global GL = n3_global(n);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane >> 4, lr = lane & 15;
+    const int lda = GL.npv, ntile = GL.ntile;
+    const int r0 = p * BW + BW, cg0 = r0 >> 4;
+    const int t = cg0 + blockIdx.x;
+    const double* Aw = wk + GL.Aw;
+    const double* Vt = wk + GL.Vt;
+    double* X0 = wk + GL.X0;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    const double* arow = Aw + (size_t)(16 * t + lr) * lda + 4 * lq;
+    for (int gq = cg0 + wave; gq < ntile; gq += 4) {
+        const d2 a01 = *reinterpret_cast<const d2*>(arow + 16 * gq);
+        const d2 a23 = *reinterpret_cast<const d2*>(arow + 16 * gq + 2);
+        const double* vb = Vt + (size_t)(16 * gq + 4 * lq) * BW + (lr & 7);
+        acc = mfma_f64(a01.x, vb[0], acc);
+        acc = mfma_f64(a01.y, vb[BW], acc);
+        acc = mfma_f64(a23.x, vb[2 * BW], acc);
+        acc = mfma_f64(a23.y, vb[3 * BW], acc);
+    }
+    if (lr < BW)
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) part[wave][(lq + 4 * i2) * BW + lr] = acc[i2];
+    __syncthreads();
+    if (tid < 128) {
+        const int row = 16 * t + tid / BW;
+        const double v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        X0[(size_t)row * BW + (tid & 7)] = (row >= r0 && row < n) ? v : 0.0;
+    }
+}
+
+// one workgroup: S0 = V^T X0, Y = T^T S0 T, W = X0 T - 1/2 V Y (rows r0 .. n-1, zero elsewhere); b <- Q_p^T b
+__global__ __launch_bounds__(256)
+void n2l_w_kernel(int n, int p, double* __restrict__ wk)
+{
+    __shared__ double part[4][64];
+    __shared__ double S0[64], Zm[64], Ym[64], Tm[64], x1[BW], x2[BW];
+    const N3Global GL = n3_global(n);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int npv = GL.npv;
+    const int r0 = p * BW + BW;
+    const double* Vt = wk + GL.Vt;
+    const double* X0 = wk + GL.X0;
+    double* Wt = wk + GL.Wt;
+    double* bvec = wk + GL.exoff + GL.ex.bvec;
+    const double* Tst = wk + GL.exoff + GL.ex.Tst + (size_t)p * BW * BW;
+    if (tid < 64) Tm[tid] = Tst[tid];
+    {
+        const int a = lane >> 3, b = lane & 7;
+        double sacc = 0.0;
+        for (int r = r0 + wave; r < n; r += 4) sacc += Vt[(size_t)r * BW + a] * X0[(size_t)r * BW + b];
+        part[wave][lane] = sacc;
+    }
+    __syncthreads();
+    if (tid < 64) S0[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+    __syncthreads();
+    if (tid < 64) {
+        const int a = tid >> 3, b = tid & 7;
+        double sacc = 0.0;
+        for (int q = 0; q < BW; ++q) sacc += S0[a * BW + q] * Tm[q * BW + b];
+        Zm[tid] = sacc;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int a = tid >> 3, b = tid & 7;
+        double sacc = 0.0;
+        for (int l = 0; l < BW; ++l) sacc += Tm[l * BW + a] * Zm[l * BW + b];
+        Ym[tid] = sacc;
+    }
+    // b <- b - V T^T (V^T b)
+    for (int col = wave; col < BW; col += 4) {
+        double a = 0.0;
+        for (int r = r0 + lane; r < n; r += 64) a += Vt[(size_t)r * BW + col] * bvec[r];
+        a = wave_sum(a);
+        if (lane == 0) x1[col] = a;
+    }
+    __syncthreads();
+    if (tid < BW) {
+        double sacc = 0.0;
+        for (int mm = 0; mm < BW; ++mm) sacc += Tm[mm * BW + tid] * x1[mm];
+        x2[tid] = sacc;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < npv * BW; idx += 256) {
+        const int r = idx / BW, j = idx - r * BW;
+        const bool in = r >= r0 && r < n;
+        double sacc = 0.0;
+        if (in)
+            for (int l = 0; l < BW; ++l)
+                sacc += X0[(size_t)r * BW + l] * Tm[l * BW + j] - 0.5 * Vt[(size_t)r * BW + l] * Ym[l * BW + j];
+        Wt[idx] = sacc;
+    }
+    for (int r = r0 + tid; r < n; r += 256) {
+        double sacc = bvec[r];
+        for (int l = 0; l < BW; ++l) sacc -= Vt[(size_t)r * BW + l] * x2[l];
+        bvec[r] = sacc;
+    }
+}
+
+// a wave per 16 x 16 tile of the trailing matrix (tiles cg0 .. ntile-1 in both directions)
+__global__ __launch_bounds__(512)
+void n2l_update_kernel(int n, int p, double* __restrict__ wk)
+{
+    const N3Global GL = n3_global(n);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane >> 4, lr = lane & 15;
+    const int lda = GL.npv, ntile = GL.ntile;
+    const int r0 = p * BW + BW, cg0 = r0 >> 4, ng = ntile - cg0;
+    const long item = (long)blockIdx.x * 8 + wave;
+    if (item >= (long)ng * ng) return;
+    const int t = cg0 + (int)(item / ng), ct = cg0 + (int)(item - (long)(item / ng) * ng);
+    double* Aw = wk + GL.Aw;
+    const double* Vt = wk + GL.Vt;
+    const double* Wt = wk + GL.Wt;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int sx = 0; sx < 4; ++sx) {
+        const int kk = 4 * sx + lq;                    // P = [V | W], Q = [W | V]
+        const double pa = kk < BW ? Vt[(size_t)(16 * t + lr) * BW + kk] : Wt[(size_t)(16 * t + lr) * BW + kk - BW];
+        const double qb = kk < BW ? Wt[(size_t)(16 * ct + lr) * BW + kk] : Vt[(size_t)(16 * ct + lr) * BW + kk - BW];
+        acc = mfma_f64(pa, qb, acc);
+    }
+#pragma unroll
+    for (int i2 = 0; i2 < 4; ++i2) {
+        double* a = Aw + (size_t)(16 * t + lq + 4 * i2) * lda + 16 * ct + lr;
+        *a -= acc[i2];
+    }
+}
+
+__global__ void n2l_tail_kernel(int n, double* __restrict__ wk)
+{
+    const N3Global GL = n3_global(n);
+    const int kend = GL.npan * BW, lda = GL.npv;
+    const double* Aw = wk + GL.Aw;
+    double* Band = wk + GL.exoff + GL.ex.Band;
+    for (int idx = threadIdx.x; idx < (n - kend) * RW; idx += blockDim.x) {
+        const int r = kend + idx / RW, c = r - (idx % RW);
+        if (c >= kend) Band[(size_t)c * RW + (r - c)] = Aw[(size_t)r * lda + c];
+    }
+}
+
 }  // namespace
 
 static int n2_cu_count()
@@ -1428,11 +1753,55 @@ static bool n2_use_band(int n, int aug)
     return true;
 }
 
-extern "C" int oovqe_newton_direction_max_n(void) { return NEWTON2_NMAX; }
+extern "C" int oovqe_newton_direction_max_n(void) { return NEWTON3_NMAX; }
+
+// n > NEWTON2_NMAX: one problem after the other, ~4 launches per panel of 8 columns
+static int n3_direction(const double* hessian, const double* gradient, int n, int batch, double lambda_min,
+                        double mu, double rho, int aug, double* work, double* dp, double* lowest, double* shift,
+                        hipStream_t st)
+{
+    const N3Global GL = n3_global(n);
+    const bool mid = n - BW <= 64 * RQ_MID;
+    const size_t panel_lds = (size_t)(2 * 64 * (mid ? RQ_MID : RQ_HUGE) + 64 + 64 + 16) * sizeof(double);
+    const size_t solve_lds = (size_t)(n2_lds2(16).total + GL.npv + 2 * RW + 16) * sizeof(double);
+    OOVQE_REQUIRE(panel_lds <= 159 * 1024 && solve_lds <= 159 * 1024, "oovqe_newton_direction: n = %d too large", n);
+    if (mid)
+        OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)n2l_panel_kernel<RQ_MID>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds),
+                        "oovqe_newton_direction: hipFuncSetAttribute");
+    else
+        OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)n2l_panel_kernel<RQ_HUGE>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds),
+                        "oovqe_newton_direction: hipFuncSetAttribute");
+    OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)newton_band_solve_kernel<true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds),
+                    "oovqe_newton_direction: hipFuncSetAttribute");
+    for (int b = 0; b < batch; ++b) {
+        double* wk = work + (size_t)b * GL.total;
+        const double* Hb = hessian + (size_t)b * n * n;
+        hipLaunchKernelGGL(n2l_copy_kernel, dim3(1024), dim3(256), 0, st, Hb, gradient + (size_t)b * n, n, GL.npv,
+                           wk + GL.Aw, wk + GL.exoff + GL.ex.bvec);
+        for (int p = 0; p < GL.npan; ++p) {
+            const int r0 = p * BW + BW, cg0 = r0 >> 4, ng = GL.ntile - cg0;
+            if (mid) hipLaunchKernelGGL(n2l_panel_kernel<RQ_MID>, dim3(1), dim3(512), panel_lds, st, n, p, wk);
+            else hipLaunchKernelGGL(n2l_panel_kernel<RQ_HUGE>, dim3(1), dim3(512), panel_lds, st, n, p, wk);
+            hipLaunchKernelGGL(n2l_x0_kernel, dim3(ng), dim3(256), 0, st, n, p, wk);
+            hipLaunchKernelGGL(n2l_w_kernel, dim3(1), dim3(256), 0, st, n, p, wk);
+            hipLaunchKernelGGL(n2l_update_kernel, dim3((unsigned)(((long)ng * ng + 7) / 8)), dim3(512), 0, st, n, p, wk);
+        }
+        hipLaunchKernelGGL(n2l_tail_kernel, dim3(1), dim3(256), 0, st, n, wk);
+        hipLaunchKernelGGL(newton_band_solve_kernel<true>, dim3(1), dim3(NT2), solve_lds, st, n, lambda_min, mu, rho,
+                           aug, wk + GL.exoff, dp + (size_t)b * n, lowest + b, shift ? shift + b : nullptr,
+                           wk + GL.scratch);
+        OOVQE_CHECK_LAUNCH("oovqe_newton_direction/large");
+    }
+    return 0;
+}
 
 extern "C" int64_t oovqe_newton_direction_work_size(int n, int batch)
 {
-    if (n < 1 || n > NEWTON2_NMAX || batch < 1) return 0;
+    if (n < 1 || n > NEWTON3_NMAX || batch < 1) return 0;
+    if (n > NEWTON2_NMAX) return (int64_t)n3_global(n).total * batch;
     const size_t a = n <= NEWTON_NMAX ? newton_work_per_problem(n) : 0;
     const size_t b = n2_work_total(n2_global(n), 1);
     return (int64_t)(a > b ? a : b) * batch;
@@ -1444,9 +1813,12 @@ extern "C" int oovqe_newton_direction(const double* hessian, const double* gradi
                                       oovqe_stream_t stream)
 {
     OOVQE_REQUIRE(hessian && gradient && work && dp && lowest_eigenvalue, "oovqe_newton_direction: null pointer");
-    OOVQE_REQUIRE(n >= 1 && n <= NEWTON2_NMAX, "oovqe_newton_direction: n = %d outside 1..%d", n, NEWTON2_NMAX);
+    OOVQE_REQUIRE(n >= 1 && n <= NEWTON3_NMAX, "oovqe_newton_direction: n = %d outside 1..%d", n, NEWTON3_NMAX);
     OOVQE_REQUIRE(batch >= 1 && batch <= 65535, "oovqe_newton_direction: batch = %d", batch);
     hipStream_t st = (hipStream_t)stream;
+    if (n > NEWTON2_NMAX)
+        return n3_direction(hessian, gradient, n, batch, lambda_min, mu, rho, aug, work, dp, lowest_eigenvalue,
+                            shift, st);
     if (n2_use_band(n, aug)) {
         const N2Global GL = n2_global(n);
         const N2Lds L = n2_lds(n);
@@ -1465,7 +1837,7 @@ extern "C" int oovqe_newton_direction(const double* hessian, const double* gradi
                                                     : (const void*)newton_band_kernel<RQ_LARGE>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                         "oovqe_newton_direction: hipFuncSetAttribute");
-        OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)newton_band_solve_kernel,
+        OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)newton_band_solve_kernel<false>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2),
                         "oovqe_newton_direction: hipFuncSetAttribute");
         // exchange blocks and status words start as all ones: the pattern the hand-offs wait to see replaced
@@ -1479,8 +1851,8 @@ extern "C" int oovqe_newton_direction(const double* hessian, const double* gradi
             hipLaunchKernelGGL(newton_band_kernel<RQ_LARGE>, dim3(batch * W), dim3(NT), lds, st, hessian, gradient, n,
                                work, W, batch);
         OOVQE_CHECK_LAUNCH("oovqe_newton_direction/band");
-        hipLaunchKernelGGL(newton_band_solve_kernel, dim3(batch), dim3(NT2), lds2, st, n, lambda_min, mu, rho, aug,
-                           work, dp, lowest_eigenvalue, shift);
+        hipLaunchKernelGGL(newton_band_solve_kernel<false>, dim3(batch), dim3(NT2), lds2, st, n, lambda_min, mu, rho, aug,
+                           work, dp, lowest_eigenvalue, shift, (double*)nullptr);
         OOVQE_CHECK_LAUNCH("oovqe_newton_direction/solve");
         return 0;
     }

@@ -3,10 +3,10 @@
 Drop-in for the reference's ``NewtonStep`` (src/auto_oo/utils/newton_raphson.py:47-211: same
 constructor, same method names and return values, same acceptance rule), built differently:
 
-* the direction comes from ONE kernel launch (``oovqe_newton_direction``: blocked Householder
-  tridiagonalisation, Sturm multisection for the lowest eigenvalue, the reference's level shift
-  ``mu + rho |lambda_low|`` and a pivoted tridiagonal solve) instead of two ``eigh`` calls and an
-  explicit inverse (newton_raphson.py:78-129);
+* the direction comes from ``oovqe_newton_direction`` (reduction of the Hessian to a band of half-width
+  8 on the matrix cores, several workgroups per problem; lowest eigenvalue by multisection on a band
+  LDL^T, one shift per lane; the reference's level shift ``mu + rho |lambda_low|``; band solve) instead
+  of two ``eigh`` calls and an explicit inverse (newton_raphson.py:78-129);
 * the line search keeps energies on the device and reads back once per trial (one small tensor:
   old energy, trial energy, Armijo slope, lowest eigenvalue) instead of once per comparison
   (newton_raphson.py:131-192).
@@ -64,7 +64,8 @@ class NewtonStep():
         H = ops.as_device(hessian, dev)
         if g.numel() <= _lib.load().oovqe_newton_direction_max_n():
             return ops.newton_direction(H, g, self.lambda_min, self.mu, self.rho, self.aug)
-        # beyond one workgroup's LDS (n > 480, e.g. N = 200 orbitals): torch's device eigh (rocSOLVER)
+        # beyond the band-reduction kernels (n > 5128: no configuration of the reference's workloads gets
+        # there -- N = 200, CAS(6e,6o) has n_kappa = 4 659): torch's device eigh
         vals, vecs = torch.linalg.eigh(H)
         low = vals[0]
         nu = torch.where((low < self.lambda_min) & bool(self.aug), self.mu + self.rho * low.abs(),

@@ -364,6 +364,16 @@ class OO_energy:
             self.__dict__["_eri_flag_cache"] = hit
         return hit[2]
 
+    def reverify_integrals(self):
+        """Call after writing into ``int2e_ao`` / ``int1e_ao`` through a path torch's version counter does
+        not see (a kernel writing through a raw pointer, ``.data`` edits, an external producer): drops the
+        cached symmetry flags and evaluation plans, so the next call verifies the tensor again bit for bit.
+        In-place torch ops (``tensor.mul_(..)``, indexing assignments) bump the version counter and need no
+        call.  (``OO_pqc_batch.reverify_integrals`` is the batched counterpart.)"""
+        self.__dict__.pop("_eri_flag_cache", None)
+        self.__dict__.pop("_plans2", None)
+        self.__dict__.pop("_full_pair_tables", None)
+
     def _cas_eval(self, mo_coeff, gamma_sets, Gamma_sets, want_matrices=False):
         """Fused energy / Fock / orbital gradient for a stack of RDM sets (set 0 = RDMs, sets k>=1
         = derivative RDMs)."""

@@ -152,7 +152,8 @@ class OO_pqc(OO_energy):
             plans = self.__dict__.setdefault("_plans2", {})
             # the plan bakes in the integrals' symmetry flags: it is valid for one STATE of the
             # tensors (object + in-place version counter); an edited int2e_ao gets a fresh plan
-            state = (id(self.pqc), id(self.int2e_ao), self.int2e_ao._version, id(self.int1e_ao))
+            state = (id(self.pqc), id(self.int2e_ao), self.int2e_ao._version, id(self.int1e_ao),
+                     self.int1e_ao._version)
             hit = plans.get(bool(derivatives))
             if hit is None or hit[0] != state:
                 pqc = self.pqc

@@ -421,9 +421,13 @@ def circuit_hessian(theta, gates_dev, n_gates, n_qubits, ncas, init_index, c1, c
     th2 = theta.reshape(1, n_theta).contiguous()
     pairs_dev, _, _ = _hessian_pair_tables(n_theta, dev)   # cached: no host->device copy per call
     n_pairs = pairs_dev.shape[0]
-    key = (n_theta, n_qubits, ncas, str(dev))
+    # scratch is cached per (shape, device, STREAM): calls on different HIP streams must not share it
+    # (the caching allocator's stream ordering does not cover a buffer that outlives the call)
+    key = (n_theta, n_qubits, ncas, str(dev), torch.cuda.current_stream().cuda_stream)
     work = _CHESS_WORK.get(key)
     if work is None:
+        if len(_CHESS_WORK) >= 8:
+            _CHESS_WORK.clear()
         work = torch.empty(lib.oovqe_circuit_hessian_work_size(n_theta, n_qubits, ncas, n_pairs), dtype=F64,
                            device=dev)
         _CHESS_WORK[key] = work
@@ -440,7 +444,8 @@ _NEWTON_WORK = {}
 
 def newton_direction(hessian, gradient, lambda_min=1e-6, mu=1e-6, rho=1.1, aug=True):
     """dp = -(H + nu I)^-1 g with the reference's level shift (newton_raphson.py:78-129), on the
-    device in one launch (``oovqe_newton_direction``).  hessian [n,n] or [G,n,n], gradient [n] or
+    device (``oovqe_newton_direction``: two launches up to n = 672, several workgroups per problem;
+    a launch sequence per panel up to n = 5128).  hessian [n,n] or [G,n,n], gradient [n] or
     [G,n] -> (dp, lowest eigenvalues [G] (0-d for one problem), shifts nu)."""
     lib = _lib.load()
     dev = _dev(hessian)
@@ -449,12 +454,13 @@ def newton_direction(hessian, gradient, lambda_min=1e-6, mu=1e-6, rho=1.1, aug=T
     g = gradient.reshape(H.shape[0], -1)
     G, n = g.shape
     if n > lib.oovqe_newton_direction_max_n():
-        raise _lib.OovqeError(f"newton_direction: n = {n} exceeds the one-workgroup kernel "
+        raise _lib.OovqeError(f"newton_direction: n = {n} exceeds the band-reduction kernels "
                               f"({lib.oovqe_newton_direction_max_n()})")
-    key = (n, G, str(dev))
+    key = (n, G, str(dev), torch.cuda.current_stream().cuda_stream)     # (per stream, see circuit_hessian)
     work = _NEWTON_WORK.get(key)
     if work is None:
-        _NEWTON_WORK.clear()
+        if len(_NEWTON_WORK) >= 4:
+            _NEWTON_WORK.clear()
         work = torch.empty(lib.oovqe_newton_direction_work_size(n, G), dtype=F64, device=dev)
         _NEWTON_WORK[key] = work
     H = H if H.is_contiguous() else H.contiguous()

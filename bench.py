@@ -580,6 +580,9 @@ def main():
     # are then 8 N^2 * N(N+1)/2 (half of SURVEY.md section 8(d)'s 8 N^4) + the packed J written
     pq_sym = bool(batch.eri_flags & ops.ERI_PQ_SYMMETRIC)
     rs_sym = bool(batch.eri_flags & ops.ERI_RS_SYMMETRIC)
+    # the stage-1 kernel the library actually dispatched for the timed calls (name + template arguments)
+    from auto_oo_amd import _lib as _aoo_lib
+    dispatched = _aoo_lib.load().oovqe_last_stage1_kernel().decode()
     tri = NAO * (NAO + 1) // 2
     if pq_sym and t3_path:
         bytes_per_eval = 8.0 * NAO ** 2 * tri + 8.0 * tri * M ** 2
@@ -588,7 +591,7 @@ def main():
             # the columns y <= z of its result are written
             slab_elems = sum(NAO - (r & ~1) for r in range(NAO))   # upper triangle, even row starts
             bytes_per_eval = 8.0 * slab_elems * tri + 8.0 * tri * (M * (M + 1) // 2)
-        kernel_name = (("half_tri_reg_kernel<11,3,8,3>" if rs_sym else "half_tri_kernel<11,3,0,8>")
+        kernel_name = (dispatched
                        + " (J[p<=q,y,z] = sum_rs C[r,y] g[p,q,r,s] C[s,z] over the "
                        "upper triangle of slabs"
                        + (", streaming the packed copy (upper triangle of each slab)"
@@ -596,16 +599,16 @@ def main():
                        + "; integrals verified p<->q" + (" and r<->s" if rs_sym else "") + " symmetric)")
     elif pq_sym:
         bytes_per_eval = 8.0 * NAO ** 2 * tri + 8.0 * NAO ** 2 * M ** 2
-        kernel_name = ("half_transform_kernel<1,11,3>, slabs p <= q mirrored into T2[p,q] and T2[q,p] "
+        kernel_name = (dispatched + ", slabs p <= q mirrored into T2[p,q] and T2[q,p] "
                        "(integrals verified p<->q symmetric)")
     elif t3_path:
         # g_ao read once + T3 (8 N M^3) written
         bytes_per_eval = 8.0 * NAO ** 4 + 8.0 * NAO * M ** 3
-        kernel_name = ("half_transform_fused_kernel<11,3> (T3[p,x,y,z] = sum_q C[q,x] "
+        kernel_name = (dispatched + " (T3[p,x,y,z] = sum_q C[q,x] "
                        "sum_rs C[r,y] g[p,q,r,s] C[s,z])")
     else:
         bytes_per_eval = 8.0 * NAO ** 4 + 8.0 * NAO ** 2 * M ** 2
-        kernel_name = "half_transform_kernel<1,11,3> (T2[p,q,y,z] = sum_rs C[r,y] g[p,q,r,s] C[s,z])"
+        kernel_name = dispatched + " (T2[p,q,y,z] = sum_rs C[r,y] g[p,q,r,s] C[s,z])"
     # evaluations per launch from the calls made (the event pool brackets at most 8192 launches of
     # a long run: the average duration is then over those, the bytes are still per launch)
     evals_per_launch = float(G)
@@ -615,16 +618,24 @@ def main():
     achieved = alg_bytes / kern_s / 1e9
     # HBM traffic of that kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 [gfx950 correction] +
     # WRITE_SIZE, separate passes; profiles/pmc_half_transform.json), scaled to this launch size
-    traffic = None
+    traffic, traffic_note = None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_half_transform.json")
     if os.path.exists(pmc_path) and t3_path:        # (the PMC passes were taken on the batched kernel)
         try:
+            import hashlib
             with open(pmc_path) as fh:
                 pmc = json.load(fh)
-            if pmc.get("pq_symmetric", False) == pq_sym:
+            with open(os.path.join(ROOT, "auto_oo_amd", "csrc", "cas.hip"), "rb") as fh:
+                sha = hashlib.sha256(fh.read()).hexdigest()
+            # the counters belong to ONE build of the stage-1 source and to ONE kernel: anything else gets no figure
+            if pmc.get("cas_hip_sha256") != sha:
+                traffic_note = "profiles/pmc_half_transform.json was measured on another version of cas.hip"
+            elif not pmc.get("kernel", "").startswith(dispatched):
+                traffic_note = f"profiles/pmc_half_transform.json is about {pmc.get('kernel')!r}, not {dispatched!r}"
+            elif pmc.get("pq_symmetric", False) == pq_sym:
                 traffic = pmc["hbm_bytes_per_launch"] / pmc.get("geometries_per_launch", 64) * evals_per_launch
-        except Exception:
-            traffic = None
+        except Exception as exc:
+            traffic, traffic_note = None, f"pmc file unreadable: {exc}"
 
     out = {
         "metric": METRIC,
@@ -659,6 +670,8 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_note": traffic_note,
+            "kernel_dispatched": dispatched,
             "algorithmic_bytes_per_launch": alg_bytes,
             "algorithmic_bytes_per_eval": bytes_per_eval,
             # SURVEY.md section 8(d)'s figure reads the full tensor (every integral 4x): for reference
@@ -680,7 +693,14 @@ def main():
             "achieved_TFLOPs_incl_tile_padding": mfma_flops / kern_s / 1e12,
             "peak_TFLOPs": 78.6,
             "frac_of_peak_at_2.4GHz": mfma_flops / kern_s / 1e12 / 78.6,
-            "note": "the core clock under this kernel is ~1.75 GHz (tools/tri_spread.hip, profiles/r02_t_stage1_cycles.txt)",
+            # 34 x 64 pipe cycles per slab, 946 slabs per geometry, 1 024 SIMDs: the launch cannot be shorter
+            "pipe_floor_us_at_2.4GHz": 34 * 64.0 * tri * evals_per_launch / 1024 / 2.4e3,
+            "pipe_floor_us_at_1.75GHz": 34 * 64.0 * tri * evals_per_launch / 1024 / 1.75e3,
+            "frac_of_pipe_floor_at_1.75GHz": (34 * 64.0 * tri * evals_per_launch / 1024 / 1.75e3) / (kern_s * 1e6),
+            "useful_flop_share_of_issued": (2.0 * 967 * 9 + 2.0 * 43 * 81) / (34 * 2048.0),
+            "note": "the core clock under this kernel is ~1.75 GHz (power-limited with the HBM stream: tools/tri_spread.hip, "
+                    "profiles/r02_t_stage1_cycles.txt); against the matrix pipe at that clock the launch stands at "
+                    "frac_of_pipe_floor -- the HBM fraction understates how close the kernel is to ITS bound",
         }
     if n_geom_total <= 64:
         # small jobs (tests): the gathered energies bit for bit, geometry by geometry

@@ -42,6 +42,9 @@ int         oovqe_profile_begin_detail(void);
  * 1 = circuit + RDMs (absent when they ride along launch 2), 2 = p->n contraction,
  * 3 = Fock-column (panel) kernel, 4 = final assembly */
 int         oovqe_profile_end_labels(double* ms_by_label, int* count_by_label, int n_labels);
+/* name and template arguments of the stage-1 (N^4 pass) kernel the last evaluation dispatched, e.g.
+ * "half_tri_reg_kernel<11,3,8,3>" ("" before the first evaluation); bench.py's roofline quotes it */
+const char* oovqe_last_stage1_kernel(void);
 
 /* ---- gate table for the statevector kernels ----------------------------------------------- *
  * One entry per excitation gate (qml.FermionicDoubleExcitation / FermionicSingleExcitation /

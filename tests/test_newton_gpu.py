@@ -58,6 +58,31 @@ def test_newton_direction_vs_eigh(n, kind):
     assert (dp.cpu() - dp_ref).abs().max() <= 1e-13 * cond * (1.0 + dp_ref.abs().max()) * n
 
 
+@pytest.mark.parametrize("n,kind", [(673, "indefinite"), (700, "pd"), (1000, "near_singular"), (1544, "indefinite"),
+                                    (1600, "pd")])
+def test_newton_direction_beyond_one_launch(n, kind):
+    """n > 672 (the operands of a panel no longer fit LDS): the host-orchestrated band reduction (four
+    launches per panel of 8 columns) + the same band LDL^T solve kernel, against eigh -- no rocSOLVER
+    fallback below n = 5128 (orbital spaces of N = 200)."""
+    rng = np.random.default_rng(n)
+    H = torch.tensor(_sym(rng, n, kind))
+    g = torch.tensor(rng.standard_normal(n))
+    dp_ref, low_ref = _reference_direction(H, g)
+    dp, low, nu = ops.newton_direction(H.cuda(), g.cuda())
+    scale = float(H.abs().max())
+    assert abs(low.item() - low_ref) < 1e-12 * max(1.0, scale) * n
+    Hs = H + nu.item() * torch.eye(n, dtype=torch.float64)
+    res = (Hs @ dp.cpu() + g).abs().max() / (1.0 + g.abs().max())
+    assert res < 1e-9, res
+    cond = float(torch.linalg.cond(Hs))
+    assert (dp.cpu() - dp_ref).abs().max() <= 1e-13 * cond * (1.0 + dp_ref.abs().max()) * n
+    # two problems in one call
+    H2 = torch.stack((H, H + 0.5 * torch.eye(n, dtype=torch.float64))).cuda()
+    g2 = torch.stack((g, -g)).cuda()
+    dp2, low2, _ = ops.newton_direction(H2, g2)
+    assert torch.equal(dp2[0], dp) and abs(low2[1].item() - low2[0].item() - 0.5) < 1e-10 * max(1.0, scale)
+
+
 def test_newton_direction_batch_and_no_augmentation():
     rng = np.random.default_rng(7)
     n, G = 58, 19
