@@ -1443,12 +1443,11 @@ void newton_band_solve_kernel(int n, double lam_threshold, double mu, double rho
 // then the same solve kernel with its band rows and factor in global scratch.  n <= NEWTON3_NMAX.
 // =====================================================================================================
 constexpr int NEWTON3_NMAX = 5128;
-constexpr int RQ_HUGE = (NEWTON3_NMAX - BW + 63) / 64;          // 80
 constexpr int RQ_MID = 24;                                      // n - 8 <= 1536
 
 struct N3Global {          // per problem, doubles: [Aw | Vst | Tst | Vt | X0 | Wt | Band | bvec | scratch]
     int npv, npan, ntile;
-    size_t Aw, Vt, X0, Wt, scratch, total;
+    size_t Aw, Vt, X0, Wt, scratch, small, total;
     N2Global ex;           // Vst / Tst / Band / bvec offsets are those of the exchange block (at `exoff`)
     size_t exoff;
 };
@@ -1465,6 +1464,7 @@ __host__ __device__ inline N3Global n3_global(int n)
     L.X0 = o; o += (size_t)L.npv * BW;
     L.Wt = o; o += (size_t)L.npv * BW;
     L.scratch = o; o += (size_t)(n + 2 * RW + 2) * RW + (size_t)(n + RW) * (BW + 2) + 16;
+    L.small = o; o += (size_t)L.ntile * 72 + 160;      // per-tile partials of V^T X0 and V^T b | TQ (16 x 8) | x2
     L.total = (o + 1) & ~(size_t)1;
     return L;
 }
@@ -1580,6 +1580,122 @@ void n2l_panel_kernel(int n, int p, double* __restrict__ wk)
     if (tid < 64) Tst[tid] = Tm[tid];
 }
 
+// The same panel factorisation for long columns (m > 64 RQ_MID): the eight columns stay where they are -- rows
+// k .. k+7 of the working copy, L2-resident -- and are streamed: 16 waves, two per column (even / odd blocks of
+// 64 rows); per step one pass for the norm and the dot products and one for the update, two barriers.
+__global__ __launch_bounds__(NT)
+void n2l_panel_stream_kernel(int n, int p, double* __restrict__ wk)
+{
+    __shared__ double part[2][BW][2];         // [half][column][s2, dc]
+    __shared__ double Tm[64], Gm[64], taus[16], Rm[64];
+    const N3Global GL = n3_global(n);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = wave & 7, half = wave >> 3;
+    const int npv = GL.npv, lda = GL.npv;
+    const int k = p * BW, r0 = k + BW, m = n - r0;
+    double* Aw = wk + GL.Aw;
+    double* ex = wk + GL.exoff;
+    double* Vst = ex + GL.ex.Vst + (size_t)p * BW * npv;
+    double* Tst = ex + GL.ex.Tst + (size_t)p * BW * BW;
+    double* Band = ex + GL.ex.Band;
+    double* Vt = wk + GL.Vt;
+    if (tid < 64) { Tm[tid] = 0.0; Gm[tid] = 0.0; Rm[tid] = 0.0; }
+    if (tid < 16) taus[tid] = 0.0;
+    for (int idx = tid; idx < BW * npv; idx += NT) Vst[idx] = 0.0;
+    for (int idx = tid; idx < npv * BW; idx += NT) Vt[idx] = 0.0;
+    if (half == 0 && lane < BW - col) Band[(size_t)(k + col) * RW + lane] = Aw[(size_t)(k + col) * lda + k + col + lane];
+    __syncthreads();
+    const int jb = (m - 1) < BW ? (m - 1) : BW;
+    double* ycol = Aw + (size_t)(k + col) * lda + r0;       // this wave's column: y[i] = ycol[i]
+    for (int j = 0; j < jb; ++j) {
+        const double* x = Aw + (size_t)(k + j) * lda + r0;  // the pivot column (col < j: the stored reflector j' = col)
+        const double* other = col < j ? Vst + (size_t)col * npv + r0 : ycol;
+        // (element j of the own column is rewritten by the column's first wave behind the barrier below: read now)
+        const double al = x[j], yj = other[j];
+        double s2 = 0.0, dc = 0.0;
+        for (int i0 = j + 1 + 64 * half; i0 < m; i0 += 512) {
+            double xv[4], ov[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i2 = i0 + 128 * u + lane;
+                xv[u] = i2 < m ? x[i2] : 0.0;
+                ov[u] = i2 < m ? other[i2] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s2 = fma(xv[u], xv[u], s2); dc = fma(xv[u], ov[u], dc); }
+        }
+        s2 = wave_sum(s2);
+        dc = wave_sum(dc);
+        if (lane == 0) { part[half][col][0] = s2; part[half][col][1] = dc; }
+        __syncthreads();
+        s2 = part[0][col][0] + part[1][col][0];
+        dc = part[0][col][1] + part[1][col][1];
+        const bool nz = s2 != 0.0;
+        const double beta = nz ? -copysign(sqrt(fma(al, al, s2)), al) : al;
+        const double tau = nz ? (beta - al) * fast_rcp(beta) : 0.0;
+        const double scale = nz ? fast_rcp(al - beta) : 0.0;
+        if (col > j) {
+            const double f = tau * fma(scale, dc, yj), fs = f * scale;
+            for (int i0 = j + 1 + 64 * half; i0 < m; i0 += 512) {
+                double xv[4], yv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i2 = i0 + 128 * u + lane;
+                    xv[u] = i2 < m ? x[i2] : 0.0;
+                    yv[u] = i2 < m ? ycol[i2] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i2 = i0 + 128 * u + lane;
+                    if (i2 < m) ycol[i2] = fma(-fs, xv[u], yv[u]);
+                }
+            }
+            if (half == 0 && lane == 0) { ycol[j] = yj - f; Rm[j * BW + col] = yj - f; }
+        } else if (col == j) {
+            for (int i2 = j + 1 + 64 * half + lane; i2 < m; i2 += 128) {
+                const double v = x[i2] * scale;
+                Vst[(size_t)j * npv + r0 + i2] = v;
+                Vt[(size_t)(r0 + i2) * BW + j] = v;
+            }
+            if (half == 0 && lane == 0) {
+                Vst[(size_t)j * npv + r0 + j] = 1.0;
+                Vt[(size_t)(r0 + j) * BW + j] = 1.0;
+                taus[j] = tau;
+                Rm[j * BW + j] = beta;
+            }
+        } else if (half == 0 && lane == 0) {
+            Gm[col * BW + j] = fma(scale, dc, yj);          // yj = v_col[j]
+        }
+        __syncthreads();
+    }
+    // rows of R that no step produced (a short last panel): the entries as they stand
+    if (tid < 64) {
+        const int i2 = tid >> 3, c = tid & 7;
+        if (i2 >= jb && i2 <= c && i2 < m) Rm[i2 * BW + c] = Aw[(size_t)(k + c) * lda + r0 + i2];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int i2 = tid >> 3, c = tid & 7;
+        if (i2 <= c && i2 < m) Band[(size_t)(k + c) * RW + BW + i2 - c] = Rm[i2 * BW + c];
+    }
+    if (tid < BW) {
+        for (int jj = 0; jj < jb; ++jj) {
+            const double tj = taus[jj];
+            double val = 0.0;
+            if (tid == jj) val = tj;
+            else if (tid < jj) {
+                double sacc = 0.0;
+                for (int mm = tid; mm < jj; ++mm) sacc += Tm[tid * BW + mm] * Gm[mm * BW + jj];
+                val = -tj * sacc;
+            }
+            Tm[tid * BW + jj] = val;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) Tst[tid] = Tm[tid];
+}
+
 // X0[r][0..7] = sum_c A[r][c] V[c][0..7] for the rows of tile blockIdx.x + cg0; 4 waves split the columns
 __global__ __launch_bounds__(256)
 void n2l_x0_kernel(int n, int p, double* __restrict__ wk)
@@ -1609,37 +1725,60 @@ void n2l_x0_kernel(int n, int p, double* __restrict__ wk)
 #pragma unroll
         for (int i2 = 0; i2 < 4; ++i2) part[wave][(lq + 4 * i2) * BW + lr] = acc[i2];
     __syncthreads();
+    __shared__ double xs[128];
     if (tid < 128) {
         const int row = 16 * t + tid / BW;
         const double v = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-        X0[(size_t)row * BW + (tid & 7)] = (row >= r0 && row < n) ? v : 0.0;
+        xs[tid] = (row >= r0 && row < n) ? v : 0.0;
+        X0[(size_t)row * BW + (tid & 7)] = xs[tid];
+    }
+    __syncthreads();
+    // this tile's share of S0 = V^T X0 and of V^T b (summed over the tiles, in order, by n2l_w_kernel)
+    double* sp = wk + GL.small + (size_t)blockIdx.x * 72;
+    if (tid < 64) {
+        const int a = tid >> 3, b = tid & 7;
+        double sacc = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) sacc += Vt[(size_t)(16 * t + rr) * BW + a] * xs[rr * BW + b];
+        sp[tid] = sacc;
+    } else if (tid < 72) {
+        const int a = tid - 64;
+        const double* bvec = wk + GL.exoff + GL.ex.bvec;
+        double sacc = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) sacc += Vt[(size_t)(16 * t + rr) * BW + a] * bvec[16 * t + rr];
+        sp[tid] = sacc;
     }
 }
 
-// one workgroup: S0 = V^T X0, Y = T^T S0 T, W = X0 T - 1/2 V Y (rows r0 .. n-1, zero elsewhere); b <- Q_p^T b
+// one workgroup: S0 (from the tiles' partial sums), Y = T^T S0 T, TQ = [T ; -1/2 Y] for the update kernel
+// (which forms W = [X0 | V] TQ for its own rows); b <- Q_p^T b = b - V T^T (V^T b)
 __global__ __launch_bounds__(256)
 void n2l_w_kernel(int n, int p, double* __restrict__ wk)
 {
-    __shared__ double part[4][64];
-    __shared__ double S0[64], Zm[64], Ym[64], Tm[64], x1[BW], x2[BW];
+    __shared__ double part[4][72];
+    __shared__ double S0[64], Zm[64], Tm[64], x1[BW], x2[BW];
     const N3Global GL = n3_global(n);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int npv = GL.npv;
-    const int r0 = p * BW + BW;
+    const int r0 = p * BW + BW, cg0 = r0 >> 4, ng = GL.ntile - cg0;
     const double* Vt = wk + GL.Vt;
-    const double* X0 = wk + GL.X0;
-    double* Wt = wk + GL.Wt;
+    const double* sp = wk + GL.small;
+    double* TQ = wk + GL.small + (size_t)GL.ntile * 72;
     double* bvec = wk + GL.exoff + GL.ex.bvec;
     const double* Tst = wk + GL.exoff + GL.ex.Tst + (size_t)p * BW * BW;
     if (tid < 64) Tm[tid] = Tst[tid];
     {
-        const int a = lane >> 3, b = lane & 7;
-        double sacc = 0.0;
-        for (int r = r0 + wave; r < n; r += 4) sacc += Vt[(size_t)r * BW + a] * X0[(size_t)r * BW + b];
-        part[wave][lane] = sacc;
+        double s0 = 0.0, s1 = 0.0;       // pair `lane` of S0; waves 0 .. 3 take every fourth tile; lanes < 8 also x1
+        for (int t = wave; t < ng; t += 4) {
+            s0 += sp[(size_t)t * 72 + lane];
+            if (lane < BW) s1 += sp[(size_t)t * 72 + 64 + lane];
+        }
+        part[wave][lane] = s0;
+        if (lane < BW) part[wave][64 + lane] = s1;
     }
     __syncthreads();
     if (tid < 64) S0[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+    if (tid < BW) x1[tid] = (part[0][64 + tid] + part[1][64 + tid]) + (part[2][64 + tid] + part[3][64 + tid]);
     __syncthreads();
     if (tid < 64) {
         const int a = tid >> 3, b = tid & 7;
@@ -1647,38 +1786,23 @@ void n2l_w_kernel(int n, int p, double* __restrict__ wk)
         for (int q = 0; q < BW; ++q) sacc += S0[a * BW + q] * Tm[q * BW + b];
         Zm[tid] = sacc;
     }
+    if (tid >= 64 && tid < 64 + BW) {
+        const int j = tid - 64;
+        double sacc = 0.0;
+        for (int mm = 0; mm < BW; ++mm) sacc += Tm[mm * BW + j] * x1[mm];
+        x2[j] = sacc;
+    }
     __syncthreads();
     if (tid < 64) {
         const int a = tid >> 3, b = tid & 7;
         double sacc = 0.0;
         for (int l = 0; l < BW; ++l) sacc += Tm[l * BW + a] * Zm[l * BW + b];
-        Ym[tid] = sacc;
-    }
-    // b <- b - V T^T (V^T b)
-    for (int col = wave; col < BW; col += 4) {
-        double a = 0.0;
-        for (int r = r0 + lane; r < n; r += 64) a += Vt[(size_t)r * BW + col] * bvec[r];
-        a = wave_sum(a);
-        if (lane == 0) x1[col] = a;
-    }
-    __syncthreads();
-    if (tid < BW) {
-        double sacc = 0.0;
-        for (int mm = 0; mm < BW; ++mm) sacc += Tm[mm * BW + tid] * x1[mm];
-        x2[tid] = sacc;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < npv * BW; idx += 256) {
-        const int r = idx / BW, j = idx - r * BW;
-        const bool in = r >= r0 && r < n;
-        double sacc = 0.0;
-        if (in)
-            for (int l = 0; l < BW; ++l)
-                sacc += X0[(size_t)r * BW + l] * Tm[l * BW + j] - 0.5 * Vt[(size_t)r * BW + l] * Ym[l * BW + j];
-        Wt[idx] = sacc;
+        TQ[tid] = Tm[tid];
+        TQ[64 + tid] = -0.5 * sacc;
     }
     for (int r = r0 + tid; r < n; r += 256) {
         double sacc = bvec[r];
+#pragma unroll
         for (int l = 0; l < BW; ++l) sacc -= Vt[(size_t)r * BW + l] * x2[l];
         bvec[r] = sacc;
     }
@@ -1698,13 +1822,33 @@ void n2l_update_kernel(int n, int p, double* __restrict__ wk)
     const int t = cg0 + (int)(item / ng), ct = cg0 + (int)(item - (long)(item / ng) * ng);
     double* Aw = wk + GL.Aw;
     const double* Vt = wk + GL.Vt;
-    const double* Wt = wk + GL.Wt;
+    const double* X0 = wk + GL.X0;
+    const double* TQ = wk + GL.small + (size_t)GL.ntile * 72;       // [T ; -1/2 Y] (16 x 8)
+    // W[r][j] = sum_l X0[r][l] T[l][j] - 1/2 V[r][l] Y[l][j] for this lane's rows of the two tiles, j = lq, lq + 4
+    // (rows outside r0 .. n-1 carry zeros in X0 and V)
+    double vrow[2][BW], wv[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const size_t r = (size_t)(16 * (h ? ct : t) + lr);
+        double xr[BW];
+#pragma unroll
+        for (int l = 0; l < BW; ++l) { xr[l] = X0[r * BW + l]; vrow[h][l] = Vt[r * BW + l]; }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = lq + 4 * jj;
+            double sacc = 0.0;
+#pragma unroll
+            for (int l = 0; l < BW; ++l) sacc += xr[l] * TQ[l * BW + j] + vrow[h][l] * TQ[(BW + l) * BW + j];
+            wv[h][jj] = sacc;
+        }
+    }
     d4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int sx = 0; sx < 4; ++sx) {
-        const int kk = 4 * sx + lq;                    // P = [V | W], Q = [W | V]
-        const double pa = kk < BW ? Vt[(size_t)(16 * t + lr) * BW + kk] : Wt[(size_t)(16 * t + lr) * BW + kk - BW];
-        const double qb = kk < BW ? Wt[(size_t)(16 * ct + lr) * BW + kk] : Vt[(size_t)(16 * ct + lr) * BW + kk - BW];
+        // k = 4 sx + lq:  P = [V | W] of the row tile, Q = [W | V] of the column tile
+        // (the V element of a lane depends on lq: fetched again rather than picked out of vrow[] by a lane-dependent index)
+        const double pa = sx < 2 ? Vt[(size_t)(16 * t + lr) * BW + 4 * sx + lq] : wv[0][sx - 2];
+        const double qb = sx < 2 ? wv[1][sx] : Vt[(size_t)(16 * ct + lr) * BW + 4 * (sx - 2) + lq];
         acc = mfma_f64(pa, qb, acc);
     }
 #pragma unroll
@@ -1761,18 +1905,12 @@ static int n3_direction(const double* hessian, const double* gradient, int n, in
                         hipStream_t st)
 {
     const N3Global GL = n3_global(n);
-    const bool mid = n - BW <= 64 * RQ_MID;
-    const size_t panel_lds = (size_t)(2 * 64 * (mid ? RQ_MID : RQ_HUGE) + 64 + 64 + 16) * sizeof(double);
+    const size_t panel_lds = (size_t)(2 * 64 * RQ_MID + 64 + 64 + 16) * sizeof(double);
     const size_t solve_lds = (size_t)(n2_lds2(16).total + GL.npv + 2 * RW + 16) * sizeof(double);
     OOVQE_REQUIRE(panel_lds <= 159 * 1024 && solve_lds <= 159 * 1024, "oovqe_newton_direction: n = %d too large", n);
-    if (mid)
-        OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)n2l_panel_kernel<RQ_MID>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds),
-                        "oovqe_newton_direction: hipFuncSetAttribute");
-    else
-        OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)n2l_panel_kernel<RQ_HUGE>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds),
-                        "oovqe_newton_direction: hipFuncSetAttribute");
+    OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)n2l_panel_kernel<RQ_MID>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)panel_lds),
+                    "oovqe_newton_direction: hipFuncSetAttribute");
     OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)newton_band_solve_kernel<true>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds),
                     "oovqe_newton_direction: hipFuncSetAttribute");
@@ -1783,8 +1921,9 @@ static int n3_direction(const double* hessian, const double* gradient, int n, in
                            wk + GL.Aw, wk + GL.exoff + GL.ex.bvec);
         for (int p = 0; p < GL.npan; ++p) {
             const int r0 = p * BW + BW, cg0 = r0 >> 4, ng = GL.ntile - cg0;
-            if (mid) hipLaunchKernelGGL(n2l_panel_kernel<RQ_MID>, dim3(1), dim3(512), panel_lds, st, n, p, wk);
-            else hipLaunchKernelGGL(n2l_panel_kernel<RQ_HUGE>, dim3(1), dim3(512), panel_lds, st, n, p, wk);
+            // (the panel shrinks by 8 rows each time: the long-column kernel until the columns fit registers)
+            if (n - r0 <= 64 * RQ_MID) hipLaunchKernelGGL(n2l_panel_kernel<RQ_MID>, dim3(1), dim3(512), panel_lds, st, n, p, wk);
+            else hipLaunchKernelGGL(n2l_panel_stream_kernel, dim3(1), dim3(NT), 0, st, n, p, wk);
             hipLaunchKernelGGL(n2l_x0_kernel, dim3(ng), dim3(256), 0, st, n, p, wk);
             hipLaunchKernelGGL(n2l_w_kernel, dim3(1), dim3(256), 0, st, n, p, wk);
             hipLaunchKernelGGL(n2l_update_kernel, dim3((unsigned)(((long)ng * ng + 7) / 8)), dim3(512), 0, st, n, p, wk);
