@@ -741,7 +741,7 @@ __device__ __forceinline__ constexpr int n2_tri(int a, int b)
 // that enters the window is fetched a step ahead, and the pivot of the next step -- and its reciprocal --
 // is formed before the other 35 updates of a step, which then run in the shadow of that dependent chain.
 template <bool SOLVE>
-__device__ bool n2_band_ldlt(const double* __restrict__ rb, int n, double sigma, double pivmin,
+__device__ __forceinline__ bool n2_band_ldlt(const double* __restrict__ rb, int n, double sigma, double pivmin,
                              double* __restrict__ rhs, double* __restrict__ Lst, double* __restrict__ dst,
                              double* __restrict__ zst)
 {
@@ -1057,29 +1057,6 @@ void newton_band_kernel(const double* __restrict__ H, const double* __restrict__
                 }
             }
         }
-        if (slot == 0) {
-            // b <- Q_p^T b = b - V T^T (V^T b), while the other workgroups' X0 rows are on their way
-            __syncthreads();
-            if (wave < BW) {
-                double a = 0.0;
-                for (int r = r0 + lane; r < n; r += 64) a += VW[wave * ldp + r] * bb[r];
-                a = wave_sum(a);
-                if (lane == 0) x1[wave] = a;
-            }
-            __syncthreads();
-            if (tid < BW) {
-                double sacc = 0.0;
-                for (int mm = 0; mm < BW; ++mm) sacc += Tm[mm * BW + tid] * x1[mm];
-                x2[tid] = sacc;
-            }
-            __syncthreads();
-            for (int r = r0 + tid; r < n; r += NT) {
-                double sacc = bb[r];
-#pragma unroll
-                for (int l = 0; l < BW; ++l) sacc -= VW[l * ldp + r] * x2[l];
-                bb[r] = sacc;
-            }
-        }
         N2_MARK(6);
         // =============== U: all of X0, W, own rows of A22 -= V W^T + W V^T ===============
         {
@@ -1182,6 +1159,31 @@ void newton_band_kernel(const double* __restrict__ H, const double* __restrict__
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         N2_MARK(9);
+        if (slot == 0) {
+            // b <- Q_p^T b = b - V T^T (V^T b) (V | T of this panel are still in LDS), while the next panel's owner
+            // factorises: this workgroup would only be waiting for it
+            if (wave < BW) {
+                double a = 0.0;
+                for (int r = r0 + lane; r < n; r += 64) a += VW[wave * ldp + r] * bb[r];
+                a = wave_sum(a);
+                if (lane == 0) x1[wave] = a;
+            }
+            __syncthreads();
+            if (tid < BW) {
+                double sacc = 0.0;
+                for (int mm = 0; mm < BW; ++mm) sacc += Tm[mm * BW + tid] * x1[mm];
+                x2[tid] = sacc;
+            }
+            __syncthreads();
+            for (int r = r0 + tid; r < n; r += NT) {
+                double sacc = bb[r];
+#pragma unroll
+                for (int l = 0; l < BW; ++l) sacc -= VW[l * ldp + r] * x2[l];
+                bb[r] = sacc;
+            }
+            __syncthreads();          // (the next panel refills VW)
+        }
+        N2_MARK(10);
     }
     // ---- band: the dense remainder behind the last panel (rows >= kend), by the owners of those rows
     if (!dead) {

@@ -23,7 +23,7 @@ int main(int argc, char** argv)
     hipMalloc(&dw, oovqe_newton_direction_work_size(n, batch) * 8);
     hipMemcpy(dH, H.data(), H.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dg, g.data(), g.size() * 8, hipMemcpyHostToDevice);
     const char* names[16] = {"copy H", "P: load panel", "P: QR", "P: T + publish", "X: wait for V | T", "X: X0 tiles", "X: reduce + publish",
-                             "U: wait for X0", "U: S0, Y, W", "U: trailing update", "-", "2: band + bounds", "2: multisection",
+                             "U: wait for X0", "U: S0, Y, W", "U: trailing update", "Q^T b (workgroup 0)", "2: band + bounds", "2: multisection",
                              "2: Q^T b", "2: LDL^T solve", "2: Q y"};
     for (int it = 0; it < 3; ++it) {
         long long zero[16] = {0};
