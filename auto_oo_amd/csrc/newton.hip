@@ -633,7 +633,9 @@ constexpr int BW = 8;                 // band half-width = panel width
 constexpr int RW = BW + 1;            // rows / columns of the LDL^T window
 constexpr int NEWTON2_NMAX = 672;
 constexpr int N2_SPIN_LIMIT = 1 << 17;
-constexpr int N2_SHIFTS = 256;        // shifts per multisection round (4 waves, one per SIMD)
+constexpr int N2_SHIFTS = 256;        // shifts per multisection round and workgroup (4 waves, one per SIMD)
+constexpr int N2_MS_ROUNDS = 16;      // at most this many multisection rounds
+constexpr int N2_MS_WGS = 32;         // at most this many workgroups share the shifts of a round
 
 typedef unsigned n2_v4u __attribute__((ext_vector_type(4)));
 typedef unsigned n2_v2u __attribute__((ext_vector_type(2)));
@@ -642,7 +644,7 @@ constexpr int N2_SC1 = 16;            // gfx950 buffer aux bit: sc1 (bypass L1 o
 struct N2Global {                     // workspace of a call: [Aw of every problem | exchange block of every problem | status words]
     int npv, npan, ntile;
     size_t aw_size;                   // doubles per problem in the first block (the working copy, [npv][npv])
-    size_t Vst, Tst, X0, Band, bvec, ex_size;   // offsets inside a problem's exchange block, and its size
+    size_t Vst, Tst, X0, Band, bvec, msx, ex_size;   // offsets inside a problem's exchange block, and its size
 };
 
 __host__ __device__ inline N2Global n2_global(int n)
@@ -658,6 +660,7 @@ __host__ __device__ inline N2Global n2_global(int n)
     L.X0 = o; o += (size_t)L.npan * L.npv * BW;
     L.Band = o; o += (size_t)L.npv * RW;
     L.bvec = o; o += (size_t)L.npv;              // Q1^T (-g), from stage 1 to the solve kernel
+    L.msx = o; o += (size_t)N2_MS_ROUNDS * N2_MS_WGS;   // multisection: first failing shift of every workgroup, per round
     L.ex_size = (o + 1) & ~(size_t)1;
     return L;
 }
@@ -1257,16 +1260,17 @@ __global__ __launch_bounds__(NT2)
 void newton_band_solve_kernel(int n, double lam_threshold, double mu, double rho, int aug,
                               const double* __restrict__ work, double* __restrict__ dp,
                               double* __restrict__ lowest, double* __restrict__ shift_out,
-                              double* __restrict__ scratch)
+                              double* __restrict__ scratch, int W2, int batch)
 {
     extern __shared__ double sm[];
     const N2Global GL = n2_global(n);
     const N2Lds2 L = n2_lds2(BIG ? 16 : n);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int prob = blockIdx.x;
+    // W2 workgroups per problem share the shifts of every multisection round (small batches leave most of
+    // the chip idle here); workgroup 0 of the problem goes on to the solve
+    const int prob = blockIdx.x % batch, slot2 = blockIdx.x / batch;
     const int npv = GL.npv, npan = GL.npan;
-    const int batch = gridDim.x;
     const double* wk = BIG ? work : work + (size_t)batch * GL.aw_size + (size_t)prob * GL.ex_size;     // the exchange block
     double* rb = BIG ? scratch : sm + L.rb;
     double* Lst = BIG ? rb + (size_t)(n + 2 * RW + 2) * RW : sm + L.Lst;
@@ -1299,6 +1303,7 @@ void newton_band_solve_kernel(int n, double lam_threshold, double mu, double rho
         }
     }
     if (__syncthreads_or(bad)) {
+        if (slot2 != 0) return;
         const double qnan = __longlong_as_double(0x7ff8000000000000ll);
         for (int i2 = tid; i2 < n; i2 += NT2) dp[(size_t)prob * n + i2] = qnan;
         if (tid == 0) {
@@ -1333,21 +1338,54 @@ void newton_band_solve_kernel(int n, double lam_threshold, double mu, double rho
         lo -= 2.0 * 2.220446049250313e-16 * span + 2.0 * pivmin;
         hi += 2.0 * 2.220446049250313e-16 * span + 2.0 * pivmin;
     }
-    // bracket down to a rounding error of the matrix norm (what eigh delivers for an eigenvalue)
-    for (int round = 0; round < 12; ++round) {
+    // bracket down to a rounding error of the matrix norm (what eigh delivers for an eigenvalue): NS = 256 W2
+    // shifts per round, workgroup w tests the shifts 256 w .. 256 w + 255 and drops the index of its first failing
+    // one into this round's slot of the exchange block (the same self-validating hand-off as in stage 1)
+    const int NS = N2_SHIFTS * W2;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double*>(wk), 0, (int)(GL.ex_size * 8), 0x00020000);
+    bool lost = false;
+    for (int round = 0; round < N2_MS_ROUNDS; ++round) {
         const double width = hi - lo;
         if (!(width > 2.220446049250313e-16 * amax + 4.0 * pivmin)) break;
-        double first = (double)N2_SHIFTS, dum = 0.0;
+        const int tg = slot2 * N2_SHIFTS + tid;
+        double first = (double)NS, dum = 0.0;
         {
-            const double x = lo + width * ((double)(tid + 1) / (double)(N2_SHIFTS + 1));
+            const double x = lo + width * ((double)(tg + 1) / (double)(NS + 1));
             const bool pd = n2_band_ldlt<false>(rb, n, x, pivmin, nullptr, nullptr, nullptr, nullptr);
-            if (!pd) first = (double)tid;
+            if (!pd) first = (double)tg;
         }
         block_min2_w4(first, dum, red, parity, lane, wave);
+        if (W2 > 1) {
+            if (tid == 0) n2_st1(rx, GL.msx + (size_t)round * N2_MS_WGS + slot2, first);
+            int spins = 0;
+            while (true) {
+                double v = (double)NS;
+                if (tid < W2) v = n2_ld1(rx, GL.msx + (size_t)round * N2_MS_WGS + tid);
+                const int bad2 = n2_is_sent(v);
+                dum = 0.0;
+                double vv = bad2 ? (double)NS : v;
+                block_min2_w4(vv, dum, red, parity, lane, wave);
+                if (!__syncthreads_or(bad2)) { first = vv; break; }
+                if (++spins > N2_SPIN_LIMIT) { lost = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lost) break;
+        }
         const int t0 = (int)first;            // first shift that is not below every eigenvalue
-        const double nlo = t0 > 0 ? lo + width * ((double)t0 / (double)(N2_SHIFTS + 1)) : lo;
-        const double nhi = t0 < N2_SHIFTS ? lo + width * ((double)(t0 + 1) / (double)(N2_SHIFTS + 1)) : hi;
+        const double nlo = t0 > 0 ? lo + width * ((double)t0 / (double)(NS + 1)) : lo;
+        const double nhi = t0 < NS ? lo + width * ((double)(t0 + 1) / (double)(NS + 1)) : hi;
         lo = nlo; hi = nhi;
+    }
+    if (slot2 != 0) return;
+    if (lost) {
+        const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+        for (int i2 = tid; i2 < n; i2 += NT2) dp[(size_t)prob * n + i2] = qnan;
+        if (tid == 0) {
+            lowest[prob] = qnan;
+            if (shift_out) shift_out[prob] = qnan;
+        }
+        return;
     }
     const double lam = 0.5 * (lo + hi);
     const double nu = (aug && lam < lam_threshold) ? mu + rho * fabs(lam) : 0.0;
@@ -1933,7 +1971,7 @@ static int n3_direction(const double* hessian, const double* gradient, int n, in
         hipLaunchKernelGGL(n2l_tail_kernel, dim3(1), dim3(256), 0, st, n, wk);
         hipLaunchKernelGGL(newton_band_solve_kernel<true>, dim3(1), dim3(NT2), solve_lds, st, n, lambda_min, mu, rho,
                            aug, wk + GL.exoff, dp + (size_t)b * n, lowest + b, shift ? shift + b : nullptr,
-                           wk + GL.scratch);
+                           wk + GL.scratch, 1, 1);
         OOVQE_CHECK_LAUNCH("oovqe_newton_direction/large");
     }
     return 0;
@@ -1992,8 +2030,10 @@ extern "C" int oovqe_newton_direction(const double* hessian, const double* gradi
             hipLaunchKernelGGL(newton_band_kernel<RQ_LARGE>, dim3(batch * W), dim3(NT), lds, st, hessian, gradient, n,
                                work, W, batch);
         OOVQE_CHECK_LAUNCH("oovqe_newton_direction/band");
-        hipLaunchKernelGGL(newton_band_solve_kernel<false>, dim3(batch), dim3(NT2), lds2, st, n, lambda_min, mu, rho, aug,
-                           work, dp, lowest_eigenvalue, shift, (double*)nullptr);
+        int W2 = 1;
+        while (2 * W2 * batch <= cus && 2 * W2 <= N2_MS_WGS) W2 *= 2;
+        hipLaunchKernelGGL(newton_band_solve_kernel<false>, dim3(batch * W2), dim3(NT2), lds2, st, n, lambda_min, mu,
+                           rho, aug, work, dp, lowest_eigenvalue, shift, (double*)nullptr, W2, batch);
         OOVQE_CHECK_LAUNCH("oovqe_newton_direction/solve");
         return 0;
     }
