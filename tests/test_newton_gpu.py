@@ -94,7 +94,10 @@ def test_newton_direction_batch_and_no_augmentation():
     assert (low - low_na).abs().max() < 1e-12 and float(nu_na.abs().max()) == 0.0
     for k in range(G):
         d1, l1, _ = ops.newton_direction(Hs[k].cuda(), gs[k].cuda())
-        assert torch.equal(d1, dp[k]) and torch.equal(l1, low[k])      # batch == one by one, bitwise
+        # batch == one by one up to rounding (round 3: a problem alone gets more workgroups and another
+        # grid of shifts than inside a batch; the same call twice gives the same bits)
+        assert abs(l1.item() - low[k].item()) < 1e-13 * max(1.0, float(Hs[k].abs().max()))
+        assert (d1 - dp[k]).abs().max() < 1e-9 * (1 + dp[k].abs().max())
         dr, lr = _reference_direction(Hs[k], gs[k])
         assert abs(low[k].item() - lr) < 1e-11
         assert (dp[k].cpu() - dr).abs().max() < 1e-8 * (1 + dr.abs().max())
