@@ -612,7 +612,8 @@ void sector_rdm_fused_kernel(const double* __restrict__ psi_c, Sector s, int bat
 #pragma unroll
             for (int mt = 0; mt < NT; ++mt)              // (A row tile mt holds the same V rows as B tile mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_f64(bv[mt], bv[nt], acc[mt][nt]);
+                for (int nt = mt; nt < NT; ++nt)         // V^T V is symmetric: the tiles mt <= nt only
+                    acc[mt][nt] = mfma_f64(bv[mt], bv[nt], acc[mt][nt]);
         }
         __syncthreads();
     }
@@ -620,7 +621,7 @@ void sector_rdm_fused_kernel(const double* __restrict__ psi_c, Sector s, int bat
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+        for (int nt = mt; nt < NT; ++nt) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) red[wave][(lq + 4 * i) * 16 + lr] = acc[mt][nt][i];
             __syncthreads();
@@ -630,7 +631,10 @@ void sector_rdm_fused_kernel(const double* __restrict__ psi_c, Sector s, int bat
                 for (int w = 1; w < 8; ++w) v += red[w][tid];
                 const int mrow = mt * 16 + tid / 16, col = nt * 16 + (tid & 15);
                 const int row = (mrow % a) * a + mrow / a;            // product row (q,p) -> Gram row (p,q)
-                R[(((size_t)split * batch + b) * (MTR * 16) + row) * (NT * 16) + col] = v;
+                double* Rb = R + ((size_t)split * batch + b) * (MTR * 16) * (NT * 16);
+                Rb[(size_t)row * (NT * 16) + col] = v;
+                // the mirror tile (nt, mt): product element (col, mrow), the same sum in the same order
+                if (mt != nt) Rb[(size_t)((col % a) * a + col / a) * (NT * 16) + mrow] = v;
             }
             __syncthreads();
         }
