@@ -88,8 +88,12 @@ __device__ __forceinline__ void tri_decode(long t, int N, int& p, int& q)
 template <int ZT, int KCH, int NST>
 __global__ __launch_bounds__(HALF_WAVES * 64)
 void half_transform_kernel(const double* __restrict__ g, const double* __restrict__ C,
-                           double* __restrict__ T2, int N, int M, int nst, int nkc, long nslabs, int sym)
+                           double* __restrict__ T2, int N, int M, int nst, int nkc, long nslabs, int sym,
+                           double* __restrict__ Vk)
 {
+    // Vk (NST > 0, sym == SYM_MIRROR only; else null): the first product of every slab p <= q as well,
+    // Vk[tri(p,q)][s][y] = sum_r g[p,q,r,s] C[r,y] -- the quarter-transformed integrals the K-type
+    // (exchange) blocks of the orbital Hessian start from (hessian.hip), from the same read of the slab
     constexpr int LDM = 16 * (ZT | 1);
     extern __shared__ double lds[];
     const int RT16 = nst * 16;
@@ -102,6 +106,7 @@ void half_transform_kernel(const double* __restrict__ g, const double* __restric
     g += (size_t)blockIdx.y * N * N * N * N;
     C += (size_t)blockIdx.y * N * N;
     T2 += (size_t)blockIdx.y * (sym == SYM_PACKED ? (size_t)nslabs : (size_t)N * N) * M * M;
+    if (Vk) Vk += (size_t)blockIdx.y * (size_t)nslabs * N * M;
 
     const long slab = (long)blockIdx.x * HALF_WAVES + wave;
     const bool have = slab < nslabs;
@@ -284,6 +289,15 @@ void half_transform_kernel(const double* __restrict__ g, const double* __restric
 #pragma unroll
                         for (int y = 0; y < ZT; ++y) jt[z][y] = mfma_f64(cz, xt[y][i], jt[z][y]);
                     }
+                if (Vk) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int sc = pp * 32 + 2 * (lq + 4 * i) + half;      // column of this row of the tile
+#pragma unroll
+                        for (int y = 0; y < ZT; ++y)
+                            if (sc < N && 16 * y + lr < M) Vk[((size_t)slab * N + sc) * M + 16 * y + lr] = xt[y][i];
+                    }
+                }
 #pragma unroll
                 for (int y = 0; y < ZT; ++y) xt[y] = d4{0.0, 0.0, 0.0, 0.0};
             }
@@ -305,6 +319,15 @@ void half_transform_kernel(const double* __restrict__ g, const double* __restric
 #pragma unroll
                     for (int y = 0; y < ZT; ++y) jt[z][y] = mfma_f64(cz, xt[y][i], jt[z][y]);
                 }
+            if (Vk) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int sc = NP * 32 + lq + 4 * i;
+#pragma unroll
+                    for (int y = 0; y < ZT; ++y)
+                        if (sc < N && 16 * y + lr < M) Vk[((size_t)slab * N + sc) * M + 16 * y + lr] = xt[y][i];
+                }
+            }
         }
     } else {
         // chunk c = st * nkc + kc
@@ -2842,7 +2865,8 @@ void cas_final_kernel(const double* __restrict__ Fcol, const double* __restrict_
 }  // namespace
 
 static int half_transform_batched(const double* g_ao, const double* C, int N, int M, double* T2,
-                                  int batch, oovqe_stream_t stream, int sym = SYM_FULL, bool rs = false);
+                                  int batch, oovqe_stream_t stream, int sym = SYM_FULL, bool rs = false,
+                                  double* Vk_tri = nullptr);
 static int device_cu_count();
 
 extern "C" int oovqe_cas_half_transform(const double* g_ao, const double* C, int N, int M, double* T2,
@@ -2852,9 +2876,11 @@ extern "C" int oovqe_cas_half_transform(const double* g_ao, const double* C, int
 }
 
 static int half_transform_batched(const double* g_ao, const double* C, int N, int M, double* T2,
-                                  int batch, oovqe_stream_t stream, int sym, bool rs)
+                                  int batch, oovqe_stream_t stream, int sym, bool rs, double* Vk_tri)
 {
     OOVQE_REQUIRE(g_ao && C && T2, "cas_half_transform: null pointer");
+    OOVQE_REQUIRE(!Vk_tri || (sym == SYM_MIRROR && N <= 48),
+                  "cas_half_transform: the quarter-transformed output needs p<->q symmetric integrals and N <= 48");
     OOVQE_REQUIRE(batch >= 1 && batch <= 65535, "cas_half_transform: batch=%d", batch);
     OOVQE_REQUIRE(N >= 1 && M >= 1 && M <= N, "cas_half_transform: bad N=%d M=%d", N, M);
     hipStream_t st = (hipStream_t)stream;
@@ -2889,7 +2915,7 @@ static int half_transform_batched(const double* g_ao, const double* C, int N, in
         oovqe_note_stage1("half_transform_kernel<%d,%d,%d>%s", Z, KC_, NS_, sym ? " (slabs p <= q)" : ""); \
         hipLaunchKernelGGL((half_transform_kernel<Z, KC_, NS_>), dim3(grid, batch),               \
                            dim3(HALF_WAVES * 64),                                                 \
-                           lds_bytes, st, g_ao, C, T2, N, M, nrb, nkc, nslabs, sym);              \
+                           lds_bytes, st, g_ao, C, T2, N, M, nrb, nkc, nslabs, sym, Vk_tri);      \
     } while (0)
 #define OOVQE_DISPATCH_KCH(Z)                                                                     \
     do {                                                                                          \
@@ -3856,11 +3882,12 @@ int oovqe_oo_eval_batched_impl(const double* theta, int n_theta, const oovqe_gat
 // hessian.hip: stage 1 (T2[p,q,y,z]) for a stack of geometries, reading only the slabs p <= q when the
 // caller vouches for the p<->q symmetry
 int oovqe_half_transform_batched_impl(const double* g_ao, const double* C, int N, int M, double* T2,
-                                      int batch, unsigned eri_flags, oovqe_stream_t stream)
+                                      int batch, unsigned eri_flags, oovqe_stream_t stream, double* Vk_tri)
 {
+    // Vk_tri [G][N(N+1)/2][N][M] (optional; p <-> q symmetric integrals, N <= 48): see half_transform_kernel
     const bool pq = (eri_flags & OOVQE_ERI_PQ_SYMMETRIC) != 0;
     const bool rs = (eri_flags & OOVQE_ERI_RS_SYMMETRIC) != 0 && oovqe_opt(OOVQE_OPT_SYM_NO_RS) == 0;
-    return half_transform_batched(g_ao, C, N, M, T2, batch, stream, pq ? SYM_MIRROR : SYM_FULL, rs);
+    return half_transform_batched(g_ao, C, N, M, T2, batch, stream, pq ? SYM_MIRROR : SYM_FULL, rs, Vk_tri);
 }
 
 extern "C" int oovqe_oo_eval(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,

@@ -200,6 +200,80 @@ void rdm_gram_kernel(const double* __restrict__ bra, const double* __restrict__ 
     }
 }
 
+// Small registers (D (2 + 2 a^2) doubles fit LDS): E_pq applied to bra and ket and all a^2 + a^4 scalar
+// products by ONE workgroup per (bra, ket) pair, everything in LDS.  (The two kernels above start
+// 2 a^2 + a^2 workgroups per pair and reduce every scalar product over a whole workgroup: at 6 qubits
+// that is 12 tree reductions of 64 numbers per workgroup -- 150 us for the 2560 pairs of a 64-geometry
+// circuit Hessian against ~10 us here.)
+__global__ __launch_bounds__(256)
+void rdms_small_kernel(const double* __restrict__ bra, const double* __restrict__ ket, int n_qubits,
+                       int ncas, double* __restrict__ gamma, double* __restrict__ Gamma)
+{
+    extern __shared__ double lds[];
+    const uint32_t D = 1u << n_qubits;
+    const int LDV = (int)D + 1;              // odd pitch: rows on different banks
+    const int na2 = ncas * ncas;
+    const size_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    double* vec = lds;                       // [2][LDV]        bra, ket
+    double* V = vec + 2 * LDV;               // [2][na2][LDV]   E_pq bra, E_pq ket
+    double* gam = V + (size_t)2 * na2 * LDV; // [na2]
+    for (uint32_t x = tid; x < D; x += 256) {
+        vec[x] = bra[b * D + x];
+        vec[LDV + x] = ket[b * D + x];
+    }
+    __syncthreads();
+    for (uint32_t idx = tid; idx < 2u * na2 * D; idx += 256) {
+        const uint32_t x = idx & (D - 1);
+        const int row = (int)(idx >> n_qubits);
+        const int which = row / na2, pq = row - which * na2;
+        const int p = pq / ncas, q = pq - p * ncas;
+        const double* src = vec + which * LDV;
+        double acc = 0.0;
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            const int P = 2 * p + sp, Q = 2 * q + sp;
+            const uint32_t bP = 1u << (n_qubits - 1 - P), bQ = 1u << (n_qubits - 1 - Q);
+            if (p == q) {
+                if (x & bP) acc += src[x];
+            } else if ((x & bP) && !(x & bQ)) {
+                const uint32_t hi = bP > bQ ? bP : bQ, lo = bP > bQ ? bQ : bP;
+                const uint32_t between = (hi - 1u) & ~((lo << 1) - 1u);
+                const double sgn = (__popc(x & between) & 1) ? -1.0 : 1.0;
+                acc += sgn * src[x ^ (bP | bQ)];
+            }
+        }
+        V[(size_t)row * LDV + x] = acc;
+    }
+    __syncthreads();
+    const double* Vb = V;
+    const double* Vk = V + (size_t)na2 * LDV;
+    for (int pq = tid; pq < na2; pq += 256) {
+        const double* vk = Vk + (size_t)pq * LDV;
+        double a0 = 0.0, a1 = 0.0;
+        for (uint32_t x = 0; x < D; x += 2) {
+            a0 += vec[x] * vk[x];
+            a1 += vec[x + 1] * vk[x + 1];
+        }
+        gam[pq] = a0 + a1;
+        gamma[b * na2 + pq] = a0 + a1;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < na2 * na2; idx += 256) {
+        const int pq = idx / na2, rs = idx - pq * na2;
+        const int p = pq / ncas, q = pq - p * ncas;
+        const int r = rs / ncas, s2 = rs - r * ncas;
+        const double* vb = Vb + (size_t)(q * ncas + p) * LDV;     // E_qp bra
+        const double* vk = Vk + (size_t)rs * LDV;
+        double a0 = 0.0, a1 = 0.0;
+        for (uint32_t x = 0; x < D; x += 2) {
+            a0 += vb[x] * vk[x];
+            a1 += vb[x + 1] * vk[x + 1];
+        }
+        Gamma[(b * na2 + pq) * na2 + rs] = (a0 + a1) - (q == r ? gam[p * ncas + s2] : 0.0);
+    }
+}
+
 // Apply E_pq to nvec vectors per batch element: vec layout [batch][nvec][D] given as psi (vector 0)
 // and dpsi (vectors 1..nvec-1);  V layout [batch][nvec][ncas^2][D].
 __global__ __launch_bounds__(256)
@@ -488,6 +562,20 @@ extern "C" int oovqe_rdms(const double* bra, const double* ket, int n_qubits, in
     const uint32_t D = 1u << n_qubits;
     const int na2 = ncas * ncas;
     hipStream_t st = (hipStream_t)stream;
+    const size_t small_bytes = ((size_t)(2 + 2 * na2) * (D + 1) + na2) * sizeof(double);
+    if (n_qubits >= 1 && small_bytes <= 150 * 1024) {
+        static size_t attr_bytes = 0;
+        if (small_bytes > 64 * 1024 && small_bytes > attr_bytes) {
+            OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)rdms_small_kernel,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_bytes),
+                            "rdms/small");
+            attr_bytes = small_bytes;
+        }
+        hipLaunchKernelGGL(rdms_small_kernel, dim3((unsigned)batch), dim3(256), small_bytes, st, bra, ket,
+                           n_qubits, ncas, gamma, Gamma);
+        OOVQE_CHECK_LAUNCH("rdms/small");
+        return 0;
+    }
     OOVQE_REQUIRE(batch <= 65535, "rdms: batch too large");
     hipLaunchKernelGGL(epq_apply_kernel, dim3((D + 255) / 256, 2 * na2, batch), dim3(256), 0, st,
                        bra, ket, n_qubits, ncas, work);

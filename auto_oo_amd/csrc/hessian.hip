@@ -149,6 +149,54 @@ __global__ void hess_cross_block_kernel(const double* __restrict__ gvec, long gv
     }
 }
 
+// T2K[p,m,n,s] = sum_q C[q,m] Vk[p,q,n,s] from the quarter-transformed slabs p <= q that stage 1 leaves
+// behind (cas.hip, half_transform_kernel: Vk_tri[tri(p,q)][s][n]; g[p,q,:,:] == g[q,p,:,:]): one workgroup
+// per (p, geometry), thread <-> element (s, n) of a row of 43 slabs, the coefficients wave-uniform; the
+// block T2K[p] (contiguous) leaves through LDS.  Replaces two K1 launches that read the whole AO tensor a
+// second time (round 3: 480 + 102 us -> see DESIGN.md for 64 geometries).
+__global__ __launch_bounds__(512)
+void t2k_tri_kernel(const double* __restrict__ Vk, const double* __restrict__ C, double* __restrict__ T2K,
+                    int N, int M)
+{
+    extern __shared__ double blk[];            // [M][M][N]
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const size_t b = blockIdx.y;
+    const long tri = (long)N * (N + 1) / 2;
+    const int E = N * M;
+    Vk += b * (size_t)tri * E;
+    C += b * (size_t)N * N;
+    T2K += (b * N + p) * (size_t)M * M * N;
+    for (int e = tid; e < E; e += 512) {
+        const int s = e / M, y = e - s * M;
+        double acc[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) acc[m] = 0.0;
+        for (int q0 = 0; q0 < N; q0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = q0 + u < N ? q0 + u : N - 1;
+                const int lo = p < q ? p : q, hi = p < q ? q : p;
+                const long t = (long)lo * (2 * N - lo + 1) / 2 + (hi - lo);
+                v[u] = Vk[(size_t)t * E + e];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (q0 + u >= N) break;
+                const double* cq = C + (size_t)(q0 + u) * N;       // wave-uniform: scalar loads
+#pragma unroll
+                for (int m = 0; m < 16; ++m)
+                    if (m < M) acc[m] += cq[m] * v[u];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m)
+            if (m < M) blk[((size_t)m * M + y) * N + s] = acc[m];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < M * M * N; idx += 512) T2K[idx] = blk[idx];
+}
+
 }  // namespace
 
 extern "C" int64_t oovqe_orbital_hessian_work_size(int N, int n_occ, int ncas)
@@ -161,7 +209,8 @@ extern "C" int64_t oovqe_orbital_hessian_work_size(int N, int n_occ, int ncas)
 
 // cas.hip: stage 1 for a stack of geometries (slabs p <= q only when the flags allow it)
 int oovqe_half_transform_batched_impl(const double* g_ao, const double* C, int N, int M, double* T2,
-                                      int batch, unsigned eri_flags, oovqe_stream_t stream);
+                                      int batch, unsigned eri_flags, oovqe_stream_t stream,
+                                      double* Vk_tri = nullptr);
 int oovqe_mode_contract_batched(const double* T, const double* Cm, double* out, long A, int K, int J,
                                 long B, int ldc, int last, int batch, long t_bs, long c_bs, long o_bs,
                                 hipStream_t st);
@@ -205,12 +254,30 @@ static int orbital_hessian_batched(const double* g_ao, const double* h_ao, const
 #define MC(T_, tb, C_, cb, O_, ob, ...) \
     if ((rc = oovqe_mode_contract_batched(T_, C_, O_, __VA_ARGS__, batch, tb, cb, ob, st))) return rc
     // ---- J-type integrals: g_mo[q,s,m,n] ---------------------------------------------------------
-    if ((rc = oovqe_half_transform_batched_impl(g_ao, C, N, M, T2, batch, eri_flags, stream))) return rc;
+    // p <-> q symmetric integrals, N <= 48: stage 1 also leaves its first products Vk[tri(p,q)][s][n]
+    // (the quarter transform of the K-type path), so the AO tensor is read once instead of twice
+    const bool vk_tri = (eri_flags & OOVQE_ERI_PQ_SYMMETRIC) != 0 && N <= 48 && M <= 16 &&
+                        (size_t)m2 * N * sizeof(double) <= 150 * 1024 && oovqe_opt(OOVQE_OPT_HESS_VK_PASS) == 0;
+    if ((rc = oovqe_half_transform_batched_impl(g_ao, C, N, M, T2, batch, eri_flags, stream, vk_tri ? Vk : nullptr)))
+        return rc;
     MC(T2, y, C, n2, Uj, y, 1, N, N, n * m2, N, 0);          // Uj[q',q,yz]  = sum_p C[p,q'] T2[p,q,yz]
     MC(Uj, y, C, n2, Jint, y, n, N, N, m2, N, 0);            // Jint[q',s',yz] = sum_q C[q,s'] Uj[q',q,yz]
     // ---- K-type integrals: g_mo[q,m,n,s] ---------------------------------------------------------
-    MC(g_ao, t4, C, n2, Vk, n2 * n * M, n2, N, M, n, N, 0);  // Vk[p,q,n,s]  = sum_r C[r,n] g[p,q,r,s]
-    MC(Vk, n2 * n * M, C, n2, T2K, y, n, N, M, (long)M * n, N, 0);   // T2K[p,m,n,s] = sum_q C[q,m] Vk[p,q,n,s]
+    if (vk_tri) {
+        const size_t lds_bytes = (size_t)m2 * N * sizeof(double);
+        static size_t attr_bytes = 0;
+        if (lds_bytes > 64 * 1024 && lds_bytes > attr_bytes) {
+            OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)t2k_tri_kernel,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes),
+                            "orbital_hessian/t2k");
+            attr_bytes = lds_bytes;
+        }
+        t2k_tri_kernel<<<dim3(N, batch), 512, lds_bytes, st>>>(Vk, C, T2K, N, M);   // T2K[p,m,n,s]
+        OOVQE_CHECK_LAUNCH("orbital_hessian/t2k");
+    } else {
+        MC(g_ao, t4, C, n2, Vk, n2 * n * M, n2, N, M, n, N, 0);  // Vk[p,q,n,s]  = sum_r C[r,n] g[p,q,r,s]
+        MC(Vk, n2 * n * M, C, n2, T2K, y, n, N, M, (long)M * n, N, 0);   // T2K[p,m,n,s] = sum_q C[q,m] Vk[p,q,n,s]
+    }
     MC(T2K, y, C, n2, W, y, n * m2, N, N, 1, N, 1);          // W[p,m,n,s']  = sum_s T2K[p,m,n,s] C[s,s']
     MC(W, y, C, n2, Kint, y, 1, N, N, m2 * n, N, 0);         // Kint[q',m,n,s'] = sum_p C[p,q'] W[p,m,n,s']
     // ---- one-electron integrals ------------------------------------------------------------------
