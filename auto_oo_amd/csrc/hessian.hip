@@ -154,6 +154,7 @@ __global__ void hess_cross_block_kernel(const double* __restrict__ gvec, long gv
 // per (p, geometry), thread <-> element (s, n) of a row of 43 slabs, the coefficients wave-uniform; the
 // block T2K[p] (contiguous) leaves through LDS.  Replaces two K1 launches that read the whole AO tensor a
 // second time (round 3: 480 + 102 us -> see DESIGN.md for 64 geometries).
+template <int MT>                              // accumulators per thread: the smallest of 4, 8, 12, 16 >= M
 __global__ __launch_bounds__(512)
 void t2k_tri_kernel(const double* __restrict__ Vk, const double* __restrict__ C, double* __restrict__ T2K,
                     int N, int M)
@@ -168,9 +169,11 @@ void t2k_tri_kernel(const double* __restrict__ Vk, const double* __restrict__ C,
     T2K += (b * N + p) * (size_t)M * M * N;
     for (int e = tid; e < E; e += 512) {
         const int s = e / M, y = e - s * M;
-        double acc[16];
+        double acc[MT];
 #pragma unroll
-        for (int m = 0; m < 16; ++m) acc[m] = 0.0;
+        for (int m = 0; m < MT; ++m) acc[m] = 0.0;
+        // eight rows in flight; straight-line sums (columns m >= M of C are other coefficients: summed,
+        // never stored; rows q >= N enter with weight zero)
         for (int q0 = 0; q0 < N; q0 += 8) {
             double v[8];
 #pragma unroll
@@ -182,15 +185,15 @@ void t2k_tri_kernel(const double* __restrict__ Vk, const double* __restrict__ C,
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                if (q0 + u >= N) break;
-                const double* cq = C + (size_t)(q0 + u) * N;       // wave-uniform: scalar loads
+                const int q = q0 + u < N ? q0 + u : N - 1;
+                const double vv = q0 + u < N ? v[u] : 0.0;
+                const double* cq = C + (size_t)q * N;              // wave-uniform: scalar loads
 #pragma unroll
-                for (int m = 0; m < 16; ++m)
-                    if (m < M) acc[m] += cq[m] * v[u];
+                for (int m = 0; m < MT; ++m) acc[m] += cq[m < N ? m : 0] * vv;
             }
         }
 #pragma unroll
-        for (int m = 0; m < 16; ++m)
+        for (int m = 0; m < MT; ++m)
             if (m < M) blk[((size_t)m * M + y) * N + s] = acc[m];
     }
     __syncthreads();
@@ -265,14 +268,22 @@ static int orbital_hessian_batched(const double* g_ao, const double* h_ao, const
     // ---- K-type integrals: g_mo[q,m,n,s] ---------------------------------------------------------
     if (vk_tri) {
         const size_t lds_bytes = (size_t)m2 * N * sizeof(double);
-        static size_t attr_bytes = 0;
-        if (lds_bytes > 64 * 1024 && lds_bytes > attr_bytes) {
-            OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)t2k_tri_kernel,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes),
-                            "orbital_hessian/t2k");
-            attr_bytes = lds_bytes;
-        }
-        t2k_tri_kernel<<<dim3(N, batch), 512, lds_bytes, st>>>(Vk, C, T2K, N, M);   // T2K[p,m,n,s]
+#define OOVQE_LAUNCH_T2K(MT_)                                                                             \
+    do {                                                                                                  \
+        static size_t attr_bytes = 0;                                                                     \
+        if (lds_bytes > 64 * 1024 && lds_bytes > attr_bytes) {                                            \
+            OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)t2k_tri_kernel<MT_>,                         \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,               \
+                                                (int)lds_bytes), "orbital_hessian/t2k");                  \
+            attr_bytes = lds_bytes;                                                                       \
+        }                                                                                                 \
+        t2k_tri_kernel<MT_><<<dim3(N, batch), 512, lds_bytes, st>>>(Vk, C, T2K, N, M); /* T2K[p,m,n,s] */  \
+    } while (0)
+        if (M <= 4) OOVQE_LAUNCH_T2K(4);
+        else if (M <= 8) OOVQE_LAUNCH_T2K(8);
+        else if (M <= 12) OOVQE_LAUNCH_T2K(12);
+        else OOVQE_LAUNCH_T2K(16);
+#undef OOVQE_LAUNCH_T2K
         OOVQE_CHECK_LAUNCH("orbital_hessian/t2k");
     } else {
         MC(g_ao, t4, C, n2, Vk, n2 * n * M, n2, N, M, n, N, 0);  // Vk[p,q,n,s]  = sum_r C[r,n] g[p,q,r,s]
