@@ -358,6 +358,49 @@ def test_batched_full_hessian_equals_single_geometry_path_at_cc_pvdz_shape():
     assert (batch.full_gradient(thetas) - grad).abs().max() < 1e-12
 
 
+@pytest.mark.parametrize("N,G", [(13, 3), (20, 2), (43, 4), (48, 2)])
+def test_batched_hessian_quarter_transform_from_stage1_equals_its_own_pass(N, G):
+    """The K-type quarter transform of the orbital Hessian leaves stage 1 together with the J-type one
+    (half_transform_kernel's Vk output + t2k_tri_kernel, hessian.hip) when the integrals are p <-> q
+    symmetric; option hess_vk_pass = 1 brings back the round-2 form (its own pass over the whole AO
+    tensor through K1).  Same sums in the same order: equal to rounding, for odd and even N, one, two
+    and three column tiles."""
+    from auto_oo_amd import _lib
+    pqc, batch, objs, probs = _batch_of(N, G)
+    rng = np.random.default_rng(11)
+    thetas = torch.tensor(rng.uniform(0, 2 * np.pi, (G, pqc.theta_shape))).cuda()
+    E, grad, H = batch.energy_gradient_hessian(thetas)
+    with _lib.debug_options(hess_vk_pass=1):
+        E0, grad0, H0 = batch.energy_gradient_hessian(thetas)
+    assert torch.equal(E, E0) and torch.equal(grad, grad0)
+    scale = H0.abs().max().item()
+    assert (H - H0).abs().max().item() <= 1e-12 * scale
+    assert torch.isfinite(H).all()
+
+
+def test_transition_rdms_small_register_kernel_vs_oracle():
+    """oovqe_rdms with different bra and ket on a register that fits LDS (rdms_small_kernel: one
+    workgroup per pair) against the oracle's transition RDMs; 6 and 8 qubits, several pairs per call."""
+    for ncas, nelec in ((3, 4), (4, 4)):
+        D = 1 << (2 * ncas)
+        rng = np.random.default_rng(ncas)
+        bra = torch.tensor(rng.standard_normal((5, D)))
+        ket = torch.tensor(rng.standard_normal((5, D)))
+        g1, g2 = ops.rdms(bra.cuda(), ket.cuda(), ncas)
+        E = R.RdmOperators(ncas).E                     # scipy sparse E_pq (active_space.py:29-53)
+        for b in range(5):
+            x, y = bra[b].numpy(), ket[b].numpy()
+            for p_ in range(ncas):
+                for q_ in range(ncas):
+                    assert abs(g1[b, p_, q_].item() - x @ (E[p_][q_] @ y)) < 1e-11
+                    for r_ in range(ncas):
+                        for s_ in range(ncas):
+                            ref = x @ (E[p_][q_] @ (E[r_][s_] @ y))
+                            if q_ == r_:
+                                ref -= x @ (E[p_][s_] @ y)
+                            assert abs(g2[b, p_, q_, r_, s_].item() - ref) < 1e-11
+
+
 def test_batched_rotation_and_energy_at_kappa():
     """OO_pqc_batch.energy(thetas, kappas) == OO_pqc.energy_from_parameters(theta, kappa) per geometry
     (one launch rotates all geometries); rotate_() == the orbital update of oo_pqc.py:191."""
