@@ -809,6 +809,36 @@ void sym_gm_kernel(const double* __restrict__ J, const double* __restrict__ C,
     }
 }
 
+// J of sym_gm_kernel, tile-major [ty][t = tri(p,q)][16] over the columns (y z) (packed: the pairs y <= z), from
+// half-transformed integrals T2[p,q,y,z] that are in memory already (the Hessian call: hessian.hip)
+__global__ __launch_bounds__(256)
+void j_from_t2_kernel(const double* __restrict__ T2, double* __restrict__ J, int N, int M, int packed)
+{
+    const long tri = (long)N * (N + 1) / 2;
+    const int m2 = M * M;
+    const int ncol = packed ? M * (M + 1) / 2 : m2;
+    const int nty = (ncol + 15) / 16;
+    T2 += (size_t)blockIdx.y * N * N * m2;
+    J += (size_t)blockIdx.y * nty * tri * 16;
+    const long total = (long)nty * tri * 16;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx & 15);
+        const long row = idx >> 4;
+        const int ty = (int)(row / tri);
+        const long t = row - (long)ty * tri;
+        const int col = ty * 16 + c;
+        double v = 0.0;
+        if (col < ncol) {
+            int p, q, y, z;
+            tri_decode(t, N, p, q);
+            if (packed) tri_decode(col, M, y, z);
+            else { y = col / M; z = col - y * M; }
+            v = T2[((size_t)p * N + q) * m2 + y * M + z];
+        }
+        J[idx] = v;
+    }
+}
+
 // Exact (bitwise) symmetry tests, one workgroup per (slab (p,q), geometry):
 //   bit 0 of *mismatch: some g[p,q,:,:] != g[q,p,:,:];  bit 1: some g[p,q,r,s] != g[p,q,s,r]
 __global__ __launch_bounds__(256)
@@ -3531,8 +3561,11 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
                             double* c2, double* E, double* gvec, double* dE, double* fock,
                             double* gmat, double* Gm, double* hmo, int batch, size_t out_stride,
                             oovqe_stream_t stream, const oovqe_circuit_job_t* cj = nullptr,
-                            unsigned eri_flags = 0, const double* g_packed = nullptr)
+                            unsigned eri_flags = 0, const double* g_packed = nullptr,
+                            const double* T2_ready = nullptr)
 {
+    // T2_ready [G][N][N][M][M]: the caller has stage 1's result in memory (the Hessian call); the
+    // packed-triangle path then builds its J from it instead of reading the integrals again
     // cj: circuit + RDM evaluations that produce gamma / Gamma; they ride along the p -> n
     // contraction launch (the caller has checked oovqe_contract_hosts_circuit for this shape)
     OOVQE_REQUIRE(g_ao && h_ao && C && gamma && Gamma && work && c0 && c1 && c2 && E && gvec,
@@ -3584,8 +3617,16 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
         } else {
             // the packed copy of the integrals (oovqe_eri_pack) is streamed when the caller holds one
             const bool use_pk = !two_step && rs_sym && g_packed != nullptr;
-            if ((rc = half_tri_batched(use_pk ? g_packed : g_ao, C, N, M, Jp, batch, st,
-                                       two_step ? 0 : rs_sym ? 2 : 1, use_pk)))
+            if (T2_ready && !two_step) {
+                const long total = (long)(nty16 / 16) * tri * 16;   // (nty16 counts all (y z); the kernel bounds itself)
+                const unsigned nbk = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+                oovqe_profile_mark_start_l(st, 0);
+                hipLaunchKernelGGL(j_from_t2_kernel, dim3(nbk, batch), dim3(256), 0, st, T2_ready, Jp, N, M,
+                                   rs_sym ? 1 : 0);
+                oovqe_profile_mark_stop(st);
+                OOVQE_CHECK_LAUNCH("cas_eval/j_from_t2");
+            } else if ((rc = half_tri_batched(use_pk ? g_packed : g_ao, C, N, M, Jp, batch, st,
+                                              two_step ? 0 : rs_sym ? 2 : 1, use_pk)))
                 return rc;
         }
         if (!two_step) {
@@ -3795,7 +3836,7 @@ static int oo_eval_batched(const double* theta, int n_theta, const oovqe_gate_t*
                            int ncas, const int32_t* kap_row, const int32_t* kap_col, int n_kappa,
                            int derivatives, int batch, double* work, double* out,
                            unsigned eri_flags, oovqe_stream_t stream, const double* g_packed = nullptr,
-                           double* fock = nullptr)
+                           double* fock = nullptr, const double* T2_ready = nullptr)
 {
     OOVQE_REQUIRE(theta && gates && g_ao && h_ao && C && work && out, "oo_eval: null pointer");
     OOVQE_REQUIRE(n_qubits == 2 * ncas, "oo_eval: n_qubits != 2*ncas");
@@ -3861,7 +3902,7 @@ static int oo_eval_batched(const double* theta, int n_theta, const oovqe_gate_t*
     return cas_eval_batched(g_ao, h_ao, C, gamma, Gamma, nvec, nuc, nuc_arr, N, n_occ, ncas, kap_row,
                             kap_col, n_kappa, cas_work, c0, c1, c2, E, gvec, dE, fock, nullptr,
                             nullptr, nullptr, batch, out_stride, stream, ride ? &cj : nullptr, eri_flags,
-                            g_packed);
+                            g_packed, T2_ready);
 }
 
 // hessian.hip (oovqe_oo_hessian_batch): the batched evaluation with the generalized Fock matrices
@@ -3872,11 +3913,12 @@ int oovqe_oo_eval_batched_impl(const double* theta, int n_theta, const oovqe_gat
                                const double* C, const double* nuc_arr, int N, int n_occ, int ncas,
                                const int32_t* kap_row, const int32_t* kap_col, int n_kappa, int derivatives,
                                int batch, double* work, double* out, unsigned eri_flags,
-                               oovqe_stream_t stream, const double* g_packed, double* fock)
+                               oovqe_stream_t stream, const double* g_packed, double* fock,
+                               const double* T2_ready)
 {
     return oo_eval_batched(theta, n_theta, gates, n_gates, n_qubits, init_index, g_ao, h_ao, C, 0.0, nuc_arr,
                            N, n_occ, ncas, kap_row, kap_col, n_kappa, derivatives, batch, work, out,
-                           eri_flags, stream, g_packed, fock);
+                           eri_flags, stream, g_packed, fock, T2_ready);
 }
 
 // hessian.hip: stage 1 (T2[p,q,y,z]) for a stack of geometries, reading only the slabs p <= q when the

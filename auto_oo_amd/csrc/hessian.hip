@@ -227,10 +227,13 @@ static int orbital_hessian_batched(const double* g_ao, const double* h_ao, const
                                    const double* fock, int N, int n_occ, int ncas, const int32_t* kap_row,
                                    const int32_t* kap_col, int n_kappa, int batch, double* work,
                                    double* H_matrix, long ldh, long h_bs, double* H_full,
-                                   unsigned eri_flags, oovqe_stream_t stream)
+                                   unsigned eri_flags, oovqe_stream_t stream, int stage = 0)
 {
-    OOVQE_REQUIRE(g_ao && h_ao && C && gamma && Gamma && fock && work, "orbital_hessian: null pointer");
-    OOVQE_REQUIRE(H_matrix || H_full, "orbital_hessian: no output requested");
+    // stage 0: everything; 1: stage 1 of the integrals only (T2 and, when available, Vk: needs neither
+    // the RDMs nor the Fock matrices); 2: the rest, on the T2 / Vk a stage-1 call left in `work`
+    OOVQE_REQUIRE(g_ao && h_ao && C && work && (stage == 1 || (gamma && Gamma && fock)),
+                  "orbital_hessian: null pointer");
+    OOVQE_REQUIRE(stage == 1 || H_matrix || H_full, "orbital_hessian: no output requested");
     OOVQE_REQUIRE(!H_matrix || (kap_row && kap_col && n_kappa > 0), "orbital_hessian: index tables");
     OOVQE_REQUIRE(N >= 1 && n_occ >= 0 && ncas >= 1 && n_occ + ncas <= N, "orbital_hessian: sizes");
     OOVQE_REQUIRE(batch >= 1 && batch <= 65535 && (batch == 1 || !H_full), "orbital_hessian: batch=%d", batch);
@@ -261,8 +264,10 @@ static int orbital_hessian_batched(const double* g_ao, const double* h_ao, const
     // (the quarter transform of the K-type path), so the AO tensor is read once instead of twice
     const bool vk_tri = (eri_flags & OOVQE_ERI_PQ_SYMMETRIC) != 0 && N <= 48 && M <= 16 &&
                         (size_t)m2 * N * sizeof(double) <= 150 * 1024 && oovqe_opt(OOVQE_OPT_HESS_VK_PASS) == 0;
-    if ((rc = oovqe_half_transform_batched_impl(g_ao, C, N, M, T2, batch, eri_flags, stream, vk_tri ? Vk : nullptr)))
+    if (stage != 2 &&
+        (rc = oovqe_half_transform_batched_impl(g_ao, C, N, M, T2, batch, eri_flags, stream, vk_tri ? Vk : nullptr)))
         return rc;
+    if (stage == 1) return 0;
     MC(T2, y, C, n2, Uj, y, 1, N, N, n * m2, N, 0);          // Uj[q',q,yz]  = sum_p C[p,q'] T2[p,q,yz]
     MC(Uj, y, C, n2, Jint, y, n, N, N, m2, N, 0);            // Jint[q',s',yz] = sum_q C[q,s'] Uj[q',q,yz]
     // ---- K-type integrals: g_mo[q,m,n,s] ---------------------------------------------------------
@@ -348,7 +353,8 @@ int oovqe_oo_eval_batched_impl(const double* theta, int n_theta, const oovqe_gat
                                const double* C, const double* nuc_arr, int N, int n_occ, int ncas,
                                const int32_t* kap_row, const int32_t* kap_col, int n_kappa, int derivatives,
                                int batch, double* work, double* out, unsigned eri_flags,
-                               oovqe_stream_t stream, const double* g_packed, double* fock);
+                               oovqe_stream_t stream, const double* g_packed, double* fock,
+                               const double* T2_ready = nullptr);
 int oovqe_circuit_hessian_batched_impl(const double* theta, int n_theta, const oovqe_gate_t* gates,
                                        int n_gates, int n_qubits, int ncas, uint32_t init_index,
                                        const double* c1, const double* c2, long c1_bs, long c2_bs,
@@ -385,22 +391,42 @@ extern "C" int oovqe_oo_hessian_batch(const double* theta, int n_theta, const oo
     double* fock = ev_work + nb * ev;                    // [G][N][N]
     double* hs_work = fock + nb * N * N;                 // circuit / orbital Hessian scratch, one after the other
     int rc;
+    // 0. stage 1 of the integrals for the orbital Hessian first (T2[p,q,y,z] and the quarter transform Vk): the
+    //    evaluation's packed-triangle path takes its J from that T2 instead of streaming the integrals again
+    //    (p <-> q symmetric integrals, N <= 48, M <= 16: the shapes that path serves; option hess_own_stage1 = 1
+    //    keeps the two passes apart)
+    const int M = n_occ + ncas;
+    const bool share = (eri_flags & OOVQE_ERI_PQ_SYMMETRIC) != 0 && N <= 48 && M <= 16 &&
+                       oovqe_opt(OOVQE_OPT_HESS_OWN_STAGE1) == 0;
+    if (share && (rc = orbital_hessian_batched(g_ao, h_ao, C, nullptr, 0, nullptr, 0, nullptr, N, n_occ, ncas,
+                                               kap_row, kap_col, n_kappa, batch, hs_work, nullptr, 0, 0, nullptr,
+                                               eri_flags, stream, 1)))
+        return rc;
     // 1. circuit + tangents -> RDM sets -> CAS path: E, dE/dtheta, dE/dkappa, d^2E/dkappa dtheta, c1, c2, F
     if ((rc = oovqe_oo_eval_batched_impl(theta, n_theta, gates, n_gates, n_qubits, init_index, g_ao, h_ao, C, nuc,
                                          N, n_occ, ncas, kap_row, kap_col, n_kappa, 1, batch, ev_work, out,
-                                         eri_flags, stream, g_packed, fock)))
+                                         eri_flags, stream, g_packed, fock, share ? hs_work : nullptr)))
         return rc;
     const long out_stride = (long)oovqe_oo_eval_out_size(n_theta, n_kappa, ncas, 1);
     const long n = (long)n_theta + n_kappa;
     const double* gvec = out + 2 + n_theta;
     const double* c1 = gvec + (size_t)nvec * n_kappa;
     const double* c2 = c1 + na2;
-    // 2. theta-theta block (top left)
+    // 2. kappa-kappa block (bottom right) from RDM set 0 of every geometry and its Fock matrix (before the
+    //    circuit Hessian: that one reuses the scratch in which T2 / Vk of step 0 live)
+    const double* gamma = ev_work;
+    const double* Gamma = gamma + nb * nvec * na2;
+    if ((rc = orbital_hessian_batched(g_ao, h_ao, C, gamma, (long)nvec * na2, Gamma, (long)nvec * na4, fock, N,
+                                      n_occ, ncas, kap_row, kap_col, n_kappa, batch, hs_work,
+                                      hessian + (size_t)n_theta * n + n_theta, n, n * n, nullptr, eri_flags, stream,
+                                      share ? 2 : 0)))
+        return rc;
+    // 3. theta-theta block (top left)
     if ((rc = oovqe_circuit_hessian_batched_impl(theta, n_theta, gates, n_gates, n_qubits, ncas, init_index, c1,
                                                  c2, out_stride, out_stride, pairs, n_pairs, batch, hs_work,
                                                  hessian, n, n * n, stream)))
         return rc;
-    // 3. kappa-theta blocks
+    // 4. kappa-theta blocks
     {
         const long total = (long)n_theta * n_kappa;
         const unsigned nbk = (unsigned)((total + 255) / 256);
@@ -408,10 +434,5 @@ extern "C" int oovqe_oo_hessian_batch(const double* theta, int n_theta, const oo
                                                                                   n_kappa, hessian, n, n * n);
         OOVQE_CHECK_LAUNCH("oo_hessian_batch/cross");
     }
-    // 4. kappa-kappa block (bottom right) from RDM set 0 of every geometry and its Fock matrix
-    const double* gamma = ev_work;
-    const double* Gamma = gamma + nb * nvec * na2;
-    return orbital_hessian_batched(g_ao, h_ao, C, gamma, (long)nvec * na2, Gamma, (long)nvec * na4, fock, N,
-                                   n_occ, ncas, kap_row, kap_col, n_kappa, batch, hs_work,
-                                   hessian + (size_t)n_theta * n + n_theta, n, n * n, nullptr, eri_flags, stream);
+    return 0;
 }

@@ -376,6 +376,15 @@ def test_batched_hessian_quarter_transform_from_stage1_equals_its_own_pass(N, G)
     scale = H0.abs().max().item()
     assert (H - H0).abs().max().item() <= 1e-12 * scale
     assert torch.isfinite(H).all()
+    # the evaluation inside the call takes its J from the orbital Hessian's T2 (one stage 1 for both); option
+    # hess_own_stage1 = 1: it streams the (packed) integrals itself, as energy_and_gradient does
+    with _lib.debug_options(hess_own_stage1=1):
+        E1, grad1, H1 = batch.energy_gradient_hessian(thetas)
+    assert (E - E1).abs().max().item() < 1e-11
+    assert (grad - grad1).abs().max().item() < 1e-11
+    assert (H - H1).abs().max().item() <= 1e-12 * scale
+    EG = batch.energy_and_gradient(thetas)
+    assert (EG[:, 0] - E1).abs().max().item() < 1e-12 and (EG[:, 1:] - grad1).abs().max().item() < 1e-12
 
 
 def test_transition_rdms_small_register_kernel_vs_oracle():
