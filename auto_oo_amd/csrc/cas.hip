@@ -108,7 +108,9 @@ void half_transform_kernel(const double* __restrict__ g, const double* __restric
     T2 += (size_t)blockIdx.y * (sym == SYM_PACKED ? (size_t)nslabs : (size_t)N * N) * M * M;
     if (Vk) Vk += (size_t)blockIdx.y * (size_t)nslabs * N * M;
 
-    const long slab = (long)blockIdx.x * HALF_WAVES + wave;
+    // (NST > 0: the waves are independent, the host picks the workgroup size: four waves, so that three
+    // workgroups = all 12 waves the 158 registers allow are resident on a CU instead of one workgroup of 8)
+    const long slab = (long)blockIdx.x * (blockDim.x >> 6) + wave;
     const bool have = slab < nslabs;
     long src = have ? slab : 0, out1 = src, out2 = -1;   // slab read, slab(s) written
     if (sym != SYM_FULL) {
@@ -814,28 +816,35 @@ void sym_gm_kernel(const double* __restrict__ J, const double* __restrict__ C,
 __global__ __launch_bounds__(256)
 void j_from_t2_kernel(const double* __restrict__ T2, double* __restrict__ J, int N, int M, int packed)
 {
+    // 16 rows t per workgroup, thread <-> (row, column c of a tile); the position of every column in the
+    // M x M block once per workgroup (LDS), (p, q) of a row once per thread
+    __shared__ int off[256];
     const long tri = (long)N * (N + 1) / 2;
     const int m2 = M * M;
     const int ncol = packed ? M * (M + 1) / 2 : m2;
     const int nty = (ncol + 15) / 16;
     T2 += (size_t)blockIdx.y * N * N * m2;
     J += (size_t)blockIdx.y * nty * tri * 16;
-    const long total = (long)nty * tri * 16;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int c = (int)(idx & 15);
-        const long row = idx >> 4;
-        const int ty = (int)(row / tri);
-        const long t = row - (long)ty * tri;
-        const int col = ty * 16 + c;
-        double v = 0.0;
-        if (col < ncol) {
-            int p, q, y, z;
-            tri_decode(t, N, p, q);
-            if (packed) tri_decode(col, M, y, z);
-            else { y = col / M; z = col - y * M; }
-            v = T2[((size_t)p * N + q) * m2 + y * M + z];
+    const int tid = threadIdx.x;
+    if (tid < nty * 16) {
+        int y = 0, z = 0, o = -1;
+        if (tid < ncol) {
+            if (packed) tri_decode(tid, M, y, z);
+            else { y = tid / M; z = tid - y * M; }
+            o = y * M + z;
         }
-        J[idx] = v;
+        off[tid] = o;
+    }
+    __syncthreads();
+    const int c = tid & 15;
+    for (long t = (long)blockIdx.x * 16 + (tid >> 4); t < tri; t += (long)gridDim.x * 16) {
+        int p, q;
+        tri_decode(t, N, p, q);
+        const double* src = T2 + ((size_t)p * N + q) * m2;
+        for (int ty = 0; ty < nty; ++ty) {
+            const int o = off[ty * 16 + c];
+            J[((size_t)ty * tri + t) * 16 + c] = o >= 0 ? src[o] : 0.0;
+        }
     }
 }
 
@@ -2924,7 +2933,6 @@ static int half_transform_batched(const double* g_ao, const double* C, int N, in
     OOVQE_REQUIRE(lds_bytes <= 160 * 1024, "cas_half_transform: N=%d M=%d needs %zu B of LDS", N, M,
                   lds_bytes);
     const long nslabs = sym == SYM_FULL ? (long)N * N : (long)N * (N + 1) / 2;
-    const unsigned grid = (unsigned)((nslabs + HALF_WAVES - 1) / HALF_WAVES);
     // k-steps per register chunk: the whole row when it fits (<= 16 k-steps), else chunks of 16
     int kch = ksteps <= 4 ? 4 : ksteps <= 8 ? 8 : ksteps <= 11 ? 11 : ksteps <= 12 ? 12 : 16;
     const int nkc = (ksteps + kch - 1) / kch;
@@ -2943,9 +2951,10 @@ static int half_transform_batched(const double* g_ao, const double* C, int N, in
             attr_done = true;                                                                     \
         }                                                                                         \
         oovqe_note_stage1("half_transform_kernel<%d,%d,%d>%s", Z, KC_, NS_, sym ? " (slabs p <= q)" : ""); \
-        hipLaunchKernelGGL((half_transform_kernel<Z, KC_, NS_>), dim3(grid, batch),               \
-                           dim3(HALF_WAVES * 64),                                                 \
-                           lds_bytes, st, g_ao, C, T2, N, M, nrb, nkc, nslabs, sym, Vk_tri);      \
+        const unsigned wpg = (NS_) > 0 ? 4u : (unsigned)HALF_WAVES;       /* waves per workgroup */      \
+        hipLaunchKernelGGL((half_transform_kernel<Z, KC_, NS_>),                                  \
+                           dim3((unsigned)((nslabs + wpg - 1) / wpg), batch), dim3(wpg * 64),     \
+                           (NS_) > 0 ? 0 : lds_bytes, st, g_ao, C, T2, N, M, nrb, nkc, nslabs, sym, Vk_tri); \
     } while (0)
 #define OOVQE_DISPATCH_KCH(Z)                                                                     \
     do {                                                                                          \
@@ -3618,8 +3627,7 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
             // the packed copy of the integrals (oovqe_eri_pack) is streamed when the caller holds one
             const bool use_pk = !two_step && rs_sym && g_packed != nullptr;
             if (T2_ready && !two_step) {
-                const long total = (long)(nty16 / 16) * tri * 16;   // (nty16 counts all (y z); the kernel bounds itself)
-                const unsigned nbk = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+                const unsigned nbk = (unsigned)((tri + 15) / 16);       // 16 rows of the triangle per workgroup
                 oovqe_profile_mark_start_l(st, 0);
                 hipLaunchKernelGGL(j_from_t2_kernel, dim3(nbk, batch), dim3(256), 0, st, T2_ready, Jp, N, M,
                                    rs_sym ? 1 : 0);
