@@ -3737,6 +3737,7 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
         const long npan_max = (long)((lds_cap - fixed_bytes - set_bytes) / per_n);
         if (npan > npan_max) npan = npan_max;
         if (npan > 8) npan = 8;   // (two workgroups per CU: 40 us against 47 us with panels of 16 at 256 geometries)
+        if (oovqe_opt(OOVQE_OPT_PANEL_ROWS) > 0) npan = oovqe_opt(OOVQE_OPT_PANEL_ROWS);   // measurement hook
         if (npan < 1) npan = 1;
         int rdm_chunk = (int)((lds_cap - fixed_bytes - (size_t)npan * per_n) / set_bytes);
         if (rdm_chunk > nrdm) rdm_chunk = nrdm;

@@ -45,6 +45,7 @@ enum oovqe_option_t {
     OOVQE_OPT_SECTOR_PROBE,          // timing probe of sector_rdm_fused_kernel (wrong results): 1 no chunk build, 2 no MFMA
     OOVQE_OPT_HESS_VK_PASS,          // orbital Hessian: the K-type quarter transform as its own pass over the AO tensor (round 2)
     OOVQE_OPT_HESS_OWN_STAGE1,       // Hessian call: the evaluation streams the integrals itself instead of taking J from the orbital Hessian's T2
+    OOVQE_OPT_PANEL_ROWS,            // cas_panel_kernel: general indices per workgroup (0: chosen by the host code)
     OOVQE_OPT_COUNT
 };
 int oovqe_opt(int id);
