@@ -68,7 +68,8 @@ typedef struct {
 /* Test / measurement switches between realisations that compute the same numbers (which kernel
  * variant a call takes): "half_stream_old", "gm_two_per_cu", "gm_one_per_cu", "fused_chunks" (int),
  * "tri_plain_w", "cas_unfused", "sym_no_rs", "sym_mirror", "sym_simple", "sym_two_step", "no_ride",
- * "tri_mode" (int), "k1_no_pair", "k1_force_wide", "gm_plain_grid", "newton_one_wg", "sector_unfused".
+ * "tri_mode" (int), "k1_no_pair", "k1_force_wide", "gm_plain_grid", "newton_one_wg", "sector_unfused",
+ * "sector_probe" (int; timing only), "hess_vk_pass", "hess_own_stage1", "panel_rows" (int).
  * All 0 by default; the library never reads environment variables.  tests/ and tools/ only. */
 int oovqe_debug_set_option(const char* name, int value);
 int oovqe_debug_get_option(const char* name);
