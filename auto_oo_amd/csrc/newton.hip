@@ -635,7 +635,7 @@ constexpr int NEWTON2_NMAX = 672;
 constexpr int N2_SPIN_LIMIT = 1 << 17;
 constexpr int N2_SHIFTS = 256;        // shifts per multisection round and workgroup (4 waves, one per SIMD)
 constexpr int N2_MS_ROUNDS = 16;      // at most this many multisection rounds
-constexpr int N2_MS_WGS = 32;         // at most this many workgroups share the shifts of a round
+constexpr int N2_MS_WGS = 128;        // at most this many workgroups share the shifts of a round
 
 typedef unsigned n2_v4u __attribute__((ext_vector_type(4)));
 typedef unsigned n2_v2u __attribute__((ext_vector_type(2)));
