@@ -969,19 +969,28 @@ void newton_band_kernel(const double* __restrict__ H, const double* __restrict__
             if (wave < BW && lane <= wave && lane < m)
                 n2_st1(rs, GL.Band + (size_t)(k + wave) * RW + BW + lane - wave, rcol);
             __syncthreads();
-            // compact WY factor: row l of T by thread l (upper triangular)
+            // compact WY factor: row l of T by thread l (upper triangular), the row and the products V^T v it needs
+            // in registers (28 independent LDS reads, then arithmetic only; the sums run over mm = l .. jj - 1 as
+            // before: the elements left of the diagonal are zeros)
             if (tid < BW) {
-                for (int jj = 0; jj < jb; ++jj) {
-                    const double tj = taus[jj];
-                    double val = 0.0;
-                    if (tid == jj) val = tj;
-                    else if (tid < jj) {
-                        double sacc = 0.0;
-                        for (int mm = tid; mm < jj; ++mm) sacc += Tm[tid * BW + mm] * Gm[mm * BW + jj];
-                        val = -tj * sacc;
-                    }
-                    Tm[tid * BW + jj] = val;
+                double trow[BW], gc[BW][BW], tj[BW];
+#pragma unroll
+                for (int jj = 0; jj < BW; ++jj) {
+                    tj[jj] = taus[jj];
+                    trow[jj] = 0.0;
+#pragma unroll
+                    for (int mm = 0; mm < jj; ++mm) gc[mm][jj] = Gm[mm * BW + jj];
                 }
+#pragma unroll
+                for (int jj = 0; jj < BW; ++jj) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int mm = 0; mm < jj; ++mm) sacc += trow[mm] * gc[mm][jj];
+                    const double val = tid == jj ? tj[jj] : (tid < jj ? -tj[jj] * sacc : 0.0);
+                    trow[jj] = jj < jb ? val : 0.0;
+                }
+#pragma unroll
+                for (int jj = 0; jj < BW; ++jj) Tm[tid * BW + jj] = trow[jj];
             }
             __syncthreads();
             for (int idx = tid; idx < BW * (npv / 2); idx += NT) {
