@@ -296,13 +296,13 @@ def test_lockstep_newton_equals_sequential_on_64_geometries():
         assert (new_b[g][1] - new_s[1]).abs().max() < 1e-10
 
 
-def _batch_of(N, G, seed0=20262, freeze_active=False):
+def _batch_of(N, G, seed0=20262, freeze_active=False, nelec=16):
     from auto_oo_amd.synthetic import synthetic_problem
     pqc = aoo.Parameterized_circuit(3, 4, None, ansatz="ucc")
     mols, coeffs, objs, probs = [], [], [], []
     for g in range(G):
         P = synthetic_problem(N, seed0 + 1000 * g)
-        mol = aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], 16)
+        mol = aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec)
         mols.append(mol)
         coeffs.append(P["oao_mo_coeff"])
         probs.append(P)
@@ -358,15 +358,17 @@ def test_batched_full_hessian_equals_single_geometry_path_at_cc_pvdz_shape():
     assert (batch.full_gradient(thetas) - grad).abs().max() < 1e-12
 
 
-@pytest.mark.parametrize("N,G", [(13, 3), (20, 2), (43, 4), (48, 2)])
-def test_batched_hessian_quarter_transform_from_stage1_equals_its_own_pass(N, G):
+@pytest.mark.parametrize("N,G,nelec", [(13, 3, 16), (20, 2, 16), (43, 4, 16), (48, 2, 16),
+                                       (20, 3, 28), (24, 3, 4), (43, 2, 30), (17, 3, 10)])
+def test_batched_hessian_quarter_transform_from_stage1_equals_its_own_pass(N, G, nelec):
     """The K-type quarter transform of the orbital Hessian leaves stage 1 together with the J-type one
     (half_transform_kernel's Vk output + t2k_tri_kernel, hessian.hip) when the integrals are p <-> q
     symmetric; option hess_vk_pass = 1 brings back the round-2 form (its own pass over the whole AO
     tensor through K1).  Same sums in the same order: equal to rounding, for odd and even N, one, two
-    and three column tiles."""
+    and three column tiles, and 3 ... 16 occupied + active orbitals (nelec: the accumulator count of
+    t2k_tri_kernel is a template argument)."""
     from auto_oo_amd import _lib
-    pqc, batch, objs, probs = _batch_of(N, G)
+    pqc, batch, objs, probs = _batch_of(N, G, nelec=nelec)
     rng = np.random.default_rng(11)
     thetas = torch.tensor(rng.uniform(0, 2 * np.pi, (G, pqc.theta_shape))).cuda()
     E, grad, H = batch.energy_gradient_hessian(thetas)
