@@ -48,6 +48,8 @@ SIGNATURES = {
                                                                       c_double_p, c_stream]),
     "oovqe_matmul_nn": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_int, c_double_p, c_stream]),
+    "oovqe_matmul_nn_batch": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, c_double_p, c_stream]),
     "oovqe_matmul_tn": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_int, c_double_p, c_stream]),
     "oovqe_mode_contract": (ctypes.c_int, [c_double_p, c_double_p, c_double_p, ctypes.c_int64,

@@ -70,18 +70,12 @@ class OO_pqc_batch:
             self.set_oao_mo_coeff(g, c)
             nuc_host[g] = m.nuc
         self.nuc.copy_(torch.as_tensor(nuc_host))
-        # exact p<->q symmetry of every geometry's integrals (true for PySCF's int2e): the N^4 pass
-        # then reads only the slabs p <= q.  int2e_ao must not be modified in place afterwards.
-        self.eri_flags = ops.eri_flags(self.int2e_ao)
-        # both symmetries: keep a packed resident copy (slabs p <= q, upper triangle of each slab:
-        # about a quarter of the tensor) for the batched N^4 pass to stream
+        # exact p<->q / r<->s symmetry of every geometry's integrals (true for PySCF's int2e), verified
+        # bit for bit per geometry: the batch runs on the flags ALL its geometries share.  int2e_ao must
+        # not be modified in place afterwards (set_molecule / reverify_integrals are the ways in).
+        self._flags_g = self._stack_flags()
         self._eri_packed = None
-        both = ops.ERI_PQ_SYMMETRIC | ops.ERI_RS_SYMMETRIC
-        psz = self.lib.oovqe_eri_packed_size(N)
-        if (self.eri_flags & both) == both and psz > 0 and self._n_occ + ncas <= 16:
-            self._eri_packed = torch.empty((self.G, psz), dtype=F64, device=self.device)
-            check(self.lib.oovqe_eri_pack(dptr(self.int2e_ao), N, self.G, dptr(self._eri_packed),
-                                          stream_ptr()), "oovqe_eri_pack")
+        self._refresh_flags(repack=range(self.G))
         self._plans = {}
 
     def set_oao_mo_coeff(self, g, oao_mo_coeff):
@@ -96,17 +90,9 @@ class OO_pqc_batch:
         e.g. when the integrals of many geometries are produced on the device: re-checks the
         symmetry flags of the whole stack bit for bit, rebuilds the packed resident copy (or drops
         it) and refreshes ``mo_coeff = S^-1/2 C_oao`` of every geometry."""
-        self.eri_flags = ops.eri_flags(self.int2e_ao)
-        both = ops.ERI_PQ_SYMMETRIC | ops.ERI_RS_SYMMETRIC
-        psz = self.lib.oovqe_eri_packed_size(self.nao)
-        if (self.eri_flags & both) == both and psz > 0 and self._n_occ + self.ncas <= 16:
-            if self._eri_packed is None:
-                self._eri_packed = torch.empty((self.G, psz), dtype=F64, device=self.device)
-            check(self.lib.oovqe_eri_pack(dptr(self.int2e_ao), self.nao, self.G, dptr(self._eri_packed),
-                                          stream_ptr()), "oovqe_eri_pack")
-        else:
-            self._eri_packed = None
-        torch.bmm(self.oao_coeff, self.oao_mo_coeff, out=self.mo_coeff)
+        self._flags_g = self._stack_flags()
+        self._refresh_flags(repack=range(self.G))
+        self.refresh_mo_coeff()
 
     def set_molecule(self, g, mol, oao_mo_coeff=None):
         """Replace geometry g of the batch (the next point of a Berry-phase loop, say): integrals,
@@ -123,14 +109,47 @@ class OO_pqc_batch:
             mol.run_rhf()
             oao_mo_coeff = mo_ao_to_mo_oao(mol.hf.mo_coeff, mol.overlap)
         self.set_oao_mo_coeff(g, oao_mo_coeff)
-        flags_g = ops.eri_flags(self.int2e_ao[g])
-        self.eri_flags &= flags_g
-        if self._eri_packed is not None:
-            if self.eri_flags == (ops.ERI_PQ_SYMMETRIC | ops.ERI_RS_SYMMETRIC):
+        self._flags_g[g] = ops.eri_flags(self.int2e_ao[g])
+        self._refresh_flags(repack=[g])
+
+    def _stack_flags(self):
+        """Per-geometry symmetry flags of the whole stack: one pass when every geometry carries both
+        symmetries (the common case), a pass per geometry otherwise."""
+        both = ops.ERI_PQ_SYMMETRIC | ops.ERI_RS_SYMMETRIC
+        if ops.eri_flags(self.int2e_ao) == both:
+            return [both] * self.G
+        return [ops.eri_flags(self.int2e_ao[g]) for g in range(self.G)]
+
+    def _refresh_flags(self, repack):
+        """eri_flags = the symmetries every geometry of the stack has (a geometry replaced by a
+        symmetric one can RESTORE a flag, not only drop it); with both of them the packed resident
+        copy (slabs p <= q, upper triangle of each slab: about a quarter of the tensor) that the batched
+        N^4 pass streams is kept up to date: the geometries in ``repack``, or all of them when the copy
+        did not exist."""
+        flags = ops.ERI_PQ_SYMMETRIC | ops.ERI_RS_SYMMETRIC
+        for f in self._flags_g:
+            flags &= f
+        self.eri_flags = flags
+        both = ops.ERI_PQ_SYMMETRIC | ops.ERI_RS_SYMMETRIC
+        psz = self.lib.oovqe_eri_packed_size(self.nao)
+        if flags != both or psz <= 0 or self._n_occ + self.ncas > 16:
+            self._eri_packed = None
+            return
+        repack = list(repack)
+        if self._eri_packed is None:
+            self._eri_packed = torch.empty((self.G, psz), dtype=F64, device=self.device)
+            repack = list(range(self.G))
+        if len(repack) == self.G:
+            check(self.lib.oovqe_eri_pack(dptr(self.int2e_ao), self.nao, self.G, dptr(self._eri_packed),
+                                          stream_ptr()), "oovqe_eri_pack")
+        else:
+            for g in repack:
                 check(self.lib.oovqe_eri_pack(dptr(self.int2e_ao[g]), self.nao, 1, dptr(self._eri_packed[g]),
                                               stream_ptr()), "oovqe_eri_pack")
-            else:
-                self._eri_packed = None
+
+    def refresh_mo_coeff(self):
+        """mo_coeff[g] = S^-1/2[g] C_oao[g] for the whole stack (oo_energy.py:173-176), one launch."""
+        ops.matmul_nn_batch(self.oao_coeff, self.oao_mo_coeff, out=self.mo_coeff)
 
     def _plan(self, derivatives, slot=0):
         key = (bool(derivatives), slot)
@@ -205,7 +224,7 @@ class OO_pqc_batch:
         oo_pqc.py:191) and mo_coeff = S^-1/2 C_oao refreshed."""
         new = self._rotate(self.oao_mo_coeff, kappas, torch.empty_like(self.oao_mo_coeff))
         self.oao_mo_coeff.copy_(new)
-        torch.bmm(self.oao_coeff, self.oao_mo_coeff, out=self.mo_coeff)
+        self.refresh_mo_coeff()
 
     # ---- configs[3]'s unit of work, batched -----------------------------------------------------------
     def energy_gradient_hessian(self, thetas):

@@ -764,6 +764,17 @@ extern "C" int oovqe_matmul_nn(const double* A, const double* B, int M, int K, i
     return oovqe_mode_contract_impl(A, B, out, M, K, N, 1, N, 1, (hipStream_t)stream);
 }
 
+extern "C" int oovqe_matmul_nn_batch(const double* A, const double* B, int M, int K, int N, int batch,
+                                     double* out, oovqe_stream_t stream)
+{
+    // out[b] = A[b] B[b] for a stack of independent products in ONE launch (the batch index is a grid
+    // dimension of the LAST-mode contraction): mo_coeff[g] = S^-1/2[g] C_oao[g] of a stack of geometries
+    OOVQE_REQUIRE(A && B && out, "matmul_nn_batch: null pointer");
+    OOVQE_REQUIRE(M >= 1 && K >= 1 && N >= 1 && batch >= 1 && batch <= 65535, "matmul_nn_batch: bad sizes");
+    return oovqe_mode_contract_batched(A, B, out, M, K, N, 1, N, 1, batch, (long)M * K, (long)K * N, (long)M * N,
+                                       (hipStream_t)stream);
+}
+
 extern "C" int oovqe_matmul_tn(const double* A, const double* B, int M, int K, int N, double* out,
                                oovqe_stream_t stream)
 {

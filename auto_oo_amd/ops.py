@@ -74,6 +74,19 @@ def matmul_nn(A, B):
     return out
 
 
+def matmul_nn_batch(A, B, out=None):
+    """A[b] @ B[b] for every b of a stack [G, M, K] x [G, K, N] in one launch"""
+    lib = _lib.load()
+    G, M, K = A.shape
+    G2, K2, N = B.shape
+    assert K == K2 and G == G2
+    if out is None:
+        out = torch.empty((G, M, N), dtype=F64, device=_dev(A))
+    check(lib.oovqe_matmul_nn_batch(dptr(A), dptr(B), M, K, N, G, dptr(out), stream_ptr()),
+          "oovqe_matmul_nn_batch")
+    return out
+
+
 def matmul_tn(A, B):
     """A.T @ B"""
     lib = _lib.load()

@@ -213,7 +213,7 @@ def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl", mode="weak")
 
     def restore():
         batch.oao_mo_coeff.copy_(c_saved)
-        torch.bmm(batch.oao_coeff, batch.oao_mo_coeff, out=batch.mo_coeff)
+        batch.refresh_mo_coeff()
 
     def lockstep():
         return batch.damped_newton_step(thetas0, bopt)[1]
@@ -664,6 +664,11 @@ def main():
             "batched_calls": n_calls,
             "host_submit_us_per_call": t_submit / max(n_calls, 1) * 1e6,
             "parallelism": f"geometry-sharded x{world}, one all_gather at the end",
+            # what torch.distributed itself reports (a SCALE line proves RCCL saw N ranks)
+            "dist_backend": dist.get_backend() if dist is not None else None,
+            "dist_world_size": dist.get_world_size() if dist is not None else 1,
+            "devices_visible": torch.cuda.device_count(),
+            "device_of_rank0": torch.cuda.current_device(),
         },
         "roofline": {
             "kernel": kernel_name,

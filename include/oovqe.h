@@ -90,6 +90,10 @@ int oovqe_matmul_nn(const double* A, const double* B, int M, int K, int N, doubl
                     oovqe_stream_t stream);
 int oovqe_matmul_tn(const double* A, const double* B, int M, int K, int N, double* out,
                     oovqe_stream_t stream);
+/* out[b] = A[b] B[b], b < batch, in one launch (A: [batch,M,K], B: [batch,K,N]): `mo_coeff = oao_coeff @
+ * oao_mo_coeff` (oo_energy.py:173-176) for every geometry of a stack */
+int oovqe_matmul_nn_batch(const double* A, const double* B, int M, int K, int N, int batch, double* out,
+                          oovqe_stream_t stream);
 
 /* generic mode contraction used by all of the above (and exported for tests):
  *   last == 0: out[a,j,b] = sum_k Cm[k*ldc + j] * T[a,k,b]     T: [A,K,B], out: [A,J,B]

@@ -404,6 +404,31 @@ def test_batch_set_molecule_keeps_flags_and_packed_copy_consistent():
     assert batch.eri_flags == 0 and batch._eri_packed is None
     check_geometry(7, bad_mol, P["oao_mo_coeff"])
     check_geometry(5, new_mol, P["oao_mo_coeff"])
+    # the asymmetric geometry replaced by a symmetric one: the flags come BACK (they are kept per
+    # geometry, not and-ed away for good) and the packed copy of the whole stack is rebuilt
+    e_general = batch.energy_and_gradient(thetas).clone()
+    batch.set_molecule(7, new_mol, P["oao_mo_coeff"])
+    assert batch.eri_flags == 3 and batch._eri_packed is not None
+    check_geometry(7, new_mol, P["oao_mo_coeff"])
+    check_geometry(36, mols[36], coeffs[36])
+    e_packed = batch.energy_and_gradient(thetas)
+    keep = [g for g in range(G) if g != 7]
+    assert (e_packed[keep] - e_general[keep]).abs().max().item() < 1e-10
+
+
+def test_matmul_nn_batch_is_the_per_geometry_product():
+    """oovqe_matmul_nn_batch (mo_coeff = S^-1/2 C_oao of a stack, one launch) against torch on the host and,
+    bit for bit, against the single-product entry point."""
+    from auto_oo_amd import ops
+    rng = np.random.default_rng(3)
+    for G, M, K, N in ((5, 43, 43, 43), (64, 13, 13, 13), (3, 50, 37, 21), (2, 200, 200, 200)):
+        A = torch.tensor(rng.normal(size=(G, M, K)), device="cuda")
+        B = torch.tensor(rng.normal(size=(G, K, N)), device="cuda")
+        out = ops.matmul_nn_batch(A, B)
+        ref = torch.bmm(A.cpu(), B.cpu())
+        assert (out.cpu() - ref).abs().max().item() < 1e-11 * K
+        for g in (0, G - 1):
+            assert torch.equal(out[g], ops.matmul_nn(A[g].contiguous(), B[g].contiguous()))
 
 
 def test_in_place_edit_of_int2e_ao_reverifies_symmetry_flags():

@@ -86,3 +86,33 @@ def test_nccl_backend_world_size_one_gathers_device_tensors():
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert res.returncode == 0, (res.stdout[-1000:], res.stderr[-3000:])
     assert "nccl world-1 ok" in res.stdout
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: the RCCL leg with N > 1")
+def test_two_gpu_rccl_job_matches_one_process():
+    """The driver's own N = 2 command (`bench.py --gpus 2`, backend nccl = RCCL over xGMI, one rank per
+    GPU) as a CHILD job -- never an exec of this process: n_gpus == 2, torch.distributed reports nccl with
+    two ranks, the energies that crossed the all_gather equal bitwise what this process computes for the
+    same shards, and the strong leg of the Berry-phase loop ran on both ranks."""
+    import bench
+    geoms_per_rank = 4
+    cmd = bench.launch_command(2, 0, ["--gpus", "2", "--backend", "nccl", "--steps", "2", "--warmup", "1",
+                                      "--geoms", str(geoms_per_rank), "--no-cpu-baseline", "--no-transform",
+                                      "--no-kupccd", "--berry-geoms", "4", "--prime-seconds", "0.05"])
+    res = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2
+    assert out["config"]["dist_backend"] == "nccl" and out["config"]["dist_world_size"] == 2
+    energies = [float.fromhex(h) for h in out["gathered_energies_hex"]]
+    assert len(energies) == 2 * geoms_per_rank
+    from auto_oo_amd.parallel import shard_geometries
+    for r in range(2):
+        mine = shard_geometries(2 * geoms_per_rank, r, 2)
+        pqc, batch, single, thetas = bench.build_geometries(mine)
+        e = batch.energy_and_gradient(thetas)[:, 0].tolist()
+        for g, eg in zip(mine, e):
+            assert eg == energies[g], (g, eg, energies[g])
+    strong = out["berry_loop"]["strong"]
+    assert strong["geometries"] == 4 and strong["lockstep"]["geometries_per_s"] > 0
+    assert strong["lockstep"]["max_abs_energy_difference_vs_sequential"] < 1e-9
