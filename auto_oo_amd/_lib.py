@@ -151,6 +151,17 @@ SIGNATURES = {
                                               ctypes.c_int, c_double_p, c_double_p, c_double_p,
                                               c_double_p, c_stream]),
     "oovqe_newton_direction_work_size": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int]),
+    "oovqe_newton_direction_pd": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_double, c_double_p, c_double_p, c_double_p,
+                                                 c_double_p, c_stream]),
+    "oovqe_newton_direction_pd_work_size": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int]),
+    "oovqe_newton_direction_pd_max_n": (ctypes.c_int, []),
+    "oovqe_newton_direction_has_pd": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "oovqe_newton_direction_rest": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                                   ctypes.c_int, c_double_p, ctypes.c_int, ctypes.c_int,
+                                                   c_double_p, c_double_p, c_double_p, c_double_p, c_stream]),
+    "oovqe_newton_direction_rest_work_size": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int]),
     "oovqe_newton_direction_max_n": (ctypes.c_int, []),
     "oovqe_orbital_hessian_batch": (ctypes.c_int, [c_double_p] * 6 + [ctypes.c_int, ctypes.c_int,
                                                                      ctypes.c_int, c_int32_p, c_int32_p,

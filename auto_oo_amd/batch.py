@@ -264,13 +264,15 @@ class OO_pqc_batch:
         """-> [G, n, n] (OO_pqc.full_hessian per geometry, oo_pqc.py:136-148)."""
         return self.energy_gradient_hessian(thetas)[2]
 
-    def damped_newton_step(self, thetas, opt=None):
+    def damped_newton_step(self, thetas, opt=None, defer_lowest=False):
         """One damped Newton step on (theta, kappa) of EVERY geometry in lockstep -- the body of
         OO_pqc.full_optimization / of the Berry-phase loop (oo_pqc.py:172-196), per geometry the
         arithmetic of NewtonStep.damped_newton_step: gradient + Hessian (one call), the G directions
         (one launch), a line search whose trials evaluate all geometries at once, then the orbitals
         of every geometry rotated in place.  Returns (new thetas [G, n_theta], energies at the new
-        parameters [G], lowest Hessian eigenvalues [G])."""
+        parameters [G], lowest Hessian eigenvalues [G]).  ``defer_lowest``: the eigenvalues come as an
+        ``ops.PendingLowest`` -- they are a diagnostic (hess_eig_l of the reference's loops) computed on a side
+        stream beside the line search; ``.result()`` joins them."""
         from .newton_raphson import BatchedNewtonStep
         if opt is None:
             opt = BatchedNewtonStep(verbose=0)
@@ -280,7 +282,8 @@ class OO_pqc_batch:
         flat = torch.cat((thetas, torch.zeros((self.G, self.n_kappa), dtype=F64, device=self.device)), dim=1)
         new, low = opt.damped_newton_steps_flat(
             lambda pts: self.energy(pts[:, :nt].contiguous(), pts[:, nt:].contiguous()), flat, grad, H,
-            energy0=E)
+            energy0=E, defer_lowest=True)
         self.rotate_(new[:, nt:].contiguous())
         new_thetas = new[:, :nt].contiguous()
-        return new_thetas, self.energy(new_thetas), low
+        energies = self.energy(new_thetas)
+        return new_thetas, energies, (low if defer_lowest else low.result())

@@ -700,6 +700,13 @@ __host__ __device__ inline N2Lds n2_lds(int n)
     return L;
 }
 
+__device__ __forceinline__ bool n2_skip(const double* __restrict__ info, int prob, int which)
+{
+    if (!info || which == 0) return false;
+    const bool fast = info[prob] == 1.0;
+    return which == 1 ? fast : !fast;
+}
+
 __device__ __forceinline__ bool n2_is_sent(double x)
 {
     return (unsigned long long)__double_as_longlong(x) == ~0ull;
@@ -828,9 +835,13 @@ __device__ __forceinline__ bool n2_band_ldlt(const double* __restrict__ rb, int 
 template <int RQMAX>
 __global__ __launch_bounds__(NT)
 void newton_band_kernel(const double* __restrict__ H, const double* __restrict__ g, int n,
-                        double* __restrict__ work, int W, int batch)
+                        double* __restrict__ work, int W, int batch, const double* __restrict__ info, int which)
 {
     extern __shared__ double sm[];
+    // info[prob] == 1: the Cholesky fast path (newton_chol.hip) already delivered this problem's direction.
+    // which = 1: only the problems it did not serve; which = 2: only those it did (their lowest eigenvalue).
+    // Every workgroup of a problem takes the same decision, so nobody is left waiting for a peer.
+    if (n2_skip(info, blockIdx.x % batch, which)) return;
     const N2Global GL = n2_global(n);
     const N2Lds L = n2_lds(n);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1269,9 +1280,10 @@ __global__ __launch_bounds__(NT2)
 void newton_band_solve_kernel(int n, double lam_threshold, double mu, double rho, int aug,
                               const double* __restrict__ work, double* __restrict__ dp,
                               double* __restrict__ lowest, double* __restrict__ shift_out,
-                              double* __restrict__ scratch, int W2, int batch)
+                              double* __restrict__ scratch, int W2, int batch, double* __restrict__ info, int which)
 {
     extern __shared__ double sm[];
+    if (!BIG && n2_skip(info, blockIdx.x % batch, which)) return;
     const N2Global GL = n2_global(n);
     const N2Lds2 L = n2_lds2(BIG ? 16 : n);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1279,6 +1291,8 @@ void newton_band_solve_kernel(int n, double lam_threshold, double mu, double rho
     // W2 workgroups per problem share the shifts of every multisection round (small batches leave most of
     // the chip idle here); workgroup 0 of the problem goes on to the solve
     const int prob = blockIdx.x % batch, slot2 = blockIdx.x / batch;
+    // the fast path served this problem: only its lowest eigenvalue is still wanted
+    const bool lowest_only = !BIG && info && info[prob] == 1.0;
     const int npv = GL.npv, npan = GL.npan;
     const double* wk = BIG ? work : work + (size_t)batch * GL.aw_size + (size_t)prob * GL.ex_size;     // the exchange block
     double* rb = BIG ? scratch : sm + L.rb;
@@ -1314,10 +1328,13 @@ void newton_band_solve_kernel(int n, double lam_threshold, double mu, double rho
     if (__syncthreads_or(bad)) {
         if (slot2 != 0) return;
         const double qnan = __longlong_as_double(0x7ff8000000000000ll);
-        for (int i2 = tid; i2 < n; i2 += NT2) dp[(size_t)prob * n + i2] = qnan;
+        if (!lowest_only)
+            for (int i2 = tid; i2 < n; i2 += NT2) dp[(size_t)prob * n + i2] = qnan;
         if (tid == 0) {
             lowest[prob] = qnan;
-            if (shift_out) shift_out[prob] = qnan;
+            if (shift_out && !lowest_only) shift_out[prob] = qnan;
+            if (info && !lowest_only) info[prob] = -1.0;      // a hand-off of stage 1 timed out
+            if (info && lowest_only) info[prob] = 2.0;        // the direction stands, its eigenvalue is missing
         }
         return;
     }
@@ -1389,16 +1406,47 @@ void newton_band_solve_kernel(int n, double lam_threshold, double mu, double rho
     if (slot2 != 0) return;
     if (lost) {
         const double qnan = __longlong_as_double(0x7ff8000000000000ll);
-        for (int i2 = tid; i2 < n; i2 += NT2) dp[(size_t)prob * n + i2] = qnan;
+        if (!lowest_only)
+            for (int i2 = tid; i2 < n; i2 += NT2) dp[(size_t)prob * n + i2] = qnan;
         if (tid == 0) {
             lowest[prob] = qnan;
-            if (shift_out) shift_out[prob] = qnan;
+            if (shift_out && !lowest_only) shift_out[prob] = qnan;
+            if (info) info[prob] = lowest_only ? 2.0 : -1.0;
         }
         return;
     }
     const double lam = 0.5 * (lo + hi);
     const double nu = (aug && lam < lam_threshold) ? mu + rho * fabs(lam) : 0.0;
     N2_MARK(12);
+    if (!(lam == lam) || !(amax <= 1.79e308)) {
+        // a NaN or an Inf in the Hessian: nothing to compute, and nothing to hand on silently
+        const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+        if (!lowest_only)
+            for (int i2 = tid; i2 < n; i2 += NT2) dp[(size_t)prob * n + i2] = qnan;
+        if (tid == 0) {
+            lowest[prob] = qnan;
+            if (shift_out && !lowest_only) shift_out[prob] = qnan;
+            if (info) info[prob] = -3.0;
+        }
+        return;
+    }
+    if (lowest_only) {
+        if (tid == 0) lowest[prob] = lam;
+        return;
+    }
+    // without the level shift (aug == 0) the band LDL^T below has no pivoting: it is only valid on a positive
+    // definite matrix.  An indefinite Hessian that is to be inverted as it stands is refused loudly (the
+    // one-workgroup kernel with its pivoted tridiagonal solve serves n <= 480; Python falls back to eigh beyond)
+    if (nu == 0.0 && !(lam > 0.0)) {
+        const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+        for (int i2 = tid; i2 < n; i2 += NT2) dp[(size_t)prob * n + i2] = qnan;
+        if (tid == 0) {
+            lowest[prob] = lam;
+            if (shift_out) shift_out[prob] = 0.0;
+            if (info) info[prob] = -2.0;
+        }
+        return;
+    }
     // ---- (Bnd + nu I) y = b = Q1^T (-g) (carried through the panels by stage 1) by the same LDL^T, one lane
     if (tid == 0) n2_band_ldlt<true>(rb, n, -nu, 0.0, bb, Lst, dst, zst);
     __syncthreads();
@@ -1935,6 +1983,11 @@ static int n2_cu_count()
     return cus;
 }
 
+int oovqe_newton_chol_launch(const double* hessian, const double* gradient, int n, int batch, double lambda_min,
+                             double* work, double* dp, double* shift, double* info, hipStream_t st);
+size_t oovqe_newton_chol_work(int n, int batch);
+int oovqe_newton_chol_max_n(void);
+
 // which kernel serves (n, aug): the two-stage multi-workgroup one whenever the level shift is on (then the
 // system it solves is positive definite by construction); without the shift (aug == 0: the reference then
 // inverts an indefinite Hessian as it stands) the one-workgroup kernel with its pivoted tridiagonal solve
@@ -1946,12 +1999,21 @@ static bool n2_use_band(int n, int aug)
     return true;
 }
 
+// does the positive-definite fast path (newton_chol.hip) run in front of the band route?
+static bool n2_use_chol(int n, int aug)
+{
+    return aug && n <= oovqe_newton_chol_max_n() && n2_use_band(n, aug) && !oovqe_opt(OOVQE_OPT_NEWTON_NO_CHOL);
+}
+
 extern "C" int oovqe_newton_direction_max_n(void) { return NEWTON3_NMAX; }
+extern "C" int oovqe_newton_direction_pd_max_n(void) { return oovqe_newton_chol_max_n(); }
+// 1 when oovqe_newton_direction(n, aug) runs the positive-definite fast path in front of the band route
+extern "C" int oovqe_newton_direction_has_pd(int n, int aug) { return n >= 1 && n2_use_chol(n, aug) ? 1 : 0; }
 
 // n > NEWTON2_NMAX: one problem after the other, ~4 launches per panel of 8 columns
 static int n3_direction(const double* hessian, const double* gradient, int n, int batch, double lambda_min,
                         double mu, double rho, int aug, double* work, double* dp, double* lowest, double* shift,
-                        hipStream_t st)
+                        double* info, hipStream_t st)
 {
     const N3Global GL = n3_global(n);
     const size_t panel_lds = (size_t)(2 * 64 * RQ_MID + 64 + 64 + 16) * sizeof(double);
@@ -1980,72 +2042,128 @@ static int n3_direction(const double* hessian, const double* gradient, int n, in
         hipLaunchKernelGGL(n2l_tail_kernel, dim3(1), dim3(256), 0, st, n, wk);
         hipLaunchKernelGGL(newton_band_solve_kernel<true>, dim3(1), dim3(NT2), solve_lds, st, n, lambda_min, mu, rho,
                            aug, wk + GL.exoff, dp + (size_t)b * n, lowest + b, shift ? shift + b : nullptr,
-                           wk + GL.scratch, 1, 1);
+                           wk + GL.scratch, 1, 1, info ? info + b : nullptr, 0);
         OOVQE_CHECK_LAUNCH("oovqe_newton_direction/large");
     }
     return 0;
 }
 
+// doubles of the band / one-workgroup route alone
+static size_t n2_route_work(int n, int batch)
+{
+    if (n > NEWTON2_NMAX) return n3_global(n).total * (size_t)batch;
+    const size_t a = n <= NEWTON_NMAX ? newton_work_per_problem(n) : 0;
+    const size_t b = n2_work_total(n2_global(n), 1);
+    return (a > b ? a : b) * (size_t)batch;
+}
+
+extern "C" int64_t oovqe_newton_direction_rest_work_size(int n, int batch)
+{
+    if (n < 1 || n > NEWTON3_NMAX || batch < 1) return 0;
+    return (int64_t)n2_route_work(n, batch);
+}
+
+extern "C" int64_t oovqe_newton_direction_pd_work_size(int n, int batch)
+{
+    if (n < 1 || n > oovqe_newton_chol_max_n() || batch < 1) return 0;
+    return (int64_t)oovqe_newton_chol_work(n, batch);
+}
+
+// [route work | Cholesky work | info] -- the one-call entry point runs the fast path in front of the band route
 extern "C" int64_t oovqe_newton_direction_work_size(int n, int batch)
 {
     if (n < 1 || n > NEWTON3_NMAX || batch < 1) return 0;
-    if (n > NEWTON2_NMAX) return (int64_t)n3_global(n).total * batch;
-    const size_t a = n <= NEWTON_NMAX ? newton_work_per_problem(n) : 0;
-    const size_t b = n2_work_total(n2_global(n), 1);
-    return (int64_t)(a > b ? a : b) * batch;
+    size_t w = n2_route_work(n, batch);
+    if (n <= oovqe_newton_chol_max_n()) w += oovqe_newton_chol_work(n, batch) + (size_t)batch + 2;
+    return (int64_t)w;
 }
 
-extern "C" int oovqe_newton_direction(const double* hessian, const double* gradient, int n, int batch,
-                                      double lambda_min, double mu, double rho, int aug, double* work,
-                                      double* dp, double* lowest_eigenvalue, double* shift,
-                                      oovqe_stream_t stream)
+// Workgroups per problem of a band-route launch: they wait for each other, so all batch * W of them must be
+// resident together.  The bound is what the occupancy query says this kernel gets per CU with its LDS (one,
+// at these sizes) times the CU count -- and only this process's launches are counted: when other work holds
+// CUs a hand-off can time out (2^17 polls), which the solve kernel reports in info[] (-1) and
+// oovqe_newton_direction_rest(..., max_wg = 1) then repeats without any inter-workgroup wait.
+static int n2_resident_limit(const void* kernel, int threads, size_t lds)
 {
-    OOVQE_REQUIRE(hessian && gradient && work && dp && lowest_eigenvalue, "oovqe_newton_direction: null pointer");
-    OOVQE_REQUIRE(n >= 1 && n <= NEWTON3_NMAX, "oovqe_newton_direction: n = %d outside 1..%d", n, NEWTON3_NMAX);
-    OOVQE_REQUIRE(batch >= 1 && batch <= 65535, "oovqe_newton_direction: batch = %d", batch);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess || per_cu < 1)
+        per_cu = 1;
+    if (per_cu > 1) per_cu = 1;            // one workgroup per CU is what the hand-off latencies were measured at
+    return per_cu * n2_cu_count();
+}
+
+static int n2_band_route(const double* hessian, const double* gradient, int n, int batch, double lambda_min, double mu,
+                         double rho, int aug, double* work, double* dp, double* lowest_eigenvalue, double* shift,
+                         double* info, int which, int max_wg, hipStream_t st)
+{
+    const N2Global GL = n2_global(n);
+    const N2Lds L = n2_lds(n);
+    const size_t lds = (size_t)L.total * sizeof(double);
+    const size_t lds2 = (size_t)n2_lds2(n).total * sizeof(double);
+    OOVQE_REQUIRE(lds <= 159 * 1024 && lds2 <= 159 * 1024, "oovqe_newton_direction: %zu bytes of LDS needed",
+                  lds > lds2 ? lds : lds2);
+    OOVQE_REQUIRE(GL.aw_size * 8 < 0x7FFFFFFFull && GL.ex_size * 8 < 0x7FFFFFFFull,
+                  "oovqe_newton_direction: workspace per problem too large");
+    const bool small_q = n - BW <= 64 * RQ_SMALL;
+    const void* k1 = small_q ? (const void*)newton_band_kernel<RQ_SMALL> : (const void*)newton_band_kernel<RQ_LARGE>;
+    OOVQE_CHECK_HIP(hipFuncSetAttribute(k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                    "oovqe_newton_direction: hipFuncSetAttribute");
+    OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)newton_band_solve_kernel<false>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2),
+                    "oovqe_newton_direction: hipFuncSetAttribute");
+    // workgroups per problem: all of them must be resident together (they wait for each other)
+    const int lim1 = n2_resident_limit(k1, NT, lds);
+    const int lim2 = n2_resident_limit((const void*)newton_band_solve_kernel<false>, NT2, lds2);
+    const int cap1 = max_wg > 0 ? max_wg : 32, cap2 = max_wg > 0 ? max_wg : N2_MS_WGS;
+    int W = 1;
+    while (2 * W * batch <= lim1 && 2 * W <= cap1 && 2 * W <= GL.ntile) W *= 2;
+    // exchange blocks and status words start as all ones: the pattern the hand-offs wait to see replaced
+    OOVQE_CHECK_HIP(hipMemsetAsync(work + (size_t)batch * GL.aw_size, 0xFF,
+                                   (size_t)batch * (GL.ex_size + 2) * sizeof(double), st),
+                    "oovqe_newton_direction: memset");
+    if (small_q)
+        hipLaunchKernelGGL(newton_band_kernel<RQ_SMALL>, dim3(batch * W), dim3(NT), lds, st, hessian, gradient, n,
+                           work, W, batch, (const double*)info, which);
+    else
+        hipLaunchKernelGGL(newton_band_kernel<RQ_LARGE>, dim3(batch * W), dim3(NT), lds, st, hessian, gradient, n,
+                           work, W, batch, (const double*)info, which);
+    OOVQE_CHECK_LAUNCH("oovqe_newton_direction/band");
+    int W2 = 1;
+    while (2 * W2 * batch <= lim2 && 2 * W2 <= cap2) W2 *= 2;
+    hipLaunchKernelGGL(newton_band_solve_kernel<false>, dim3(batch * W2), dim3(NT2), lds2, st, n, lambda_min, mu,
+                       rho, aug, work, dp, lowest_eigenvalue, shift, (double*)nullptr, W2, batch, info, which);
+    OOVQE_CHECK_LAUNCH("oovqe_newton_direction/solve");
+    return 0;
+}
+
+extern "C" int oovqe_newton_direction_pd(const double* hessian, const double* gradient, int n, int batch,
+                                         double lambda_min, double* work, double* dp, double* shift, double* info,
+                                         oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(hessian && gradient && work && dp && info, "oovqe_newton_direction_pd: null pointer");
+    OOVQE_REQUIRE(batch >= 1 && batch <= 32767, "oovqe_newton_direction_pd: batch = %d", batch);
+    return oovqe_newton_chol_launch(hessian, gradient, n, batch, lambda_min, work, dp, shift, info, (hipStream_t)stream);
+}
+
+extern "C" int oovqe_newton_direction_rest(const double* hessian, const double* gradient, int n, int batch,
+                                           double lambda_min, double mu, double rho, int aug, double* info, int which,
+                                           int max_wg, double* work, double* dp, double* lowest_eigenvalue,
+                                           double* shift, oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(hessian && gradient && work && dp && lowest_eigenvalue, "oovqe_newton_direction_rest: null pointer");
+    OOVQE_REQUIRE(n >= 1 && n <= NEWTON3_NMAX, "oovqe_newton_direction_rest: n = %d outside 1..%d", n, NEWTON3_NMAX);
+    OOVQE_REQUIRE(batch >= 1 && batch <= 65535, "oovqe_newton_direction_rest: batch = %d", batch);
+    OOVQE_REQUIRE(which >= 0 && which <= 2 && (which == 0 || info), "oovqe_newton_direction_rest: which = %d", which);
     hipStream_t st = (hipStream_t)stream;
-    if (n > NEWTON2_NMAX)
+    if (n > NEWTON2_NMAX) {
+        OOVQE_REQUIRE(which == 0, "oovqe_newton_direction_rest: n = %d has no fast path to complement", n);
         return n3_direction(hessian, gradient, n, batch, lambda_min, mu, rho, aug, work, dp, lowest_eigenvalue,
-                            shift, st);
-    if (n2_use_band(n, aug)) {
-        const N2Global GL = n2_global(n);
-        const N2Lds L = n2_lds(n);
-        const size_t lds = (size_t)L.total * sizeof(double);
-        const size_t lds2 = (size_t)n2_lds2(n).total * sizeof(double);
-        OOVQE_REQUIRE(lds <= 159 * 1024 && lds2 <= 159 * 1024, "oovqe_newton_direction: %zu bytes of LDS needed",
-                      lds > lds2 ? lds : lds2);
-        OOVQE_REQUIRE(GL.aw_size * 8 < 0x7FFFFFFFull && GL.ex_size * 8 < 0x7FFFFFFFull,
-                      "oovqe_newton_direction: workspace per problem too large");
-        // workgroups per problem: all of them must be resident together (they wait for each other), one per CU
-        const int cus = n2_cu_count();
-        int W = 1;
-        while (2 * W * batch <= cus && 2 * W <= 32 && 2 * W <= GL.ntile) W *= 2;
-        const bool small_q = n - BW <= 64 * RQ_SMALL;
-        OOVQE_CHECK_HIP(hipFuncSetAttribute(small_q ? (const void*)newton_band_kernel<RQ_SMALL>
-                                                    : (const void*)newton_band_kernel<RQ_LARGE>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                        "oovqe_newton_direction: hipFuncSetAttribute");
-        OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)newton_band_solve_kernel<false>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2),
-                        "oovqe_newton_direction: hipFuncSetAttribute");
-        // exchange blocks and status words start as all ones: the pattern the hand-offs wait to see replaced
-        OOVQE_CHECK_HIP(hipMemsetAsync(work + (size_t)batch * GL.aw_size, 0xFF,
-                                       (size_t)batch * (GL.ex_size + 2) * sizeof(double), st),
-                        "oovqe_newton_direction: memset");
-        if (small_q)
-            hipLaunchKernelGGL(newton_band_kernel<RQ_SMALL>, dim3(batch * W), dim3(NT), lds, st, hessian, gradient, n,
-                               work, W, batch);
-        else
-            hipLaunchKernelGGL(newton_band_kernel<RQ_LARGE>, dim3(batch * W), dim3(NT), lds, st, hessian, gradient, n,
-                               work, W, batch);
-        OOVQE_CHECK_LAUNCH("oovqe_newton_direction/band");
-        int W2 = 1;
-        while (2 * W2 * batch <= cus && 2 * W2 <= N2_MS_WGS) W2 *= 2;
-        hipLaunchKernelGGL(newton_band_solve_kernel<false>, dim3(batch * W2), dim3(NT2), lds2, st, n, lambda_min, mu,
-                           rho, aug, work, dp, lowest_eigenvalue, shift, (double*)nullptr, W2, batch);
-        OOVQE_CHECK_LAUNCH("oovqe_newton_direction/solve");
-        return 0;
+                            shift, info, st);
     }
+    if (n2_use_band(n, aug))
+        return n2_band_route(hessian, gradient, n, batch, lambda_min, mu, rho, aug, work, dp, lowest_eigenvalue,
+                             shift, info, which, max_wg, st);
+    OOVQE_REQUIRE(which == 0, "oovqe_newton_direction_rest: the one-workgroup kernel serves every problem");
     OOVQE_REQUIRE(n <= NEWTON_NMAX, "oovqe_newton_direction: n = %d > %d needs the level shift (aug != 0)", n,
                   NEWTON_NMAX);
     const Layout L = make_layout(n);
@@ -2058,4 +2176,26 @@ extern "C" int oovqe_newton_direction(const double* hessian, const double* gradi
                        gradient, n, lambda_min, mu, rho, aug, work, dp, lowest_eigenvalue, shift);
     OOVQE_CHECK_LAUNCH("oovqe_newton_direction");
     return 0;
+}
+
+extern "C" int oovqe_newton_direction(const double* hessian, const double* gradient, int n, int batch,
+                                      double lambda_min, double mu, double rho, int aug, double* work,
+                                      double* dp, double* lowest_eigenvalue, double* shift,
+                                      oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(hessian && gradient && work && dp && lowest_eigenvalue, "oovqe_newton_direction: null pointer");
+    OOVQE_REQUIRE(n >= 1 && n <= NEWTON3_NMAX, "oovqe_newton_direction: n = %d outside 1..%d", n, NEWTON3_NMAX);
+    OOVQE_REQUIRE(batch >= 1 && batch <= 65535, "oovqe_newton_direction: batch = %d", batch);
+    if (n2_use_chol(n, aug) && batch <= 32767) {
+        // positive-definite Hessians: direction from the Cholesky factorisation, the band route only adds the
+        // lowest eigenvalue; the others go through the band route entirely
+        double* cw = work + n2_route_work(n, batch);
+        double* info = cw + oovqe_newton_chol_work(n, batch);
+        int rc = oovqe_newton_direction_pd(hessian, gradient, n, batch, lambda_min, cw, dp, shift, info, stream);
+        if (rc) return rc;
+        return oovqe_newton_direction_rest(hessian, gradient, n, batch, lambda_min, mu, rho, aug, info, 0, 0, work, dp,
+                                           lowest_eigenvalue, shift, stream);
+    }
+    return oovqe_newton_direction_rest(hessian, gradient, n, batch, lambda_min, mu, rho, aug, nullptr, 0, 0, work, dp,
+                                       lowest_eigenvalue, shift, stream);
 }

@@ -57,25 +57,66 @@ class NewtonStep():
         self.verbose = verbose
 
     # ---- direction ----------------------------------------------------------------------------
-    def _direction(self, gradient, hessian):
-        """(dp, lowest eigenvalue, shift) as device tensors; no host synchronisation."""
-        dev = _lib.require_device()
-        g = ops.as_device(gradient, dev).reshape(-1)
-        H = ops.as_device(hessian, dev)
-        if g.numel() <= _lib.load().oovqe_newton_direction_max_n():
-            return ops.newton_direction(H, g, self.lambda_min, self.mu, self.rho, self.aug)
-        # beyond the band-reduction kernels (n > 5128: no configuration of the reference's workloads gets
-        # there -- N = 200, CAS(6e,6o) has n_kappa = 4 659): torch's device eigh
+    def _eigh_direction(self, H, g):
+        """The reference's own algebra on the device (newton_raphson.py:105-128) -- only beyond the library's
+        kernels: n > 5128 (no configuration of the reference's workloads gets there: N = 200, CAS(6e,6o) has
+        n_kappa = 4 659), or an indefinite Hessian that is to be inverted as it stands (aug = False) at
+        n > 480."""
         vals, vecs = torch.linalg.eigh(H)
-        low = vals[0]
-        nu = torch.where((low < self.lambda_min) & bool(self.aug), self.mu + self.rho * low.abs(),
-                         torch.zeros_like(low))
-        return -(vecs @ ((vecs.T @ g) / (vals + nu))), low, nu
+        low = vals[..., 0]
+        nu = torch.zeros_like(low)
+        if self.aug:
+            nu = torch.where(low < self.lambda_min, self.mu + self.rho * low.abs(), nu)
+        proj = torch.einsum("...ji,...j->...i", vecs, g) / (vals + nu[..., None])
+        return -torch.einsum("...ij,...j->...i", vecs, proj), low, nu
+
+    def _direction(self, gradient, hessian, batched=False):
+        """(dp, lowest eigenvalue, shift, info) as device tensors; no host synchronisation.  info [G]: the
+        library's per-problem verdict (ops.NEWTON_INFO; negative = it failed loudly and dp is NaN), checked on
+        the host together with the line search's first readback (``_check_direction``)."""
+        dev = _lib.require_device()
+        g = ops.as_device(gradient, dev)
+        H = ops.as_device(hessian, dev)
+        if not batched:
+            g = g.reshape(-1)
+        if g.shape[-1] <= _lib.load().oovqe_newton_direction_max_n():
+            return ops.newton_direction(H, g, self.lambda_min, self.mu, self.rho, self.aug, want_info=True)
+        dp, low, nu = self._eigh_direction(H, g)
+        return dp, low, nu, torch.zeros(low.numel(), dtype=dp.dtype, device=dp.device)
+
+    def _check_direction(self, gradient, hessian, dp, low, nu, info_host, batched=False):
+        """Act on negative entries of the library's info (host values): a timed-out hand-off between the
+        workgroups of a problem is repeated with one workgroup per problem (no inter-workgroup wait left to
+        time out); an indefinite Hessian without level shift beyond the pivoted kernel goes through eigh.
+        Anything else negative, or a second failure, raises -- a NaN direction is never handed on."""
+        codes = [int(c) for c in info_host]
+        if min(codes) >= 0:
+            return dp, low, nu
+        dev = _lib.require_device()
+        g = ops.as_device(gradient, dev)
+        H = ops.as_device(hessian, dev)
+        if not batched:
+            g = g.reshape(-1)
+        if -2 in codes and min(codes) >= -2:
+            return self._eigh_direction(H, g)
+        if all(c >= -1 for c in codes):
+            dp, low, nu, info = ops.newton_direction(H, g, self.lambda_min, self.mu, self.rho, self.aug,
+                                                     want_info=True, max_wg=1)
+            again = [int(c) for c in info.tolist()]
+            if min(again) >= 0:
+                return dp, low, nu
+            codes = again
+        bad = sorted(set(c for c in codes if c < 0))
+        raise _lib.OovqeError("oovqe_newton_direction failed: " +
+                              "; ".join(f"{c}: {ops.NEWTON_INFO.get(c, 'unknown')}" for c in bad))
 
     def newton_step(self, gradient, hessian):
         """newton_raphson.py:78-129 -> (dp, lowest Hessian eigenvalue as a float)."""
-        dp, low, nu = self._direction(gradient, hessian)
-        lowest_eigenvalue, shift = torch.stack((low, nu)).tolist()
+        dp, low, nu, info = self._direction(gradient, hessian)
+        lowest_eigenvalue, shift, code = torch.stack((low.reshape(()), nu.reshape(()), info.reshape(()))).tolist()
+        if code < 0:
+            dp, low, nu = self._check_direction(gradient, hessian, dp, low, nu, [code])
+            lowest_eigenvalue, shift = torch.stack((low.reshape(()), nu.reshape(()))).tolist()
         if self.verbose:
             print("lowest eigval hessian =", lowest_eigenvalue)
             if shift != 0.0:
@@ -98,14 +139,17 @@ class NewtonStep():
             pack += [x.reshape(()) for x in extra]
         host = torch.stack(pack).tolist()                      # the one readback of the common case
         old, trial, slope_h = host[0], host[1], host[2]
+        if slope_h != slope_h:
+            raise _lib.OovqeError("Newton direction is not finite (NaN in <gradient, dp>)")
         step, reductions = 1.0, 0
-        if trial > old + step * slope_h:
+        # (a NaN trial energy is never accepted: it counts as a failed Armijo test)
+        if not trial <= old + step * slope_h:
             if not slope_h < 0:
                 raise AssertionError("Newton direction is not a descent direction")
             if self.verbose:
                 print("test_energy:", trial, "... old energy:", old)
                 print("do backtracking line search...")
-            while trial > old + step * slope_h:
+            while not trial <= old + step * slope_h:
                 step *= self.beta
                 reductions += 1
                 if self.verbose:
@@ -133,9 +177,18 @@ class NewtonStep():
     def damped_newton_step(self, objective_fn, parameters, gradient, hessian):
         """newton_raphson.py:194-211 -> (new parameters, lowest Hessian eigenvalue).  One launch
         for the direction, the lowest eigenvalue rides on the line search's readback."""
-        dp, low, nu = self._direction(gradient, hessian)
-        new, _, (lowest_eigenvalue, shift) = self._search(objective_fn, parameters, dp, gradient,
-                                                          extra=(low, nu))
+        dp, low, nu, info = self._direction(gradient, hessian)
+        try:
+            new, _, (lowest_eigenvalue, shift, code) = self._search(objective_fn, parameters, dp, gradient,
+                                                                    extra=(low, nu, info))
+        except _lib.OovqeError:
+            code = info.reshape(()).item()
+            if code >= 0:
+                raise
+        if code < 0:            # the library refused loudly: repeat / fall back, then search again
+            dp, low, nu = self._check_direction(gradient, hessian, dp, low, nu, [code])
+            new, _, (lowest_eigenvalue, shift) = self._search(objective_fn, parameters, dp, gradient,
+                                                              extra=(low, nu))
         if self.verbose:
             print("lowest eigval hessian =", lowest_eigenvalue)
             if shift != 0.0:
@@ -152,19 +205,11 @@ class BatchedNewtonStep(NewtonStep):
 
     def newton_steps(self, gradients, hessians):
         """gradients [G, n], hessians [G, n, n] -> (dp [G, n], lowest eigenvalues [G])"""
-        dev = _lib.require_device()
-        g = ops.as_device(gradients, dev)
-        H = ops.as_device(hessians, dev)
-        if g.shape[-1] <= _lib.load().oovqe_newton_direction_max_n():
-            dp, low, _ = ops.newton_direction(H, g, self.lambda_min, self.mu, self.rho, self.aug)
-            return dp, low
-        vals, vecs = torch.linalg.eigh(H)
-        low = vals[:, 0]
-        shift = torch.zeros_like(low)
-        if self.aug:
-            shift = torch.where(low < self.lambda_min, self.mu + self.rho * low.abs(), shift)
-        proj = torch.einsum("gji,gj->gi", vecs, g) / (vals + shift[:, None])
-        return -torch.einsum("gij,gj->gi", vecs, proj), low
+        dp, low, nu, info = self._direction(gradients, hessians, batched=True)
+        codes = info.tolist()
+        if min(codes) < 0:
+            dp, low, nu = self._check_direction(gradients, hessians, dp, low, nu, codes, batched=True)
+        return dp, low
 
     def damped_newton_steps(self, objective_fns, parameters, gradients, hessians):
         """objective_fns[g](*parameters[g]) -> 0-d tensor; parameters[g] = tuple of tensors.
@@ -180,21 +225,46 @@ class BatchedNewtonStep(NewtonStep):
         newp, low = self.damped_newton_steps_flat(evaluate, flat, gradients, hessians)
         return [tuple(split_list_shapes(newp[g], shapes[g])) for g in range(G)], low
 
-    def damped_newton_steps_flat(self, objective, flat, gradients, hessians, energy0=None):
+    def damped_newton_steps_flat(self, objective, flat, gradients, hessians, energy0=None, defer_lowest=False):
         """The same with ONE objective for all problems: objective(points [G, n]) -> energies [G]
         (e.g. ``OO_pqc_batch.energy``: every line-search trial is one batched evaluation).
         flat [G, n] = the current parameters; energy0 [G] = objective(flat) when the caller has it.
-        Returns (new parameters [G, n], lowest Hessian eigenvalues [G])."""
-        dp, low = self.newton_steps(gradients, hessians)
+        Returns (new parameters [G, n], lowest Hessian eigenvalues [G]); with ``defer_lowest`` the eigenvalues
+        come as an ``ops.PendingLowest`` (they are computed beside the line search on a side stream and
+        nothing in the step reads them)."""
+        dev = _lib.require_device()
+        g = ops.as_device(gradients, dev)
+        H = ops.as_device(hessians, dev)
         G = flat.shape[0]
+        if g.shape[-1] <= _lib.load().oovqe_newton_direction_max_n():
+            dp, low, nu, info = ops.newton_direction(H, g, self.lambda_min, self.mu, self.rho, self.aug,
+                                                     defer_lowest=True, want_info=True)
+        else:
+            dp, low, nu = self._eigh_direction(H, g)
+            low, info = ops.PendingLowest(low, None), torch.zeros(G, dtype=dp.dtype, device=dev)
         evaluate = objective
         energy = evaluate(flat) if energy0 is None else energy0
-        slope = self.alpha * (ops.as_device(gradients, flat.device) * dp).sum(dim=1)   # wolfe(t) = t * slope
+        slope = self.alpha * (g * dp).sum(dim=1)                    # wolfe(t) = t * slope
         t = torch.ones(G, dtype=flat.dtype, device=flat.device)
         test = evaluate(flat + t[:, None] * dp)
-        active = test > energy + t * slope
+        # a NaN trial energy is never accepted: "not <=" counts it as a failed Armijo test
+        active = ~(test <= energy + t * slope)
+        # the one readback of the common case: any problem still searching? did the library refuse one?
+        first = torch.stack((active.any().to(flat.dtype), info.min(),
+                             torch.isnan(slope).any().to(flat.dtype))).tolist()
+        if first[1] < 0:
+            # repeat without inter-workgroup waits / eigh fallback (or raise), then search from scratch
+            dp, low_t, nu = self._check_direction(g, H, dp, None, nu, info.tolist(), batched=True)
+            low = ops.PendingLowest(low_t, None)
+            slope = self.alpha * (g * dp).sum(dim=1)
+            test = evaluate(flat + t[:, None] * dp)
+            active = ~(test <= energy + t * slope)
+            first = [float(bool(active.any())), 0.0, float(bool(torch.isnan(slope).any()))]
+        if first[2] != 0.0:
+            raise _lib.OovqeError("Newton direction is not finite (NaN in <gradient, dp>)")
         num = 0
-        while bool(active.any()):
+        searching = first[0] != 0.0
+        while searching:
             if bool((slope[active] >= 0).any()):
                 raise AssertionError("Newton direction is not a descent direction")
             t = torch.where(active, self.beta * t, t)
@@ -207,5 +277,6 @@ class BatchedNewtonStep(NewtonStep):
                     print("Warning: line search failed. Output previous parameters.")
                 break
             test = torch.where(active, trial, test)
-            active = active & (test > energy + t * slope)
-        return flat + t[:, None] * dp, low
+            active = active & ~(test <= energy + t * slope)
+            searching = bool(active.any())
+        return flat + t[:, None] * dp, (low if defer_lowest else low.result())

@@ -453,13 +453,71 @@ def circuit_hessian(theta, gates_dev, n_gates, n_qubits, ncas, init_index, c1, c
 
 
 _NEWTON_WORK = {}
+_NEWTON_SIDE = {}
+
+NEWTON_INFO = {1: "direction from the Cholesky fast path", 0: "direction from the band route",
+               2: "direction from the fast path; its lowest eigenvalue could not be computed",
+               -1: "a hand-off between the workgroups of a problem timed out (co-residency not granted)",
+               -2: "indefinite Hessian without level shift beyond the pivoted kernel (n > 480)",
+               -3: "the Hessian holds a NaN or an Inf"}
 
 
-def newton_direction(hessian, gradient, lambda_min=1e-6, mu=1e-6, rho=1.1, aug=True):
-    """dp = -(H + nu I)^-1 g with the reference's level shift (newton_raphson.py:78-129), on the
-    device (``oovqe_newton_direction``: two launches up to n = 672, several workgroups per problem;
-    a launch sequence per panel up to n = 5128).  hessian [n,n] or [G,n,n], gradient [n] or
-    [G,n] -> (dp, lowest eigenvalues [G] (0-d for one problem), shifts nu)."""
+def _newton_work(kind, n, G, dev, size):
+    # scratch is cached per (kind, shape, device, STREAM): calls on different HIP streams must not share it
+    key = (kind, n, G, str(dev), torch.cuda.current_stream().cuda_stream)
+    work = _NEWTON_WORK.get(key)
+    if work is None:
+        if len(_NEWTON_WORK) >= 12:
+            _NEWTON_WORK.clear()
+        work = torch.empty(int(size), dtype=F64, device=dev)
+        _NEWTON_WORK[key] = work
+    return work
+
+
+def _side_stream(dev):
+    side = _NEWTON_SIDE.get(str(dev))
+    if side is None:
+        side = torch.cuda.Stream(device=dev)
+        _NEWTON_SIDE[str(dev)] = side
+    return side
+
+
+class PendingLowest:
+    """Lowest Hessian eigenvalues still being computed on the library's side stream (the band route runs
+    beside the line search: the eigenvalue of a positive definite Hessian is a reported number that no step of
+    the optimisation reads, newton_raphson.py:105-128).  ``result()`` makes the current stream wait for them
+    and returns the tensor."""
+
+    def __init__(self, tensor, event):
+        self._tensor, self._event = tensor, event
+
+    def result(self):
+        if self._event is not None:
+            torch.cuda.current_stream().wait_event(self._event)
+            self._event = None
+        return self._tensor
+
+    def tolist(self):
+        """Host values; raises if the band route could not deliver an eigenvalue (NaN)."""
+        vals = self.result().reshape(-1).tolist()
+        if any(v != v for v in vals):
+            raise _lib.OovqeError("lowest Hessian eigenvalue missing (NaN): a hand-off of the band route timed out")
+        return vals
+
+
+def newton_direction(hessian, gradient, lambda_min=1e-6, mu=1e-6, rho=1.1, aug=True, defer_lowest=False,
+                     want_info=False, max_wg=0):
+    """dp = -(H + nu I)^-1 g with the reference's level shift (newton_raphson.py:78-129), on the device.
+    hessian [n,n] or [G,n,n], gradient [n] or [G,n] -> (dp, lowest eigenvalues [G] (0-d for one problem),
+    shifts nu[, info]).
+
+    Positive definite Hessians (lowest eigenvalue above lambda_min: the reference does not shift) take their
+    direction from a blocked Cholesky factorisation (``oovqe_newton_direction_pd``, one workgroup per
+    factorisation), and their lowest eigenvalue -- which nothing downstream of the direction reads -- from the
+    band-reduction route on a side stream; every other problem goes through the band route on the calling
+    stream (``oovqe_newton_direction_rest``).  ``defer_lowest``: return the eigenvalues as a
+    ``PendingLowest`` instead of making the calling stream wait for the side stream.  ``info`` [G] (see
+    ``NEWTON_INFO``; negative = failed loudly, dp = NaN)."""
     lib = _lib.load()
     dev = _dev(hessian)
     single = hessian.dim() == 2
@@ -469,21 +527,49 @@ def newton_direction(hessian, gradient, lambda_min=1e-6, mu=1e-6, rho=1.1, aug=T
     if n > lib.oovqe_newton_direction_max_n():
         raise _lib.OovqeError(f"newton_direction: n = {n} exceeds the band-reduction kernels "
                               f"({lib.oovqe_newton_direction_max_n()})")
-    key = (n, G, str(dev), torch.cuda.current_stream().cuda_stream)     # (per stream, see circuit_hessian)
-    work = _NEWTON_WORK.get(key)
-    if work is None:
-        if len(_NEWTON_WORK) >= 4:
-            _NEWTON_WORK.clear()
-        work = torch.empty(lib.oovqe_newton_direction_work_size(n, G), dtype=F64, device=dev)
-        _NEWTON_WORK[key] = work
     H = H if H.is_contiguous() else H.contiguous()
     g = g if g.is_contiguous() else g.contiguous()
     dpc = torch.empty((G, n), dtype=F64, device=dev)
     low = torch.empty(G, dtype=F64, device=dev)
     nu = torch.empty(G, dtype=F64, device=dev)
-    check(lib.oovqe_newton_direction(dptr(H), dptr(g), n, G, float(lambda_min), float(mu), float(rho),
-                                     int(bool(aug)), dptr(work), dptr(dpc), dptr(low), dptr(nu),
-                                     stream_ptr()), "oovqe_newton_direction")
+    info = torch.zeros(G, dtype=F64, device=dev)
+    args = (float(lambda_min), float(mu), float(rho), int(bool(aug)))
+    event = None
+    if lib.oovqe_newton_direction_has_pd(n, int(bool(aug))) and G <= 32767:
+        wpd = _newton_work("pd", n, G, dev, lib.oovqe_newton_direction_pd_work_size(n, G))
+        check(lib.oovqe_newton_direction_pd(dptr(H), dptr(g), n, G, float(lambda_min), dptr(wpd), dptr(dpc),
+                                            dptr(nu), dptr(info), stream_ptr()), "oovqe_newton_direction_pd")
+        main = torch.cuda.current_stream()
+        forked = torch.cuda.Event()
+        forked.record(main)
+        # the problems the fast path did not serve: here, on the calling stream (a no-op launch when there
+        # are none); the lowest eigenvalue of the others: beside it
+        wmain = _newton_work("rest", n, G, dev, lib.oovqe_newton_direction_rest_work_size(n, G))
+        check(lib.oovqe_newton_direction_rest(dptr(H), dptr(g), n, G, *args, dptr(info), 1, int(max_wg), dptr(wmain),
+                                              dptr(dpc), dptr(low), dptr(nu), stream_ptr()),
+              "oovqe_newton_direction_rest")
+        side = _side_stream(dev)
+        with torch.cuda.stream(side):
+            side.wait_event(forked)
+            wside = _newton_work("rest", n, G, dev, lib.oovqe_newton_direction_rest_work_size(n, G))
+            check(lib.oovqe_newton_direction_rest(dptr(H), dptr(g), n, G, *args, dptr(info), 2, int(max_wg),
+                                                  dptr(wside), dptr(dpc), dptr(low), dptr(nu), stream_ptr()),
+                  "oovqe_newton_direction_rest")
+            event = torch.cuda.Event()
+            event.record(side)
+        for t in (H, g, low, info, dpc, nu):
+            t.record_stream(side)
+    else:
+        work = _newton_work("rest", n, G, dev, lib.oovqe_newton_direction_rest_work_size(n, G))
+        check(lib.oovqe_newton_direction_rest(dptr(H), dptr(g), n, G, *args, dptr(info), 0, int(max_wg), dptr(work),
+                                              dptr(dpc), dptr(low), dptr(nu), stream_ptr()),
+              "oovqe_newton_direction_rest")
     if single:
-        return dpc[0], low[0], nu[0]
+        dpc, low, nu = dpc[0], low[0], nu[0]
+    if defer_lowest:
+        low = PendingLowest(low, event)
+    elif event is not None:
+        torch.cuda.current_stream().wait_event(event)
+    if want_info:
+        return dpc, low, nu, info
     return dpc, low, nu

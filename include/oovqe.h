@@ -282,17 +282,51 @@ int oovqe_circuit_hessian_assemble(const double* gamma, const double* Gamma, con
  * replaces NewtonStep.newton_step (src/auto_oo/utils/newton_raphson.py:78-129): lowest eigenvalue
  * of the (n_theta + n_kappa)^2 Hessian, level shift nu = mu + rho |lambda_low| when
  * lambda_low < lambda_min and aug != 0 (the reference's augmented Hessian, :107-120), and
- * dp = -(H + nu I)^-1 g (:121-128), for `batch` independent problems, one workgroup each:
- * blocked Householder tridiagonalisation + Sturm multisection + pivoted tridiagonal solve.
- * hessian [batch,n,n] (symmetric, not modified), gradient [batch,n], dp [batch,n],
+ * dp = -(H + nu I)^-1 g (:121-128), for `batch` independent problems.
+ * hessian [batch,n,n] (symmetric, lower triangle read, not modified), gradient [batch,n], dp [batch,n],
  * lowest_eigenvalue [batch], shift [batch] (nu; may be NULL); n <= oovqe_newton_direction_max_n();
- * work: oovqe_newton_direction_work_size(n, batch) doubles. */
+ * work: oovqe_newton_direction_work_size(n, batch) doubles.
+ * One call = the positive-definite fast path below (aug != 0, n <= oovqe_newton_direction_pd_max_n()) followed
+ * by the band-reduction route, which then only adds the lowest eigenvalue of the problems the fast path
+ * served and does everything for the others.  Failures are loud: dp = NaN (see `info` below). */
 int oovqe_newton_direction(const double* hessian, const double* gradient, int n, int batch,
                            double lambda_min, double mu, double rho, int aug, double* work,
                            double* dp, double* lowest_eigenvalue, double* shift,
                            oovqe_stream_t stream);
 int64_t oovqe_newton_direction_work_size(int n, int batch);
 int oovqe_newton_direction_max_n(void);
+/* The same in two calls, so that the caller can keep the eigenvalue of a positive definite Hessian -- a
+ * reported number the line search never reads (newton_raphson.py:105-128: dp depends on lambda_low only when
+ * lambda_low < lambda_min) -- off the critical path, e.g. on a second stream:
+ *
+ * oovqe_newton_direction_pd: blocked Cholesky of H (and of H - lambda_min I, the test "the reference would not
+ * shift"), one workgroup per factorisation, no workgroup ever waits for another.  info[b] = 1: dp[b] =
+ * -H^-1 g and shift[b] = 0 are final; info[b] = 0: not positive definite above lambda_min, dp[b] untouched.
+ * work: oovqe_newton_direction_pd_work_size(n, batch) doubles.  n <= oovqe_newton_direction_pd_max_n().
+ *
+ * oovqe_newton_direction_rest: the band-reduction route (lowest eigenvalue by multisection, level shift, band
+ * solve) under the fast path's verdict.  info may be NULL (every problem in full).  which = 0: every problem
+ * (lowest eigenvalue only where info[b] == 1); 1: only the problems with info[b] != 1 (the others are not
+ * touched: `lowest_eigenvalue` keeps its content); 2: only the lowest eigenvalue of the problems with
+ * info[b] == 1.  max_wg: 0, or an upper bound on the workgroups per problem (1: no workgroup waits for
+ * another -- the retry after a timed-out hand-off).  On return info[b] (when given) is 1 / 0 as before,
+ * 2 = direction from the fast path but its eigenvalue could not be computed (NaN), -1 = a hand-off between
+ * workgroups timed out (their co-residency was not granted: dp, lowest, shift = NaN; repeat with max_wg = 1),
+ * -2 = aug == 0 (or lambda_min <= 0) and an indefinite Hessian beyond the pivoted one-workgroup kernel
+ * (n > 480): dp = NaN, lowest_eigenvalue valid; -3 = the Hessian holds a NaN or an Inf (all outputs NaN).
+ * work: oovqe_newton_direction_rest_work_size(n, batch) doubles (its own: not shared with a concurrent call). */
+int oovqe_newton_direction_pd(const double* hessian, const double* gradient, int n, int batch,
+                              double lambda_min, double* work, double* dp, double* shift, double* info,
+                              oovqe_stream_t stream);
+int64_t oovqe_newton_direction_pd_work_size(int n, int batch);
+int oovqe_newton_direction_pd_max_n(void);
+/* 1 when oovqe_newton_direction(n, aug) itself runs the fast path in front of the band route */
+int oovqe_newton_direction_has_pd(int n, int aug);
+int oovqe_newton_direction_rest(const double* hessian, const double* gradient, int n, int batch,
+                                double lambda_min, double mu, double rho, int aug, double* info, int which,
+                                int max_wg, double* work, double* dp, double* lowest_eigenvalue,
+                                double* shift, oovqe_stream_t stream);
+int64_t oovqe_newton_direction_rest_work_size(int n, int batch);
 
 /* The theta-theta block in one call: the five launches above chained (state + tangents, second
  * tangents, operand lists, transition RDMs, contraction).  pairs [n_pairs][2] with j <= k; H

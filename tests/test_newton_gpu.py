@@ -458,3 +458,131 @@ def test_batched_newton_step_equals_per_geometry_steps():
                                                            ooo.full_gradient(th), ooo.full_hessian(th))
     assert abs(low[0].item() - low_r) < 1e-9
     assert abs(e_new[0].item() - ooo.energy_from_parameters(new_r[0], new_r[1]).item()) < 1e-9
+
+
+def _pd_stack(rng, n, G, low=0.05):
+    out = []
+    for k in range(G):
+        A = rng.standard_normal((n, n))
+        Q, _ = np.linalg.qr(A)
+        ev = np.sort(rng.uniform(low, 4.0, n))
+        ev[0] = low * (1.0 + 0.1 * k)
+        out.append((Q * ev) @ Q.T)
+    S = np.stack(out)
+    return 0.5 * (S + S.transpose(0, 2, 1))
+
+
+@pytest.mark.parametrize("n,G", [(331, 1), (331, 8), (331, 64), (100, 5), (33, 7), (17, 3), (16, 2), (15, 2), (2, 3),
+                                 (1, 1), (479, 2), (495, 2)])
+def test_cholesky_fast_path_vs_band_route_and_numpy(n, G):
+    """Positive definite Hessians (the reference does not shift: newton_raphson.py:107-128): the direction of
+    the Cholesky fast path (newton_chol.hip) against numpy's solve and against the band route (debug option
+    newton_no_chol), info == 1, no shift; the lowest eigenvalue -- band route on the side stream -- equals the
+    one-route value bit for bit."""
+    rng = np.random.default_rng(17 * n + G)
+    Hn = _pd_stack(rng, n, G)
+    gn = rng.standard_normal((G, n))
+    Hs, gs = torch.tensor(Hn).cuda(), torch.tensor(gn).cuda()
+    dp, low, nu, info = ops.newton_direction(Hs, gs, want_info=True)
+    assert info.tolist() == [1.0] * G and float(nu.abs().max()) == 0.0
+    with aoo._lib.debug_options(newton_no_chol=1):
+        dpb, lowb, nub, infob = ops.newton_direction(Hs, gs, want_info=True)
+    assert infob.tolist() == [0.0] * G
+    assert torch.equal(low, lowb)
+    for k in range(G):
+        ref = -np.linalg.solve(Hn[k], gn[k])
+        cond = np.linalg.cond(Hn[k])
+        tol = 1e-14 * cond * (1.0 + np.abs(ref).max()) * max(n, 8)
+        assert np.abs(dp[k].cpu().numpy() - ref).max() <= tol, (k, np.abs(dp[k].cpu().numpy() - ref).max(), tol)
+        assert (dp[k] - dpb[k]).abs().max().item() <= 10 * tol
+        assert abs(low[k].item() - np.linalg.eigvalsh(Hn[k])[0]) < 1e-12 * n
+    # one problem alone and the deferred form give the same bits as the batch
+    d0, l0, _ = ops.newton_direction(Hs[0], gs[0], defer_lowest=True)
+    assert torch.equal(d0, dp[0]) and abs(l0.result().item() - low[0].item()) < 1e-12 * n
+
+
+def test_fast_path_decision_walks_across_lambda_min():
+    """The fast path's verdict is the reference's branch (newton_raphson.py:107): lowest eigenvalue above
+    lambda_min -> plain -H^-1 g from the Cholesky factor; below it (still positive, or negative) -> level
+    shift through the band route.  Walking the lowest eigenvalue across lambda_min, both sides of the branch
+    reproduce the oracle's step, in one batch."""
+    rng = np.random.default_rng(5)
+    n, lam_min = 120, 1e-6
+    lows = [1.0, 1e-3, 1e-5, 2e-6, 1.2e-6, 1.01e-6, 0.99e-6, 0.8e-6, 1e-7, 0.0, -1e-7, -0.3]
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    Hn = []
+    for lo in lows:
+        ev = np.linspace(0.4, 2.0, n)
+        ev[0] = lo
+        S = (Q * ev) @ Q.T
+        Hn.append(0.5 * (S + S.T))
+    Hn = np.stack(Hn)
+    gn = rng.standard_normal((len(lows), n))
+    dp, low, nu, info = ops.newton_direction(torch.tensor(Hn).cuda(), torch.tensor(gn).cuda(), want_info=True)
+    for k, lo in enumerate(lows):
+        # (the constructed eigenvalue is only exact to ~1e-16 * |H|: keep a margin around the threshold)
+        if lo > lam_min * 1.005:
+            assert info[k].item() == 1.0 and nu[k].item() == 0.0
+        if lo < lam_min * 0.995:
+            assert info[k].item() == 0.0
+            assert abs(nu[k].item() - (1e-6 + 1.1 * abs(low[k].item()))) < 1e-18 + 1e-12 * abs(nu[k].item())
+        dr, lr = _reference_direction(torch.tensor(Hn[k]), torch.tensor(gn[k]))
+        assert abs(low[k].item() - lr) < 1e-13
+        shift = nu[k].item()
+        Hs = Hn[k] + shift * np.eye(n)
+        cond = np.linalg.cond(Hs)
+        assert np.abs(dp[k].cpu().numpy() - dr.numpy()).max() <= 1e-13 * cond * (1.0 + np.abs(dr.numpy()).max()) * n
+
+
+@pytest.mark.parametrize("n", [500, 700])
+def test_indefinite_hessian_without_level_shift_beyond_the_pivoted_kernel(n):
+    """aug = False inverts an indefinite Hessian as it stands (newton_raphson.py:107: the shift is skipped).
+    Beyond the one-workgroup kernel with its pivoted solve (n > 480) the band LDL^T has no pivoting, so the
+    library refuses loudly (info = -2, dp = NaN, lowest eigenvalue valid) and NewtonStep falls back to eigh;
+    a positive definite Hessian still goes through."""
+    rng = np.random.default_rng(n)
+    H = torch.tensor(_sym(rng, n, "indefinite"))
+    g = torch.tensor(rng.standard_normal(n))
+    dp, low, nu, info = ops.newton_direction(H.cuda(), g.cuda(), aug=False, want_info=True)
+    assert info.item() == -2.0 and bool(torch.isnan(dp).all())
+    dr, lr = _reference_direction(H, g, aug=False)
+    assert abs(low.item() - lr) < 1e-11 * n
+    opt = aoo.NewtonStep(aug=False, verbose=0)
+    dpn, lown = opt.newton_step(g.cuda(), H.cuda())
+    cond = float(torch.linalg.cond(H))
+    assert (dpn.cpu() - dr).abs().max() <= 1e-13 * cond * (1.0 + dr.abs().max()) * n
+    assert abs(lown - lr) < 1e-11 * n
+    Hp = torch.tensor(_sym(rng, n, "pd"))
+    dpp, lowp, _, infop = ops.newton_direction(Hp.cuda(), g.cuda(), aug=False, want_info=True)
+    assert infop.item() == 0.0
+    drp, lrp = _reference_direction(Hp, g, aug=False)
+    assert (dpp.cpu() - drp).abs().max() < 1e-9 * (1 + drp.abs().max()) and abs(lowp.item() - lrp) < 1e-11
+
+
+def test_non_finite_hessian_raises_instead_of_returning_nan_parameters():
+    """A Hessian with an Inf (or NaN) in it must not come back as NaN parameters: the damped Newton step
+    raises, single and batched."""
+    rng = np.random.default_rng(3)
+    n = 40
+    H = torch.tensor(_sym(rng, n, "pd"))
+    g = torch.tensor(rng.standard_normal(n)).cuda()
+    x0 = torch.zeros(n, dtype=torch.float64, device="cuda")
+    Hg = H.cuda()
+    fn = lambda x: 0.5 * x @ (Hg @ x) + g @ x                      # noqa: E731
+    for bad in (float("inf"), float("nan")):
+        Hb = H.clone()
+        Hb[3, 2] = Hb[2, 3] = bad
+        with pytest.raises((aoo._lib.OovqeError, AssertionError)):
+            aoo.NewtonStep(verbose=0).damped_newton_step(fn, (x0,), g, Hb.cuda())
+        with pytest.raises((aoo._lib.OovqeError, AssertionError)):
+            aoo.BatchedNewtonStep(verbose=0).damped_newton_steps_flat(
+                lambda pts: torch.stack([fn(p) for p in pts]), x0[None].repeat(2, 1), g[None].repeat(2, 1),
+                torch.stack((H, Hb)).cuda())
+    # and a NaN trial energy is never accepted: the step backtracks and finally keeps the old parameters
+    calls = []
+
+    def nan_objective(x):
+        calls.append(1)
+        return fn(x) if float(x.abs().max()) == 0.0 else torch.tensor(float("nan"), dtype=torch.float64, device="cuda")
+    new, _ = aoo.NewtonStep(verbose=0, lmax=3).damped_newton_step(nan_objective, (x0,), g, Hg)
+    assert float(new.abs().max()) == 0.0 and len(calls) >= 4
