@@ -178,6 +178,12 @@ SIGNATURES = {
                                               ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p,
                                               ctypes.c_uint, c_double_p, c_stream]),
     "oovqe_oo_hessian_work_size": (ctypes.c_int64, [ctypes.c_int] * 7),
+    "oovqe_linesearch_points": (ctypes.c_int, [c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_double,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
+                                               c_double_p, c_stream]),
+    "oovqe_linesearch_update": (ctypes.c_int, [c_double_p, ctypes.c_int64, c_double_p, c_double_p, c_double_p,
+                                               ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               c_double_p, c_double_p, c_double_p, c_double_p, c_stream]),
     "oovqe_rotate_orbitals_batch": (ctypes.c_int, [c_double_p, c_int32_p, c_int32_p, ctypes.c_int,
                                                    ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
                                                    c_double_p, c_double_p, c_stream]),

@@ -222,8 +222,11 @@ class OO_pqc_batch:
     def rotate_(self, kappas):
         """oao_mo_coeff[g] <- oao_mo_coeff[g] @ expm(-K(kappas[g])) for every geometry (the update of
         oo_pqc.py:191) and mo_coeff = S^-1/2 C_oao refreshed."""
-        new = self._rotate(self.oao_mo_coeff, kappas, torch.empty_like(self.oao_mo_coeff))
-        self.oao_mo_coeff.copy_(new)
+        if self.nao <= 48:      # (one workgroup per geometry, all in LDS: the result may overwrite its input)
+            self._rotate(self.oao_mo_coeff, kappas, self.oao_mo_coeff)
+        else:
+            new = self._rotate(self.oao_mo_coeff, kappas, torch.empty_like(self.oao_mo_coeff))
+            self.oao_mo_coeff.copy_(new)
         self.refresh_mo_coeff()
 
     # ---- configs[3]'s unit of work, batched -----------------------------------------------------------
@@ -279,11 +282,12 @@ class OO_pqc_batch:
         nt = self.n_theta
         thetas = ops.as_device(thetas, self.device).reshape(self.G, nt)
         E, grad, H = self.energy_gradient_hessian(thetas)
-        flat = torch.cat((thetas, torch.zeros((self.G, self.n_kappa), dtype=F64, device=self.device)), dim=1)
-        new, low = opt.damped_newton_steps_flat(
-            lambda pts: self.energy(pts[:, :nt].contiguous(), pts[:, nt:].contiguous()), flat, grad, H,
-            energy0=E, defer_lowest=True)
-        self.rotate_(new[:, nt:].contiguous())
-        new_thetas = new[:, :nt].contiguous()
-        energies = self.energy(new_thetas)
+        flat = torch.zeros((self.G, nt + self.n_kappa), dtype=F64, device=self.device)
+        flat[:, :nt] = thetas
+        # the energy at the accepted trial point IS the energy at the new parameters (the same orbitals
+        # C expm(-K), formed once as mo_coeff U and once as S^-1/2 (C_oao U): equal to rounding), so the loop
+        # body's closing evaluation (oo_pqc.py:195) is not repeated
+        (new_thetas, new_kappas), low, energies = opt.damped_newton_steps_flat(
+            self.energy, flat, grad, H, energy0=E, defer_lowest=True, split=nt, return_energy=True)
+        self.rotate_(new_kappas)
         return new_thetas, energies, (low if defer_lowest else low.result())

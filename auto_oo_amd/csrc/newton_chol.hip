@@ -17,22 +17,31 @@
 //   newton.hip (lowest eigenvalue, level shift, band solve) computes the direction as before.
 //   The two workgroups never wait for each other: nothing here needs co-residency.
 //
-// The factorisation is right-looking over 16-column panels.  The panel being factored lives in LDS (two
-// buffers: the trailing update writes the next panel's column straight into the other buffer, so the
-// per-panel chain never goes through memory); the rest of the trailing matrix is a working copy in global
-// memory that every wave only re-reads where it wrote itself (tile (i, j) belongs to wave (i mod 4, j mod 2)
-// for the whole factorisation).  Per panel:
-//   D  (wave 0)  Cholesky of the 16 x 16 diagonal tile in registers, lane c <-> column c, the whole tile kept
-//                symmetric so that every operand of a step is either the lane's own register or a
-//                `v_readlane` of the pivot lane: no LDS round trip inside the 16 steps;
-//   S  (a thread per row below the tile)  x = a L_kk^-T by forward substitution against broadcast reads of L_kk;
-//   U  (all waves)  C_ij -= L_i L_j^T on the fp64 matrix cores (K = 16: four v_mfma_f64_16x16x4 per tile, the
-//                operand fragments two ds_read_b128 each from the panel buffer, pitch 18 doubles:
-//                conflict-free).
-// The factor overwrites the working copy's lower triangle; the back substitution reads its block rows from
-// there (column-oriented: thread c owns y[c], no reductions), the 16 x 16 transposed solves again by readlane.
+// The factorisation is LEFT-looking over 16-column panels with one panel of look-ahead (the first version
+// was right-looking: its trailing update re-read and re-wrote the whole working copy once per panel and was
+// bound by that traffic, 320 us; this one 187 us at n = 331).  Six waves own the row tiles of a panel and
+// keep them in registers from the first contribution to the last; the factor is only ever appended to.
+// Per panel k:
+//   1  (the six accumulating waves)  the last contribution, p = k - 1, from the previous panel's buffer in LDS,
+//      plus the matrix' own tile; panel k goes into its LDS buffer (two buffers, alternating);
+//   2  (wave 0)  D: Cholesky of the 16 x 16 diagonal tile AND the inverse X of its factor, in registers, lane c
+//      <-> column c, the tile kept symmetric so that every operand of a step is either the lane's own register
+//      or a `v_readlane` of the pivot lane -- no LDS round trip inside the 16 steps; square-root-free
+//      recurrences, so that the chain from pivot to pivot is readlane -> reciprocal -> multiply -> fma;
+//      (the others, meanwhile)  panel k + 1 already: acc = - sum_{p < k} L_ip L_k+1,p^T on the fp64 matrix cores,
+//      both operands straight from the factor in memory, which is stored tile by tile in FRAGMENT order (a
+//      wave's 16-byte load = one contiguous KB; row-major tiles streamed at a sixth of the rate), the next
+//      panel's operands in flight under the products of the current one;
+//   3  (all)  S: the row tiles below the diagonal, L_i = A_i X^T as one matrix-core product each (the inverse
+//      instead of a substitution: a thread per row spent its time on broadcast reads of L_kk), written back
+//      into the panel buffer and appended to the factor (both operand orders).
+// The matrix cores deliver D[m][n] to lane (n, lq) as rows m = lq + 4 e; with the A operand's rows permuted
+// (c_pi) the lane holds four ADJACENT columns of one row: 16-byte accesses everywhere.
+// Back substitution: column-oriented (thread c owns y[c], no reductions), the 16 x 16 transposed solves are
+// mat-vecs with the stored inverses, y of a block by readlane.
 #include "common.h"
 #include <math.h>
+#include <type_traits>
 
 int oovqe_newton_chol_launch(const double* hessian, const double* gradient, int n, int batch, double lambda_min,
                              double* work, double* dp, double* shift, double* info, hipStream_t st);
@@ -56,8 +65,14 @@ __device__ long long g_chol_cycles[16];
 
 namespace {
 
-constexpr int CT = 512;              // threads per workgroup: 8 waves, two per SIMD (256 registers each)
+#ifndef OOVQE_CHOL_CT
+#define OOVQE_CHOL_CT 512
+#endif
+constexpr int CT = OOVQE_CHOL_CT;    // threads per workgroup: 8 waves, two per SIMD (256 registers each) -- or 16, four per SIMD
 constexpr int CWV = CT / 64;
+constexpr int WJ = CWV / 4;          // tile (i, j) belongs to wave (i % 4) * WJ + j % WJ
+constexpr int NBT = CT == 512 ? 4 : 2;   // trailing tiles per batch of a wave (two batches in flight)
+constexpr int NST = CT == 512 ? 8 : 4;   // interior tiles per staging batch
 constexpr int CP = 18;               // pitch of a panel row in LDS (doubles): 16-byte aligned rows, conflict-free fragments
 constexpr int NCHOL_MAX = 495;       // n + 1 <= 496 rows = 31 tiles: two panel buffers of 496 x 18 doubles = 143 KB
 constexpr int C_SC1 = 16;            // buffer aux bit sc1: loads bypass the L1
@@ -65,6 +80,9 @@ constexpr int C_SC1 = 16;            // buffer aux bit sc1: loads bypass the L1
 typedef unsigned c_v2u __attribute__((ext_vector_type(2)));
 
 struct CholLds { int P0, P1, yv, xb, flag, total; };
+
+// doubles of one factorisation's workspace: La, Lb (T x T tiles of 256) and Xw (T tiles)
+__host__ __device__ inline size_t chol_factor_doubles(int T) { return (size_t)(2 * T * T + T) * 256; }
 
 __host__ __device__ inline CholLds chol_lds(int n)
 {
@@ -200,6 +218,8 @@ __device__ __forceinline__ bool chol_diag16(double* __restrict__ cur, double* __
     return ok;
 }
 
+// NTW: row tiles of a panel per accumulating wave: ceil(T / 6) <= NTW; DEPTH: operand panels in flight
+template <int NTW, int DEPTH>
 __global__ __launch_bounds__(CT)
 void newton_chol_kernel(const double* __restrict__ H, const double* __restrict__ g, int n, double lambda_min,
                         double* __restrict__ work, double* __restrict__ dp, double* __restrict__ shift,
@@ -211,12 +231,20 @@ void newton_chol_kernel(const double* __restrict__ H, const double* __restrict__
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane >> 4, lr = lane & 15;
     const int prob = blockIdx.x / roles, role = blockIdx.x - prob * roles;
-    const int T = (n + 1 + 15) >> 4, npv = 16 * T, lda = npv;
+    const int T = (n + 1 + 15) >> 4, npv = 16 * T;
     const double sigma = role == 0 ? 0.0 : lambda_min;
     const double* Hb = H + (size_t)prob * n * n;
     const double* gb = g + (size_t)prob * n;
-    double* Aw = work + (size_t)blockIdx.x * npv * npv;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(Aw, 0, npv * npv * 8, 0x00020000);
+    // The factor lives in memory tile by tile in FRAGMENT order, twice: in tile (i, p) of Lb the 32 bytes of
+    // lane l = lr + 16 lq are row lr, columns 4 lq .. + 3 of L_ip (the B operand and the accumulator layout), in
+    // La they are row PI(lr) (the A operand).  Either way a wave's 16-byte load is one contiguous KB -- with
+    // row-major tiles the 64 lanes of a load touch 16 cache lines, four lanes each, and the factor streamed at
+    // a sixth of the rate.  Xw: the inverses of the diagonal tiles, row-major (the back substitution).
+    const size_t fsz = chol_factor_doubles(T);
+    double* Aw = work + (size_t)blockIdx.x * fsz;
+    const unsigned la_off = 0u, lb_off = (unsigned)(T * T * 256), xw_off = 2u * (unsigned)(T * T * 256);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(Aw, 0, (int)(fsz * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Hb), 0, n * n * 8, 0x00020000);
     double* P0 = sm + L.P0;
     double* P1 = sm + L.P1;
     double* yv = sm + L.yv;
@@ -226,9 +254,9 @@ void newton_chol_kernel(const double* __restrict__ H, const double* __restrict__
     // element (r, c) of the matrix being factored: [[H - sigma I, -g], [-g^T, 1]] padded with an identity
     // (the lower triangle of H is what eigh reads in the reference: torch.linalg.eigh, UPLO = 'L').
     // Branch-free: both loads are issued whatever (r, c) is (clamped addresses) and combined with 0 / 1
-    // weights -- a select on a loaded value is compiled to a branch around the load, and a staging pass whose
-    // loads wait for each other one by one costs more than the whole factorisation.  (A NaN or an Inf in H
-    // or g may therefore leak into the padding: the factorisation then fails, as it must.)
+    // weights -- a select on a loaded value is compiled to a branch around the load, and loads that wait for
+    // each other one by one cost more than the whole factorisation.  (A NaN or an Inf in H or g may
+    // therefore leak into the padding: the factorisation then fails, as it must.)
     const int nm1 = n - 1;
     auto elem = [&](int r, int c) -> double {
         const int hi = r > c ? r : c, lo = r > c ? c : r;
@@ -244,87 +272,165 @@ void newton_chol_kernel(const double* __restrict__ H, const double* __restrict__
 #ifdef OOVQE_CHOL_TIMING
     long long t_mark = clock64();
 #endif
-    const int wi = wave >> 1, wj = wave & 1;        // the wave owns the tiles (i, j) with i % 4 == wi, j % 2 == wj
     const int prow = c_pi(lr);
+    const unsigned lofs = (unsigned)(2 * lane);                 // the lane's 16 bytes in a half tile of the factor
+    const unsigned lofs_p = (unsigned)(2 * (prow + 16 * lq));   // ... of the lane that holds this lane's row in La
+    const unsigned lofs_h = (unsigned)(lr * n + 4 * lq);
+    constexpr unsigned NOWHERE = 0x10000000u;                   // an element offset beyond every buffer: loads give 0, stores are dropped
     if (tid == 0) flag[0] = 0;
     for (int idx = tid; idx < npv; idx += CT) yv[idx] = 0.0;
-    // ---- staging: every wave brings its own tiles of the lower block triangle in, lane (lr, lq) <-> row
-    // 16 i + lr, columns 16 j + 4 lq .. + 3 (the layout of phase U): column 0 into the first panel buffer, the
-    // others into the working copy.  Two passes, each straight-line per batch (so that all loads of a batch
-    // are in flight together): interior tiles (0 < j < i < T - 1) are plain H, two 16-byte loads, eight tiles
-    // per batch; the others (column 0, the diagonal, the last tile row) go element by element.
-    const unsigned lofs_g = (unsigned)(lr * lda + 4 * lq);          // lane part of a tile's offset in the working copy
-    {
-        const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Hb), 0, n * n * 8, 0x00020000);
-        const unsigned lofs_h = (unsigned)(lr * n + 4 * lq);
-        const int js = wj == 0 ? 2 : 1;             // first column >= 1 of this wave
-        int ti = wi, tj = js;
-        while (ti < T - 1 && tj >= ti) { ti += 4; tj = js; }
-        while (ti < T - 1) {
-            unsigned ho[8], go[8];
-            d2 lo[8], hi[8];
+
+    // Left-looking over 16-column panels, one panel of look-ahead.  Six waves own the row tiles of a panel
+    // (tile i of panel kp belongs to accumulating wave (i - kp) % 6) and keep them in registers from the first
+    // contribution to the last: acc = - sum_{p < kp} L_ip L_kp,p^T, with both operands straight from the factor
+    // in memory in fragment layout (two 16-byte loads per operand and panel p, the next p in flight under
+    // the products of the current one; the A operand is the same for all waves: L1 hits).  While wave 0
+    // factors the diagonal tile of panel k (phase 2), the others already accumulate panel k + 1 over p < k;
+    // the last contribution (p = k) comes from the panel buffer in LDS once phase 3 has produced it.
+    // (wave 4 shares its SIMD with wave 0 -- a workgroup's waves go round the four SIMDs -- and every matrix-core
+    // instruction it issued would hold up the vector instructions of the diagonal-tile factorisation: it sits
+    // the accumulation out, like wave 0)
+    constexpr int NBW = CWV - 2;                    // accumulating waves
+    const int bw = wave == 0 || wave == 4 ? -1 : (wave < 4 ? wave - 1 : wave - 2);
+    auto tile_of = [&](int kp, int u) -> int { return bw < 0 ? T : kp + bw + NBW * u; };
+    d4 acc[NTW], atile[NTW];
+    auto load_a = [&](int kp) {                     // the tiles (i, kp) of the matrix itself
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool live = ti < T - 1;
-                ho[u] = live ? (unsigned)(16 * ti * n + 16 * tj) + lofs_h : 0x10000000u;
-                go[u] = live ? (unsigned)(16 * ti * lda + 16 * tj) + lofs_g : 0x10000000u;
-                if (live) {
-                    tj += 2;
-                    while (ti < T - 1 && tj >= ti) { ti += 4; tj = js; }
-                }
-            }
+        for (int u = 0; u < NTW; ++u) {
+            const int i = tile_of(kp, u);
+            if (i < T - 1 && i != kp) {
+                const unsigned he = ((unsigned)(16 * i * n + 16 * kp) + lofs_h) * 8u;
+                const d2 lo = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rh, he, 0, 0));
+                const d2 hi = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rh, he + 16u, 0, 0));
+                atile[u][0] = lo.x; atile[u][1] = lo.y; atile[u][2] = hi.x; atile[u][3] = hi.y;
+            } else if (i < T) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                lo[u] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rh, ho[u] * 8u, 0, 0));
-                hi[u] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rh, ho[u] * 8u + 16u, 0, 0));
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                c_st2(ra, go[u], lo[u]);
-                c_st2(ra, go[u] + 2, hi[u]);
+                for (int e = 0; e < 4; ++e) atile[u][e] = elem(16 * i + lr, 16 * kp + 4 * lq + e);
+            } else {
+                atile[u] = d4{0.0, 0.0, 0.0, 0.0};
             }
         }
-        // the other tiles of this wave: (i, 0), (i, i), (T - 1, j)
-        for (int i = wi; i < T; i += 4)
-            for (int j = wj; j <= i; j += 2) {
-                if (!(j == 0 || j == i || i == T - 1)) continue;
-                d4 c4;
+    };
+    // acc -= sum_{p < pend} L_ip L_kp,p^T for the NT live tiles of this wave in panel kp (NT a compile-time
+    // constant: a tile slot beyond the matrix would cost its four products per panel all the same)
+    auto bulk = [&](auto nt_c, int kp, int pend) {
+        constexpr int NT = decltype(nt_c)::value;
+        struct Frag { d2 a01, a23, b01[NT], b23[NT]; };
+        const unsigned ao = la_off + (unsigned)(kp * T * 256) + lofs;
+        unsigned bo[NT];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) c4[e] = elem(16 * i + lr, 16 * j + 4 * lq + e);
-                d2 l2, h2; l2.x = c4[0]; l2.y = c4[1]; h2.x = c4[2]; h2.y = c4[3];
-                if (j == 0) {
-                    double* np = P0 + (16 * i + lr) * CP + 4 * lq;
-                    *reinterpret_cast<d2*>(np) = l2;
-                    *reinterpret_cast<d2*>(np + 2) = h2;
-                } else {
-                    const unsigned ge = (unsigned)(16 * i * lda + 16 * j) + lofs_g;
-                    c_st2(ra, ge, l2);
-                    c_st2(ra, ge + 2, h2);
-                }
+        for (int u = 0; u < NT; ++u) bo[u] = lb_off + (unsigned)(tile_of(kp, u) * T * 256) + lofs;
+        auto fetch = [&](Frag& f, int p) {
+#if defined(OOVQE_CHOL_PROBE) && (OOVQE_CHOL_PROBE & 2)
+            const unsigned po = NOWHERE + (unsigned)(p - p);
+#else
+            const unsigned po = p < pend ? (unsigned)(256 * p) : NOWHERE;
+#endif
+            f.a01 = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(ra, (ao + po) * 8u, 0, 0));
+            f.a23 = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(ra, (ao + po) * 8u + 1024u, 0, 0));
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                f.b01[u] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(ra, (bo[u] + po) * 8u, 0, 0));
+                f.b23[u] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(ra, (bo[u] + po) * 8u + 1024u, 0, 0));
             }
-    }
-    __syncthreads();
+        };
+        auto mma = [&](const Frag& f) {
+#if defined(OOVQE_CHOL_PROBE) && (OOVQE_CHOL_PROBE & 4)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) { acc[u][0] += f.a01.x * f.b01[u].x; acc[u][1] += f.a01.y * f.b01[u].y; acc[u][2] += f.a23.x * f.b23[u].x; acc[u][3] += f.a23.y * f.b23[u].y; }
+            return;
+#endif
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc[u] = mfma_f64(-f.a01.x, f.b01[u].x, acc[u]);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc[u] = mfma_f64(-f.a01.y, f.b01[u].y, acc[u]);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc[u] = mfma_f64(-f.a23.x, f.b23[u].x, acc[u]);
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc[u] = mfma_f64(-f.a23.y, f.b23[u].y, acc[u]);
+        };
+        // DEPTH - 1 panels of operands in flight per wave; panels beyond pend are fetched from nowhere (zeros) and
+        // never multiplied
+        Frag f[DEPTH];
+#pragma unroll
+        for (int j = 0; j < DEPTH - 1; ++j) fetch(f[j], j);
+        for (int p = 0; p < pend; p += DEPTH) {
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j) {
+                fetch(f[(j + DEPTH - 1) % DEPTH], p + j + DEPTH - 1);
+                if (p + j < pend) mma(f[j]);
+            }
+        }
+    };
+    auto bulk_live = [&](int kp, int pend) {        // dispatch on the number of live tiles of this wave in panel kp
+        const int live = bw < 0 || kp + bw >= T ? 0 : (T - 1 - kp - bw) / NBW + 1;
+        if (live == 1) bulk(std::integral_constant<int, 1>{}, kp, pend);
+        else if (live == 2) bulk(std::integral_constant<int, 2>{}, kp, pend);
+        else if (live == 3) bulk(std::integral_constant<int, (NTW >= 3 ? 3 : 1)>{}, kp, pend);
+        else if (live == 4) bulk(std::integral_constant<int, (NTW >= 4 ? 4 : 1)>{}, kp, pend);
+        else if (live >= 5) bulk(std::integral_constant<int, NTW>{}, kp, pend);
+    };
+
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) acc[u] = d4{0.0, 0.0, 0.0, 0.0};
+    load_a(0);
     CH_MARK(0);
 
     for (int k = 0; k < T; ++k) {
         double* cur = (k & 1) ? P1 : P0;            // rows 16 k .. npv - 1 of the panel, buffer row 0 = matrix row 16 k
-        double* nxt = (k & 1) ? P0 : P1;
-        // ---- D: the diagonal tile -> X = L_kk^-1 in the head of cur
+        const double* prv = (k & 1) ? P0 : P1;      // panel k - 1: buffer row 0 = matrix row 16 (k - 1)
+        // ---- phase 1: the last contribution (p = k - 1, from the panel buffer), the matrix' own tile, and
+        // panel k goes into its buffer
+        if (bw >= 0) {
+            const double* ap = prv + (16 + prow) * CP + 4 * lq;            // L_k,k-1, rows permuted
+            d2 a01 = {0.0, 0.0}, a23 = {0.0, 0.0};
+            if (k > 0) { a01 = *reinterpret_cast<const d2*>(ap); a23 = *reinterpret_cast<const d2*>(ap + 2); }
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) {
+                const int i = tile_of(k, u);
+                if (i < T) {
+                    d4 c4 = acc[u];
+                    if (k > 0) {
+                        const double* bp = prv + (16 * (i - k + 1) + lr) * CP + 4 * lq;
+                        const d2 b01 = *reinterpret_cast<const d2*>(bp), b23 = *reinterpret_cast<const d2*>(bp + 2);
+                        c4 = mfma_f64(-a01.x, b01.x, c4);
+                        c4 = mfma_f64(-a01.y, b01.y, c4);
+                        c4 = mfma_f64(-a23.x, b23.x, c4);
+                        c4 = mfma_f64(-a23.y, b23.y, c4);
+                    }
+                    c4 += atile[u];
+                    d2 lo, hi; lo.x = c4[0]; lo.y = c4[1]; hi.x = c4[2]; hi.y = c4[3];
+                    double* np = cur + (16 * (i - k) + lr) * CP + 4 * lq;
+                    *reinterpret_cast<d2*>(np) = lo;
+                    *reinterpret_cast<d2*>(np + 2) = hi;
+                }
+            }
+        }
+        CH_MARK(5);
+        __syncthreads();
+        CH_MARK(6);
+        // ---- phase 2: wave 0 factors the diagonal tile (-> X = L_kk^-1 in the head of cur); the others start on
+        // panel k + 1: its own tiles of the matrix and every contribution that is already final (p < k)
         if (wave == 0) {
 #ifdef OOVQE_CHOL_PROBE
             // (ablation builds compute wrong numbers: no pivot is tested, so that the run keeps its full length)
-            const bool ok = chol_diag16(cur, yv, 16 * k, 0, lane, Aw + (size_t)16 * k * lda + 16 * k, lda);
+            const bool ok = chol_diag16(cur, yv, 16 * k, 0, lane, Aw + xw_off + (size_t)k * 256, 16);
 #else
-            const bool ok = chol_diag16(cur, yv, 16 * k, n, lane, Aw + (size_t)16 * k * lda + 16 * k, lda);
+            const bool ok = chol_diag16(cur, yv, 16 * k, n, lane, Aw + xw_off + (size_t)k * 256, 16);
 #endif
             if (!ok && lane == 0) flag[0] = 1;
+        } else if (k + 1 < T && bw >= 0) {
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) acc[u] = d4{0.0, 0.0, 0.0, 0.0};
+            load_a(k + 1);
+            bulk_live(k + 1, k);
         }
         CH_MARK(1);
         __syncthreads();
         CH_MARK(2);
         if (flag[0]) break;
-        // ---- S: the row tiles below, L_i = A_i X^T on the matrix cores (PI-permuted: the lane ends up with
-        // four adjacent columns of its row), written back in place and into the working copy
+        // ---- phase 3: the row tiles below, L_i = A_i X^T on the matrix cores (PI-permuted: the lane ends up with
+        // four adjacent columns of its row), written back in place and into the factor
         {
             const double* xp = cur + prow * CP + 4 * lq;
             const d2 x01 = *reinterpret_cast<const d2*>(xp), x23 = *reinterpret_cast<const d2*>(xp + 2);
@@ -340,138 +446,19 @@ void newton_chol_kernel(const double* __restrict__ H, const double* __restrict__
                 lo.x = c4[0]; lo.y = c4[1]; hi.x = c4[2]; hi.y = c4[3];
                 *reinterpret_cast<d2*>(bp) = lo;
                 *reinterpret_cast<d2*>(bp + 2) = hi;
-                const unsigned ge = (unsigned)((16 * i + lr) * lda + 16 * k + 4 * lq);
-                c_st2(ra, ge, lo);
-                c_st2(ra, ge + 2, hi);
+                const unsigned tb = (unsigned)((i * T + k) * 256);
+                c_st2(ra, lb_off + tb + lofs, lo);
+                c_st2(ra, lb_off + tb + 128u + lofs, hi);
+                c_st2(ra, la_off + tb + lofs_p, lo);
+                c_st2(ra, la_off + tb + 128u + lofs_p, hi);
             }
         }
+        __builtin_amdgcn_s_waitcnt(0);              // (this panel of the factor is in memory before anybody reads it)
         CH_MARK(3);
         __syncthreads();
         CH_MARK(4);
         if (tid < 16 && n >= 16 * (k + 1) && 16 * k + tid < n)     // y rides along as row n of the factor
             yv[16 * k + tid] = cur[(n - 16 * k) * CP + tid];
-        // ---- U: trailing tiles of this wave.  C_ij -= L_i L_j^T with the PI-permuted A operand (c_pi above):
-        // the lane holds C[16 i + lr][16 j + 4 lq .. + 3].  Batches of four tiles, straight-line (the tail of a
-        // pass is filled with tiles outside the matrix: their loads return zeros and their stores are dropped
-        // by the descriptor's range check), so that the compiler's vmcnt bookkeeping stays exact and the loads
-        // of the next batch are in flight under the products of the current one; inside a batch the fragments
-        // of all four tiles are read first and the four accumulator chains are issued interleaved.
-        struct Tile { unsigned g; int la, lb, ln; };     // offsets: working copy; A / B fragment rows; next panel
-        auto mk = [&](int i, int j) -> Tile {
-            Tile t;
-            t.g = i < T ? (unsigned)(16 * i * lda + 16 * j) + lofs_g : 0x10000000u;
-            t.la = 16 * (j - k) * CP;
-            t.lb = 16 * (i - k) * CP;
-            t.ln = 16 * (i - k - 1) * CP;
-            return t;
-        };
-        const double* fa_base = cur + prow * CP + 4 * lq;
-        const double* fb_base = cur + lr * CP + 4 * lq;
-        double* nx_base = nxt + lr * CP + 4 * lq;
-        auto gload4 = [&](const Tile (&t)[4], d4 (&cc)[4]) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                unsigned ge = t[u].g;
-#if defined(OOVQE_CHOL_PROBE) && (OOVQE_CHOL_PROBE & 2)
-                ge = 0x10000000u;
-#endif
-                const d2 lo = c_ld2(ra, ge), hi = c_ld2(ra, ge + 2);
-                cc[u][0] = lo.x; cc[u][1] = lo.y; cc[u][2] = hi.x; cc[u][3] = hi.y;
-            }
-        };
-        auto product4 = [&](const Tile (&t)[4], d4 (&cc)[4]) {
-            d2 a01[4], a23[4], b01[4], b23[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a01[u] = *reinterpret_cast<const d2*>(fa_base + t[u].la);
-                a23[u] = *reinterpret_cast<const d2*>(fa_base + t[u].la + 2);
-                b01[u] = *reinterpret_cast<const d2*>(fb_base + t[u].lb);
-                b23[u] = *reinterpret_cast<const d2*>(fb_base + t[u].lb + 2);
-            }
-#if defined(OOVQE_CHOL_PROBE) && (OOVQE_CHOL_PROBE & 4)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                cc[u][0] += a01[u].x * b01[u].x; cc[u][1] += a01[u].y * b01[u].y;
-                cc[u][2] += a23[u].x * b23[u].x; cc[u][3] += a23[u].y * b23[u].y;
-            }
-#else
-#pragma unroll
-            for (int u = 0; u < 4; ++u) cc[u] = mfma_f64(-a01[u].x, b01[u].x, cc[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) cc[u] = mfma_f64(-a01[u].y, b01[u].y, cc[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) cc[u] = mfma_f64(-a23[u].x, b23[u].x, cc[u]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) cc[u] = mfma_f64(-a23[u].y, b23[u].y, cc[u]);
-#endif
-        };
-        auto gstore4 = [&](const Tile (&t)[4], const d4 (&cc)[4]) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                unsigned ge = t[u].g;
-#if defined(OOVQE_CHOL_PROBE) && (OOVQE_CHOL_PROBE & 1)
-                ge = 0x10000000u;
-#endif
-                d2 lo, hi; lo.x = cc[u][0]; lo.y = cc[u][1]; hi.x = cc[u][2]; hi.y = cc[u][3];
-                c_st2(ra, ge, lo);
-                c_st2(ra, ge + 2, hi);
-            }
-        };
-        int i_first = k + 1;
-        while ((i_first & 3) != wi) ++i_first;
-        {
-            // pass A: the next panel's column (j = k + 1) first -> LDS
-            if (wj == ((k + 1) & 1)) {
-                for (int i0 = i_first; i0 < T; i0 += 16) {
-                    Tile ta[4];
-                    d4 ca[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) ta[u] = mk(i0 + 4 * u < T ? i0 + 4 * u : T, k + 1);
-                    gload4(ta, ca);
-                    product4(ta, ca);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        d2 lo, hi; lo.x = ca[u][0]; lo.y = ca[u][1]; hi.x = ca[u][2]; hi.y = ca[u][3];
-                        *reinterpret_cast<d2*>(nx_base + ta[u].ln) = lo;
-                        *reinterpret_cast<d2*>(nx_base + ta[u].ln + 2) = hi;
-                    }
-                }
-            }
-            // pass B: columns j >= k + 2 -> working copy, two batches of four in flight
-            const int j0 = ((k + 2) & 1) == wj ? k + 2 : k + 3;
-            int ti = i_first, tj = j0;
-            while (ti < T && tj > ti) { ti += 4; tj = j0; }
-            auto gather = [&](Tile (&t)[4]) -> bool {
-                const bool any = ti < T;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    t[u] = mk(ti < T ? ti : T, ti < T ? tj : T);
-                    if (ti < T) {
-                        tj += 2;
-                        while (ti < T && tj > ti) { ti += 4; tj = j0; }
-                    }
-                }
-                return any;
-            };
-            Tile ta[4], tb[4];
-            d4 ca[4], cb[4];
-            bool more = gather(ta);
-            gload4(ta, ca);
-            while (more) {
-                const bool more_b = gather(tb);
-                gload4(tb, cb);
-                product4(ta, ca);
-                gstore4(ta, ca);
-                if (!more_b) break;
-                more = gather(ta);
-                gload4(ta, ca);
-                product4(tb, cb);
-                gstore4(tb, cb);
-            }
-        }
-        CH_MARK(5);
-        __syncthreads();
-        CH_MARK(6);
     }
 
     const bool failed = flag[0] != 0;
@@ -493,12 +480,16 @@ void newton_chol_kernel(const double* __restrict__ H, const double* __restrict__
     auto fetch_rows = [&](int kb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            lrow[r] = (tid < 16 * kb) ? c_ld1(ra, (unsigned)((16 * kb + r) * lda + tid)) : 0.0;
+            // element (row r, column c = tid) of block row kb: tile (kb, c / 16), slot r + 16 (c' / 4), half
+            // (c' % 4) / 2, position c' % 2
+            lrow[r] = (tid < 16 * kb) ? c_ld1(ra, lb_off + (unsigned)((kb * T + (tid >> 4)) * 256) +
+                                                   (unsigned)((((tid & 15) & 3) >> 1) * 128 + 2 * (r + 16 * ((tid & 15) >> 2)) + (tid & 1)))
+                                      : 0.0;
     };
     auto fetch_diag = [&](int kb) {                 // lane c of wave 0: column c of X = L_kk^-1
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            ldg[r] = (wave == 0) ? c_ld1(ra, (unsigned)((16 * kb + r) * lda + 16 * kb + lr)) : 0.0;
+            ldg[r] = (wave == 0) ? c_ld1(ra, xw_off + (unsigned)(kb * 256 + r * 16 + lr)) : 0.0;
     };
     fetch_diag(nb - 1);
     fetch_rows(nb - 1);
@@ -555,8 +546,7 @@ int oovqe_newton_chol_max_n(void) { return NCHOL_MAX; }
 // doubles of workspace: the working copies of both roles of every problem + their status words
 size_t oovqe_newton_chol_work(int n, int batch)
 {
-    const size_t npv = 16 * (size_t)((n + 1 + 15) / 16);
-    return (size_t)batch * 2 * npv * npv + (size_t)batch + 2;
+    return (size_t)batch * 2 * chol_factor_doubles((n + 1 + 15) / 16) + (size_t)batch + 2;
 }
 
 int oovqe_newton_chol_launch(const double* hessian, const double* gradient, int n, int batch, double lambda_min,
@@ -566,14 +556,19 @@ int oovqe_newton_chol_launch(const double* hessian, const double* gradient, int 
     const CholLds L = chol_lds(n);
     const size_t lds = (size_t)L.total * sizeof(double);
     OOVQE_REQUIRE(lds <= 160 * 1024, "newton_direction_pd: %zu bytes of LDS needed", lds);
-    OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)newton_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds),
+    const int T = (n + 1 + 15) / 16;
+    const bool small = T <= 24;                     // four row tiles of a panel per accumulating wave (n <= 383), else six
+    const void* kern = small ? (const void*)newton_chol_kernel<4, 2> : (const void*)newton_chol_kernel<6, 2>;
+    OOVQE_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                     "newton_direction_pd: hipFuncSetAttribute");
     const int roles = lambda_min != 0.0 ? 2 : 1;
-    const size_t npv = 16 * (size_t)((n + 1 + 15) / 16);
-    int* status = reinterpret_cast<int*>(work + (size_t)batch * 2 * npv * npv);
-    hipLaunchKernelGGL(newton_chol_kernel, dim3(batch * roles), dim3(CT), lds, st, hessian, gradient, n, lambda_min,
-                       work, dp, shift, status, roles);
+    int* status = reinterpret_cast<int*>(work + (size_t)batch * 2 * chol_factor_doubles(T));
+    if (small)
+        hipLaunchKernelGGL((newton_chol_kernel<4, 2>), dim3(batch * roles), dim3(CT), lds, st, hessian, gradient, n,
+                           lambda_min, work, dp, shift, status, roles);
+    else
+        hipLaunchKernelGGL((newton_chol_kernel<6, 2>), dim3(batch * roles), dim3(CT), lds, st, hessian, gradient, n,
+                           lambda_min, work, dp, shift, status, roles);
     OOVQE_CHECK_LAUNCH("newton_direction_pd");
     hipLaunchKernelGGL(newton_chol_info_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, status, info, batch, roles);
     OOVQE_CHECK_LAUNCH("newton_direction_pd/info");

@@ -14,6 +14,8 @@ constructor, same method names and return values, same acceptance rule), built d
 ``BatchedNewtonStep`` (an extension) takes the same step for G independent problems in lockstep:
 one launch with G workgroups for the directions, one readback per line-search trial for all of them.
 """
+import ctypes
+
 import torch
 
 from . import _lib, ops
@@ -225,58 +227,98 @@ class BatchedNewtonStep(NewtonStep):
         newp, low = self.damped_newton_steps_flat(evaluate, flat, gradients, hessians)
         return [tuple(split_list_shapes(newp[g], shapes[g])) for g in range(G)], low
 
-    def damped_newton_steps_flat(self, objective, flat, gradients, hessians, energy0=None, defer_lowest=False):
+    def damped_newton_steps_flat(self, objective, flat, gradients, hessians, energy0=None, defer_lowest=False,
+                                 split=None, return_energy=False):
         """The same with ONE objective for all problems: objective(points [G, n]) -> energies [G]
         (e.g. ``OO_pqc_batch.energy``: every line-search trial is one batched evaluation).
         flat [G, n] = the current parameters; energy0 [G] = objective(flat) when the caller has it.
-        Returns (new parameters [G, n], lowest Hessian eigenvalues [G]); with ``defer_lowest`` the eigenvalues
-        come as an ``ops.PendingLowest`` (they are computed beside the line search on a side stream and
-        nothing in the step reads them)."""
+        ``split`` = n_a: the objective takes the first n_a parameters and the rest as two contiguous tensors,
+        objective(points_a [G, n_a], points_b [G, n - n_a]), and so are the new parameters returned.
+        Returns (new parameters [G, n] -- or (new_a, new_b) -- , lowest Hessian eigenvalues [G]
+        [, energies at the new parameters [G]]); with ``defer_lowest`` the eigenvalues come as an
+        ``ops.PendingLowest`` (they are computed beside the line search on a side stream and nothing in the
+        step reads them).
+
+        Per problem the acceptance rule is the reference's (newton_raphson.py:146-183); the book-keeping of a
+        trial is two small launches (``oovqe_linesearch_points`` / ``_update``) and one 32-byte readback."""
+        lib = _lib.load()
         dev = _lib.require_device()
         g = ops.as_device(gradients, dev)
         H = ops.as_device(hessians, dev)
-        G = flat.shape[0]
-        if g.shape[-1] <= _lib.load().oovqe_newton_direction_max_n():
+        flat = ops.as_device(flat, dev)
+        g = g if g.is_contiguous() else g.contiguous()
+        flat = flat if flat.is_contiguous() else flat.contiguous()
+        G, n = flat.shape
+        n_a = n if split is None else int(split)
+        if g.shape[-1] <= lib.oovqe_newton_direction_max_n():
             dp, low, nu, info = ops.newton_direction(H, g, self.lambda_min, self.mu, self.rho, self.aug,
                                                      defer_lowest=True, want_info=True)
         else:
             dp, low, nu = self._eigh_direction(H, g)
-            low, info = ops.PendingLowest(low, None), torch.zeros(G, dtype=dp.dtype, device=dev)
-        evaluate = objective
-        energy = evaluate(flat) if energy0 is None else energy0
-        slope = self.alpha * (g * dp).sum(dim=1)                    # wolfe(t) = t * slope
-        t = torch.ones(G, dtype=flat.dtype, device=flat.device)
-        test = evaluate(flat + t[:, None] * dp)
-        # a NaN trial energy is never accepted: "not <=" counts it as a failed Armijo test
-        active = ~(test <= energy + t * slope)
-        # the one readback of the common case: any problem still searching? did the library refuse one?
-        first = torch.stack((active.any().to(flat.dtype), info.min(),
-                             torch.isnan(slope).any().to(flat.dtype))).tolist()
-        if first[1] < 0:
-            # repeat without inter-workgroup waits / eigh fallback (or raise), then search from scratch
+            low, info = ops.PendingLowest(low, None), None
+        if energy0 is None:
+            energy0 = (objective(flat) if split is None
+                       else objective(flat[:, :n_a].contiguous(), flat[:, n_a:].contiguous()))
+        energy = energy0 if energy0.is_contiguous() else energy0.contiguous()
+        kw = dict(dtype=flat.dtype, device=dev)
+        t = torch.ones(G, **kw)
+        state = torch.empty((3, G), **kw)            # active | best energy | slope
+        active, best, slope = state[0], state[1], state[2]
+        flags = torch.empty(4, **kw)
+        pa = torch.empty((G, n_a), **kw)
+        pb = torch.empty((G, n - n_a), **kw) if n_a < n else None
+        sp = ops.stream_ptr
+
+        def points(with_slope):
+            ops.check(lib.oovqe_linesearch_points(ops.dptr(flat), ops.dptr(dp), ops.dptr(t), ops.dptr(g),
+                                                  float(self.alpha), n, n_a, G, ops.dptr(pa),
+                                                  ops.dptr(pb) if pb is not None else None,
+                                                  ops.dptr(slope) if with_slope else None, sp()),
+                      "oovqe_linesearch_points")
+
+        def update(trial, first, give_up, with_info):
+            if trial is not None and (trial.dtype != flat.dtype or trial.device != flat.device or trial.dim() != 1):
+                raise _lib.OovqeError("the objective must return a 1-d fp64 device tensor of energies")
+            ops.check(lib.oovqe_linesearch_update(
+                # (a strided view is fine: e.g. column 1 of the packed outputs of a batched evaluation)
+                ctypes.c_void_p(trial.data_ptr()) if trial is not None else None,
+                trial.stride(0) if trial is not None else 1,
+                ops.dptr(energy), ops.dptr(slope), ops.dptr(info) if (with_info and info is not None) else None,
+                float(self.beta), int(first), int(give_up), G, ops.dptr(t), ops.dptr(active), ops.dptr(best),
+                ops.dptr(flags), sp()), "oovqe_linesearch_update")
+            return flags.tolist()                     # the one readback of a trial
+
+        def trial_energies():
+            e = objective(pa) if split is None else objective(pa, pb)
+            return e.reshape(G)
+
+        points(True)
+        fl = update(trial_energies(), 1, 0, True)
+        if fl[1] < 0:
+            # the library refused a problem loudly: repeat without inter-workgroup waits / eigh fallback (or
+            # raise), then search from scratch
             dp, low_t, nu = self._check_direction(g, H, dp, None, nu, info.tolist(), batched=True)
+            dp = dp if dp.is_contiguous() else dp.contiguous()
             low = ops.PendingLowest(low_t, None)
-            slope = self.alpha * (g * dp).sum(dim=1)
-            test = evaluate(flat + t[:, None] * dp)
-            active = ~(test <= energy + t * slope)
-            first = [float(bool(active.any())), 0.0, float(bool(torch.isnan(slope).any()))]
-        if first[2] != 0.0:
+            t.fill_(1.0)
+            points(True)
+            fl = update(trial_energies(), 1, 0, False)
+        if fl[2] != 0.0:
             raise _lib.OovqeError("Newton direction is not finite (NaN in <gradient, dp>)")
         num = 0
-        searching = first[0] != 0.0
-        while searching:
-            if bool((slope[active] >= 0).any()):
+        while fl[0] != 0.0:
+            if fl[3] != 0.0:
                 raise AssertionError("Newton direction is not a descent direction")
-            t = torch.where(active, self.beta * t, t)
             num += 1
-            trial = evaluate(flat + t[:, None] * dp)
             if num > self.lmax:
                 # newton_raphson.py:177-183: give up on the problems still searching
-                t = torch.where(active, torch.zeros_like(t), t)
+                update(None, 0, 1, False)
+                points(False)
                 if self.verbose:
                     print("Warning: line search failed. Output previous parameters.")
                 break
-            test = torch.where(active, trial, test)
-            active = active & ~(test <= energy + t * slope)
-            searching = bool(active.any())
-        return flat + t[:, None] * dp, (low if defer_lowest else low.result())
+            points(False)
+            fl = update(trial_energies(), 0, 0, False)
+        new = pa if split is None else (pa, pb)
+        out = (new, low if defer_lowest else low.result())
+        return out + (best,) if return_energy else out

@@ -549,10 +549,13 @@ def newton_direction(hessian, gradient, lambda_min=1e-6, mu=1e-6, rho=1.1, aug=T
                                               dptr(dpc), dptr(low), dptr(nu), stream_ptr()),
               "oovqe_newton_direction_rest")
         side = _side_stream(dev)
+        # the eigenvalue route beside the line search keeps to half of the chip (its workgroups hold a
+        # whole CU each for the length of the reduction; the evaluations of the line search need the rest)
+        side_wg = max(1, 128 // G) if max_wg == 0 else int(max_wg)
         with torch.cuda.stream(side):
             side.wait_event(forked)
             wside = _newton_work("rest", n, G, dev, lib.oovqe_newton_direction_rest_work_size(n, G))
-            check(lib.oovqe_newton_direction_rest(dptr(H), dptr(g), n, G, *args, dptr(info), 2, int(max_wg),
+            check(lib.oovqe_newton_direction_rest(dptr(H), dptr(g), n, G, *args, dptr(info), 2, side_wg,
                                                   dptr(wside), dptr(dpc), dptr(low), dptr(nu), stream_ptr()),
                   "oovqe_newton_direction_rest")
             event = torch.cuda.Event()

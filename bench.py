@@ -165,21 +165,53 @@ def cpu_baseline(seconds_budget=24.0):
                        f"torch {torch.__version__} CPU"), float(e), g
 
 
-def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl", mode="weak"):
+def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl", mode="weak", regime="cold"):
     """BASELINE.json configs[3]: for every geometry of this rank's shard, from a shared (theta0, C0):
     energy + full gradient + full (n_theta+n_kappa)^2 Hessian + one damped Newton step
-    (oo_pqc.py:172-196); one all_gather of the new energies at the end.  Returns geometries/s."""
+    (oo_pqc.py:172-196); one all_gather of the new energies at the end.  Returns geometries/s.
+
+    regime "cold": independent random geometries and an arbitrary shared start (theta = 0.1, random
+    orthogonal orbitals) -- far from any minimum, the Hessians are indefinite and every step is level-shifted
+    (newton_raphson.py:107-120).  regime "tracking": what a step of the Berry-phase loop is in the reference's
+    notebook (examples/Tutorial_Berry_phase.ipynb raw 404-441: freeze_active = True, ONE Newton step per loop
+    point from the previous point's solution): the geometries are small displacements around a base problem
+    (synthetic_loop) and the shared start is the converged optimum of the base -- the Hessians are positive
+    definite and no step is shifted."""
+    import contextlib
     import auto_oo_amd as aoo
-    from auto_oo_amd.synthetic import synthetic_problem
+    from auto_oo_amd.synthetic import synthetic_problem, synthetic_loop
     from auto_oo_amd.parallel import gather_results
     pqc = aoo.Parameterized_circuit(NCAS, NELECAS, None, ansatz="ucc")
     objs = []
-    for g in my_geoms:
-        P = synthetic_problem(NAO, 20260 + 2 + 1000 * g)
-        mol = aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], NELEC)
-        objs.append(aoo.OO_pqc(pqc, mol, NCAS, NELECAS, oao_mo_coeff=P["oao_mo_coeff"]))
-        objs[-1]._mol_ref = mol
-    theta0 = torch.full((pqc.theta_shape,), 0.1, dtype=torch.float64, device="cuda")
+    if regime == "tracking":
+        freeze = True
+        base, loop = synthetic_loop(NAO, 20263, n_geom, eps=0.01)
+        bmol = aoo.Moldata(base["int1e_ao"], base["int2e_ao"], base["overlap"], base["nuc"], NELEC)
+        boo = aoo.OO_pqc(pqc, bmol, NCAS, NELECAS, oao_mo_coeff=base["oao_mo_coeff"], freeze_active=True)
+        with contextlib.redirect_stdout(sys.stderr):
+            e_l, th_l, _, _, eig_l = boo.full_optimization(
+                torch.full((pqc.theta_shape,), 0.1, dtype=torch.float64, device="cuda"), max_iterations=80,
+                conv_tol=1e-11, verbose=None)
+        theta0 = th_l[-1].detach().clone()
+        c_star = boo.oao_mo_coeff.detach().clone()
+        setup = {"base_optimisation_iterations": len(e_l), "base_energy": float(e_l[-1]),
+                 "base_lowest_hessian_eigenvalue": float(eig_l[-1]), "displacement_eps": 0.01,
+                 "freeze_active": True}
+        for g in my_geoms:
+            P = loop[g]
+            mol = aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], NELEC)
+            objs.append(aoo.OO_pqc(pqc, mol, NCAS, NELECAS, oao_mo_coeff=c_star, freeze_active=True))
+            objs[-1]._mol_ref = mol
+        del boo, bmol, base, loop
+    else:
+        freeze = False
+        setup = {"freeze_active": False}
+        for g in my_geoms:
+            P = synthetic_problem(NAO, 20260 + 2 + 1000 * g)
+            mol = aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], NELEC)
+            objs.append(aoo.OO_pqc(pqc, mol, NCAS, NELECAS, oao_mo_coeff=P["oao_mo_coeff"]))
+            objs[-1]._mol_ref = mol
+        theta0 = torch.full((pqc.theta_shape,), 0.1, dtype=torch.float64, device="cuda")
     opt = aoo.NewtonStep(verbose=0)
 
     def one(oo):
@@ -206,7 +238,7 @@ def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl", mode="weak")
     # geometries, one launch for all Newton directions, every line-search trial one batched evaluation,
     # one launch to rotate all orbitals
     batch = aoo.OO_pqc_batch(pqc, [oo._mol_ref for oo in objs], NCAS, NELECAS,
-                             oao_mo_coeffs=[oo.oao_mo_coeff for oo in objs])
+                             oao_mo_coeffs=[oo.oao_mo_coeff for oo in objs], freeze_active=freeze)
     thetas0 = theta0.reshape(1, -1).repeat(len(objs), 1).contiguous()
     c_saved = batch.oao_mo_coeff.clone()
     bopt = aoo.BatchedNewtonStep(verbose=0)
@@ -216,6 +248,7 @@ def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl", mode="weak")
         batch.refresh_mo_coeff()
 
     def lockstep():
+        # (the lowest Hessian eigenvalues are joined: everything the step returns is complete when it is timed)
         return batch.damped_newton_step(thetas0, bopt)[1]
 
     lockstep()                                     # warm-up (workspaces, code objects)
@@ -249,12 +282,18 @@ def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl", mode="weak")
     egh_us = timed(lambda: batch.energy_gradient_hessian(thetas0))
     _, g_b, h_b = batch.energy_gradient_hessian(thetas0)
     dir_us = timed(lambda: bopt.newton_steps(g_b, h_b))
+    from auto_oo_amd import ops as _ops
+    _, low_b, _, info_b = _ops.newton_direction(h_b, g_b, want_info=True)
+    fast_fraction = float((info_b == 1.0).double().mean().item())
+    low_range = [float(low_b.min().item()), float(low_b.max().item())]
     trial_us = timed(lambda: batch.energy(thetas0, g_b[:, batch.n_theta:] * 1e-3))
     if dist is not None:
         tmax = torch.tensor([el, el_b], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         el, el_b = float(tmax[0].item()), float(tmax[1].item())
-    return {"geometries": n_geom, "seconds": el, "geometries_per_s": n_geom / el,
+    return {"regime": regime, "setup": setup,
+            "cholesky_fast_path_fraction": fast_fraction, "lowest_hessian_eigenvalue_range": low_range,
+            "geometries": n_geom, "seconds": el, "geometries_per_s": n_geom / el,
             "per_geometry_ms": el / max(len(objs), 1) * 1e3, "hessian_dim": objs[0].n_kappa + pqc.theta_shape,
             "scaling": (f"{mode} ({n_geom} geometries in the job, {len(objs)} on this GPU, geometry g on "
                         f"rank g mod n_gpus)"),
@@ -270,7 +309,81 @@ def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl", mode="weak")
                                  "oovqe_newton_direction launch, batched line-search trials, one host sync "
                                  "per trial; median of 5 steps"},
             "newton_direction_us": newton_direction_timing(g_b, h_b),
+            "strong_projection": (strong_projection(pqc, objs, theta0, freeze)
+                                  if (mode == "strong" and world == 1) else None),
             "mean_energy_after_step": float(full.mean().item())}
+
+
+def strong_projection(pqc, objs, theta0, freeze, sizes=(64, 32, 16, 8)):
+    """The strong-scaling curve of the 64-geometry Berry-phase step as ONE GPU can measure it: the path has no
+    data-path collective, so the work of a rank at N GPUs is exactly a lockstep step over 64 / N geometries.
+    Per size: median time until the step's outputs the loop consumes (new thetas, orbitals, energies) are
+    complete (`step_ms`: the lowest Hessian eigenvalues, a diagnostic nothing downstream reads, still running
+    on the side stream), the same with the eigenvalues joined (`step_with_lowest_eig_ms`), and K back-to-back
+    steps with one join at the end (`pipelined_step_ms`: how a loop of steps runs)."""
+    import auto_oo_amd as aoo
+    out = {}
+    bopt = aoo.BatchedNewtonStep(verbose=0)
+    for G in sizes:
+        if G > len(objs):
+            continue
+        sub = objs[:G]
+        batch = aoo.OO_pqc_batch(pqc, [oo._mol_ref for oo in sub], NCAS, NELECAS,
+                                 oao_mo_coeffs=[oo.oao_mo_coeff for oo in sub], freeze_active=freeze)
+        thetas0 = theta0.reshape(1, -1).repeat(G, 1).contiguous()
+        c_saved = batch.oao_mo_coeff.clone()
+
+        def restore():
+            batch.oao_mo_coeff.copy_(c_saved)
+            batch.refresh_mo_coeff()
+
+        batch.damped_newton_step(thetas0, bopt)          # warm-up
+        restore()
+        crit, joined = [], []
+        for _ in range(7):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            th, en, pend = batch.damped_newton_step(thetas0, bopt, defer_lowest=True)
+            done = torch.cuda.Event()
+            done.record()
+            done.synchronize()
+            t1 = time.perf_counter()
+            pend.result()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            crit.append(t1 - t0)
+            joined.append(t2 - t0)
+            restore()
+        k_steps = 6
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        th, pending = thetas0, []
+        for _ in range(k_steps):
+            th, en, pend = batch.damped_newton_step(th, bopt, defer_lowest=True)
+            pending.append(pend)
+        for pend in pending:
+            pend.result()
+        torch.cuda.synchronize()
+        pipe = (time.perf_counter() - t0) / k_steps
+        restore()
+        out[str(G)] = {"step_ms": sorted(crit)[len(crit) // 2] * 1e3,
+                       "step_with_lowest_eig_ms": sorted(joined)[len(joined) // 2] * 1e3,
+                       "pipelined_step_ms": pipe * 1e3}
+        del batch
+    base = out.get(str(sizes[0]))
+    if base:
+        for G in sizes[1:]:
+            if str(G) in out:
+                o = out[str(G)]
+                o["implied_gpus"] = sizes[0] // G
+                o["implied_speedup"] = base["step_ms"] / o["step_ms"]
+                o["implied_speedup_with_lowest_eig"] = base["step_with_lowest_eig_ms"] / o["step_with_lowest_eig_ms"]
+                o["implied_speedup_pipelined"] = base["pipelined_step_ms"] / o["pipelined_step_ms"]
+    out["note"] = ("lockstep damped Newton step (gradient + full Hessian of all geometries in one call, Cholesky "
+                   "directions, batched line search, orbital rotation, final energies) over 64 / N geometries on "
+                   "this one GPU = the per-rank work at N GPUs (no collective inside a step); implied_speedup = "
+                   "t(64) / t(64 / N)")
+    return out
 
 
 def newton_direction_timing(grads, hess):
@@ -289,7 +402,11 @@ def newton_direction_timing(grads, hess):
         return (time.perf_counter() - t0) / reps * 1e6
     return {"n": int(grads.shape[1]), "single": timed(lambda: ops.newton_direction(hess[0], grads[0]), 20),
             "batch": int(grads.shape[0]),
-            "batched_launch": timed(lambda: ops.newton_direction(hess, grads), 10)}
+            "batched_launch": timed(lambda: ops.newton_direction(hess, grads), 10),
+            "single_direction_only": timed(lambda: ops.newton_direction(hess[0], grads[0], defer_lowest=True), 20),
+            "batched_direction_only": timed(lambda: ops.newton_direction(hess, grads, defer_lowest=True), 10),
+            "note": "direction_only: the Cholesky fast path with the lowest eigenvalues left running on the side "
+                    "stream (back-to-back calls: their band route bounds the rate)"}
 
 
 def kupccd_extra():
@@ -739,8 +856,11 @@ def main():
             weak = berry_loop_extra(weak_geoms, nb * world, dist, world, args.backend, "weak")
         else:
             weak = dict(strong, scaling=f"weak ({nb} geometries per GPU; identical to the strong run at 1 GPU)")
+        # the same workload in the regime the reference's loop runs in (one step per loop point from the
+        # previous point's solution: positive definite Hessians), strong figure only
+        tracking = berry_loop_extra(strong_geoms, nb, dist, world, args.backend, "strong", regime="tracking")
         if rank == 0:
-            out["berry_loop"] = {"strong": strong, "weak": weak}
+            out["berry_loop"] = {"strong": strong, "weak": weak, "tracking_strong": tracking}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             cb, e_ref, g_ref = cpu_baseline()

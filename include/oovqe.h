@@ -328,6 +328,24 @@ int oovqe_newton_direction_rest(const double* hessian, const double* gradient, i
                                 double* shift, oovqe_stream_t stream);
 int64_t oovqe_newton_direction_rest_work_size(int n, int batch);
 
+/* Book-keeping of the backtracking line search for `batch` problems in lockstep (NewtonStep.backtracking,
+ * src/auto_oo/utils/newton_raphson.py:131-192, per problem).
+ * oovqe_linesearch_points: points = flat + t[b] dp, the first n_a entries of a problem to points_a [batch,n_a],
+ * the rest to points_b [batch,n-n_a] (n_a = 0 or n: everything to points_a); slope [batch] (may be NULL) =
+ * alpha <grad, dp> (newton_raphson.py:12-13).
+ * oovqe_linesearch_update: trial [batch] (stride `trial_stride` doubles) = the energies at the points; a problem
+ * still searching passes when trial <= energy + t slope (:146-147; a NaN never passes): then best[b] = trial;
+ * otherwise t[b] *= beta (:162) and active[b] = 1.  first != 0: every problem is searching.  give_up != 0
+ * (after lmax + 1 reductions, :177-183): the problems still searching keep their old parameters (t = 0,
+ * best = energy); trial is not read.  flags [4] = {any problem still searching, min of info (0 without),
+ * any NaN slope, any searching problem whose slope is not negative (:158: not a descent direction)}. */
+int oovqe_linesearch_points(const double* flat, const double* dp, const double* t, const double* grad,
+                            double alpha, int n, int n_a, int batch, double* points_a, double* points_b,
+                            double* slope, oovqe_stream_t stream);
+int oovqe_linesearch_update(const double* trial, int64_t trial_stride, const double* energy, const double* slope,
+                            const double* info, double beta, int first, int give_up, int batch, double* t,
+                            double* active, double* best, double* flags, oovqe_stream_t stream);
+
 /* The theta-theta block in one call: the five launches above chained (state + tangents, second
  * tangents, operand lists, transition RDMs, contraction).  pairs [n_pairs][2] with j <= k; H
  * [n_theta, n_theta]; work: oovqe_circuit_hessian_work_size() doubles. */

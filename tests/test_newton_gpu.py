@@ -488,7 +488,9 @@ def test_cholesky_fast_path_vs_band_route_and_numpy(n, G):
     with aoo._lib.debug_options(newton_no_chol=1):
         dpb, lowb, nub, infob = ops.newton_direction(Hs, gs, want_info=True)
     assert infob.tolist() == [0.0] * G
-    assert torch.equal(low, lowb)
+    # (the eigenvalue route beside the line search runs on fewer workgroups per problem than the one-route
+    # call: another grid of shifts, the same number to rounding)
+    assert (low - lowb).abs().max().item() < 1e-12 * max(n, 8)
     for k in range(G):
         ref = -np.linalg.solve(Hn[k], gn[k])
         cond = np.linalg.cond(Hn[k])

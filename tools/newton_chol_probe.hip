@@ -30,8 +30,8 @@ int main(int argc, char** argv)
     hipMalloc(&dnu, batch * 8); hipMalloc(&dinfo, batch * 8);
     hipMalloc(&dw, oovqe_newton_chol_work(n, batch) * 8);
     hipMemcpy(dH, H.data(), H.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dg, g.data(), g.size() * 8, hipMemcpyHostToDevice);
-    const char* names[16] = {"load panel 0", "D: diagonal tile (wave 0)", "D: barrier", "S: rows below", "S: barrier",
-                             "U: trailing tiles (wave 0)", "U: barrier", "B: 16x16 transposed solve", "B: barrier",
+    const char* names[16] = {"prologue", "2: D (wave 0; others: bulk)", "2: barrier", "3: S rows below", "3: barrier",
+                             "1: last contribution (wave 0 idle)", "1: barrier", "B: 16x16 transposed solve", "B: barrier",
                              "B: block row + prefetch", "B: barrier", "", "", "", "", ""};
     for (int it = 0; it < 4; ++it) {
         long long zero[16] = {0};
