@@ -46,6 +46,7 @@ enum oovqe_option_t {
     OOVQE_OPT_HESS_VK_PASS,          // orbital Hessian: the K-type quarter transform as its own pass over the AO tensor (round 2)
     OOVQE_OPT_HESS_OWN_STAGE1,       // Hessian call: the evaluation streams the integrals itself instead of taking J from the orbital Hessian's T2
     OOVQE_OPT_PANEL_ROWS,            // cas_panel_kernel: general indices per workgroup (0: chosen by the host code)
+    OOVQE_OPT_K1_FORCE_NT,           // K1 / K1P: this many 16-wide tiles of J per wave (0: all that fit, up to 13)
     OOVQE_OPT_NEWTON_NO_CHOL,        // oovqe_newton_direction: never the Cholesky fast path (band route for every problem)
     OOVQE_OPT_COUNT
 };

@@ -666,6 +666,7 @@ static int contract_plan(long A, int K, int J, long B, int last, int batch, int*
         if (wgs * ((JT + nt2 - 1) / nt2) * batch > 512) break;
         nt = nt2;
     }
+    if (oovqe_opt(OOVQE_OPT_K1_FORCE_NT) > 0 && oovqe_opt(OOVQE_OPT_K1_FORCE_NT) < nt) nt = oovqe_opt(OOVQE_OPT_K1_FORCE_NT);
     const int ngroups = (JT + nt - 1) / nt;
     nt = (JT + ngroups - 1) / ngroups;   // even split
     *nt_out = nt;

@@ -54,6 +54,10 @@ namespace {
 constexpr int PWAVES = 4;
 constexpr int PTHREADS = PWAVES * 64;
 
+// (Round 4 tried narrow builds, NT <= 7 = two j-groups at J = 200, with TWO workgroups per CU -- 190
+// registers, the waves of a SIMD then belong to different workgroups and are not in step: 55.9 TFLOP/s against
+// 62.4 with NT = 13 and one workgroup per CU at N = 200.  T is streamed once per j-group and every MFMA gets
+// half the fragment reuse: occupancy does not pay for that.  tools/k1_standalone.hip 200 nt=7.)
 template <int NT, int KSTEPS>
 __global__ __launch_bounds__(PTHREADS, 1)
 void contract_pair_kernel(const double* __restrict__ T, const double* __restrict__ Cm,

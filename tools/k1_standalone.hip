@@ -35,6 +35,7 @@ int main(int argc, char** argv)
     }
     const int N = argc > 1 ? atoi(argv[1]) : 200;
     if (argc > 2 && !strcmp(argv[2], "nopair")) oovqe_debug_set_option("k1_no_pair", 1);
+    if (argc > 2 && !strncmp(argv[2], "nt=", 3)) oovqe_debug_set_option("k1_force_nt", atoi(argv[2] + 3));
     const long n = N, n2 = n * n, n3 = n2 * n, n4 = n3 * n;
     double *g, *w, *C;
     (void)hipMalloc(&g, n4 * 8);
