@@ -29,6 +29,30 @@ extern "C" int oovqe_device_count(void)
     return n;
 }
 
+// ---- dynamic-LDS limit of a kernel, raised at most once per (kernel, device) --------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute: a process-wide `static` next to the
+// launch would skip the call on a second device (or race between host threads) and the launch above 64 KB
+// would fail there.
+#include <mutex>
+#include <map>
+int oovqe_ensure_dynamic_lds(const void* kernel, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = done[std::make_pair(kernel, dev)];
+    if (bytes <= have) return 0;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        oovqe_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu): %s", bytes, hipGetErrorString(e));
+        return OOVQE_ERR_HIP;
+    }
+    have = bytes;
+    return 0;
+}
+
 // ---- test / measurement switches (common.h: oovqe_option_t) -------------------------------------
 static int g_opts[OOVQE_OPT_COUNT] = {0};
 static const char* const g_opt_names[OOVQE_OPT_COUNT] = {

@@ -564,12 +564,9 @@ extern "C" int oovqe_rdms(const double* bra, const double* ket, int n_qubits, in
     hipStream_t st = (hipStream_t)stream;
     const size_t small_bytes = ((size_t)(2 + 2 * na2) * (D + 1) + na2) * sizeof(double);
     if (n_qubits >= 1 && small_bytes <= 150 * 1024) {
-        static size_t attr_bytes = 0;
-        if (small_bytes > 64 * 1024 && small_bytes > attr_bytes) {
-            OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)rdms_small_kernel,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_bytes),
-                            "rdms/small");
-            attr_bytes = small_bytes;
+        if (small_bytes > 64 * 1024) {
+            int rc_lds = oovqe_ensure_dynamic_lds((const void*)rdms_small_kernel, small_bytes);
+            if (rc_lds) return rc_lds;
         }
         hipLaunchKernelGGL(rdms_small_kernel, dim3((unsigned)batch), dim3(256), small_bytes, st, bra, ket,
                            n_qubits, ncas, gamma, Gamma);
@@ -707,7 +704,21 @@ int oovqe_circuit_hessian_batched_impl(const double* theta, int n_theta, const o
 {
     OOVQE_REQUIRE(theta && gates && c1 && c2 && pairs && work && H, "circuit_hessian: null pointer");
     OOVQE_REQUIRE(n_pairs >= 1 && 4 * n_pairs <= 65535, "circuit_hessian: n_pairs=%d", n_pairs);
-    OOVQE_REQUIRE(batch >= 1 && (long)batch * 4 * n_pairs <= 65535, "circuit_hessian: batch=%d", batch);
+    OOVQE_REQUIRE(batch >= 1, "circuit_hessian: batch=%d", batch);
+    if ((long)batch * 4 * n_pairs > 65535 || batch > 65535) {
+        // the launches below put (geometry, pair) into 16-bit grid dimensions: larger stacks go through in
+        // chunks of geometries, one after the other on the stream, sharing the workspace
+        const int chunk = 65535 / (4 * n_pairs);
+        for (int b0 = 0; b0 < batch; b0 += chunk) {
+            const int nbc = batch - b0 < chunk ? batch - b0 : chunk;
+            int rcc = oovqe_circuit_hessian_batched_impl(theta + (size_t)b0 * n_theta, n_theta, gates, n_gates, n_qubits,
+                                                         ncas, init_index, c1 + (long)b0 * c1_bs, c2 + (long)b0 * c2_bs,
+                                                         c1_bs, c2_bs, pairs, n_pairs, nbc, work, H + (long)b0 * h_bs,
+                                                         ldh, h_bs, stream);
+            if (rcc) return rcc;
+        }
+        return 0;
+    }
     const size_t D = (size_t)1 << n_qubits, na2 = (size_t)ncas * ncas, nb = (size_t)batch;
     double* psi = work;                                       // [G][D]
     double* dpsi = psi + nb * D;                              // [G][n_theta][D]

@@ -51,6 +51,8 @@ enum oovqe_option_t {
     OOVQE_OPT_COUNT
 };
 int oovqe_opt(int id);
+// raise a kernel's dynamic-LDS limit to `bytes` (cached per kernel AND device, thread-safe); 0 or OOVQE_ERR_HIP
+int oovqe_ensure_dynamic_lds(const void* kernel, size_t bytes);
 void oovqe_note_stage1(const char* fmt, ...);
 
 #define OOVQE_CHECK_LAUNCH(name)                                                          \

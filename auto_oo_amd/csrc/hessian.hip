@@ -275,12 +275,9 @@ static int orbital_hessian_batched(const double* g_ao, const double* h_ao, const
         const size_t lds_bytes = (size_t)m2 * N * sizeof(double);
 #define OOVQE_LAUNCH_T2K(MT_)                                                                             \
     do {                                                                                                  \
-        static size_t attr_bytes = 0;                                                                     \
-        if (lds_bytes > 64 * 1024 && lds_bytes > attr_bytes) {                                            \
-            OOVQE_CHECK_HIP(hipFuncSetAttribute((const void*)t2k_tri_kernel<MT_>,                         \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize,               \
-                                                (int)lds_bytes), "orbital_hessian/t2k");                  \
-            attr_bytes = lds_bytes;                                                                       \
+        if (lds_bytes > 64 * 1024) {                                                                      \
+            int rc_lds = oovqe_ensure_dynamic_lds((const void*)t2k_tri_kernel<MT_>, lds_bytes);           \
+            if (rc_lds) return rc_lds;                                                                    \
         }                                                                                                 \
         t2k_tri_kernel<MT_><<<dim3(N, batch), 512, lds_bytes, st>>>(Vk, C, T2K, N, M); /* T2K[p,m,n,s] */  \
     } while (0)

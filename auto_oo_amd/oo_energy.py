@@ -94,12 +94,13 @@ def _matvec(H, v):
 
 
 def _apply_rows(fn, v, shape):
-    """fn on a direction v, or row by row on a stack of directions (torch.func's vmap over the
-    cotangents of a Hessian hands a batched tangent to a derivative rule)."""
+    """fn on ONE direction v.  A stack of directions (torch.func's vmap over the cotangents of a Hessian hands
+    a derivative rule a functorch BatchedTensor) is refused loudly: the kernels take one direction per call,
+    and looping over the rows of the stack from inside a rule means re-entering functorch's interpreter
+    stack by hand (round 4 tried: unwrap the stack, apply row by row, re-wrap with _add_batch_dim -- fine for a
+    lone vmap, but under hessian's jvp-over-vmap nesting the rows come back wrapped at the wrong level).
+    torch.autograd.functional.hessian / jacobian (vectorize=False) and torch.func at kappa = 0 cover it."""
     if torch._C._functorch.is_functorch_wrapped_tensor(v) and torch._C._functorch.is_batchedtensor(v):
-        raw = v
-        while torch._C._functorch.is_functorch_wrapped_tensor(raw):
-            raw = torch._C._functorch.get_unwrapped(raw)
         raise NotImplementedError("batched tangents at kappa != 0: use torch.autograd.functional.hessian "
                                   "(or vectorize=False)")
     return fn(unwrap(v).reshape(-1)).reshape(shape)

@@ -11,6 +11,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+import auto_oo_amd as aoo                            # noqa: E402
 from auto_oo_amd import ops, excitations as X   # noqa: E402
 from oracle import cpu_ref as R                  # noqa: E402
 
@@ -705,3 +706,33 @@ def test_sector_fused_kernels_equal_the_unfused_ones(ncas, nelecas, batch):
     # the adjoint no longer depends on a preceding RDM call on the same workspace
     eng2 = SectorEngine(ncas, hf, gd, len(gates), n_theta, X.basis_index(hf), torch.device(DEV))
     assert torch.equal(eng2.adjoint(th, psi_c, c1, c2), dth)
+
+
+def test_batched_circuit_hessian_beyond_one_grid_of_pairs():
+    """oovqe_circuit_hessian_batch puts (geometry, pair) into 16-bit grid dimensions; a stack with
+    batch * 4 * n_pairs > 65535 (here 1 700 geometries x 40) goes through in chunks of geometries.  Every
+    geometry's block equals the single-geometry call bit for bit."""
+    import ctypes
+    from auto_oo_amd import _lib, ops
+    from auto_oo_amd._lib import dptr, stream_ptr, check
+    lib = _lib.load()
+    pqc = aoo.Parameterized_circuit(3, 4, None, ansatz="ucc")
+    nt, a = int(pqc.theta_shape), 3
+    G = 1700
+    rng = np.random.default_rng(2)
+    theta = torch.tensor(rng.uniform(0, 2 * np.pi, (G, nt))).cuda()
+    c1 = torch.tensor(rng.standard_normal((G, a * a))).cuda()
+    c2 = torch.tensor(rng.standard_normal((G, a ** 4))).cuda()
+    pairs_dev, _, _ = ops._hessian_pair_tables(nt, theta.device)
+    n_pairs = pairs_dev.shape[0]
+    assert G * 4 * n_pairs > 65535
+    work = torch.empty(G * lib.oovqe_circuit_hessian_work_size(nt, pqc.n_qubits, a, n_pairs), dtype=torch.float64,
+                       device="cuda")
+    H = torch.empty((G, nt, nt), dtype=torch.float64, device="cuda")
+    check(lib.oovqe_circuit_hessian_batch(dptr(theta), nt, dptr(pqc._gates_dev, torch.uint8), pqc._n_gates,
+                                          pqc.n_qubits, a, ctypes.c_uint32(pqc._init_index), dptr(c1), dptr(c2),
+                                          dptr(pairs_dev, torch.int32), n_pairs, G, dptr(work), dptr(H), stream_ptr()),
+          "oovqe_circuit_hessian_batch")
+    for g in (0, 1, 408, 409, 410, 819, 1638, 1699):
+        Hg = ops.circuit_hessian(theta[g], pqc._gates_dev, pqc._n_gates, pqc.n_qubits, a, pqc._init_index, c1[g], c2[g])
+        assert torch.equal(H[g], Hg), g

@@ -588,3 +588,41 @@ def test_non_finite_hessian_raises_instead_of_returning_nan_parameters():
         return fn(x) if float(x.abs().max()) == 0.0 else torch.tensor(float("nan"), dtype=torch.float64, device="cuda")
     new, _ = aoo.NewtonStep(verbose=0, lmax=3).damped_newton_step(nan_objective, (x0,), g, Hg)
     assert float(new.abs().max()) == 0.0 and len(calls) >= 4
+
+
+def test_band_route_beside_a_kernel_that_holds_the_chip():
+    """The workgroups of a problem in the band route wait for each other, so they must all become resident.
+    Launched while a long matrix-core kernel on ANOTHER stream holds every CU (an N = 160 four-index transform:
+    four launches of ~4 ms), the call must still deliver the right step: either its workgroups get their CUs
+    in time, or the hand-off times out loudly (info = -1, NaN outputs) and NewtonStep repeats the direction
+    with one workgroup per problem.  Never a silent wrong answer."""
+    rng = np.random.default_rng(11)
+    n, G = 331, 4
+    Hs = torch.tensor(np.stack([_sym(rng, n, "indefinite") for _ in range(G)])).cuda()
+    gs = torch.tensor(rng.standard_normal((G, n))).cuda()
+    N = 160
+    big = torch.rand((N, N, N, N), dtype=torch.float64, device="cuda")
+    C = torch.rand((N, N), dtype=torch.float64, device="cuda")
+    out, work = torch.empty_like(big), torch.empty_like(big)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            ops.general_4index_transform(big, C, C, C, C, out=out, work=work)
+    dp, low, nu, info = ops.newton_direction(Hs, gs, want_info=True)
+    opt = aoo.BatchedNewtonStep(verbose=0)
+    with torch.cuda.stream(side):
+        ops.general_4index_transform(big, C, C, C, C, out=out, work=work)
+    dp2, low2 = opt.newton_steps(gs, Hs)
+    torch.cuda.synchronize()
+    codes = info.tolist()
+    assert all(c in (0.0, -1.0) for c in codes), codes
+    for k in range(G):
+        dr, lr = _reference_direction(Hs[k].cpu(), gs[k].cpu())
+        cond = float(torch.linalg.cond(Hs[k] + (1e-6 + 1.1 * abs(lr)) * torch.eye(n, dtype=torch.float64, device="cuda")))
+        tol = 1e-13 * cond * (1.0 + dr.abs().max()) * n
+        if codes[k] == 0.0:
+            assert abs(low[k].item() - lr) < 1e-11 * n and (dp[k].cpu() - dr).abs().max() <= tol
+        else:
+            assert bool(torch.isnan(dp[k]).all())
+        assert abs(low2[k].item() - lr) < 1e-11 * n and (dp2[k].cpu() - dr).abs().max() <= tol
