@@ -118,6 +118,10 @@ SIGNATURES = {
                                           ctypes.c_int, ctypes.c_uint32, c_int32_p, c_int32_p,
                                           c_int32_p, c_int32_p, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, c_double_p, c_double_p, c_stream]),
+    "oovqe_sector_state_deriv": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_uint32, c_int32_p, c_int32_p,
+                                                c_int32_p, c_int32_p, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, c_int32_p, ctypes.c_int, c_double_p, c_stream]),
     "oovqe_sector_rdms": (ctypes.c_int, [c_double_p, ctypes.c_int, c_int32_p, c_int32_p, c_int32_p,
                                          c_int32_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          c_double_p, c_double_p, c_double_p, c_stream]),

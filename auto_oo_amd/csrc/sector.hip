@@ -169,6 +169,98 @@ void sector_circuit_kernel(const double* __restrict__ theta, int n_theta,
     for (int d = tid; d < Dc; d += SEC_THREADS) psi_c[(size_t)b * Dc + d] = st[d];
 }
 
+// d^order/dtheta^order of one Givens pass applied to a sector vector (order = 1, 2): on the pairs the gate
+// rotates the 2 x 2 block [c, s; -s, c] (c, s = cos, sin of sign theta / 2) becomes its derivative --
+// (sign / 2) [-s, c; -c, -s], then (1 / 4) [-c, -s; s, -c] -- and every amplitude the gate leaves alone is
+// annihilated (the derivative of an identity block).  `c`, `sn` arrive already differentiated.
+template <int MAXIT>
+__device__ __forceinline__ void sec_gate_deriv(double* st, const Sector& s, const uint32_t* xfull, int Dc,
+                                               const oovqe_gate_t& g, double c, double sn)
+{
+    const uint32_t fm = g.mask_hi | g.mask_lo;
+    int e[MAXIT];
+    double pi[MAXIT];
+    bool idle[MAXIT];
+#pragma unroll
+    for (int i = 0; i < MAXIT; ++i) {
+        const int d = threadIdx.x + i * SEC_THREADS;
+        e[i] = -1;
+        idle[i] = false;
+        if (d < Dc) {
+            const uint32_t x = xfull[d];
+            if ((x & fm) == g.mask_hi) {
+                e[i] = sec_rank(s, x ^ fm);
+                pi[i] = (__popc(x & g.mask_par) & 1) ? -sn : sn;
+            } else if ((x & fm) != g.mask_lo) {
+                idle[i] = true;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXIT; ++i) {
+        const int d = threadIdx.x + i * SEC_THREADS;
+        if (e[i] >= 0) {
+            const double ax = st[d], ay = st[e[i]];
+            st[d] = c * ax + pi[i] * ay;
+            st[e[i]] = c * ay - pi[i] * ax;
+        } else if (idle[i]) {
+            st[d] = 0.0;
+        }
+    }
+}
+
+// The circuit with up to two of its gates differentiated: output o of geometry b is
+//   prod_g G_g^(m_g)(theta) |init>,  m_g = how often gate g appears in deriv[o] = (g_a, g_b)  (-1: none),
+// i.e. a first tangent d psi / d theta_j (g_a = the gate of theta_j, g_b = -1), a second tangent
+// d^2 psi / d theta_j d theta_k (both set; g_a == g_b: the second derivative of that gate) or psi itself,
+// for circuits in which every parameter drives ONE gate (UCCD / UCCSD / kUpCCD: one Givens pass per
+// excitation).  grid = (batch, n_out); one sector vector in LDS per workgroup, as in the plain kernel.
+template <int MAXIT>
+__global__ __launch_bounds__(SEC_THREADS)
+void sector_circuit_deriv_kernel(const double* __restrict__ theta, int n_theta,
+                                 const oovqe_gate_t* __restrict__ gates, int n_gates, Sector s,
+                                 uint32_t init_index, const int32_t* __restrict__ deriv, int n_out,
+                                 double* __restrict__ psi_c)
+{
+    extern __shared__ double lds[];
+    const int Dc = s.na * s.nb;
+    double* st = lds;                                   // [Dc]
+    double* cs = st + Dc;                               // [n_gates][2]
+    oovqe_gate_t* gl = reinterpret_cast<oovqe_gate_t*>(cs + 2 * n_gates);
+    uint32_t* xfull;
+    const Sector sg = s;
+    s = sec_stage_lds(sg, reinterpret_cast<uint32_t*>(gl + n_gates), &xfull, SEC_THREADS);
+    const int tid = threadIdx.x, b = blockIdx.x, o = blockIdx.y;
+    const double* th = theta + (size_t)b * n_theta;
+    const int ga = deriv[2 * o], gb = deriv[2 * o + 1];
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(gates);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(gl);
+        for (int i = tid; i < n_gates * (int)(sizeof(oovqe_gate_t) / 4); i += SEC_THREADS) dst[i] = src[i];
+        for (int g = tid; g < n_gates; g += SEC_THREADS) {
+            const int ti = gates[g].theta_idx;
+            double sn = 0.0, c = 1.0;
+            if (ti >= 0) sincos(0.5 * (double)gates[g].sign * th[ti], &sn, &c);
+            const int order = (g == ga ? 1 : 0) + (g == gb ? 1 : 0);
+            const double h = 0.5 * (double)gates[g].sign;
+            if (order == 1) { const double c1 = -h * sn, s1 = h * c; c = c1; sn = s1; }
+            if (order == 2) { c *= -0.25; sn *= -0.25; }
+            cs[2 * g] = c;
+            cs[2 * g + 1] = sn;
+        }
+        const int c0 = sec_rank(sg, init_index);
+        for (int d = tid; d < Dc; d += SEC_THREADS) st[d] = (d == c0) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int g = 0; g < n_gates; ++g) {
+        if (gl[g].theta_idx < 0) continue;
+        if (g == ga || g == gb) sec_gate_deriv<MAXIT>(st, s, xfull, Dc, gl[g], cs[2 * g], cs[2 * g + 1]);
+        else sec_gate<MAXIT>(st, s, xfull, Dc, gl[g], cs[2 * g], cs[2 * g + 1], false);
+        __syncthreads();
+    }
+    for (int d = tid; d < Dc; d += SEC_THREADS) psi_c[((size_t)b * n_out + o) * Dc + d] = st[d];
+}
+
 // sector vector -> dense 2^n vector (zeros outside the sector)
 __global__ void sector_to_dense_kernel(const double* __restrict__ psi_c, Sector s, uint32_t D,
                                        double* __restrict__ psi)
@@ -1007,6 +1099,41 @@ extern "C" int oovqe_sector_state(const double* theta, int n_theta, const oovqe_
                                                         batch), dim3(256), 0, st, psi_c, s, D, psi_dense);
         OOVQE_CHECK_LAUNCH("sector_state/dense");
     }
+    return 0;
+}
+
+// States of the circuit with up to two gates differentiated (sector_circuit_deriv_kernel): deriv [n_out][2]
+// gate indices (device, -1 = none), psi_out [batch][n_out][Dc].
+extern "C" int oovqe_sector_state_deriv(const double* theta, int n_theta, const oovqe_gate_t* gates,
+                                        int n_gates, int ncas, uint32_t init_index, const uint32_t* unrank_a,
+                                        const uint32_t* unrank_b, const int32_t* rank_a, const int32_t* rank_b,
+                                        int na, int nb, int batch, const int32_t* deriv, int n_out,
+                                        double* psi_out, oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(theta && gates && unrank_a && unrank_b && rank_a && rank_b && deriv && psi_out,
+                  "sector_state_deriv: null pointer");
+    OOVQE_REQUIRE(ncas >= 1 && ncas <= 13 && na >= 1 && nb >= 1 && batch >= 1 && n_gates >= 1 && n_out >= 1 &&
+                  n_out <= 65535 && batch <= 65535, "sector_state_deriv: bad sizes");
+    const int Dc = na * nb;
+    const size_t lds_bytes = circuit_lds(na, nb, ncas, n_gates);
+    OOVQE_REQUIRE(lds_bytes <= 160 * 1024 && Dc <= SEC_MAXIT * SEC_THREADS,
+                  "sector_state_deriv: sector of %d determinants needs %zu B LDS", Dc, lds_bytes);
+    hipStream_t st = (hipStream_t)stream;
+    Sector s = make_sector(unrank_a, unrank_b, rank_a, rank_b, na, nb, ncas);
+    const int nit = (Dc + SEC_THREADS - 1) / SEC_THREADS;
+#define OOVQE_SEC_CIRCD(MI)                                                                        \
+    do {                                                                                           \
+        int rc_lds = oovqe_ensure_dynamic_lds((const void*)sector_circuit_deriv_kernel<MI>, 160 * 1024); \
+        if (rc_lds) return rc_lds;                                                                 \
+        hipLaunchKernelGGL(sector_circuit_deriv_kernel<MI>, dim3(batch, n_out), dim3(SEC_THREADS), lds_bytes, \
+                           st, theta, n_theta, gates, n_gates, s, init_index, deriv, n_out, psi_out); \
+    } while (0)
+    if (nit <= 1) OOVQE_SEC_CIRCD(1);
+    else if (nit <= 2) OOVQE_SEC_CIRCD(2);
+    else if (nit <= 5) OOVQE_SEC_CIRCD(5);
+    else OOVQE_SEC_CIRCD(8);
+#undef OOVQE_SEC_CIRCD
+    OOVQE_CHECK_LAUNCH("sector_state_deriv");
     return 0;
 }
 

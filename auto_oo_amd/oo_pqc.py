@@ -218,8 +218,11 @@ class OO_pqc(OO_energy):
         with the CAS coefficients, ``oovqe_circuit_second_tangents`` / ``_hessian_assemble``)."""
         pqc = self.pqc
         c0, c1, c2 = self.get_active_integrals(self.mo_coeff)
-        th = pqc._theta2d(theta).reshape(-1)
         n = self._n_theta()
+        if getattr(pqc, "_use_sector", False):
+            # large registers (kUpCCD CAS(8e,8o)): tangents and quadratic forms inside the (N_alpha, N_beta) sector
+            return pqc._sector.circuit_hessian(pqc._theta2d(theta), pqc._gates, self._t(c1), self._t(c2)).reshape(n, n)
+        th = pqc._theta2d(theta).reshape(-1)
         return ops.circuit_hessian(th, pqc._gates_dev, pqc._n_gates, pqc.n_qubits, self.ncas,
                                    pqc._init_index, c1, c2).reshape(n, n)
 
@@ -234,23 +237,22 @@ class OO_pqc(OO_energy):
         through the CAS path together (set 0 yields c1, c2 and the Fock matrix, sets k >= 1 the
         kappa-theta columns), then the circuit block and the orbital block follow from those."""
         pqc = self.pqc
+        C = self._t(self.mo_coeff)
+        gamma, Gamma = pqc.rdms_with_derivatives(theta)
+        res = self._cas_eval(C, gamma, Gamma, want_matrices=True)
+        hessian_vqe_oo = res["gvec"][1:].T
+        n = self._n_theta()
         if getattr(pqc, "_use_sector", False):
-            hessian_vqe_vqe = self.circuit_circuit_hessian(theta)
-            hessian_vqe_oo = self.orbital_circuit_hessian(theta)
-            hessian_oo_oo = self.orbital_orbital_hessian(theta)
+            hessian_vqe_vqe = pqc._sector.circuit_hessian(pqc._theta2d(theta), pqc._gates, res["c1"],
+                                                          res["c2"]).reshape(n, n)
         else:
-            C = self._t(self.mo_coeff)
-            gamma, Gamma = pqc.rdms_with_derivatives(theta)
-            res = self._cas_eval(C, gamma, Gamma, want_matrices=True)
-            hessian_vqe_oo = res["gvec"][1:].T
-            n = self._n_theta()
             hessian_vqe_vqe = ops.circuit_hessian(pqc._theta2d(theta).reshape(-1), pqc._gates_dev, pqc._n_gates,
                                                   pqc.n_qubits, self.ncas, pqc._init_index, res["c1"],
                                                   res["c2"]).reshape(n, n)
-            hessian_oo_oo = ops.orbital_hessian(self.int2e_ao, self.int1e_ao, C, gamma[0].contiguous(),
-                                                Gamma[0].contiguous(), res["fock"], self._n_occ, self.ncas,
-                                                self._kap_row, self._kap_col, want_matrix=True,
-                                                want_full=False)[0]
+        hessian_oo_oo = ops.orbital_hessian(self.int2e_ao, self.int1e_ao, C, gamma[0].contiguous(),
+                                            Gamma[0].contiguous(), res["fock"], self._n_occ, self.ncas,
+                                            self._kap_row, self._kap_col, want_matrix=True,
+                                            want_full=False)[0]
         return torch.cat((torch.cat((hessian_vqe_vqe, hessian_vqe_oo.T), dim=1),
                           torch.cat((hessian_vqe_oo, hessian_oo_oo), dim=1)), dim=0)
 

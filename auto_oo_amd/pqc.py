@@ -129,6 +129,8 @@ class Parameterized_circuit():
         """gamma [1+n_theta, a, a], Gamma [1+n_theta, a,a,a,a]: set 0 = RDMs of psi(theta), set k =
         d/dtheta_k (what autograd yields in the reference, oo_pqc.py:86-95,113-119)."""
         th = self._theta2d(theta)
+        if self._use_sector:
+            return self._sector.rdms_with_derivatives(th, self._gates)
         gamma, Gamma = ops.circuit_rdms(th, self._gates_dev, self._n_gates, self.n_qubits,
                                         self.ncas, self._init_index, tangents=True)
         return gamma[0], Gamma[0]

@@ -52,6 +52,88 @@ class SectorEngine:
         self.gates_dev, self.n_gates, self.n_theta = gates_dev, n_gates, n_theta
         self.init_index = init_index
         self._work = {}
+        self._param_gate = None
+
+    # ---- derivatives (round 4) --------------------------------------------------------------------
+    def param_gates(self, gates_host):
+        """gate index of every parameter, for circuits in which each parameter drives exactly one gate
+        (UCCD / UCCSD / kUpCCD: one Givens pass per excitation); None otherwise (GateFabric's orbital
+        rotations spread a parameter over several gates: their tangents need the product rule)."""
+        if self._param_gate is None:
+            owner = [[] for _ in range(self.n_theta)]
+            for gi, g in enumerate(gates_host):
+                if g.theta_idx >= 0:
+                    owner[g.theta_idx].append(gi)
+            self._param_gate = [o[0] for o in owner] if all(len(o) == 1 for o in owner) else False
+        return self._param_gate or None
+
+    def derivative_states(self, theta, specs):
+        """theta [batch, n_theta], specs: list of (gate_a, gate_b) (-1 = none) -> [batch, len(specs), Dc]:
+        the circuit with those gates differentiated (oovqe_sector_state_deriv)."""
+        batch = theta.shape[0]
+        spec = torch.as_tensor(np.asarray(specs, dtype=np.int32).reshape(-1, 2)).to(self.device)
+        out = torch.empty((batch, spec.shape[0], self.Dc), dtype=F64, device=self.device)
+        check(self.lib.oovqe_sector_state_deriv(dptr(theta), self.n_theta, dptr(self.gates_dev, torch.uint8),
+                                                self.n_gates, self.ncas, ctypes.c_uint32(self.init_index),
+                                                *self._tabs(), batch, dptr(spec, torch.int32), int(spec.shape[0]),
+                                                dptr(out), stream_ptr()), "oovqe_sector_state_deriv")
+        return out
+
+    def rdms_chunked(self, states, chunk=256):
+        """RDMs of a long list of sector vectors [n, Dc], ``chunk`` at a time (the workspace of
+        ``oovqe_sector_rdms`` grows with the batch)."""
+        g1, g2 = [], []
+        for i in range(0, states.shape[0], chunk):
+            a, b = self.rdms(states[i:i + chunk].contiguous())
+            g1.append(a)
+            g2.append(b)
+        return torch.cat(g1), torch.cat(g2)
+
+    def rdms_with_derivatives(self, theta, gates_host):
+        """gamma [1 + n_theta, a, a], Gamma [1 + n_theta, a,a,a,a] of ONE parameter point theta [1, n_theta]:
+        set 0 = the RDMs of psi, set k = their derivative with respect to theta_k.  The RDMs are quadratic
+        forms of the (real) state, so with the tangent tau_k = d psi / d theta_k the derivative is EXACTLY
+        [RDM(psi + tau_k) - RDM(psi - tau_k)] / 2 -- the plain RDM kernel on 2 n_theta + 1 vectors, no
+        transition-RDM kernel."""
+        pg = self.param_gates(gates_host)
+        if pg is None:
+            raise NotImplementedError("sector derivatives need one gate per parameter (UCCD / UCCSD / kUpCCD)")
+        nt = self.n_theta
+        st = self.derivative_states(theta, [(-1, -1)] + [(pg[k], -1) for k in range(nt)])[0]   # [1 + nt, Dc]
+        psi, tau = st[0:1], st[1:]
+        g1, g2 = self.rdms_chunked(torch.cat((psi, psi + tau, psi - tau)))
+        gamma = torch.cat((g1[0:1], 0.5 * (g1[1:1 + nt] - g1[1 + nt:])))
+        Gamma = torch.cat((g2[0:1], 0.5 * (g2[1:1 + nt] - g2[1 + nt:])))
+        return gamma, Gamma
+
+    def circuit_hessian(self, theta, gates_host, c1, c2):
+        """d^2/dtheta^2 of E = c0 + c1 . gamma(theta) + c2 . Gamma(theta) = c0 + Q(psi), Q the quadratic form
+        of the active-space Hamiltonian (oo_pqc.py:103-111), inside the (N_alpha, N_beta) sector:
+            H_jk = 2 B(tau_jk, psi) + 2 B(tau_j, tau_k),   B(a, b) = [Q(a + b) - Q(a - b)] / 4
+        with first and second tangent states from ``oovqe_sector_state_deriv`` and Q from the plain RDM
+        kernel -- 4 n_pairs sector vectors of 4 900 amplitudes at CAS(8e,8o) instead of second tangents on
+        the dense 2^16 register."""
+        pg = self.param_gates(gates_host)
+        if pg is None:
+            raise NotImplementedError("sector derivatives need one gate per parameter (UCCD / UCCSD / kUpCCD)")
+        nt = self.n_theta
+        pairs = [(j, k) for j in range(nt) for k in range(j, nt)]
+        specs = [(-1, -1)] + [(pg[k], -1) for k in range(nt)] + [(pg[j], pg[k]) for j, k in pairs]
+        st = self.derivative_states(theta, specs)[0]
+        psi, tau, tau2 = st[0], st[1:1 + nt], st[1 + nt:]
+        ja = torch.as_tensor([j for j, _ in pairs], device=self.device)
+        ka = torch.as_tensor([k for _, k in pairs], device=self.device)
+        vecs = torch.cat((tau2 + psi, tau2 - psi, tau[ja] + tau[ka], tau[ja] - tau[ka]))
+        g1, g2 = self.rdms_chunked(vecs)
+        a = self.ncas
+        q = ((g1.reshape(-1, a * a) * c1.reshape(1, -1)).sum(dim=1)
+             + (g2.reshape(-1, a ** 4) * c2.reshape(1, -1)).sum(dim=1))
+        npair = len(pairs)
+        val = 0.5 * (q[:npair] - q[npair:2 * npair]) + 0.5 * (q[2 * npair:3 * npair] - q[3 * npair:])
+        H = torch.zeros((nt, nt), dtype=F64, device=self.device)
+        H[ja, ka] = val
+        H[ka, ja] = val
+        return H
 
     def fits(self):
         """The sector vector (+ gate table) must fit one workgroup's LDS twice (adjoint sweep)."""

@@ -483,6 +483,23 @@ def kupccd_extra():
         th1 = torch.tensor(rng.uniform(0, 2 * np.pi, n_theta), device="cuda")
         rec["oo_eval_us"] = timed(lambda: oo.energy_and_gradient(th1), warm=3, reps=20) * 1e6
         rec["n_kappa"] = oo.n_kappa
+        if k == 1:
+            # round 4: second derivatives inside the sector -- the full (n_theta + n_kappa)^2 Hessian of
+            # OO_pqc.full_hessian (oo_pqc.py:136-148) and one damped Newton step of full_optimization's body
+            rec["full_hessian_us"] = timed(lambda: oo.full_hessian(th1), warm=2, reps=5) * 1e6
+            th_s = torch.tensor(rng.normal(0, 0.3, n_theta), device="cuda")
+            kap0 = torch.zeros(oo.n_kappa, dtype=torch.float64, device="cuda")
+            e_before = oo.energy_from_parameters(th_s).item()
+            opt = aoo.NewtonStep(verbose=0)
+
+            def newton_step():
+                g = oo.full_gradient(th_s)
+                H = oo.full_hessian(th_s)
+                return opt.damped_newton_step(oo.energy_from_parameters, (th_s, kap0), g, H)
+            rec["newton_step_us"] = timed(newton_step, warm=1, reps=3) * 1e6
+            new, low = newton_step()
+            rec["newton_step_energy_drop"] = e_before - oo.energy_from_parameters(new[0], new[1]).item()
+            rec["hessian_dim"] = n_theta + oo.n_kappa
         layers.append(rec)
     return {"layers": layers}
 

@@ -380,6 +380,15 @@ int oovqe_sector_state(const double* theta, int n_theta, const oovqe_gate_t* gat
                        int ncas, uint32_t init_index, const uint32_t* unrank_a, const uint32_t* unrank_b,
                        const int32_t* rank_a, const int32_t* rank_b, int na, int nb, int batch,
                        double* psi_c, double* psi_dense, oovqe_stream_t stream);
+/* The sector circuit with up to two of its gates differentiated (first / second tangent states d psi / d theta_j,
+ * d^2 psi / d theta_j d theta_k for the second derivatives of src/auto_oo/oo_pqc.py:103-125; circuits in which
+ * every parameter drives one gate: UCCD / UCCSD / kUpCCD): deriv [n_out][2] gate indices (device; -1 = none,
+ * twice the same gate = its second derivative), psi_out [batch][n_out][Dc]. */
+int oovqe_sector_state_deriv(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
+                             int ncas, uint32_t init_index, const uint32_t* unrank_a,
+                             const uint32_t* unrank_b, const int32_t* rank_a, const int32_t* rank_b,
+                             int na, int nb, int batch, const int32_t* deriv, int n_out, double* psi_out,
+                             oovqe_stream_t stream);
 int oovqe_sector_rdms(const double* psi_c, int ncas, const uint32_t* unrank_a, const uint32_t* unrank_b,
                       const int32_t* rank_a, const int32_t* rank_b, int na, int nb, int batch,
                       double* gamma, double* Gamma, double* work, oovqe_stream_t stream);
