@@ -382,7 +382,7 @@ def test_sector_second_derivatives_vs_oracle_autograd_cas44():
     (test/test_oo_pqc.py:101-125 for this ansatz), 1e-8."""
     from oracle import cpu_ref as R
     from torch.autograd.functional import hessian as thessian
-    P, mol, pqc, oo = _kupccd_problem(10, 4, 4, 8, 440)
+    P, mol, pqc, oo = _kupccd_problem(8, 4, 4, 8, 440)
     assert pqc._sector.fits()
     pqc._use_sector = True
     omol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], 8)
