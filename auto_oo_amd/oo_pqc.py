@@ -69,9 +69,6 @@ class _ParametersEnergyModel(_OrbitalRotationRule):
         between kappa and the local rotation parameters (_OrbitalRotationRule)."""
         oo = self.oo
         pqc = oo.pqc
-        if getattr(pqc, "_use_sector", False):
-            raise NotImplementedError("second derivatives at kappa != 0 are built for the dense-register "
-                                      "circuits (n_qubits <= 10)")
         cache = getattr(self, "_rot", None)
         if cache is None:
             with kernel_scope():
@@ -83,8 +80,11 @@ class _ParametersEnergyModel(_OrbitalRotationRule):
                                    want_matrices=True, eri_flags=oo._eri_flags())
                 Hxt = res["gvec"][1:].T.contiguous()                       # [P, n_theta]
                 nt = oo._n_theta()
-                Htt = ops.circuit_hessian(pqc._theta2d(theta).reshape(-1), pqc._gates_dev, pqc._n_gates,
-                                          pqc.n_qubits, oo.ncas, pqc._init_index, res["c1"], res["c2"]).reshape(nt, nt)
+                if getattr(pqc, "_use_sector", False):     # large registers: inside the (N_alpha, N_beta) sector
+                    Htt = pqc._sector.circuit_hessian(pqc._theta2d(theta), pqc._gates, res["c1"], res["c2"]).reshape(nt, nt)
+                else:
+                    Htt = ops.circuit_hessian(pqc._theta2d(theta).reshape(-1), pqc._gates_dev, pqc._n_gates,
+                                              pqc.n_qubits, oo.ncas, pqc._init_index, res["c1"], res["c2"]).reshape(nt, nt)
                 Hxx = ops.orbital_hessian(oo.int2e_ao, oo.int1e_ao, C, gamma[0].contiguous(), Gamma[0].contiguous(),
                                           res["fock"], oo._n_occ, oo.ncas, tr, tc, want_matrix=True)[0]
                 cache = self._rot = (U, K, res["gmat"], Hxx, Hxt, Htt)

@@ -390,10 +390,12 @@ def test_sector_second_derivatives_vs_oracle_autograd_cas44():
     theta = torch.tensor(np.random.default_rng(44).uniform(0, 2 * np.pi, pqc.theta_shape))
     H = oo.full_hessian(theta.to(DEV)).cpu()
     nt, nk = int(pqc.theta_shape), oo.n_kappa
-    href = thessian(ooo.energy_from_parameters, (theta, torch.zeros(nk, dtype=torch.float64)))
-    assert (H[:nt, :nt] - href[0][0]).abs().max().item() < 1e-8
-    assert (H[nt:, :nt] - href[1][0]).abs().max().item() < 1e-8
-    assert (H[nt:, nt:] - href[1][1]).abs().max().item() < 1e-8
+    # (the blocks the sector engine is behind: theta-theta and kappa-theta; the kappa-kappa block never sees
+    # the circuit kernels and is pinned by the dense-register tests)
+    htt = thessian(ooo.energy_from_parameters, theta)
+    hkt = torch.autograd.functional.jacobian(ooo.orbital_gradient, theta)
+    assert (H[:nt, :nt] - htt).abs().max().item() < 1e-8
+    assert (H[nt:, :nt] - hkt).abs().max().item() < 1e-8
     assert (oo.full_gradient(theta.to(DEV)).cpu()[:nt]
             - torch.autograd.functional.jacobian(ooo.energy_from_parameters, theta)).abs().max().item() < 1e-8
 
@@ -423,3 +425,25 @@ def test_kupccd_cas88_damped_newton_step_lowers_the_energy():
     new, low = aoo.NewtonStep(verbose=0).damped_newton_step(oo.energy_from_parameters, (theta, kappa), g, H)
     E1 = oo.energy_from_parameters(new[0], new[1]).item()
     assert E1 < E0 - 1e-6, (E0, E1)
+
+
+def test_sector_second_order_autodiff_at_nonzero_kappa_equals_dense_register():
+    """hessian(energy_from_parameters)(theta, kappa) at kappa != 0 (oo_pqc.py:103-125 differentiates at any
+    point) on a sector circuit (kUpCCD CAS(6e,6o), 12 qubits): the sector engine's second derivatives behind
+    torch autodiff against the dense-register kernels behind the same rules."""
+    from torch.autograd.functional import hessian as thessian
+    P, mol, pqc, oo = _kupccd_problem(16, 6, 6, 10, 661)
+    assert pqc._use_sector
+    rng = np.random.default_rng(67)
+    theta = torch.tensor(rng.uniform(0, 2 * np.pi, pqc.theta_shape))
+    kappa = torch.tensor(rng.normal(0, 0.05, oo.n_kappa))
+    hs = thessian(oo.energy_from_parameters, (theta, kappa))
+    pqc._use_sector = False
+    try:
+        hd = thessian(oo.energy_from_parameters, (theta, kappa))
+    finally:
+        pqc._use_sector = True
+    for i in range(2):
+        for j in range(2):
+            scale = max(1.0, hd[i][j].abs().max().item())
+            assert (hs[i][j] - hd[i][j]).abs().max().item() < 1e-9 * scale, (i, j)
