@@ -72,19 +72,23 @@ class NewtonStep():
         proj = torch.einsum("...ji,...j->...i", vecs, g) / (vals + nu[..., None])
         return -torch.einsum("...ij,...j->...i", vecs, proj), low, nu
 
-    def _direction(self, gradient, hessian, batched=False):
+    def _direction(self, gradient, hessian, batched=False, defer_lowest=False):
         """(dp, lowest eigenvalue, shift, info) as device tensors; no host synchronisation.  info [G]: the
         library's per-problem verdict (ops.NEWTON_INFO; negative = it failed loudly and dp is NaN), checked on
-        the host together with the line search's first readback (``_check_direction``)."""
+        the host together with the line search's first readback (``_check_direction``).  ``defer_lowest``: the
+        eigenvalue as an ``ops.PendingLowest`` (still being computed beside whatever follows)."""
         dev = _lib.require_device()
         g = ops.as_device(gradient, dev)
         H = ops.as_device(hessian, dev)
         if not batched:
             g = g.reshape(-1)
         if g.shape[-1] <= _lib.load().oovqe_newton_direction_max_n():
-            return ops.newton_direction(H, g, self.lambda_min, self.mu, self.rho, self.aug, want_info=True)
+            return ops.newton_direction(H, g, self.lambda_min, self.mu, self.rho, self.aug, want_info=True,
+                                        defer_lowest=defer_lowest)
         dp, low, nu = self._eigh_direction(H, g)
-        return dp, low, nu, torch.zeros(low.numel(), dtype=dp.dtype, device=dp.device)
+        if defer_lowest:
+            low = ops.PendingLowest(low, None)
+        return dp, low, nu, torch.zeros(dp.shape[0] if batched else 1, dtype=dp.dtype, device=dp.device)
 
     def _check_direction(self, gradient, hessian, dp, low, nu, info_host, batched=False):
         """Act on negative entries of the library's info (host values): a timed-out hand-off between the
@@ -177,20 +181,21 @@ class NewtonStep():
         return new, energy
 
     def damped_newton_step(self, objective_fn, parameters, gradient, hessian):
-        """newton_raphson.py:194-211 -> (new parameters, lowest Hessian eigenvalue).  One launch
-        for the direction, the lowest eigenvalue rides on the line search's readback."""
-        dp, low, nu, info = self._direction(gradient, hessian)
+        """newton_raphson.py:194-211 -> (new parameters, lowest Hessian eigenvalue).  The lowest eigenvalue of
+        a positive definite Hessian is computed BESIDE the line search (side stream) and read back after it:
+        the direction does not depend on it (newton_raphson.py:105-128)."""
+        dp, low, nu, info = self._direction(gradient, hessian, defer_lowest=True)
         try:
-            new, _, (lowest_eigenvalue, shift, code) = self._search(objective_fn, parameters, dp, gradient,
-                                                                    extra=(low, nu, info))
+            new, _, (shift, code) = self._search(objective_fn, parameters, dp, gradient, extra=(nu, info))
         except _lib.OovqeError:
             code = info.reshape(()).item()
             if code >= 0:
                 raise
         if code < 0:            # the library refused loudly: repeat / fall back, then search again
-            dp, low, nu = self._check_direction(gradient, hessian, dp, low, nu, [code])
-            new, _, (lowest_eigenvalue, shift) = self._search(objective_fn, parameters, dp, gradient,
-                                                              extra=(low, nu))
+            dp, low_t, nu = self._check_direction(gradient, hessian, dp, None, nu, [code])
+            low = ops.PendingLowest(low_t, None)
+            new, _, (shift,) = self._search(objective_fn, parameters, dp, gradient, extra=(nu,))
+        lowest_eigenvalue = low.result().reshape(()).item()
         if self.verbose:
             print("lowest eigval hessian =", lowest_eigenvalue)
             if shift != 0.0:
