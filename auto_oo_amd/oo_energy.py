@@ -90,7 +90,8 @@ def _is_zero(t):
 
 
 def _matvec(H, v):
-    return None if v is None else torch.matmul(H, v.reshape(-1))
+    # (a row-wise product and sum: the second-order rules stay off the vendor BLAS)
+    return None if v is None else (H * v.reshape(1, -1)).sum(dim=1)
 
 
 def _apply_rows(fn, v, shape):
@@ -202,7 +203,7 @@ class _OrbitalRotationRule:
         """sum_i g_i d^2 x_i / d kappa d kappa . v  for the local gradient G (skew matrix)."""
         oo = self.oo
         Z = 0.5 * self._frechet2(K.contiguous(), ops.matmul_nn(U, Gm.contiguous()), self._kmat(v)) \
-            + 0.25 * self._frechet(K.contiguous(), ops.matmul_nn(U, (Gm @ B.T + B.T @ Gm).contiguous()))
+            + 0.25 * self._frechet(K.contiguous(), ops.matmul_nn(U, (ops.matmul_nn(Gm.contiguous(), B.T.contiguous()) + ops.matmul_nn(B.T.contiguous(), Gm.contiguous())).contiguous()))
         r, c = oo._kap_row.long(), oo._kap_col.long()
         return Z[r, c] - Z[c, r]
 
@@ -271,7 +272,7 @@ class _KappaEnergyModel(_OrbitalRotationRule):
         def one(v):
             with kernel_scope():
                 xv, B = self.local_push(U, K, v)
-                return self.local_pull(U, K, Hm @ xv) + self.local_curvature(U, K, Gm, v, B)
+                return self.local_pull(U, K, _matvec(Hm, xv)) + self.local_curvature(U, K, Gm, v, B)
         return _apply_rows(one, vs[0], kappa.shape), None, None
 
 

@@ -99,11 +99,11 @@ class _ParametersEnergyModel(_OrbitalRotationRule):
             out_t = out_x = curv = None
             if vt is not None:
                 t = unwrap(vt).reshape(-1)
-                out_t, out_x = Htt @ t, Hxt @ t
+                out_t, out_x = _matvec(Htt, t), _matvec(Hxt, t)
             if vk is not None:
                 v = unwrap(vk).reshape(-1)
                 xv, B = self.local_push(U, K, v)
-                bt, bx = Hxt.T @ xv, Hxx @ xv
+                bt, bx = _matvec(Hxt.T, xv), _matvec(Hxx, xv)
                 out_t = bt if out_t is None else out_t + bt
                 out_x = bx if out_x is None else out_x + bx
                 curv = self.local_curvature(U, K, Gm, v, B)

@@ -475,11 +475,13 @@ def _newton_work(kind, n, G, dev, size):
 
 
 def _side_stream(dev):
-    side = _NEWTON_SIDE.get(str(dev))
-    if side is None:
-        side = torch.cuda.Stream(device=dev)
-        _NEWTON_SIDE[str(dev)] = side
-    return side
+    """Two side streams, taken in turn: the eigenvalue routes of consecutive steps run beside each other (a
+    quarter of the chip each), so that a loop of steps is not paced by one of them."""
+    entry = _NEWTON_SIDE.get(str(dev))
+    if entry is None:
+        entry = _NEWTON_SIDE[str(dev)] = [[torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)], 0]
+    entry[1] ^= 1
+    return entry[0][entry[1]]
 
 
 class PendingLowest:
@@ -549,9 +551,11 @@ def newton_direction(hessian, gradient, lambda_min=1e-6, mu=1e-6, rho=1.1, aug=T
                                               dptr(dpc), dptr(low), dptr(nu), stream_ptr()),
               "oovqe_newton_direction_rest")
         side = _side_stream(dev)
-        # the eigenvalue route beside the line search keeps to half of the chip (its workgroups hold a
-        # whole CU each for the length of the reduction; the evaluations of the line search need the rest)
-        side_wg = max(1, 128 // G) if max_wg == 0 else int(max_wg)
+        # the eigenvalue route beside the line search keeps to a quarter of the chip (half for larger stacks,
+        # whose band reduction would otherwise crawl on one workgroup per problem: its workgroups hold a
+        # whole CU each for the length of the reduction; the evaluations of the line search need the rest,
+        # and the route of the previous step may still be running on the other side stream)
+        side_wg = (max(1, 64 // G) if G <= 16 else max(1, 128 // G)) if max_wg == 0 else int(max_wg)
         with torch.cuda.stream(side):
             side.wait_event(forked)
             wside = _newton_work("rest", n, G, dev, lib.oovqe_newton_direction_rest_work_size(n, G))
