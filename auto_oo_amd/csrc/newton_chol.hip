@@ -559,8 +559,10 @@ int oovqe_newton_chol_launch(const double* hessian, const double* gradient, int 
     const int T = (n + 1 + 15) / 16;
     const bool small = T <= 24;                     // four row tiles of a panel per accumulating wave (n <= 383), else six
     const void* kern = small ? (const void*)newton_chol_kernel<4, 2> : (const void*)newton_chol_kernel<6, 2>;
-    OOVQE_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                    "newton_direction_pd: hipFuncSetAttribute");
+    {
+        int rc_lds = oovqe_ensure_dynamic_lds(kern, lds);
+        if (rc_lds) return rc_lds;
+    }
     const int roles = lambda_min != 0.0 ? 2 : 1;
     int* status = reinterpret_cast<int*>(work + (size_t)batch * 2 * chol_factor_doubles(T));
     if (small)
