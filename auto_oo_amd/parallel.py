@@ -18,6 +18,21 @@ def shard_geometries(n_geom, rank, world):
     return list(range(rank, n_geom, world))
 
 
+_INDEX_CACHE = {}
+
+
+def _index_tensor(my_geoms, device):
+    """Device copy of the shard's geometry indices, made once (a host-to-device copy inside a timed loop is a
+    blocking call)."""
+    key = (tuple(my_geoms), str(device))
+    idx = _INDEX_CACHE.get(key)
+    if idx is None:
+        if len(_INDEX_CACHE) > 64:
+            _INDEX_CACHE.clear()
+        idx = _INDEX_CACHE[key] = torch.as_tensor(list(my_geoms), device=device)
+    return idx
+
+
 def gather_results(local, my_geoms, n_geom, dist=None):
     """local [len(my_geoms), n_out] -> [n_geom, n_out] on every rank (row g = geometry g).
 
@@ -25,7 +40,7 @@ def gather_results(local, my_geoms, n_geom, dist=None):
     n_out = local.shape[1]
     if dist is None or not dist.is_initialized():
         full = torch.zeros((n_geom, n_out), dtype=local.dtype, device=local.device)
-        full[torch.as_tensor(my_geoms, device=local.device)] = local
+        full[_index_tensor(my_geoms, local.device)] = local
         return full
     world = dist.get_world_size()
     per = (n_geom + world - 1) // world

@@ -1,20 +1,41 @@
-"""Batched calls issued alternately on two HIP streams (workspace slots 0/1) against one stream:
-do the small tail launches of one call fill the gaps of the other's N^4 pass?"""
-import os, sys, time, torch
+"""Independent batched evaluations issued alternately on two HIP streams (workspace slots 0 / 1): the stage-1 sweep
+of one call keeps one workgroup per geometry busy for ~380 us and fills their CUs' register files; with fewer than
+256 geometries per call the remaining CUs are free for the latency-bound tail kernels of the OTHER stream's call.
+    python tools/two_stream_probe.py [G ...]"""
+import os
+import sys
+import time
+
+import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench
-G = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-pqc, batch, single, thetas = bench.build_geometries([g % 8 for g in range(G)])
-streams = [torch.cuda.Stream() for _ in range(4)]
-def run(n, ns):
-    for i in range(n):
-        if ns > 1:
-            with torch.cuda.stream(streams[i % ns]):
-                batch.energy_and_gradient(thetas, slot=i % ns)
-        else:
-            batch.energy_and_gradient(thetas)
-for ns in (1, 2, 3, 4, 1, 2):
-    run(24, ns); torch.cuda.synchronize()
-    t0 = time.perf_counter(); run(240, ns); torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 240
-    print(f"G={G} streams={ns}: {dt*1e6:.1f} us per call -> {G/dt:.0f} evals/s", flush=True)
+import bench                                            # noqa: E402
+
+sizes = [int(a) for a in sys.argv[1:]] or [256, 240, 224, 208, 192, 176, 160, 128]
+pqc, batch, single, thetas = bench.build_geometries(list(range(max(sizes))))
+streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+
+def run(G, n_calls, two):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if two:
+        for s in streams:
+            s.wait_stream(torch.cuda.current_stream())
+        for i in range(n_calls):
+            with torch.cuda.stream(streams[i & 1]):
+                batch.evaluate(thetas, count=G, slot=i & 1)
+    else:
+        for i in range(n_calls):
+            batch.evaluate(thetas, count=G)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n_calls
+
+
+for G in sizes:
+    for two in (False, True):
+        run(G, 6, two)
+    t1 = min(run(G, 60, False) for _ in range(3))
+    t2 = min(run(G, 60, True) for _ in range(3))
+    print(f"G = {G:3d}: one stream {t1 * 1e6:7.1f} us per call = {G / t1 / 1e3:6.1f}K evaluations/s; "
+          f"two streams {t2 * 1e6:7.1f} us = {G / t2 / 1e3:6.1f}K", flush=True)
