@@ -77,6 +77,8 @@ class OO_pqc_batch:
         self._eri_packed = None
         self._refresh_flags(repack=range(self.G))
         self._plans = {}
+        self._flat0 = None
+        self._trial_orbitals = None
 
     def set_oao_mo_coeff(self, g, oao_mo_coeff):
         """Replace the orbitals of geometry g and refresh mo_coeff[g] = S^-1/2 C_oao
@@ -282,12 +284,33 @@ class OO_pqc_batch:
         nt = self.n_theta
         thetas = ops.as_device(thetas, self.device).reshape(self.G, nt)
         E, grad, H = self.energy_gradient_hessian(thetas)
-        flat = torch.zeros((self.G, nt + self.n_kappa), dtype=F64, device=self.device)
-        flat[:, :nt] = thetas
-        # the energy at the accepted trial point IS the energy at the new parameters (the same orbitals
-        # C expm(-K), formed once as mo_coeff U and once as S^-1/2 (C_oao U): equal to rounding), so the loop
-        # body's closing evaluation (oo_pqc.py:195) is not repeated
+        flat = self._flat0
+        if flat is None:
+            flat = self._flat0 = torch.zeros((self.G, nt + self.n_kappa), dtype=F64, device=self.device)
+        flat[:, :nt] = thetas                        # (the kappa part stays zero: steps start at the current orbitals)
+        if self._trial_orbitals is None:
+            self._trial_orbitals = (torch.empty_like(self.oao_mo_coeff), torch.empty_like(self.mo_coeff))
+
+        def trial(pa, pb):
+            # the orbitals of a trial are formed as an accepted step forms them -- C_oao expm(-K), then
+            # S^-1/2 (C_oao U) (oo_pqc.py:191, oo_energy.py:173-176) -- so the accepted trial's orbitals ARE the new
+            # ones: the step adopts them by exchanging buffers, nothing is launched behind the last readback
+            t_oao, t_mo = self._trial_orbitals
+            self._rotate(self.oao_mo_coeff, pb, t_oao)
+            ops.matmul_nn_batch(self.oao_coeff, t_oao, out=t_mo)
+            return self.evaluate(pa, derivatives=False, mo_coeff=t_mo)[:, 1]
+
+        # the energy at the accepted trial point IS the energy at the new parameters, so the loop body's closing
+        # evaluation (oo_pqc.py:195) is not repeated
         (new_thetas, new_kappas), low, energies = opt.damped_newton_steps_flat(
-            self.energy, flat, grad, H, energy0=E, defer_lowest=True, split=nt, return_energy=True)
-        self.rotate_(new_kappas)
+            trial, flat, grad, H, energy0=E, defer_lowest=True, split=nt, return_energy=True)
+        if opt.last_search_gave_up:
+            self.rotate_(new_kappas)                 # (some problems went back to their old parameters)
+        else:
+            # every trial evaluates ALL geometries at their current points, the accepted ones at their accepted
+            # point: the last trial's orbitals are the new orbitals of the whole stack.  Like the reference's
+            # `self.oao_mo_coeff = ...` the attributes are rebound, not written in place.
+            t_oao, t_mo = self._trial_orbitals
+            self._trial_orbitals = (self.oao_mo_coeff, self.mo_coeff)
+            self.oao_mo_coeff, self.mo_coeff = t_oao, t_mo
         return new_thetas, energies, (low if defer_lowest else low.result())

@@ -57,6 +57,7 @@ class NewtonStep():
         self.lambda_min = lambda_min
         self.aug = aug
         self.verbose = verbose
+        self.last_search_gave_up = False       # (set by damped_newton_steps_flat: the search ended in a give-up)
 
     # ---- direction ----------------------------------------------------------------------------
     def _eigh_direction(self, H, g):
@@ -297,6 +298,7 @@ class BatchedNewtonStep(NewtonStep):
             e = objective(pa) if split is None else objective(pa, pb)
             return e.reshape(G)
 
+        self.last_search_gave_up = False
         points(True)
         fl = update(trial_energies(), 1, 0, True)
         if fl[1] < 0:
@@ -319,6 +321,7 @@ class BatchedNewtonStep(NewtonStep):
                 # newton_raphson.py:177-183: give up on the problems still searching
                 update(None, 0, 1, False)
                 points(False)
+                self.last_search_gave_up = True       # (the returned points are no trial's: some are the old ones)
                 if self.verbose:
                     print("Warning: line search failed. Output previous parameters.")
                 break

@@ -474,12 +474,23 @@ def _newton_work(kind, n, G, dev, size):
     return work
 
 
-def _side_stream(dev):
-    """Two side streams, taken in turn: the eigenvalue routes of consecutive steps run beside each other (a
-    quarter of the chip each), so that a loop of steps is not paced by one of them."""
+def side_streams(dev=None):
+    """The library's two side streams of a device (created once).  A process should not create many more streams than
+    these: HIP multiplexes its streams over a handful of hardware queues (four by default), and two streams that
+    share a queue run one after the other -- callers that want a second stream of their own (e.g. two evaluation
+    calls in flight, ``OO_pqc_batch.evaluate(slot=...)``) can take these."""
+    dev = _lib.require_device() if dev is None else dev
     entry = _NEWTON_SIDE.get(str(dev))
     if entry is None:
         entry = _NEWTON_SIDE[str(dev)] = [[torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)], 0]
+    return entry[0]
+
+
+def _side_stream(dev):
+    """Two side streams, taken in turn: the eigenvalue routes of consecutive steps run beside each other (a
+    quarter of the chip each), so that a loop of steps is not paced by one of them."""
+    side_streams(dev)
+    entry = _NEWTON_SIDE[str(dev)]
     entry[1] ^= 1
     return entry[0][entry[1]]
 

@@ -709,7 +709,7 @@ def main():
     # streams 12.5 % fewer bytes in the same time -- `value` and `roofline` stay on the one-stream design point.
     two_stream = None
     if world == 1 and G >= 224 and not args.general_eri:
-        streams2 = [torch.cuda.Stream(), torch.cuda.Stream()]
+        streams2 = ops.side_streams()       # (no further streams: HIP's few hardware queues are shared round robin)
 
         def run2(n, count):
             torch.cuda.synchronize()

@@ -438,13 +438,20 @@ def test_batched_newton_step_equals_per_geometry_steps():
     the OO_pqc object of each geometry, and geometry 0 against the oracle's step (1e-9 Ha)."""
     pqc, batch, objs, probs = _batch_of(43, 8)
     theta0 = torch.full((8, pqc.theta_shape), 0.1, dtype=torch.float64, device="cuda")
+    c_before = batch.oao_mo_coeff.clone()
     new_t, e_new, low = batch.damped_newton_step(theta0)
+    # the step adopted the accepted trial's orbitals (buffers exchanged, nothing recomputed): they are the
+    # orbitals the returned energies were evaluated at, and mo_coeff = S^-1/2 C_oao holds
+    assert (batch.energy(new_t) - e_new).abs().max().item() == 0.0
+    for g in range(8):
+        assert (batch.mo_coeff[g] - batch.oao_coeff[g] @ batch.oao_mo_coeff[g]).abs().max() < 1e-13
     opt = aoo.NewtonStep(verbose=0)
     for g, oo in enumerate(objs):
         kappa = torch.zeros(oo.n_kappa, dtype=torch.float64, device="cuda")
         new, low_s = opt.damped_newton_step(oo.energy_from_parameters, (theta0[g], kappa),
                                             oo.full_gradient(theta0[g]), oo.full_hessian(theta0[g]))
         e_s = oo.energy_from_parameters(new[0], new[1]).item()
+        assert (batch.oao_mo_coeff[g] - c_before[g] @ oo.kappa_to_mo_coeff(new[1])).abs().max() < 1e-9
         assert abs(low[g].item() - low_s) < 1e-10
         assert abs(e_new[g].item() - e_s) < 1e-10
         assert (new_t[g] - new[0]).abs().max() < 1e-9
@@ -458,6 +465,26 @@ def test_batched_newton_step_equals_per_geometry_steps():
                                                            ooo.full_gradient(th), ooo.full_hessian(th))
     assert abs(low[0].item() - low_r) < 1e-9
     assert abs(e_new[0].item() - ooo.energy_from_parameters(new_r[0], new_r[1]).item()) < 1e-9
+
+
+def test_batched_newton_step_that_gives_up_keeps_parameters_and_orbitals():
+    """newton_raphson.py:177-183 in lockstep: with an Armijo constant no step can meet and lmax = 1 every problem
+    gives up, the old parameters come back and the orbitals of the batch are the old ones (the trial's orbitals
+    are NOT adopted)."""
+    pqc, batch, objs, probs = _batch_of(43, 4)
+    theta0 = torch.full((4, pqc.theta_shape), 0.1, dtype=torch.float64, device="cuda")
+    c_before, m_before = batch.oao_mo_coeff.clone(), batch.mo_coeff.clone()
+    e_before = batch.energy(theta0)
+    opt = aoo.BatchedNewtonStep(verbose=0, alpha=50.0, lmax=1)
+    new_t, e_new, low = batch.damped_newton_step(theta0, opt)
+    assert opt.last_search_gave_up
+    assert torch.equal(new_t, theta0)
+    assert torch.equal(batch.oao_mo_coeff, c_before)
+    assert (batch.mo_coeff - m_before).abs().max() < 1e-14
+    assert (e_new - e_before).abs().max() < 1e-11
+    # and a step with the usual constants afterwards goes down from there
+    new_t, e_new, low = batch.damped_newton_step(theta0)
+    assert (e_new < e_before).all()
 
 
 def _pd_stack(rng, n, G, low=0.05):
