@@ -91,6 +91,10 @@ SIGNATURES = {
                                                         ctypes.c_int, ctypes.c_int, c_int32_p,
                                                         c_int32_p, ctypes.c_int]
                        + [c_double_p] * 11 + [ctypes.c_uint, c_stream]),
+    "oovqe_cas_eval_packed": (ctypes.c_int, [c_double_p] * 5 + [ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                                               ctypes.c_int, ctypes.c_int, c_int32_p,
+                                                               c_int32_p, ctypes.c_int]
+                              + [c_double_p] * 11 + [ctypes.c_uint, c_double_p, c_stream]),
     "oovqe_eri_symmetry_flags": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_int,
                                                 ctypes.POINTER(ctypes.c_uint), c_stream]),
     "oovqe_cas_eval_work_size": (ctypes.c_int64, [ctypes.c_int] * 4),

@@ -134,7 +134,7 @@ class OO_pqc_batch:
         self.eri_flags = flags
         both = ops.ERI_PQ_SYMMETRIC | ops.ERI_RS_SYMMETRIC
         psz = self.lib.oovqe_eri_packed_size(self.nao)
-        if flags != both or psz <= 0 or self._n_occ + self.ncas > 16:
+        if flags != both or psz <= 0 or (self.nao <= 48 and self._n_occ + self.ncas > 16):
             self._eri_packed = None
             return
         repack = list(repack)

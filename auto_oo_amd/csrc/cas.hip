@@ -600,6 +600,195 @@ void half_stream_kernel(const double* __restrict__ g, const double* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------
+// Stage 1 for large N on the TILE-PACKED copy of integrals that carry both symmetry flags
+// (oovqe_eri_pack, N > 48): per geometry the slabs p <= q; of each slab, column tile S = 0 .. nst-1 (16
+// columns s), row tiles R = 0 .. S (16 rows r) -- the tile triangle half_stream_kernel<.., RS> reads out of
+// the unpacked slabs -- each 16 x 16 tile stored as the four MFMA A-operand fragments it is consumed as
+// ([k-step pair][lane][2]: one 16-byte load per lane and pair, 1 KB contiguous per wave instruction), the
+// diagonal tiles already multiplied by 1/2, rows and columns beyond N zero.  Against the unpacked stream:
+//   * no weights in the loop (they cost ~2 VALU instructions per k-step, and a VALU instruction does not run
+//     in the shadow of a v_mfma_f64), no column / row masks: every byte of a tile is an operand;
+//   * a chunk is ONE tile (4 k-steps): the work of a slab is exactly its tile triangle (91 tiles at N = 200),
+//     where chunks of 10 k-steps padded every column tile to a multiple of 40 rows (+13 %);
+//   * a wave-instruction fetches 1 KB of one 2 KB tile instead of four 128-byte row pieces.
+// Same sums in the same order per accumulator as the RS stream except for the chunking, J = Z + Z^T formed
+// the same way; the slab's result goes to T2[p,q] and T2[q,p].
+// ------------------------------------------------------------------------------------------
+template <int ZT, int DEPTH, int AUX = AUX_NT>
+__global__ __launch_bounds__(HALF_WAVES * 64)
+void half_tiles_kernel(const double* __restrict__ gt, const double* __restrict__ C, double* __restrict__ T2,
+                       int N, int M, int nst, long nslabs, long geom_doubles)
+{
+    constexpr int LDM = 16 * (ZT | 1);
+    extern __shared__ double lds[];
+    const int RT16 = nst * 16;
+    double* Cl = lds;   // [RT16][LDM], zero padded
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane >> 4, lr = lane & 15;
+    double* patch = lds + (((size_t)RT16 * LDM + 511) / 512) * 512 + (size_t)wave * (16 * 17);
+    gt += (size_t)blockIdx.y * geom_doubles;
+    C += (size_t)blockIdx.y * N * N;
+    T2 += (size_t)blockIdx.y * (size_t)N * N * M * M;
+
+    const long stride = (long)gridDim.x * HALF_WAVES;
+    const long slab0 = (long)blockIdx.x * HALF_WAVES + wave;
+    const int n_mine = slab0 < nslabs ? (int)((nslabs - slab0 + stride - 1) / stride) : 0;
+    const int slab_tiles = nst * (nst + 1) / 2;
+    const unsigned slab_bytes = (unsigned)slab_tiles * 2048u;
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+    d4 jt[ZT][ZT];   // [z tile][y tile]
+#pragma unroll
+    for (int z = 0; z < ZT; ++z)
+#pragma unroll
+        for (int y = 0; y < ZT; ++y) jt[z][y] = d4{0.0, 0.0, 0.0, 0.0};
+    d4 xt[ZT];       // [y tile]
+#pragma unroll
+    for (int y = 0; y < ZT; ++y) xt[y] = d4{0.0, 0.0, 0.0, 0.0};
+
+    // load side: tile lt of the wave's lk-th slab.  Tiles past the wave's last slab are out of range for
+    // the descriptor and come back as zeros (no branch around a load: the s_waitcnt counts stay exact).
+    int lk = 0, lt = 0;
+    const unsigned vo = (unsigned)lane * 16u;
+    auto issue = [&](d4& dst) {
+        const long sl = lk < n_mine ? slab0 + (long)lk * stride : 0;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<double*>(gt) + (size_t)sl * slab_tiles * 256, 0, lk < n_mine ? (int)slab_bytes : 0, 0x00020000);
+        const unsigned sb = (unsigned)lt * 2048u;
+        const v4u lo = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, sb, AUX);
+        const v4u hi = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, sb + 1024u, AUX);
+        struct pair_t { v4u a, b; } pr{lo, hi};
+        dst = __builtin_bit_cast(d4, pr);
+        if (++lt == slab_tiles) { lt = 0; ++lk; }
+    };
+    // compute side: tile (cR, cS) of the wave's ck-th slab.  The rows of C a tile multiplies (its B operands,
+    // from LDS) are read one tile ahead, into the other half of cfb: the next tile is (cR + 1, cS), or row
+    // tile 0 of the next column tile after a diagonal one.
+    int ck = 0, cS = 0, cR = 0;
+    double cfb[2][4][ZT];
+    const double* cl_lane = Cl + lq * LDM + lr;
+    auto load_cf = [&](int R, double (&cf)[4][ZT]) {
+        const double* cb = cl_lane + R * (16 * LDM);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int y = 0; y < ZT; ++y) cf[i][y] = cb[i * 4 * LDM + y * 16];
+    };
+    auto compute = [&](const d4& a, const double (&cf)[4][ZT], double (&cf_next)[4][ZT]) {
+        load_cf(cR != cS ? cR + 1 : 0, cf_next);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int y = 0; y < ZT; ++y) xt[y] = mfma_f64(a[i], cf[i][y], xt[y]);
+        if (cR != cS) { ++cR; return; }
+        // the diagonal tile closes column tile cS: second product with the rows of C it has just used
+        cR = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int z = 0; z < ZT; ++z)
+#pragma unroll
+                for (int y = 0; y < ZT; ++y) jt[z][y] = mfma_f64(cf[i][z], xt[y][i], jt[z][y]);
+#pragma unroll
+        for (int y = 0; y < ZT; ++y) xt[y] = d4{0.0, 0.0, 0.0, 0.0};
+        if (++cS != nst) return;
+        cS = 0;
+        // J = Z + Z^T: tile (z, y) takes the transpose of tile (y, z)
+        auto transposed = [&](const d4& t) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) patch[(lq + 4 * i) * 17 + lr] = t[i];
+            d4 r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = patch[lr * 17 + lq + 4 * i];
+            return r;
+        };
+#pragma unroll
+        for (int z = 0; z < ZT; ++z)
+#pragma unroll
+            for (int y = z; y < ZT; ++y) {
+                const d4 tzy = transposed(jt[z][y]);
+                if (y == z) {
+                    jt[z][z] += tzy;
+                } else {
+                    const d4 tyz = transposed(jt[y][z]);
+                    jt[z][y] += tyz;
+                    jt[y][z] += tzy;
+                }
+            }
+        if (ck < n_mine) {
+            int p, q;
+            tri_decode(slab0 + (long)ck * stride, N, p, q);
+            p = __builtin_amdgcn_readfirstlane(p);
+            q = __builtin_amdgcn_readfirstlane(q);
+            double* dst = T2 + ((size_t)p * N + q) * M * M;
+            double* dst2 = T2 + ((size_t)q * N + p) * M * M;
+#pragma unroll
+            for (int z = 0; z < ZT; ++z)
+#pragma unroll
+                for (int y = 0; y < ZT; ++y)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int zz = z * 16 + lq + 4 * i, yy = y * 16 + lr;
+                        if (yy < M && zz < M) {
+                            dst[yy * M + zz] = jt[z][y][i];
+                            if (p != q) dst2[yy * M + zz] = jt[z][y][i];
+                        }
+                    }
+        }
+        ++ck;
+#pragma unroll
+        for (int z = 0; z < ZT; ++z)
+#pragma unroll
+            for (int y = 0; y < ZT; ++y) jt[z][y] = d4{0.0, 0.0, 0.0, 0.0};
+    };
+
+    d4 ab[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d) issue(ab[d]);
+    for (int idx = tid; idx < RT16 * LDM; idx += HALF_WAVES * 64) {
+        const int r = idx / LDM, z = idx - r * LDM;
+        Cl[idx] = (r < N && z < M) ? C[(size_t)r * N + z] : 0.0;
+    }
+    __syncthreads();
+    static_assert(DEPTH % 2 == 0, "the B-operand double buffer alternates with the ring position");
+    load_cf(0, cfb[0]);
+    // the stream is padded to a multiple of DEPTH tiles: the padding tiles load nothing and add zeros
+    const int rounds = (n_mine * slab_tiles + DEPTH - 1) / DEPTH;
+    for (int it = 0; it < rounds; ++it) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            issue(ab[(d + DEPTH - 1) % DEPTH]);
+            compute(ab[d], cfb[d & 1], cfb[(d + 1) & 1]);
+        }
+    }
+}
+
+// The tile-packed copy itself: one workgroup per (slab p <= q, geometry), thread <-> output element.
+__global__ __launch_bounds__(256)
+void eri_tiles_pack_kernel(const double* __restrict__ g, double* __restrict__ out, int N, int nst)
+{
+    int p, q;
+    tri_decode((long)blockIdx.x, N, p, q);
+    const long slab_tiles = (long)nst * (nst + 1) / 2;
+    const long tri = (long)N * (N + 1) / 2;
+    const double* gs = g + (size_t)blockIdx.y * N * N * N * N + ((size_t)p * N + q) * N * N;
+    double* o = out + ((size_t)blockIdx.y * tri + blockIdx.x) * slab_tiles * 256;
+    for (long e = threadIdx.x; e < slab_tiles * 256; e += 256) {
+        const int tile = (int)(e >> 8), rem = (int)(e & 255);
+        int S = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+        while (S * (S + 1) / 2 > tile) --S;
+        while ((S + 1) * (S + 2) / 2 <= tile) ++S;
+        const int R = tile - S * (S + 1) / 2;
+        const int ln = (rem >> 1) & 63, j = 2 * (rem >> 7) + (rem & 1);
+        const int r = 16 * R + 4 * j + (ln >> 4), c = 16 * S + (ln & 15);
+        double v = 0.0;
+        if (r < N && c < N) v = gs[(size_t)r * N + c] * (R == S ? 0.5 : 1.0);
+        o[e] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // q -> x on the packed triangle (p <-> q symmetric integrals):
 //   T3[p,x,(y z)] = sum_q C[q,x] J[tri(min(p,q), max(p,q)), (y z)],   x < M
 // One workgroup per (p, geometry), one thread per (y z); the coefficients are wave-uniform (scalar
@@ -2905,7 +3094,7 @@ void cas_final_kernel(const double* __restrict__ Fcol, const double* __restrict_
 
 static int half_transform_batched(const double* g_ao, const double* C, int N, int M, double* T2,
                                   int batch, oovqe_stream_t stream, int sym = SYM_FULL, bool rs = false,
-                                  double* Vk_tri = nullptr);
+                                  double* Vk_tri = nullptr, const double* g_tiles = nullptr);
 static int device_cu_count();
 
 extern "C" int oovqe_cas_half_transform(const double* g_ao, const double* C, int N, int M, double* T2,
@@ -2915,8 +3104,10 @@ extern "C" int oovqe_cas_half_transform(const double* g_ao, const double* C, int
 }
 
 static int half_transform_batched(const double* g_ao, const double* C, int N, int M, double* T2,
-                                  int batch, oovqe_stream_t stream, int sym, bool rs, double* Vk_tri)
+                                  int batch, oovqe_stream_t stream, int sym, bool rs, double* Vk_tri,
+                                  const double* g_tiles)
 {
+    // g_tiles: the tile-packed copy of g_ao (oovqe_eri_pack, N > 48; both symmetry flags) or null
     OOVQE_REQUIRE(g_ao && C && T2, "cas_half_transform: null pointer");
     OOVQE_REQUIRE(!Vk_tri || (sym == SYM_MIRROR && N <= 48),
                   "cas_half_transform: the quarter-transformed output needs p<->q symmetric integrals and N <= 48");
@@ -2978,6 +3169,35 @@ static int half_transform_batched(const double* g_ao, const double* C, int N, in
         // r <-> s symmetric slabs: upper tile triangle only (needs a 16 x 17 patch per wave in LDS)
         const size_t lds_rs = lds_bytes + (size_t)HALF_WAVES * 16 * 17 * sizeof(double);
         const bool use_rs = rs && lds_rs <= 160 * 1024;
+        if (g_tiles && use_rs && sym == SYM_MIRROR) {
+            // both flags and a resident tile-packed copy: half_tiles_kernel streams that instead
+            const long slab_doubles = (long)nrb * (nrb + 1) / 2 * 256;
+#define OOVQE_LAUNCH_TILES(Z, D_, A_)                                                             \
+    do {                                                                                          \
+        const void* fn = (const void*)half_tiles_kernel<Z, D_, A_>;                               \
+        int rc_ = oovqe_ensure_dynamic_lds(fn, 160 * 1024);                                       \
+        if (rc_) return rc_;                                                                      \
+        long per = (long)device_cu_count() / batch;      /* one workgroup per CU (LDS) */         \
+        if (per < 1) per = 1;                                                                     \
+        if (per > want) per = want;                                                               \
+        oovqe_note_stage1("half_tiles_kernel<%d,%d>", Z, D_);                                     \
+        hipLaunchKernelGGL((half_tiles_kernel<Z, D_, A_>), dim3((unsigned)per, batch),            \
+                           dim3(HALF_WAVES * 64), lds_rs, st, g_tiles, C, T2, N, M, nrb, nslabs,  \
+                           nslabs * slab_doubles);                                                \
+    } while (0)
+            const int variant = oovqe_opt(OOVQE_OPT_TILES_VARIANT);
+            oovqe_profile_mark_start(st);
+            if (ZT == 1) OOVQE_LAUNCH_TILES(1, 8, AUX_NT);
+            else if (ZT == 3) OOVQE_LAUNCH_TILES(3, 4, AUX_NT);
+            else if (variant == 1) OOVQE_LAUNCH_TILES(2, 4, AUX_NT);
+            else if (variant == 2) OOVQE_LAUNCH_TILES(2, 6, AUX_NT);
+            else if (variant == 4) OOVQE_LAUNCH_TILES(2, 8, AUX_PLAIN);
+            else OOVQE_LAUNCH_TILES(2, 8, AUX_NT);   // (N = 200, M = 26: 833 us per evaluation; ring of 6: 860-920, of 4: 858; default cache policy: 900)
+            oovqe_profile_mark_stop(st);
+#undef OOVQE_LAUNCH_TILES
+            OOVQE_CHECK_LAUNCH("cas_half_transform/tiles");
+            return 0;
+        }
 #define OOVQE_LAUNCH_STREAM(Z, KC_, D_)                                                           \
     do {                                                                                          \
         if (use_rs) OOVQE_LAUNCH_STREAM_RS(Z, KC_, D_, true, lds_rs);                             \
@@ -3248,15 +3468,26 @@ static unsigned eri_slab_packed_elems(int N) { return eri_slab_pitch(N); }
 
 extern "C" int64_t oovqe_eri_packed_size(int N)
 {
-    // doubles per geometry; 0: no packed form for this N (the batched packed-triangle kernels cover N <= 48)
-    if (N < 1 || N > 48) return 0;
+    // doubles per geometry.  N <= 48: the triangle format of the batched packed-triangle kernels; N > 48: the
+    // tile format of half_tiles_kernel (slabs p <= q, tile triangle of each slab, 16 x 16 tiles)
+    if (N < 1) return 0;
+    if (N > 48) {
+        const int64_t nst = (N + 15) / 16;
+        return (int64_t)N * (N + 1) / 2 * (nst * (nst + 1) / 2) * 256;
+    }
     return (int64_t)N * (N + 1) / 2 * eri_slab_packed_elems(N);
 }
 
 extern "C" int oovqe_eri_pack(const double* g_ao, int N, int batch, double* packed, oovqe_stream_t stream)
 {
     OOVQE_REQUIRE(g_ao && packed, "eri_pack: null pointer");
-    OOVQE_REQUIRE(N >= 1 && N <= 48 && batch >= 1 && batch <= 65535, "eri_pack: N=%d batch=%d", N, batch);
+    OOVQE_REQUIRE(N >= 1 && N <= 4096 && batch >= 1 && batch <= 65535, "eri_pack: N=%d batch=%d", N, batch);
+    if (N > 48) {
+        hipLaunchKernelGGL(eri_tiles_pack_kernel, dim3((unsigned)((long)N * (N + 1) / 2), batch), dim3(256), 0,
+                           (hipStream_t)stream, g_ao, packed, N, (N + 15) / 16);
+        OOVQE_CHECK_LAUNCH("eri_pack/tiles");
+        return 0;
+    }
     hipLaunchKernelGGL(eri_pack_kernel, dim3((unsigned)(N * (N + 1) / 2), batch), dim3(256), 0,
                        (hipStream_t)stream, g_ao, packed, N, eri_slab_packed_elems(N));
     OOVQE_CHECK_LAUNCH("eri_pack");
@@ -3673,7 +3904,9 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
                                          cj->gamma, cj->Gamma, nullptr, stream)))
                 return rc;
         }
-        if ((rc = half_transform_batched(g_ao, C, N, M, T2, batch, stream, half_sym, rs_sym))) return rc;
+        if ((rc = half_transform_batched(g_ao, C, N, M, T2, batch, stream, half_sym, rs_sym, nullptr,
+                                         N > 48 ? g_packed : nullptr)))
+            return rc;
         const size_t na2s = (size_t)ncas * ncas, na4s = na2s * na2s;
         for (int g = 0; g < batch; ++g) {
             const size_t gi = (size_t)g;
@@ -3715,7 +3948,9 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
         }
         return 0;
     } else {
-        if ((rc = half_transform_batched(g_ao, C, N, M, T2, batch, stream, half_sym, rs_sym))) return rc;
+        if ((rc = half_transform_batched(g_ao, C, N, M, T2, batch, stream, half_sym, rs_sym, nullptr,
+                                         N > 48 ? g_packed : nullptr)))
+            return rc;
         // U[n,(q y z)] = sum_p C[p,n] T2[p,(q y z)]
         oovqe_profile_mark_start_l(st, 2);
         if ((rc = oovqe_mode_contract_batched_circ(T2, C, U, 1, N, N, (long)N * m2, N, 0, batch,
@@ -3806,6 +4041,21 @@ extern "C" int oovqe_cas_eval(const double* g_ao, const double* h_ao, const doub
     return cas_eval_batched(g_ao, h_ao, C, gamma, Gamma, nrdm, nuc, nullptr, N, n_occ, ncas, kap_row,
                             kap_col, n_kappa, work, c0, c1, c2, E, gvec, dE, fock, gmat, Gm, hmo, 1, 0,
                             stream, nullptr, eri_flags);
+}
+
+extern "C" int oovqe_cas_eval_packed(const double* g_ao, const double* h_ao, const double* C,
+                                     const double* gamma, const double* Gamma, int nrdm, double nuc, int N,
+                                     int n_occ, int ncas, const int32_t* kap_row, const int32_t* kap_col,
+                                     int n_kappa, double* work, double* c0, double* c1, double* c2,
+                                     double* E, double* gvec, double* dE, double* fock, double* gmat,
+                                     double* Gm, double* hmo, unsigned eri_flags, const double* g_packed,
+                                     oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(!g_packed || eri_flags == (OOVQE_ERI_PQ_SYMMETRIC | OOVQE_ERI_RS_SYMMETRIC),
+                  "cas_eval: a packed copy needs both symmetry flags");
+    return cas_eval_batched(g_ao, h_ao, C, gamma, Gamma, nrdm, nuc, nullptr, N, n_occ, ncas, kap_row,
+                            kap_col, n_kappa, work, c0, c1, c2, E, gvec, dE, fock, gmat, Gm, hmo, 1, 0,
+                            stream, nullptr, eri_flags, g_packed);
 }
 
 extern "C" int64_t oovqe_cas_eval_work_size(int N, int n_occ, int ncas, int nrdm)

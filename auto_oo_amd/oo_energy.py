@@ -366,6 +366,20 @@ class OO_energy:
             self.__dict__["_eri_flag_cache"] = hit
         return hit[2]
 
+    def _eri_packed(self, g_ao=None):
+        """The packed resident copy of ``int2e_ao`` for the N^4 pass (ops.eri_pack), kept per tensor STATE like
+        the flags: only for integrals that carry both symmetry flags and N > 48 (29 % of the tensor at N = 200,
+        in the order and with the weights stage 1 consumes it; below that size a single geometry's pass is
+        latency-bound and reads the tensor itself).  None otherwise."""
+        g_ao = self.int2e_ao if g_ao is None else g_ao
+        if g_ao.shape[-1] <= 48 or self._eri_flags(g_ao) != 3:
+            return None
+        hit = self.__dict__.get("_eri_pack_cache")
+        if hit is None or hit[0] is not g_ao or hit[1] != g_ao._version:
+            hit = (g_ao, g_ao._version, ops.eri_pack(g_ao))
+            self.__dict__["_eri_pack_cache"] = hit
+        return hit[2]
+
     def reverify_integrals(self):
         """Call after writing into ``int2e_ao`` / ``int1e_ao`` through a path torch's version counter does
         not see (a kernel writing through a raw pointer, ``.data`` edits, an external producer): drops the
@@ -373,6 +387,7 @@ class OO_energy:
         In-place torch ops (``tensor.mul_(..)``, indexing assignments) bump the version counter and need no
         call.  (``OO_pqc_batch.reverify_integrals`` is the batched counterpart.)"""
         self.__dict__.pop("_eri_flag_cache", None)
+        self.__dict__.pop("_eri_pack_cache", None)
         self.__dict__.pop("_plans2", None)
         self.__dict__.pop("_full_pair_tables", None)
 
@@ -381,7 +396,8 @@ class OO_energy:
         = derivative RDMs)."""
         return ops.cas_eval(self.int2e_ao, self.int1e_ao, self._t(mo_coeff), gamma_sets, Gamma_sets,
                             self.nuc, self._n_occ, self.ncas, self._kap_row, self._kap_col,
-                            want_matrices=want_matrices, eri_flags=self._eri_flags())
+                            want_matrices=want_matrices, eri_flags=self._eri_flags(),
+                            g_packed=self._eri_packed())
 
     def _rdm_stack(self, one_rdm, two_rdm):
         g1 = self._t(one_rdm).reshape(1, self.ncas, self.ncas)

@@ -160,7 +160,8 @@ class OO_pqc(OO_energy):
                 plan = ops.OoEvalPlan(pqc._gates_dev, pqc._n_gates, self._n_theta(), pqc.n_qubits,
                                       pqc._init_index, self.int2e_ao, self.int1e_ao, self.nuc,
                                       self._n_occ, self.ncas, self._kap_row, self._kap_col,
-                                      derivatives=derivatives, eri_flags=self._eri_flags())
+                                      derivatives=derivatives, eri_flags=self._eri_flags(),
+                                      g_packed=self._eri_packed())
                 plans[bool(derivatives)] = hit = (state, plan)
             plan = hit[1]
             th = self.pqc._theta2d(theta).reshape(-1)

@@ -306,10 +306,26 @@ def eri_flags(g_ao):
     return int(flags.value)
 
 
+def eri_pack(g_ao):
+    """The packed resident copy of integrals that carry BOTH symmetry flags (oovqe_eri_pack; include/oovqe.h):
+    [N,N,N,N] -> [size] or a stack [G,N,N,N,N] -> [G, size]; None when this N has no packed form."""
+    lib = _lib.load()
+    dev = _dev(g_ao)
+    N = g_ao.shape[-1]
+    G = g_ao.shape[0] if g_ao.dim() == 5 else 1
+    size = int(lib.oovqe_eri_packed_size(N))
+    if size <= 0:
+        return None
+    out = torch.empty((G, size) if g_ao.dim() == 5 else (size,), dtype=F64, device=dev)
+    check(lib.oovqe_eri_pack(dptr(g_ao), N, G, dptr(out), stream_ptr()), "oovqe_eri_pack")
+    return out
+
+
 def cas_eval(g_ao, h_ao, C, gamma, Gamma, nuc, n_occ, ncas, kap_row, kap_col, want_matrices=False,
-             want_integrals=False, work=None, eri_flags=0):
+             want_integrals=False, work=None, eri_flags=0, g_packed=None):
     """The whole CAS path (oovqe_cas_eval).  gamma [nrdm,a,a], Gamma [nrdm,a,a,a,a].
-    eri_flags: see ops.eri_flags (0 = assume nothing about g_ao)."""
+    eri_flags: see ops.eri_flags (0 = assume nothing about g_ao).  g_packed: ``eri_pack(g_ao)`` when the
+    caller keeps one (both flags): stage 1 streams it where a kernel for it exists (N > 48)."""
     lib = _lib.load()
     dev = _dev(g_ao)
     N = C.shape[0]
@@ -332,11 +348,13 @@ def cas_eval(g_ao, h_ao, C, gamma, Gamma, nuc, n_occ, ncas, kap_row, kap_col, wa
     gmat = torch.empty((N, N), dtype=F64, device=dev) if want_matrices else None
     Gm = torch.empty((N, M, M, M), dtype=F64, device=dev) if want_integrals else None
     hmo = torch.empty((N, M), dtype=F64, device=dev) if want_integrals else None
-    check(lib.oovqe_cas_eval(dptr(g_ao), dptr(h_ao), dptr(C), dptr(gamma), dptr(Gamma), nrdm,
-                             float(nuc), N, n_occ, ncas, dptr(kap_row, torch.int32),
-                             dptr(kap_col, torch.int32), n_kappa, dptr(work), dptr(c0), dptr(c1),
-                             dptr(c2), dptr(E), dptr(gvec), dptr(dE), dptr(fock), dptr(gmat),
-                             dptr(Gm), dptr(hmo), int(eri_flags), stream_ptr()), "oovqe_cas_eval")
+    args = (dptr(g_ao), dptr(h_ao), dptr(C), dptr(gamma), dptr(Gamma), nrdm, float(nuc), N, n_occ, ncas,
+            dptr(kap_row, torch.int32), dptr(kap_col, torch.int32), n_kappa, dptr(work), dptr(c0), dptr(c1),
+            dptr(c2), dptr(E), dptr(gvec), dptr(dE), dptr(fock), dptr(gmat), dptr(Gm), dptr(hmo), int(eri_flags))
+    if g_packed is not None:
+        check(lib.oovqe_cas_eval_packed(*args, dptr(g_packed), stream_ptr()), "oovqe_cas_eval_packed")
+    else:
+        check(lib.oovqe_cas_eval(*args, stream_ptr()), "oovqe_cas_eval")
     packed = small[1:2 + (nrdm - 1) + n_kappa] if nrdm > 1 else None   # [E, dE..., gvec[0]...]
     return dict(c0=c0, c1=c1, c2=c2, E=E, fock=fock, gmat=gmat, gvec=gvec, dE=dE[:nrdm - 1],
                 Gm=Gm, hmo=hmo, packed=packed)
@@ -347,9 +365,12 @@ class OoEvalPlan:
     Calling it costs one small allocation (the packed result) and one ctypes call."""
 
     def __init__(self, gates_dev, n_gates, n_theta, n_qubits, init_index, g_ao, h_ao, nuc, n_occ,
-                 ncas, kap_row, kap_col, derivatives=True, eri_flags=0):
+                 ncas, kap_row, kap_col, derivatives=True, eri_flags=0, g_packed=None):
         self.lib = _lib.load()
         self.eri_flags = int(eri_flags)
+        # g_packed (eri_pack(g_ao), both flags): the call goes through oovqe_oo_eval_batch with a batch of one,
+        # the entry point that takes the packed copy
+        self.g_packed = g_packed
         self.dev = _dev(g_ao)
         self.N = h_ao.shape[0]
         self.n_theta, self.ncas, self.derivatives = n_theta, ncas, bool(derivatives)
@@ -366,10 +387,21 @@ class OoEvalPlan:
         self._post = (float(nuc), self.N, n_occ, ncas, dptr(kap_row, torch.int32),
                       dptr(kap_col, torch.int32), self.n_kappa, int(self.derivatives),
                       dptr(self.work))
+        if g_packed is not None:
+            self._nuc_dev = torch.full((1,), float(nuc), dtype=F64, device=self.dev)
+            self._post_b = (dptr(self._nuc_dev),) + self._post[1:8] + (1, dptr(self.work))
 
     def __call__(self, theta, C):
         """theta: contiguous fp64 device tensor [n_theta]; C: mo_coeff [N,N].  -> packed output."""
         out = torch.empty(self.out_size, dtype=F64, device=self.dev)
+        if self.g_packed is not None:
+            rc = self.lib.oovqe_oo_eval_batch(ctypes.c_void_p(theta.data_ptr()), *self._pre,
+                                              ctypes.c_void_p(C.data_ptr()), *self._post_b,
+                                              ctypes.c_void_p(out.data_ptr()), self.eri_flags,
+                                              dptr(self.g_packed), stream_ptr())
+            if rc != 0:
+                check(rc, "oovqe_oo_eval_batch")
+            return out
         rc = self.lib.oovqe_oo_eval(ctypes.c_void_p(theta.data_ptr()), *self._pre,
                                     ctypes.c_void_p(C.data_ptr()), *self._post,
                                     ctypes.c_void_p(out.data_ptr()), self.eri_flags, stream_ptr())

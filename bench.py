@@ -568,13 +568,13 @@ def oo_evaluation_large(N, g, C):
     work = torch.empty(aoo._lib.load().oovqe_cas_eval_work_size(N, n_occ, ncas, 1), dtype=torch.float64,
                        device="cuda")
 
-    def timed(flags):
+    def timed(flags, packed=None):
         for _ in range(2):
-            ops.cas_eval(g, h, Q, g1, g2, 31.0, n_occ, ncas, kr, kc, work=work, eri_flags=flags)
+            ops.cas_eval(g, h, Q, g1, g2, 31.0, n_occ, ncas, kr, kc, work=work, eri_flags=flags, g_packed=packed)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(5):
-            ops.cas_eval(g, h, Q, g1, g2, 31.0, n_occ, ncas, kr, kc, work=work, eri_flags=flags)
+            ops.cas_eval(g, h, Q, g1, g2, 31.0, n_occ, ncas, kr, kc, work=work, eri_flags=flags, g_packed=packed)
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / 5
     t_gen = timed(0)
@@ -582,7 +582,18 @@ def oo_evaluation_large(N, g, C):
     g.add_(g.transpose(0, 1).clone()).mul_(0.5)
     g.add_(g.transpose(2, 3).clone()).mul_(0.5)
     flags = ops.eri_flags(g)
-    t_sym = timed(flags)
+    t_sym_unpacked = timed(flags)
+    # the resident tile-packed copy an OO_energy / OO_pqc object keeps of such integrals (ops.eri_pack, one-off):
+    # slabs p <= q, tile triangle of each slab, in the order and with the weights stage 1 consumes it
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    packed = ops.eri_pack(g)
+    torch.cuda.synchronize()
+    t_pack = time.perf_counter() - t0
+    t_sym = timed(flags, packed)
+    packed_bytes = 8.0 * packed.numel()
+    stage1_kernel = aoo._lib.load().oovqe_last_stage1_kernel().decode()
+    del packed
     full = 8.0 * N ** 4
     # both flags, N > 48: slabs p <= q, and per slab the row tiles up to the diagonal one of every
     # 16-column tile (half_stream_kernel<.., RS>)
@@ -592,12 +603,17 @@ def oo_evaluation_large(N, g, C):
     return {"N": N, "ncas": ncas, "nelecas": nelecas, "n_occ": n_occ, "M": M, "n_kappa": int(kr.numel()),
             "general_tensor": {"us": t_gen * 1e6, "stage1_bytes": full, "effective_GBs": full / t_gen / 1e9},
             "symmetric_tensor": {"us": t_sym * 1e6, "eri_flags": int(flags),
-                                 "stage1_bytes": sym_bytes,
-                                 "effective_GBs": sym_bytes / t_sym / 1e9},
+                                 "stage1_kernel": stage1_kernel,
+                                 "stage1_bytes": packed_bytes,
+                                 "effective_GBs": packed_bytes / t_sym / 1e9,
+                                 "packed_copy_GB": packed_bytes / 1e9, "pack_once_ms": t_pack * 1e3,
+                                 "without_packed_copy": {"us": t_sym_unpacked * 1e6, "stage1_bytes": sym_bytes,
+                                                         "effective_GBs": sym_bytes / t_sym_unpacked / 1e9}},
             "note": "energy + orbital gradient for one RDM set; effective_GBs = bytes of g_ao the stage-1 sweep "
                     "must read (all of it; with both symmetry flags the slabs p <= q and in each slab the "
-                    "row tiles up to the diagonal one) / whole-evaluation time (the later stages are inside "
-                    "the time)"}
+                    "row tiles up to the diagonal one -- from the resident tile-packed copy, as OO_pqc evaluates; "
+                    "'without_packed_copy': the same tiles picked out of g_ao) / whole-evaluation time (the later "
+                    "stages are inside the time)"}
 
 
 def launch_command(n_ranks, port, argv):

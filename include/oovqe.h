@@ -183,14 +183,25 @@ int oovqe_spin_rdms(const double* bra, const double* ket, int n_qubits, int batc
  * [batch][N^4] (one pass over the tensor; synchronises `stream`). */
 int oovqe_eri_symmetry_flags(const double* g_ao, int N, int batch, unsigned* eri_flags,
                              oovqe_stream_t stream);
-/* Packed resident copy of integrals that carry BOTH flags, for oovqe_oo_eval_batch (g_packed): per
- * geometry the slabs p <= q, of each slab the upper triangle with the diagonal halved (row r = its
- * columns (r & ~1) .. N-1, 0 left of the diagonal, rows back to back) -- 27 % of the tensor at
- * N = 43; the batched N^4 pass then streams this copy instead of picking cache-line fragments out
- * of g_ao.  oovqe_eri_packed_size: doubles per geometry (0 when
- * this N has no packed form).  g_ao itself stays the argument of every other entry point. */
+/* Packed resident copy of integrals that carry BOTH flags (g_packed of oovqe_oo_eval_batch /
+ * oovqe_oo_hessian_batch / oovqe_cas_eval_packed).  N <= 48: per geometry the slabs p <= q, of each slab the
+ * upper triangle with the diagonal halved (row r = its columns (r & ~1) .. N-1, 0 left of the diagonal, rows
+ * back to back) -- 27 % of the tensor at N = 43; the batched N^4 pass then streams this copy instead of
+ * picking cache-line fragments out of g_ao.  N > 48: per geometry the slabs p <= q, of each slab the 16 x 16
+ * tiles (R, S), R <= S, column tile by column tile, every tile as the four matrix-core operand fragments it
+ * is consumed as, diagonal tiles halved, zero beyond N -- 29 % of the tensor at N = 200
+ * (half_tiles_kernel).  oovqe_eri_packed_size: doubles per geometry.  g_ao itself stays an argument of
+ * every entry point (paths that cannot use the copy read it). */
 int64_t oovqe_eri_packed_size(int N);
 int oovqe_eri_pack(const double* g_ao, int N, int batch, double* packed, oovqe_stream_t stream);
+/* oovqe_cas_eval (below) with the packed copy of g_ao: the same outputs; stage 1 streams g_packed where a
+ * kernel for it exists (N > 48: the T2 paths), g_ao otherwise.  eri_flags must carry both bits. */
+int oovqe_cas_eval_packed(const double* g_ao, const double* h_ao, const double* C, const double* gamma,
+                          const double* Gamma, int nrdm, double nuc, int N, int n_occ, int ncas,
+                          const int32_t* kap_row, const int32_t* kap_col, int n_kappa, double* work,
+                          double* c0, double* c1, double* c2, double* E, double* gvec, double* dE,
+                          double* fock, double* gmat, double* Gm, double* hmo, unsigned eri_flags,
+                          const double* g_packed, oovqe_stream_t stream);
 int oovqe_cas_half_transform(const double* g_ao, const double* C, int N, int M, double* T2,
                              oovqe_stream_t stream);
 /* Stage 2: Gm[n,x,y,z] = sum_pq C[p,n] C[q,x] T2[p,q,y,z]; hmo[n,x] = (C^T h_ao C)[n,x].

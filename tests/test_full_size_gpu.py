@@ -227,6 +227,15 @@ def test_oo_evaluation_n200_cas66_fused_vs_staged():
     kr, kc = torch.as_tensor(rows).to(DEV), torch.as_tensor(cols).to(DEV)
     fused = ops.cas_eval(g, h, Q.contiguous(), g1[None].contiguous(), g2[None].contiguous(), 31.0, n_occ, ncas,
                          kr, kc, want_matrices=True, eri_flags=ops.eri_flags(g))
+    # ... and with the tile-packed resident copy of the integrals (stage 1 = half_tiles_kernel)
+    tiles = ops.eri_pack(g)
+    assert tiles.numel() == 20100 * 91 * 256
+    packed = ops.cas_eval(g, h, Q.contiguous(), g1[None].contiguous(), g2[None].contiguous(), 31.0, n_occ, ncas,
+                          kr, kc, want_matrices=True, eri_flags=3, g_packed=tiles)
+    assert "half_tiles_kernel" in aoo._lib.load().oovqe_last_stage1_kernel().decode()
+    del tiles
+    for key in ("E", "gvec", "c1", "c2", "fock", "gmat"):
+        assert (packed[key] - fused[key]).abs().max() <= 1e-11 * max(1.0, float(fused[key].abs().max())), key
     T2 = ops.cas_half_transform(g, Q.contiguous(), M)
     Gm, hmo = ops.cas_finish_transform(T2, h, Q.contiguous(), M)
     staged = ops.cas_energy_gradient(Gm, hmo, g1[None].contiguous(), g2[None].contiguous(), 31.0, n_occ, ncas,
@@ -241,12 +250,13 @@ def test_oo_evaluation_n200_cas66_fused_vs_staged():
     assert fused["fock"][M:].abs().max() == 0.0
 
 
-@pytest.mark.parametrize("N,n_occ,ncas", [(64, 4, 6), (100, 34, 6), (130, 14, 6), (96, 10, 6)])
+@pytest.mark.parametrize("N,n_occ,ncas", [(64, 4, 6), (100, 34, 6), (130, 14, 6), (96, 10, 6), (53, 3, 4)])
 def test_cas_eval_large_n_rs_symmetry_reads_the_tile_triangle(N, n_occ, ncas):
     """N > 48 with both symmetry flags: stage 1 reads, for every column tile of a slab, only the row
     tiles up to the diagonal one (54-60 % of the bytes) and symmetrises the slab's result in
     registers.  Same outputs as with the p <-> q flag alone and with no flag (one, two and three
-    16-wide tiles of occupied + active orbitals), to rounding."""
+    16-wide tiles of occupied + active orbitals), to rounding -- and the same again from the tile-packed
+    resident copy of the integrals (oovqe_eri_pack + oovqe_cas_eval_packed: half_tiles_kernel)."""
     import auto_oo_amd as aoo
     from auto_oo_amd import ops
     M = n_occ + ncas
@@ -266,10 +276,48 @@ def test_cas_eval_large_n_rs_symmetry_reads_the_tile_triangle(N, n_occ, ncas):
     assert ops.eri_flags(g) == 3
     outs = [ops.cas_eval(g, h, Q.contiguous(), g1, g2, 3.0, n_occ, ncas, kr, kc, want_matrices=True,
                          want_integrals=True, eri_flags=f) for f in (0, 1, 3)]
+    tiles = ops.eri_pack(g)
+    outs.append(ops.cas_eval(g, h, Q.contiguous(), g1, g2, 3.0, n_occ, ncas, kr, kc, want_matrices=True,
+                             want_integrals=True, eri_flags=3, g_packed=tiles))
+    assert "half_tiles_kernel" in aoo._lib.load().oovqe_last_stage1_kernel().decode()
     for key in ("c0", "c1", "c2", "E", "gvec", "fock", "gmat", "Gm", "hmo"):
         scale = max(1.0, float(outs[0][key].abs().max()))
         for o in outs[1:]:
             assert (outs[0][key] - o[key]).abs().max() <= 2e-12 * scale, key
+    # a packed copy without both flags is refused
+    with pytest.raises(aoo._lib.OovqeError):
+        ops.cas_eval(g, h, Q.contiguous(), g1, g2, 3.0, n_occ, ncas, kr, kc, eri_flags=1, g_packed=tiles)
+
+
+def test_tile_packed_copy_layout():
+    """The format include/oovqe.h documents for N > 48: slabs p <= q; per slab the tiles (R, S), R <= S, column
+    tile by column tile; per tile [k-step pair][lane][2] with lane = 16 (row mod 4) + column, k-step = row / 4;
+    diagonal tiles halved; zero beyond N."""
+    from auto_oo_amd import ops
+    N = 53
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    B = torch.randn((6, N, N), generator=gen, dtype=torch.float64, device=DEV)
+    B = 0.5 * (B + B.transpose(1, 2))
+    g = (torch.einsum("Lpq,Lrs->pqrs", B, B) / 6.0).contiguous()
+    nst = (N + 15) // 16
+    tiles = ops.eri_pack(g).reshape(N * (N + 1) // 2, nst * (nst + 1) // 2, 2, 64, 2).cpu()
+    gc = g.cpu()
+    pad = torch.zeros((16 * nst, 16 * nst), dtype=torch.float64)
+    slab = 0
+    for p in range(N):
+        for q in range(p, N):
+            if (p, q) in ((0, 0), (0, 7), (3, 3), (17, 40), (52, 52)):
+                pad.zero_()
+                pad[:N, :N] = gc[p, q]
+                t = 0
+                for S in range(nst):
+                    for R in range(S + 1):
+                        blk = pad[16 * R:16 * R + 16, 16 * S:16 * S + 16] * (0.5 if R == S else 1.0)
+                        # blk[4 j + lq, lr] sits at [j // 2][16 lq + lr][j % 2]
+                        want = blk.reshape(2, 2, 4, 16).permute(0, 2, 3, 1).reshape(2, 64, 2)
+                        assert torch.equal(tiles[slab, t], want), (p, q, R, S)
+                        t += 1
+            slab += 1
 
 
 def test_batched_evaluation_beyond_n48_matches_single():
