@@ -223,8 +223,8 @@ def test_active_space_helpers_match_oracle():
 def test_packed_eri_size_and_synthetic_symmetry():
     """Host-side pieces of the symmetric-integral path (no GPU): oovqe_eri_packed_size follows the
     documented layout (slabs p <= q, row r = its columns (r & ~1) .. N-1, the slab pitch rounded
-    up to an even number of doubles so that every slab starts on a 16-byte boundary), N > 48 has no
-    packed form, and the synthetic generator delivers bit-for-bit p<->q / r<->s symmetric integrals (what
+    up to an even number of doubles so that every slab starts on a 16-byte boundary), N > 48 has the
+    tile-triangle form (slabs p <= q, 16 x 16 tiles R <= S), and the synthetic generator delivers bit-for-bit p<->q / r<->s symmetric integrals (what
     the device-side flag check relies on in bench.py and the tests)."""
     from auto_oo_amd import _lib
     from auto_oo_amd.synthetic import synthetic_problem
@@ -233,7 +233,11 @@ def test_packed_eri_size_and_synthetic_symmetry():
         slab = sum(N - (r & ~1) for r in range(N))
         assert lib.oovqe_eri_packed_size(N) == N * (N + 1) // 2 * ((slab + 1) & ~1)
     assert lib.oovqe_eri_packed_size(43) == 946 * 968      # 967 stored elements + 1 pad
-    assert lib.oovqe_eri_packed_size(49) == 0 and lib.oovqe_eri_packed_size(0) == 0
+    assert lib.oovqe_eri_packed_size(0) == 0
+    for N in (49, 64, 65, 200):
+        nst = (N + 15) // 16
+        assert lib.oovqe_eri_packed_size(N) == N * (N + 1) // 2 * (nst * (nst + 1) // 2) * 256
+    assert lib.oovqe_eri_packed_size(200) == 20100 * 91 * 256
     g = synthetic_problem(13, 77)["int2e_ao"]
     assert np.array_equal(g, g.transpose(1, 0, 2, 3))
     assert np.array_equal(g, g.transpose(0, 1, 3, 2))
