@@ -378,7 +378,7 @@ void half_transform_kernel(const double* __restrict__ g, const double* __restric
 #ifdef OOVQE_STREAM_PROBE
 __device__ long long g_stream_cyc[16];   // workgroup 0: [0] core cycles, [1] 100 MHz ticks, [2] MFMAs of wave 0
 #endif
-template <int ZT, int KCH, int DEPTH, bool RS>
+template <int ZT, int KCH, int DEPTH, bool RS, int AUXS = (ZT == 1 ? AUX_NT : AUX_PLAIN), bool PFS = true>
 __global__ __launch_bounds__(HALF_WAVES * 64)
 void half_stream_kernel(const double* __restrict__ g, const double* __restrict__ C,
                         double* __restrict__ T2, int N, int M, int nst, int nkc, long nslabs, int sym)
@@ -462,7 +462,7 @@ void half_stream_kernel(const double* __restrict__ g, const double* __restrict__
         const unsigned sb = (unsigned)lkc * KCH * rowblk_bytes;
 #pragma unroll
         for (int i = 0; i < KCH; ++i) {
-            const v2u v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, vo, sb + i * rowblk_bytes, ZT == 1 ? AUX_NT : AUX_PLAIN);
+            const v2u v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, vo, sb + i * rowblk_bytes, AUXS);
             dst[i] = __builtin_bit_cast(double, v);
         }
         if (++lkc == tile_chunks(lst)) {
@@ -473,19 +473,30 @@ void half_stream_kernel(const double* __restrict__ g, const double* __restrict__
     // compute side.  Rows of Cl beyond N are zero and dropped loads return zero, so every k-step
     // runs unconditionally (straight-line MFMA stream, C fragments read ahead).
     int ck = 0, cst = 0, ckc = 0;
-    auto compute = [&](const double (&a_in)[KCH]) {
+    // the rows of C a chunk multiplies (B operands, from LDS) are read one chunk ahead into the other half of
+    // cfb (round 4: the LDS latency sat in front of every chunk's first MFMA; -9 % in half_tiles_kernel, -1...3 %
+    // here: N = 200 general tensor 3 030-3 100 -> 2 990 us; nt loads, which help the 1 KB loads of the tile kernel,
+    // cost this kernel's 128-byte row pieces 15 %)
+    // (ZT = 3 has no registers for the second buffer: it reads them in front of the chunk, as before)
+    constexpr bool PF = PFS && ZT <= 2;
+    const double* cl_lane = Cl + lq * LDM + lr;
+    double cfb[PF ? 2 : 1][KCH][ZT];
+    auto load_cf = [&](int kc, double (&cf)[KCH][ZT]) {
+        const double* cb = cl_lane + kc * (KCH * 4 * LDM);
+#pragma unroll
+        for (int i = 0; i < KCH; ++i)
+#pragma unroll
+            for (int y = 0; y < ZT; ++y) cf[i][y] = cb[i * 4 * LDM + y * 16];
+    };
+    auto compute = [&](const double (&a_in)[KCH], const double (&cf)[KCH][ZT], double (&cf_next)[KCH][ZT]) {
         double a[KCH];
 #pragma unroll
         for (int i = 0; i < KCH; ++i) {
             a[i] = a_in[i];
             if (RS) a[i] *= ((ckc * KCH + i) >> 2) == cst ? 0.5 : 1.0;   // rows of the diagonal tile
         }
-        const double* cb = Cl + (size_t)(ckc * KCH * 4 + lq) * LDM + lr;
-        double cf[KCH][ZT];
-#pragma unroll
-        for (int i = 0; i < KCH; ++i)
-#pragma unroll
-            for (int y = 0; y < ZT; ++y) cf[i][y] = cb[i * 4 * LDM + y * 16];
+        if constexpr (PF) load_cf(ckc + 1 == tile_chunks(cst) ? 0 : ckc + 1, cf_next);
+        else load_cf(ckc, cf_next);                                     // (cf_next and cf are the one buffer)
 #pragma unroll
         for (int i = 0; i < KCH; ++i)
 #pragma unroll
@@ -582,19 +593,22 @@ void half_stream_kernel(const double* __restrict__ g, const double* __restrict__
         slab_chunks = 0;
         for (int t = 0; t < nst; ++t) slab_chunks += tile_chunks(t);
     }
-    const int rounds = (n_mine * slab_chunks + DEPTH - 1) / DEPTH;
+    // (two turns of the ring per trip, so that the B-operand buffer alternates statically whatever DEPTH)
+    const int rounds = (n_mine * slab_chunks + 2 * DEPTH - 1) / (2 * DEPTH);
+    if constexpr (PF) load_cf(0, cfb[0]);
     for (int it = 0; it < rounds; ++it) {
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
+        for (int d2 = 0; d2 < 2 * DEPTH; ++d2) {
+            const int d = d2 % DEPTH;
             issue(ab[(d + DEPTH - 1) % DEPTH]);
-            compute(ab[d]);
+            compute(ab[d], cfb[PF ? (d2 & 1) : 0], cfb[PF ? ((d2 + 1) & 1) : 0]);
         }
     }
 #ifdef OOVQE_STREAM_PROBE
     if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
         g_stream_cyc[0] = __builtin_readcyclecounter() - pc0;
         g_stream_cyc[1] = wall_clock64() - pw0;
-        g_stream_cyc[2] = (long long)rounds * DEPTH * KCH * ZT + (long long)n_mine * nst * 4 * ZT * ZT;
+        g_stream_cyc[2] = (long long)rounds * 2 * DEPTH * KCH * ZT + (long long)n_mine * nst * 4 * ZT * ZT;
     }
 #endif
 }
