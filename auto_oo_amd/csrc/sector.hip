@@ -940,6 +940,279 @@ void sector_lambda_tab_kernel(const double* __restrict__ W, const uint16_t* __re
     if (slice == 0 && c < Dc) lam[b * Dc + c] = part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl];
 }
 
+// ---- round 4: lambda without W in memory ---------------------------------------------------------------------
+// lambda = sum_jk Ms[k][j] E_j E_k psi with E_j = A_j + B_j (alpha part, beta part).  In the determinant basis
+// whose signs are those of "all alpha operators, then all beta operators" -- psi' = sigma psi with
+//   sigma(ia, ib) = (-1)^(sum over the alpha electrons i of the number of beta electrons in orbitals j < i)
+// (the Jordan-Wigner order interleaves the spins, spin orbital 2p = alpha_p; sigma is the sign of sorting one into
+// the other) -- A_j acts on the alpha string only and B_j on the beta string only, each with its OWN parity bit
+// (the cross parities of the tables are exactly sigma(ia, ib) sigma(src, ib)).  With Psi' the na x nb matrix of
+// psi':
+//   lambda' = G_a Psi' + Psi' G_b^T + sum_j A_j ( sum_k K[k][j] B_k Psi' ),     K = Ms + Ms^T,
+//   G_a = sum_jk Ms[k][j] A_j A_k  (na x na),   G_b = sum_jk Ms[k][j] B_j B_k  (nb x nb)
+// (the string-driven sigma build of determinant CI).  G_a, G_b depend on the coefficients only: one small
+// kernel per call.  The mixed term is LOCAL in the beta string for its gather (A_j moves alpha electrons only):
+// a workgroup forms, for a chunk of SEC_LCH / LA beta strings and ALL alpha strings, the 64 vectors B_k Psi' in
+// LDS, multiplies by K on the matrix cores INTO THE SAME LDS, and gathers with A_j there.  W (2.5 MB per
+// CAS(8e,8o) state, 642 MB written and gathered again per 256 states: 290 + 190 us) never exists.
+constexpr int SEC_LCH = 144;                 // determinants of a column chunk (whole beta strings x padded na)
+constexpr int SEC_LCHP = SEC_LCH;            // LDS pitch of a row of the chunk: 144 doubles, rows 32 banks apart
+static_assert(SEC_LCHP % 32 == 16, "k-step rows lq, lq + 1 of an MFMA operand read must fall into different bank halves");
+
+__host__ __device__ inline size_t sec_lambda_lds_bytes(int na, int nb, int ncas)
+{
+    const size_t na2 = (size_t)ncas * ncas;
+    const size_t Dt = (size_t)nb * ((na + 7) & ~7);            // Psi' transposed, rows padded to LA
+    size_t bytes = (Dt + na2 * SEC_LCHP + 4 * SEC_LCH) * sizeof(double);
+    bytes += (((size_t)na + nb) * na2 * sizeof(uint16_t) + 7) & ~(size_t)7;
+    return bytes;
+}
+
+// grid: na + nb + ceil(Dc / 256) workgroups of 256 threads.  Workgroup r < na: row r of G_a (thread j < a^2: the
+// chains A_j A_k from string r, its own partial row in LDS, summed over j in fixed order); the next nb: rows of
+// G_b; the rest: sigma of 256 determinants each.
+__global__ __launch_bounds__(256)
+void sector_gmat_kernel(const double* __restrict__ Ms, Sector s, double* __restrict__ Ga,
+                        double* __restrict__ Gb, double* __restrict__ sigma, uint16_t* __restrict__ tabs)
+{
+    // tabs [a^2][na] | [a^2][nb]: the excitation tables, for the kernels of the launches that follow
+    extern __shared__ double lds[];
+    const int a = s.ncas, na2 = a * a, tid = threadIdx.x;
+    int blk = blockIdx.x;
+    if (blk >= s.na + s.nb) {
+        const int c = (blk - s.na - s.nb) * 256 + tid;
+        if (c < s.na * s.nb) {
+            const int ia = c / s.nb, ib = c - ia * s.nb;
+            const uint32_t sa = s.unrank_a[ia], sb = s.unrank_b[ib];
+            uint32_t par = 0;
+            for (int i = 1; i < a; ++i)
+                if (sa & (1u << (a - 1 - i))) par ^= __popc(sb & sec_orb_mask(a, 0, i - 1)) & 1u;
+            sigma[c] = par ? -1.0 : 1.0;
+        }
+        return;
+    }
+    const bool alpha = blk < s.na;
+    const int nstr = alpha ? s.na : s.nb, row = alpha ? blk : blk - s.na;
+    double* part = lds;                                                    // [a^2][nstr]
+    uint16_t* tab = reinterpret_cast<uint16_t*>(part + (size_t)na2 * nstr);  // [a^2][nstr]
+    sec_build_table(alpha ? s.unrank_a : s.unrank_b, alpha ? s.rank_a : s.rank_b, nstr, a, alpha, tab, 256);
+    for (int i = tid; i < na2 * nstr; i += 256) part[i] = 0.0;
+    __syncthreads();
+    if (row == 0) {
+        uint16_t* out = tabs + (alpha ? 0 : (size_t)s.na * na2);
+        for (int i = tid; i < na2 * nstr; i += 256) out[i] = tab[i];
+    }
+    if (tid < na2) {
+        const int j = tid;
+        const uint32_t e1 = tab[j * nstr + row];
+        if (e1 & 2048u) {
+            const int s1 = e1 & 2047u;
+            double* pj = part + (size_t)j * nstr;
+            for (int k = 0; k < na2; ++k) {
+                const uint32_t e2 = tab[k * nstr + s1];
+                if (!(e2 & 2048u)) continue;
+                const double m = Ms[(size_t)k * na2 + j];
+                pj[e2 & 2047u] += (((e1 ^ e2) >> 12) & 1u) ? -m : m;
+            }
+        }
+    }
+    __syncthreads();
+    double* G = (alpha ? Ga : Gb) + (size_t)row * nstr;
+    for (int t = tid; t < nstr; t += 256) {
+        double v = 0.0;
+        for (int j = 0; j < na2; ++j) v += part[(size_t)j * nstr + t];
+        G[t] = v;
+    }
+}
+
+// lam'[b] = G_a Psi' + Psi' G_b^T (still in the sigma basis): grid = batch, 512 threads; Psi' zero padded in LDS,
+// the 16 x 16 output tiles dealt to the 8 waves, both products on the matrix cores.
+__global__ __launch_bounds__(512)
+void sector_lambda_dense_kernel(const double* __restrict__ psi_c, const double* __restrict__ Ga,
+                                const double* __restrict__ Gb, const double* __restrict__ sigma, int na, int nb,
+                                double* __restrict__ lam)
+{
+    extern __shared__ double lds[];
+    const int Dc = na * nb, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane >> 4, lr = lane & 15;
+    const int ta = (na + 15) / 16, tb = (nb + 15) / 16;
+    const int ka = (na + 3) / 4, kb = (nb + 3) / 4;
+    const int RP = ta * 16 > 4 * ka ? ta * 16 : 4 * ka;              // rows of the padded Psi'
+    const int PP = (tb * 16 > 4 * kb ? tb * 16 : 4 * kb) + 4;        // its pitch
+    double* P = lds;
+    double* Gal = P + (size_t)RP * PP;                               // [na][na]
+    double* Gbl = Gal + (size_t)na * na;                             // [nb][nb]
+    const size_t b = blockIdx.x;
+    for (int i = tid; i < RP * PP; i += 512) {
+        const int r = i / PP, c = i - r * PP;
+        P[i] = (r < na && c < nb) ? sigma[r * nb + c] * psi_c[b * Dc + r * nb + c] : 0.0;
+    }
+    for (int i = tid; i < na * na; i += 512) Gal[i] = Ga[i];
+    for (int i = tid; i < nb * nb; i += 512) Gbl[i] = Gb[i];
+    __syncthreads();
+    for (int tile = wave; tile < ta * tb; tile += 8) {
+        const int ti = tile / tb, tj = tile - ti * tb;
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        const int ia = 16 * ti + lr, ib = 16 * tj + lr;
+        const int iac = ia < na ? ia : na - 1, ibc = ib < nb ? ib : nb - 1;
+        for (int ks = 0; ks < ka; ++ks) {          // sum_k G_a[ia][k] Psi'[k][ib]  (rows k >= na of Psi' are zero)
+            const int k = 4 * ks + lq;
+            const double av = ia < na ? Gal[iac * na + (k < na ? k : na - 1)] : 0.0;
+            acc = mfma_f64(av, P[k * PP + 16 * tj + lr], acc);
+        }
+        for (int ks = 0; ks < kb; ++ks) {          // sum_k Psi'[ia][k] G_b[ib][k]  (columns k >= nb of Psi' are zero)
+            const int k = 4 * ks + lq;
+            const double bv = ib < nb ? Gbl[ibc * nb + (k < nb ? k : nb - 1)] : 0.0;
+            acc = mfma_f64(P[(16 * ti + lr) * PP + k], bv, acc);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 16 * ti + lq + 4 * i, c = 16 * tj + lr;
+            if (r < na && c < nb) lam[b * Dc + r * nb + c] = acc[i];
+        }
+    }
+}
+
+// The mixed term, and the way back to the Jordan-Wigner basis:  lam[b] = sigma (lam'[b] + sum_j A_j Y_j),
+// Y_j = sum_k K[k][j] B_k Psi'.  grid (batch, nsplit), 512 threads; the chunks of a state dealt to the nsplit
+// workgroups; lam' comes from sector_lambda_dense_kernel (the launch before).
+template <int NT>
+__global__ __launch_bounds__(512)
+void sector_lambda_fused_kernel(const double* __restrict__ psi_c, const double* __restrict__ Ms,
+                                const double* __restrict__ sigma, const uint16_t* __restrict__ tabs, Sector s,
+                                double* __restrict__ lam, int probe)
+{
+    // probe (timing only, wrong results): 1 no chunk build after the first, 2 no MFMA, 3 no gather
+    extern __shared__ double lds[];
+    const int na = s.na, nb = s.nb, Dc = na * nb, a = s.ncas, na2 = a * a;
+    const int LA = (na + 7) & ~7;                        // columns of one beta string inside a chunk
+    const int NBC = SEC_LCH / LA;                        // beta strings per chunk (>= 1: checked by the host)
+    const int CH = NBC * LA, CT = (CH + 15) / 16;
+    // Psi' TRANSPOSED, [nb][LA]: the lanes of a wave hold consecutive alpha strings of one beta string, so the
+    // amplitude reads of the build are consecutive words (row-major, 70 doubles apart, they were 4-way bank
+    // conflicts: the build was LDS-bandwidth bound)
+    double* src = lds;
+    double* Vc = src + (size_t)nb * LA;                  // [a^2][SEC_LCHP]: B_k Psi' of the chunk, then Y
+    double* red = Vc + (size_t)na2 * SEC_LCHP;           // [4][SEC_LCH]
+    uint16_t* tabA = reinterpret_cast<uint16_t*>(red + 4 * SEC_LCH);
+    uint16_t* tabB = tabA + (size_t)na * na2;
+    const size_t b = blockIdx.x;
+    const int split = blockIdx.y, nsplit = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane >> 4, lr = lane & 15;
+    for (int i = tid; i < Dc; i += 512) {
+        const int ia = i / nb, ib2 = i - ia * nb;
+        src[ib2 * LA + ia] = sigma[i] * psi_c[b * Dc + i];
+    }
+    for (int i = tid; i < (na + nb) * na2; i += 512) tabA[i] = tabs[i];      // (tabB follows tabA in both)
+    constexpr int KS = NT * 4;
+    const int jt = wave % NT, ct0 = wave / NT;
+    constexpr int CSTEP = 8 / NT;
+    constexpr int MAXT = (SEC_LCH / 16 + CSTEP - 1) / CSTEP;
+    constexpr int MAXOP = NT == 4 ? 24 : 8;              // >= operators per thread (a^2 / 3 rounded up), multiple of 8
+    double af[KS];                                       // A[m = j][k] = K[k][16 jt + lr], k = 4 ks + lq
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k = 4 * ks + lq, j = 16 * jt + lr;
+        af[ks] = Ms[(size_t)k * na2 + j] + Ms[(size_t)j * na2 + k];
+    }
+    // the chunk column of this thread: NP = 512 / (columns of a chunk) threads per column, each with a share of
+    // the operator range (3 x 22 operators for the 144 columns of CAS(8e,8o))
+    const int LW = CT * 16;
+    const int NP = 512 / LW < 4 ? 512 / LW : 4;
+    const int part = tid / LW, l = tid - part * LW;
+    const int ibl = l / LA, ial = l - ibl * LA;
+    const int opp = (na2 + NP - 1) / NP;                 // operators per part
+    const int o0 = part * opp, o1 = (o0 + opp < na2 ? o0 + opp : na2);
+    const bool worker = part < NP;
+    const int nchunk = (nb + NBC - 1) / NBC;
+    __syncthreads();
+    // table words in registers: the gather's (they depend on the alpha string of the thread's column only: the same
+    // for every chunk) and the build's, read one chunk ahead
+    uint32_t ea[MAXOP], eb[MAXOP];
+#pragma unroll
+    for (int u = 0; u < MAXOP; ++u)
+        ea[u] = (worker && o0 + u < o1 && l < CH && ial < na) ? tabA[(o0 + u) * na + ial] : 0u;
+    auto load_eb = [&](int chn) {
+        const int ibn = chn * NBC + ibl;
+        const bool ok = worker && l < CH && ial < na && chn < nchunk && ibn < nb;
+#pragma unroll
+        for (int u = 0; u < MAXOP; ++u) eb[u] = (ok && o0 + u < o1) ? tabB[(o0 + u) * nb + ibn] : 0u;
+    };
+    load_eb(split);
+    for (int ch = split; ch < nchunk; ch += nsplit) {
+        const int ib = ch * NBC + ibl;
+        const bool live = worker && l < CH && ial < na && ib < nb;
+        // lam' of this thread's determinant: needed at the end of the trip, asked for now
+        double lam_dense = 0.0;
+        if (live && part == 0) lam_dense = lam[b * Dc + (size_t)ial * nb + ib];
+        // 1. Vc[k][l] = (B_k Psi')[ial, ib] = own sign * Psi'[ial, src_b(k, ib)]  (eb = 0: not valid -> 0)
+        if (worker && !(probe == 1 && ch != split)) {
+            const double* cola = src + (live ? ial : 0);
+#pragma unroll
+            for (int u0 = 0; u0 < MAXOP; u0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = cola[(eb[u0 + u] & 2047u) * LA];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (o0 + u0 + u < o1)
+                        Vc[(o0 + u0 + u) * SEC_LCHP + l] =
+                            (eb[u0 + u] & 2048u) ? ((eb[u0 + u] & 4096u) ? -v[u] : v[u]) : 0.0;
+            }
+        }
+        load_eb(ch + nsplit);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (LDS only: the global load / store of lam stay in flight)
+        // 2. Y[j][l] = sum_k K[k][j] Vc[k][l]: the tiles of this wave in registers, then over Vc
+        d4 acc[MAXT];
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            const int ct = ct0 + t * CSTEP;
+            acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+            if (ct < CT && probe != 2) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    acc[t] = mfma_f64(af[ks], Vc[(4 * ks + lq) * SEC_LCHP + 16 * ct + lr], acc[t]);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (LDS only: the global load / store of lam stay in flight)
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            const int ct = ct0 + t * CSTEP;
+            if (ct < CT)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Vc[(16 * jt + lq + 4 * i) * SEC_LCHP + 16 * ct + lr] = acc[t][i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (LDS only: the global load / store of lam stay in flight)
+        // 3. sum_j (A_j Y_j)[ial, ib] = sum_j own sign * Y[j][(ibl, src_a(j, ial))]
+        double sum = 0.0;
+        if (live && probe != 3) {
+            const double* yb = Vc + ibl * LA;
+#pragma unroll
+            for (int u0 = 0; u0 < MAXOP; u0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = yb[(o0 + u0 + u < o1 ? o0 + u0 + u : o0) * SEC_LCHP + (ea[u0 + u] & 2047u)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (ea[u0 + u] & 2048u) sum += (ea[u0 + u] & 4096u) ? -v[u] : v[u];
+            }
+        }
+        if (worker && l < SEC_LCH) red[part * SEC_LCH + l] = sum;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (LDS only: the global load / store of lam stay in flight)
+        if (live && part == 0) {
+            double t = red[l];
+            for (int pp = 1; pp < NP; ++pp) t += red[pp * SEC_LCH + l];
+            lam[b * Dc + (size_t)ial * nb + ib] = sigma[ial * nb + ib] * (lam_dense + t);
+        }
+        // (the next chunk's build writes Vc and, three barriers later, red: both are free by then -- every
+        // thread has passed the barrier above, and the last readers of Vc are in front of it)
+    }
+}
+
 // ---- adjoint sweep: grid = batch --------------------------------------------------------------------
 template <int MAXIT>
 __global__ __launch_bounds__(SEC_THREADS)
@@ -1256,6 +1529,45 @@ extern "C" int oovqe_sector_adjoint(const double* theta, int n_theta, const oovq
     const bool fused = na2 % 16 == 0 && na2 <= 64 && fused_lds <= 140 * 1024 && na < SEC_TAB_MAXSTR &&
                        nb < SEC_TAB_MAXSTR &&
                        oovqe_opt(OOVQE_OPT_SECTOR_UNFUSED) == 0;
+    // round 4: lambda from the string-driven form (G_a Psi' + Psi' G_b^T + the mixed term in LDS): no W
+    const int LAp = (na + 7) & ~7;
+    const int ta16 = (na + 15) / 16 * 16, tb16 = (nb + 15) / 16 * 16;
+    const size_t dense_lds = (size_t)(ta16 > (na + 3) / 4 * 4 ? ta16 : (na + 3) / 4 * 4) *
+                             ((tb16 > (nb + 3) / 4 * 4 ? tb16 : (nb + 3) / 4 * 4) + 4) * sizeof(double) +
+                             ((size_t)na * na + (size_t)nb * nb) * sizeof(double);
+    const size_t gmat_lds = (size_t)na2 * (na > nb ? na : nb) * (sizeof(double) + sizeof(uint16_t)) + 8;
+    const size_t lam_lds = sec_lambda_lds_bytes(na, nb, ncas);
+    const bool string_driven = fused && (na2 == 16 || na2 == 64) && LAp <= SEC_LCH && lam_lds <= 160 * 1024 &&
+                               dense_lds <= 160 * 1024 && gmat_lds <= 160 * 1024 &&
+                               (size_t)na * na + (size_t)nb * nb + Dc + ((size_t)(na + nb) * na2 + 3) / 4 <= nb_ * (2 * (size_t)na2 + 1) * Dc &&
+                               oovqe_opt(OOVQE_OPT_SECTOR_LAMBDA_W) == 0;
+    if (string_driven) {
+        double* Ga = W12;                                   // (the W region of the workspace is free here)
+        double* Gb = Ga + (size_t)na * na;
+        double* sigma = Gb + (size_t)nb * nb;
+        uint16_t* tabs2 = reinterpret_cast<uint16_t*>(sigma + Dc);      // [a^2][na] | [a^2][nb]
+        if ((rc = oovqe_ensure_dynamic_lds((const void*)sector_gmat_kernel, gmat_lds))) return rc;
+        hipLaunchKernelGGL(sector_gmat_kernel, dim3(na + nb + (Dc + 255) / 256), dim3(256), gmat_lds, st, M12, s, Ga,
+                           Gb, sigma, tabs2);
+        OOVQE_CHECK_LAUNCH("sector_adjoint/gmat");
+        if ((rc = oovqe_ensure_dynamic_lds((const void*)sector_lambda_dense_kernel, dense_lds))) return rc;
+        hipLaunchKernelGGL(sector_lambda_dense_kernel, dim3(batch), dim3(512), dense_lds, st, psi_c, Ga, Gb, sigma,
+                           na, nb, lam);
+        OOVQE_CHECK_LAUNCH("sector_adjoint/lambda_dense");
+        const int nchunk = (nb + SEC_LCH / LAp - 1) / (SEC_LCH / LAp);
+        int nsplit = batch >= 128 ? 1 : (batch >= 64 ? 2 : (batch >= 16 ? 4 : 8));
+        if (nsplit > nchunk) nsplit = nchunk;
+        if (na2 == 64) {
+            if ((rc = oovqe_ensure_dynamic_lds((const void*)sector_lambda_fused_kernel<4>, lam_lds))) return rc;
+            hipLaunchKernelGGL(sector_lambda_fused_kernel<4>, dim3(batch, nsplit), dim3(512), lam_lds, st, psi_c,
+                               M12, sigma, tabs2, s, lam, oovqe_opt(OOVQE_OPT_SECTOR_PROBE));
+        } else {
+            if ((rc = oovqe_ensure_dynamic_lds((const void*)sector_lambda_fused_kernel<1>, lam_lds))) return rc;
+            hipLaunchKernelGGL(sector_lambda_fused_kernel<1>, dim3(batch, nsplit), dim3(512), lam_lds, st, psi_c,
+                               M12, sigma, tabs2, s, lam, oovqe_opt(OOVQE_OPT_SECTOR_PROBE));
+        }
+        OOVQE_CHECK_LAUNCH("sector_adjoint/lambda_fused");
+    } else {
     if (fused) {
         // W straight from psi: the E_pq vectors are formed chunk by chunk in LDS and contracted there
         const int nchunk = (Dc + SEC_CH - 1) / SEC_CH;
@@ -1297,6 +1609,7 @@ extern "C" int oovqe_sector_adjoint(const double* theta, int n_theta, const oovq
         hipLaunchKernelGGL(sector_lambda_kernel, dim3((Dc + 63) / 64, batch), dim3(256),
                            256 * sizeof(double) + 2 * ((size_t)1 << ncas) * sizeof(int32_t), st, W12, s, lam);
     OOVQE_CHECK_LAUNCH("sector_adjoint/lambda");
+    }
     const int nit = (Dc + SEC_THREADS - 1) / SEC_THREADS;
 #define OOVQE_SEC_ADJ(MI)                                                                          \
     do {                                                                                           \

@@ -473,12 +473,17 @@ def kupccd_extra():
                               "hbm_bytes_algorithmic": batch * (eng.Dc + a2 + a2 * a2) * 8.0,
                               "note": "psi read, gamma / Gamma written; the a^2 vectors E_pq psi live in LDS only; "
                                       "flops = the matrix-core work of the symmetric Gram (tiles mt <= nt)"},
-                "adjoint_stage": {"us": t_adj * 1e6, "bound": "hbm", "bytes": w_bytes,
-                                  "achieved": w_bytes / t_adj / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": w_bytes / t_adj / 1e9 / HBM_PEAK_GBS,
-                                  "mfma_flops": gram_flops,
-                                  "note": "W = Ms^T (E psi) written once and gathered once by the lambda kernel "
-                                          "(+ the same 2 a^4 Dc flop as the Gram to form it, + the reverse sweep)"}})
+                "adjoint_stage": {"us": t_adj * 1e6, "bound": "mfma", "flops": gram_flops,
+                                  "achieved": gram_flops / t_adj / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": gram_flops / t_adj / 1e12 / FP64_PEAK_TFLOPS,
+                                  "hbm_bytes_algorithmic": batch * 2.0 * eng.Dc * 8,
+                                  "round3_w_bytes_no_longer_moved": w_bytes,
+                                  "note": "round 4: lambda = (Hop + Hop^T) psi in the string-driven form -- G_a Psi + Psi "
+                                          "G_b^T from two small dense matrices per call, the mixed alpha-beta term formed, "
+                                          "multiplied by the a^2 x a^2 coefficients on the matrix cores (flops = 2 a^4 Dc) and "
+                                          "gathered inside LDS; W = Ms^T (E psi), 2.5 MB per state written and gathered "
+                                          "again in round 3, no longer exists.  The time also holds the reverse sweep "
+                                          "through the gates (latency-bound, one workgroup per state)"}})
         oo = aoo.OO_pqc(pqc, mol, ncas, nelecas, oao_mo_coeff=P["oao_mo_coeff"])
         th1 = torch.tensor(rng.uniform(0, 2 * np.pi, n_theta), device="cuda")
         rec["oo_eval_us"] = timed(lambda: oo.energy_and_gradient(th1), warm=3, reps=20) * 1e6

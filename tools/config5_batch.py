@@ -20,3 +20,9 @@ def T(f, n=10):
 t, psi = T(lambda: eng.state(th)); print(f"batch {B} k {k}: state   {t:9.1f} us")
 t, _ = T(lambda: eng.rdms(psi)); print(f"batch {B} k {k}: rdms    {t:9.1f} us")
 t, _ = T(lambda: eng.adjoint(th, psi, c1, c2)); print(f"batch {B} k {k}: adjoint {t:9.1f} us")
+if len(sys.argv) > 3:
+    from auto_oo_amd._lib import debug_options
+    for pr in (0, 1, 2, 3):
+        with debug_options(sector_probe=pr):
+            t, _ = T(lambda: eng.adjoint(th, psi, c1, c2))
+        print(f"batch {B} k {k}: adjoint with sector_probe = {pr}: {t:9.1f} us")
