@@ -1326,6 +1326,18 @@ size_t adjoint_lds(int na, int nb, int ncas, int n_gates, int n_theta)
 
 }  // namespace
 
+static int sector_cu_count()
+{
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
 extern "C" int oovqe_sector_state(const double* theta, int n_theta, const oovqe_gate_t* gates,
                                   int n_gates, int ncas, uint32_t init_index, const uint32_t* unrank_a,
                                   const uint32_t* unrank_b, const int32_t* rank_a, const int32_t* rank_b,
@@ -1540,7 +1552,10 @@ extern "C" int oovqe_sector_adjoint(const double* theta, int n_theta, const oovq
     const bool string_driven = fused && (na2 == 16 || na2 == 64) && LAp <= SEC_LCH && lam_lds <= 160 * 1024 &&
                                dense_lds <= 160 * 1024 && gmat_lds <= 160 * 1024 &&
                                (size_t)na * na + (size_t)nb * nb + Dc + ((size_t)(na + nb) * na2 + 3) / 4 <= nb_ * (2 * (size_t)na2 + 1) * Dc &&
-                               oovqe_opt(OOVQE_OPT_SECTOR_LAMBDA_W) == 0;
+                               // (its two small extra launches cost ~55 us: CAS(8e,8o) 230 us whatever the batch up
+                               // to 32 states, where W in memory takes 175 ... 230 us; 64: 264 vs 315; 256: 485 vs 603)
+                               (oovqe_opt(OOVQE_OPT_SECTOR_LAMBDA_W) == 2 ||
+                                (oovqe_opt(OOVQE_OPT_SECTOR_LAMBDA_W) == 0 && batch >= 32));
     if (string_driven) {
         double* Ga = W12;                                   // (the W region of the workspace is free here)
         double* Gb = Ga + (size_t)na * na;
@@ -1555,7 +1570,9 @@ extern "C" int oovqe_sector_adjoint(const double* theta, int n_theta, const oovq
                            na, nb, lam);
         OOVQE_CHECK_LAUNCH("sector_adjoint/lambda_dense");
         const int nchunk = (nb + SEC_LCH / LAp - 1) / (SEC_LCH / LAp);
-        int nsplit = batch >= 128 ? 1 : (batch >= 64 ? 2 : (batch >= 16 ? 4 : 8));
+        int nsplit = sector_cu_count() / batch;             // one workgroup per CU (LDS), the chip filled once
+        if (nsplit > 8) nsplit = 8;
+        if (nsplit < 1) nsplit = 1;
         if (nsplit > nchunk) nsplit = nchunk;
         if (na2 == 64) {
             if ((rc = oovqe_ensure_dynamic_lds((const void*)sector_lambda_fused_kernel<4>, lam_lds))) return rc;

@@ -679,7 +679,7 @@ def test_mode_contract_random_shapes():
         assert err < 1e-11 * max(1.0, float(ref.abs().max())), (trial, last, A, K, J, B, err)
 
 
-@pytest.mark.parametrize("ncas,nelecas,batch", [(4, 4, 5), (8, 8, 3), (8, 8, 130)])
+@pytest.mark.parametrize("ncas,nelecas,batch", [(4, 4, 5), (4, 2, 40), (8, 8, 3), (8, 8, 130), (8, 6, 33)])
 def test_sector_fused_kernels_equal_the_unfused_ones(ncas, nelecas, batch):
     """Round 3: RDMs and adjoint gradient with the E_pq vectors formed chunk by chunk in LDS
     (sector_rdm_fused_kernel / sector_w_fused_kernel, the default for a^2 = 16, 64) against the round-2
@@ -703,6 +703,12 @@ def test_sector_fused_kernels_equal_the_unfused_ones(ncas, nelecas, batch):
         dth_u = eng.adjoint(th, psi_c, c1, c2)
     assert (g1 - h1).abs().max() < 1e-12 and (g2 - h2).abs().max() < 1e-12
     assert (dth - dth_u).abs().max() < 1e-11 * max(1.0, float(dth_u.abs().max()))
+    # round 4: lambda in the string-driven form (G_a Psi + Psi G_b^T + the mixed term inside LDS; the default from
+    # 32 states on) and through W = Ms^T V in memory (the default below), each forced, against the round-2 kernels
+    for forced in (1, 2):
+        with debug_options(sector_lambda_w=forced):
+            dth_f = eng.adjoint(th, psi_c, c1, c2)
+        assert (dth_f - dth_u).abs().max() < 1e-11 * max(1.0, float(dth_u.abs().max())), forced
     # the adjoint no longer depends on a preceding RDM call on the same workspace
     eng2 = SectorEngine(ncas, hf, gd, len(gates), n_theta, X.basis_index(hf), torch.device(DEV))
     assert torch.equal(eng2.adjoint(th, psi_c, c1, c2), dth)
