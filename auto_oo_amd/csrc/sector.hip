@@ -1302,6 +1302,207 @@ void sector_adjoint_kernel(const double* __restrict__ theta, int n_theta,
     }
 }
 
+// ---- round 4: the gates as PAIR LISTS -----------------------------------------------------------------------------
+// A Givens pass rotates the pairs (d, e = rank(x_d ^ flip)) of determinants with (x_d & flip) == mask_hi: 400 of the
+// 4 900 determinants of CAS(8e,8o) for a pair double excitation.  The sweeps above find them per gate and per
+// workgroup -- every thread reads the full index of its determinants, tests the mask, compacts two bit strings and
+// looks two ranks up: 1.4 us per gate of dependent LDS round trips -- although they depend on the gate table alone.
+// sector_pairs_kernel lists them once per circuit (one 32-bit word per pair: d | e << 15 | parity << 31, ascending
+// d); the sweeps below read the words of the NEXT gate from L2 while they rotate the pairs of the current one.
+constexpr int SEC_PL_THREADS = 512;
+
+__host__ __device__ inline int sec_pair_stride(int Dc) { return ((Dc / 2 + 63) / 64) * 64 + 64; }
+
+// grid = n_gates, 1024 threads.  pairs: [n_gates] counts | [n_gates][stride] words.
+__global__ __launch_bounds__(1024)
+void sector_pairs_kernel(const oovqe_gate_t* __restrict__ gates, int n_gates, Sector s, uint32_t* __restrict__ pairs)
+{
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Dc = s.na * s.nb, stride = sec_pair_stride(Dc);
+    const oovqe_gate_t gt = gates[g];
+    const uint32_t fm = gt.mask_hi | gt.mask_lo;
+    uint32_t* out = pairs + n_gates + (size_t)g * stride;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int d0 = 0; d0 < Dc; d0 += 1024) {
+        const int d = d0 + tid;
+        bool hit = false;
+        uint32_t word = 0;
+        if (d < Dc && gt.theta_idx >= 0) {
+            const uint32_t x = sec_full(s, d);
+            if ((x & fm) == gt.mask_hi) {
+                hit = true;
+                word = (uint32_t)d | ((uint32_t)sec_rank(s, x ^ fm) << 15) | ((uint32_t)(__popc(x & gt.mask_par) & 1) << 31);
+            }
+        }
+        const unsigned long long m = __ballot(hit);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (hit) out[off + before] = word;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += wsum[w];
+            base += t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) pairs[g] = (uint32_t)base;
+}
+
+// forward circuit from the pair lists: grid = batch, 512 threads; LDS: the vector, cos / sin, counts
+template <int MAXP>
+__global__ __launch_bounds__(SEC_PL_THREADS)
+void sector_circuit_pl_kernel(const double* __restrict__ theta, int n_theta, const oovqe_gate_t* __restrict__ gates,
+                              int n_gates, Sector s, uint32_t init_index, const uint32_t* __restrict__ pairs,
+                              double* __restrict__ psi_c)
+{
+    extern __shared__ double lds[];
+    const int Dc = s.na * s.nb, c0 = sec_rank(s, init_index);
+    double* st = lds;                                   // [Dc]
+    double* cs = st + Dc;                               // [n_gates][2]
+    int* cnt = reinterpret_cast<int*>(cs + 2 * n_gates);   // [n_gates], -1: not a rotation
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int stride = sec_pair_stride(Dc);
+    const uint32_t* lists = pairs + n_gates;
+    const double* th = theta + (size_t)b * n_theta;
+    for (int g = tid; g < n_gates; g += SEC_PL_THREADS) {
+        const int ti = gates[g].theta_idx;
+        double sn = 0.0, c = 1.0;
+        if (ti >= 0) sincos(0.5 * (double)gates[g].sign * th[ti], &sn, &c);
+        cs[2 * g] = c;
+        cs[2 * g + 1] = sn;
+        cnt[g] = ti >= 0 ? (int)pairs[g] : -1;
+    }
+    for (int d = tid; d < Dc; d += SEC_PL_THREADS) st[d] = (d == c0) ? 1.0 : 0.0;
+    __syncthreads();
+    uint32_t w[MAXP], nw[MAXP];
+    auto fetch = [&](int g, uint32_t (&dst)[MAXP]) {
+        const int n = g < n_gates ? cnt[g] : 0;
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int idx = tid + i * SEC_PL_THREADS;
+            dst[i] = idx < n ? lists[(size_t)g * stride + idx] : 0u;
+        }
+    };
+    fetch(0, w);
+    for (int g = 0; g < n_gates; ++g) {
+        fetch(g + 1, nw);                               // (in flight while this gate's pairs rotate)
+        const int n = cnt[g];
+        if (n > 0) {
+            const double c = cs[2 * g], sn = cs[2 * g + 1];
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) {
+                if (tid + i * SEC_PL_THREADS < n) {
+                    const int d = w[i] & 0x7fffu, e = (w[i] >> 15) & 0x7fffu;
+                    const double pi = (w[i] >> 31) ? -sn : sn;
+                    const double ax = st[d], ay = st[e];
+                    st[d] = c * ax + pi * ay;
+                    st[e] = c * ay - pi * ax;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (LDS only: the next words stay in flight)
+        }
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) w[i] = nw[i];
+    }
+    __syncthreads();
+    for (int d = tid; d < Dc; d += SEC_PL_THREADS) psi_c[(size_t)b * Dc + d] = st[d];
+}
+
+// reverse sweep from the pair lists (the arithmetic of sector_adjoint_kernel on every pair)
+template <int MAXP>
+__global__ __launch_bounds__(SEC_PL_THREADS)
+void sector_adjoint_pl_kernel(const double* __restrict__ theta, int n_theta, const oovqe_gate_t* __restrict__ gates,
+                              int n_gates, int Dc, const uint32_t* __restrict__ pairs,
+                              const double* __restrict__ psi_c, const double* __restrict__ lam,
+                              double* __restrict__ dtheta)
+{
+    extern __shared__ double lds[];
+    constexpr int NWV = SEC_PL_THREADS / 64;
+    double* ps = lds;                                   // [Dc]
+    double* lm = ps + Dc;                               // [Dc]
+    double* cs = lm + Dc;                               // [n_gates][2]
+    double* part = cs + 2 * n_gates;                    // [n_gates][NWV]
+    int* cnt = reinterpret_cast<int*>(part + (size_t)n_gates * NWV);   // [n_gates]
+    int* tix = cnt + n_gates;                           // [n_gates] theta index
+    int* sgn = tix + n_gates;                           // [n_gates] sign of the angle
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const int stride = sec_pair_stride(Dc);
+    const uint32_t* lists = pairs + n_gates;
+    const double* th = theta + (size_t)b * n_theta;
+    for (int g = tid; g < n_gates; g += SEC_PL_THREADS) {
+        const int ti = gates[g].theta_idx;
+        double sn = 0.0, c = 1.0;
+        if (ti >= 0) sincos(0.5 * (double)gates[g].sign * th[ti], &sn, &c);
+        cs[2 * g] = c;
+        cs[2 * g + 1] = sn;
+        cnt[g] = ti >= 0 ? (int)pairs[g] : -1;
+        tix[g] = ti;
+        sgn[g] = gates[g].sign;
+    }
+    for (int i = tid; i < n_gates * NWV; i += SEC_PL_THREADS) part[i] = 0.0;
+    for (int d = tid; d < Dc; d += SEC_PL_THREADS) {
+        ps[d] = psi_c[(size_t)b * Dc + d];
+        lm[d] = lam[(size_t)b * Dc + d];
+    }
+    __syncthreads();
+    uint32_t w[MAXP], nw[MAXP];
+    auto fetch = [&](int g, uint32_t (&dst)[MAXP]) {
+        const int n = g >= 0 ? cnt[g] : 0;
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int idx = tid + i * SEC_PL_THREADS;
+            dst[i] = idx < n ? lists[(size_t)g * stride + idx] : 0u;
+        }
+    };
+    fetch(n_gates - 1, w);
+    for (int g = n_gates - 1; g >= 0; --g) {
+        fetch(g - 1, nw);
+        const int n = cnt[g];
+        if (n > 0) {
+            const double c = cs[2 * g], sn = cs[2 * g + 1];
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) {
+                if (tid + i * SEC_PL_THREADS < n) {
+                    const int d = w[i] & 0x7fffu, ee = (w[i] >> 15) & 0x7fffu;
+                    const double pi = (w[i] >> 31) ? -1.0 : 1.0;
+                    const double px = ps[d], py = ps[ee], lx = lm[d], ly = lm[ee];
+                    acc += pi * (lx * py - ly * px);              // lambda^T A psi on this pair
+                    const double ps_ = pi * sn;
+                    ps[d] = c * px - ps_ * py;                    // U^T
+                    ps[ee] = c * py + ps_ * px;
+                    lm[d] = c * lx - ps_ * ly;
+                    lm[ee] = c * ly + ps_ * lx;
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+            if (lane == 0) part[(size_t)g * NWV + wave] = acc;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) w[i] = nw[i];
+    }
+    __syncthreads();
+    // gth[k] = sum over the gates driven by theta_k, in the order of the sweep (last gate first)
+    for (int k = tid; k < n_theta; k += SEC_PL_THREADS) {
+        double acc = 0.0;
+        for (int g = n_gates - 1; g >= 0; --g) {
+            if (tix[g] != k) continue;
+            double tot = 0.0;
+            for (int wv = 0; wv < NWV; ++wv) tot += part[(size_t)g * NWV + wv];
+            acc += 0.5 * (double)sgn[g] * tot;
+        }
+        dtheta[(size_t)b * n_theta + k] = acc;
+    }
+}
+
 Sector make_sector(const uint32_t* ua, const uint32_t* ub, const int32_t* ra, const int32_t* rb, int na,
                    int nb, int ncas)
 {
@@ -1338,22 +1539,93 @@ static int sector_cu_count()
     return n;
 }
 
+extern "C" int oovqe_sector_state_pl(const double* theta, int n_theta, const oovqe_gate_t* gates,
+                                     int n_gates, int ncas, uint32_t init_index, const uint32_t* unrank_a,
+                                     const uint32_t* unrank_b, const int32_t* rank_a, const int32_t* rank_b,
+                                     int na, int nb, int batch, const uint32_t* pairs, int max_pairs,
+                                     double* psi_c, double* psi_dense, oovqe_stream_t stream);
+
+extern "C" int64_t oovqe_sector_pairs_size(int n_gates, int na, int nb)
+{
+    if (n_gates < 1 || na < 1 || nb < 1) return 0;
+    return (int64_t)n_gates * (1 + sec_pair_stride(na * nb));      // 32-bit words
+}
+
+// The pair lists of a gate table (once per circuit): pairs [oovqe_sector_pairs_size] 32-bit words -- per gate the
+// number of pairs, then per gate its pairs d | e << 15 | parity << 31 in ascending d.
+extern "C" int oovqe_sector_pairs(const oovqe_gate_t* gates, int n_gates, int ncas, const uint32_t* unrank_a,
+                                  const uint32_t* unrank_b, const int32_t* rank_a, const int32_t* rank_b, int na,
+                                  int nb, uint32_t* pairs, oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(gates && unrank_a && unrank_b && rank_a && rank_b && pairs, "sector_pairs: null pointer");
+    OOVQE_REQUIRE(ncas >= 1 && ncas <= 13 && na >= 1 && nb >= 1 && n_gates >= 1 && n_gates <= 65535 &&
+                  (long)na * nb <= 32767, "sector_pairs: bad sizes (at most 32 767 determinants)");
+    Sector s = make_sector(unrank_a, unrank_b, rank_a, rank_b, na, nb, ncas);
+    hipLaunchKernelGGL(sector_pairs_kernel, dim3(n_gates), dim3(1024), 0, (hipStream_t)stream, gates, n_gates, s,
+                       pairs);
+    OOVQE_CHECK_LAUNCH("sector_pairs");
+    return 0;
+}
+
+static size_t circuit_pl_lds(int Dc, int n_gates)
+{
+    return ((size_t)Dc + 2 * n_gates) * sizeof(double) + (size_t)n_gates * sizeof(int) + 8;
+}
+
+static size_t adjoint_pl_lds(int Dc, int n_gates)
+{
+    return ((size_t)2 * Dc + 2 * n_gates + (size_t)n_gates * (SEC_PL_THREADS / 64)) * sizeof(double) +
+           3 * (size_t)n_gates * sizeof(int) + 8;
+}
+
 extern "C" int oovqe_sector_state(const double* theta, int n_theta, const oovqe_gate_t* gates,
                                   int n_gates, int ncas, uint32_t init_index, const uint32_t* unrank_a,
                                   const uint32_t* unrank_b, const int32_t* rank_a, const int32_t* rank_b,
                                   int na, int nb, int batch, double* psi_c, double* psi_dense,
                                   oovqe_stream_t stream)
 {
+    return oovqe_sector_state_pl(theta, n_theta, gates, n_gates, ncas, init_index, unrank_a, unrank_b, rank_a, rank_b,
+                                 na, nb, batch, nullptr, 0, psi_c, psi_dense, stream);
+}
+
+// The same from the pair lists of oovqe_sector_pairs (pairs == NULL: the gate sweep above).  max_pairs = the
+// largest per-gate count (the caller read the counts once).
+extern "C" int oovqe_sector_state_pl(const double* theta, int n_theta, const oovqe_gate_t* gates,
+                                     int n_gates, int ncas, uint32_t init_index, const uint32_t* unrank_a,
+                                     const uint32_t* unrank_b, const int32_t* rank_a, const int32_t* rank_b,
+                                     int na, int nb, int batch, const uint32_t* pairs, int max_pairs,
+                                     double* psi_c, double* psi_dense, oovqe_stream_t stream)
+{
     OOVQE_REQUIRE(theta && gates && unrank_a && unrank_b && rank_a && rank_b && psi_c,
                   "sector_state: null pointer");
     OOVQE_REQUIRE(ncas >= 1 && ncas <= 13 && na >= 1 && nb >= 1 && batch >= 1 && n_gates >= 1,
                   "sector_state: bad sizes");
     const int Dc = na * nb;
+    hipStream_t st = (hipStream_t)stream;
+    Sector s = make_sector(unrank_a, unrank_b, rank_a, rank_b, na, nb, ncas);
+    if (pairs) {
+        const size_t lb = circuit_pl_lds(Dc, n_gates);
+        OOVQE_REQUIRE(Dc <= 32767 && lb <= 160 * 1024 && max_pairs >= 0 && max_pairs <= 16 * SEC_PL_THREADS,
+                      "sector_state: pair lists for %d determinants (%zu B LDS, %d pairs)", Dc, lb, max_pairs);
+        int rc;
+#define OOVQE_SEC_CPL(MP)                                                                          \
+    do {                                                                                           \
+        if ((rc = oovqe_ensure_dynamic_lds((const void*)sector_circuit_pl_kernel<MP>, lb))) return rc; \
+        hipLaunchKernelGGL(sector_circuit_pl_kernel<MP>, dim3(batch), dim3(SEC_PL_THREADS), lb, st, theta,  \
+                           n_theta, gates, n_gates, s, init_index, pairs, psi_c);                  \
+    } while (0)
+        const int mp = (max_pairs + SEC_PL_THREADS - 1) / SEC_PL_THREADS;
+        if (mp <= 1) OOVQE_SEC_CPL(1);
+        else if (mp <= 2) OOVQE_SEC_CPL(2);
+        else if (mp <= 4) OOVQE_SEC_CPL(4);
+        else if (mp <= 8) OOVQE_SEC_CPL(8);
+        else OOVQE_SEC_CPL(16);
+#undef OOVQE_SEC_CPL
+        OOVQE_CHECK_LAUNCH("sector_state/pairs");
+    } else {
     const size_t lds_bytes = circuit_lds(na, nb, ncas, n_gates);
     OOVQE_REQUIRE(lds_bytes <= 160 * 1024 && Dc <= SEC_MAXIT * SEC_THREADS,
                   "sector_state: sector of %d determinants needs %zu B LDS", Dc, lds_bytes);
-    hipStream_t st = (hipStream_t)stream;
-    Sector s = make_sector(unrank_a, unrank_b, rank_a, rank_b, na, nb, ncas);
     const int nit = (Dc + SEC_THREADS - 1) / SEC_THREADS;
 #define OOVQE_SEC_CIRC(MI)                                                                         \
     do {                                                                                           \
@@ -1377,6 +1649,7 @@ extern "C" int oovqe_sector_state(const double* theta, int n_theta, const oovqe_
     else OOVQE_SEC_CIRC(8);
 #undef OOVQE_SEC_CIRC
     OOVQE_CHECK_LAUNCH("sector_state");
+    }
     if (psi_dense) {
         const uint32_t D = 1u << (2 * ncas);
         OOVQE_REQUIRE(batch <= 65535, "sector_state: batch too large for dense output");
@@ -1511,6 +1784,14 @@ extern "C" int oovqe_sector_rdms(const double* psi_c, int ncas, const uint32_t* 
 // dtheta[b,k] = d/dtheta_k ( c1 . gamma(theta_b) + c2 . Gamma(theta_b) ).  psi_c and the V block of
 // `work` must be those of oovqe_sector_state / oovqe_sector_rdms for the same theta (same work).
 // c1 [a,a], c2 [a,a,a,a] shared by the batch (c_stride = 0) or per element (c_stride = a^2+a^4 ...).
+extern "C" int oovqe_sector_adjoint_pl(const double* theta, int n_theta, const oovqe_gate_t* gates,
+                                       int n_gates, int ncas, const uint32_t* unrank_a,
+                                       const uint32_t* unrank_b, const int32_t* rank_a,
+                                       const int32_t* rank_b, int na, int nb, int batch,
+                                       const double* psi_c, const double* c1, const double* c2,
+                                       const uint32_t* pairs, int max_pairs, double* work, double* dtheta,
+                                       oovqe_stream_t stream);
+
 extern "C" int oovqe_sector_adjoint(const double* theta, int n_theta, const oovqe_gate_t* gates,
                                     int n_gates, int ncas, const uint32_t* unrank_a,
                                     const uint32_t* unrank_b, const int32_t* rank_a,
@@ -1518,13 +1799,28 @@ extern "C" int oovqe_sector_adjoint(const double* theta, int n_theta, const oovq
                                     const double* psi_c, const double* c1, const double* c2,
                                     double* work, double* dtheta, oovqe_stream_t stream)
 {
+    return oovqe_sector_adjoint_pl(theta, n_theta, gates, n_gates, ncas, unrank_a, unrank_b, rank_a, rank_b, na, nb,
+                                   batch, psi_c, c1, c2, nullptr, 0, work, dtheta, stream);
+}
+
+// The same with the reverse sweep from the pair lists of oovqe_sector_pairs (pairs == NULL: the gate sweep).
+extern "C" int oovqe_sector_adjoint_pl(const double* theta, int n_theta, const oovqe_gate_t* gates,
+                                       int n_gates, int ncas, const uint32_t* unrank_a,
+                                       const uint32_t* unrank_b, const int32_t* rank_a,
+                                       const int32_t* rank_b, int na, int nb, int batch,
+                                       const double* psi_c, const double* c1, const double* c2,
+                                       const uint32_t* pairs, int max_pairs, double* work, double* dtheta,
+                                       oovqe_stream_t stream)
+{
     OOVQE_REQUIRE(theta && gates && psi_c && c1 && c2 && work && dtheta, "sector_adjoint: null pointer");
     OOVQE_REQUIRE(ncas >= 1 && ncas <= 13 && batch >= 1 && batch <= 65535, "sector_adjoint: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     const int Dc = na * nb, na2 = ncas * ncas;
     const int MT = (na2 + 1 + 15) / 16, NT = (na2 + 15) / 16;
-    const size_t lds_bytes = adjoint_lds(na, nb, ncas, n_gates, n_theta);
+    const size_t lds_bytes = pairs ? adjoint_pl_lds(na * nb, n_gates) : adjoint_lds(na, nb, ncas, n_gates, n_theta);
     OOVQE_REQUIRE(lds_bytes <= 160 * 1024, "sector_adjoint: needs %zu B LDS", lds_bytes);
+    OOVQE_REQUIRE(!pairs || (na * nb <= 32767 && max_pairs >= 0 && max_pairs <= 16 * SEC_PL_THREADS),
+                  "sector_adjoint: pair lists for %d determinants, %d pairs", na * nb, max_pairs);
     Sector s = make_sector(unrank_a, unrank_b, rank_a, rank_b, na, nb, ncas);
     const size_t nb_ = (size_t)batch;
     double* V = work;
@@ -1626,6 +1922,23 @@ extern "C" int oovqe_sector_adjoint(const double* theta, int n_theta, const oovq
         hipLaunchKernelGGL(sector_lambda_kernel, dim3((Dc + 63) / 64, batch), dim3(256),
                            256 * sizeof(double) + 2 * ((size_t)1 << ncas) * sizeof(int32_t), st, W12, s, lam);
     OOVQE_CHECK_LAUNCH("sector_adjoint/lambda");
+    }
+    if (pairs) {
+#define OOVQE_SEC_APL(MP)                                                                          \
+    do {                                                                                           \
+        if ((rc = oovqe_ensure_dynamic_lds((const void*)sector_adjoint_pl_kernel<MP>, lds_bytes))) return rc; \
+        hipLaunchKernelGGL(sector_adjoint_pl_kernel<MP>, dim3(batch), dim3(SEC_PL_THREADS), lds_bytes, st,  \
+                           theta, n_theta, gates, n_gates, Dc, pairs, psi_c, lam, dtheta);         \
+    } while (0)
+        const int mp = (max_pairs + SEC_PL_THREADS - 1) / SEC_PL_THREADS;
+        if (mp <= 1) OOVQE_SEC_APL(1);
+        else if (mp <= 2) OOVQE_SEC_APL(2);
+        else if (mp <= 4) OOVQE_SEC_APL(4);
+        else if (mp <= 8) OOVQE_SEC_APL(8);
+        else OOVQE_SEC_APL(16);
+#undef OOVQE_SEC_APL
+        OOVQE_CHECK_LAUNCH("sector_adjoint/sweep_pairs");
+        return 0;
     }
     const int nit = (Dc + SEC_THREADS - 1) / SEC_THREADS;
 #define OOVQE_SEC_ADJ(MI)                                                                          \

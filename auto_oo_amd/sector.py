@@ -53,6 +53,7 @@ class SectorEngine:
         self.init_index = init_index
         self._work = {}
         self._param_gate = None
+        self._pairs = None
 
     # ---- derivatives (round 4) --------------------------------------------------------------------
     def param_gates(self, gates_host):
@@ -135,6 +136,24 @@ class SectorEngine:
         H[ka, ja] = val
         return H
 
+    def pair_lists(self):
+        """(pairs, max_pairs): the gates of the circuit as lists of the determinant pairs they rotate
+        (oovqe_sector_pairs, include/oovqe.h) -- built once per engine; the forward and the reverse sweep then read
+        a gate's pairs instead of finding them (mask test, two rank look-ups per determinant, per gate, per state).
+        (None, 0) beyond 32 767 determinants."""
+        if self._pairs is None:
+            if self.Dc > 32767:
+                self._pairs = (None, 0)
+            else:
+                n = int(self.lib.oovqe_sector_pairs_size(self.n_gates, self.na, self.nb))
+                pairs = torch.empty(n, dtype=torch.int32, device=self.device)
+                check(self.lib.oovqe_sector_pairs(dptr(self.gates_dev, torch.uint8), self.n_gates, self.ncas,
+                                                  *self._tabs(), dptr(pairs, torch.int32), stream_ptr()),
+                      "oovqe_sector_pairs")
+                # (one readback when the engine is set up: the largest count sizes the sweeps' register arrays)
+                self._pairs = (pairs, int(pairs[:self.n_gates].max().item()))
+        return self._pairs
+
     def fits(self):
         """The sector vector (+ gate table) must fit one workgroup's LDS twice (adjoint sweep)."""
         words = self.na + self.nb + 2 * (1 << self.ncas) + self.Dc
@@ -158,10 +177,12 @@ class SectorEngine:
         psi_c = torch.empty((batch, self.Dc), dtype=F64, device=self.device)
         psi = (torch.empty((batch, 1 << (2 * self.ncas)), dtype=F64, device=self.device)
                if dense else None)
-        check(self.lib.oovqe_sector_state(dptr(theta), self.n_theta, dptr(self.gates_dev, torch.uint8),
-                                          self.n_gates, self.ncas, ctypes.c_uint32(self.init_index),
-                                          *self._tabs(), batch, dptr(psi_c), dptr(psi), stream_ptr()),
-              "oovqe_sector_state")
+        pairs, max_pairs = self.pair_lists()
+        check(self.lib.oovqe_sector_state_pl(dptr(theta), self.n_theta, dptr(self.gates_dev, torch.uint8),
+                                             self.n_gates, self.ncas, ctypes.c_uint32(self.init_index),
+                                             *self._tabs(), batch, dptr(pairs, torch.int32), max_pairs, dptr(psi_c),
+                                             dptr(psi), stream_ptr()),
+              "oovqe_sector_state_pl")
         return (psi_c, psi) if dense else psi_c
 
     def rdms(self, psi_c):
@@ -178,10 +199,12 @@ class SectorEngine:
         """d/dtheta (c1.gamma + c2.Gamma) for each batch element; call after rdms(psi_c)."""
         batch = theta.shape[0]
         dth = torch.empty((batch, self.n_theta), dtype=F64, device=self.device)
-        check(self.lib.oovqe_sector_adjoint(dptr(theta), self.n_theta,
-                                            dptr(self.gates_dev, torch.uint8), self.n_gates,
-                                            self.ncas, *self._tabs(), batch, dptr(psi_c),
-                                            dptr(c1.contiguous()), dptr(c2.contiguous()),
-                                            dptr(self.work(batch)), dptr(dth), stream_ptr()),
-              "oovqe_sector_adjoint")
+        pairs, max_pairs = self.pair_lists()
+        check(self.lib.oovqe_sector_adjoint_pl(dptr(theta), self.n_theta,
+                                               dptr(self.gates_dev, torch.uint8), self.n_gates,
+                                               self.ncas, *self._tabs(), batch, dptr(psi_c),
+                                               dptr(c1.contiguous()), dptr(c2.contiguous()),
+                                               dptr(pairs, torch.int32), max_pairs,
+                                               dptr(self.work(batch)), dptr(dth), stream_ptr()),
+              "oovqe_sector_adjoint_pl")
         return dth

@@ -409,6 +409,27 @@ int oovqe_sector_adjoint(const double* theta, int n_theta, const oovqe_gate_t* g
                          const double* psi_c, const double* c1, const double* c2, double* work,
                          double* dtheta, oovqe_stream_t stream);
 int64_t oovqe_sector_work_size(int ncas, int na, int nb, int batch);
+/* Round 4: the gates of a circuit as PAIR LISTS.  A Givens pass rotates the pairs (d, e) of determinants whose
+ * occupations match the gate's masks -- 400 of the 4 900 determinants of CAS(8e,8o) for a pair double excitation;
+ * which ones depends on the gate table alone.  oovqe_sector_pairs lists them once per circuit
+ * (pairs: oovqe_sector_pairs_size() 32-bit words = [n_gates] counts, then per gate its pairs d | e << 15 |
+ * parity << 31 in ascending d; at most 32 767 determinants); oovqe_sector_state_pl / oovqe_sector_adjoint_pl are
+ * oovqe_sector_state / oovqe_sector_adjoint sweeping the lists (max_pairs = the largest count; pairs == NULL: the
+ * plain entry points).  Same results to rounding (the sums of the adjoint run in another order). */
+int64_t oovqe_sector_pairs_size(int n_gates, int na, int nb);
+int oovqe_sector_pairs(const oovqe_gate_t* gates, int n_gates, int ncas, const uint32_t* unrank_a,
+                       const uint32_t* unrank_b, const int32_t* rank_a, const int32_t* rank_b, int na, int nb,
+                       uint32_t* pairs, oovqe_stream_t stream);
+int oovqe_sector_state_pl(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates, int ncas,
+                          uint32_t init_index, const uint32_t* unrank_a, const uint32_t* unrank_b,
+                          const int32_t* rank_a, const int32_t* rank_b, int na, int nb, int batch,
+                          const uint32_t* pairs, int max_pairs, double* psi_c, double* psi_dense,
+                          oovqe_stream_t stream);
+int oovqe_sector_adjoint_pl(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates, int ncas,
+                            const uint32_t* unrank_a, const uint32_t* unrank_b, const int32_t* rank_a,
+                            const int32_t* rank_b, int na, int nb, int batch, const double* psi_c,
+                            const double* c1, const double* c2, const uint32_t* pairs, int max_pairs,
+                            double* work, double* dtheta, oovqe_stream_t stream);
 
 /* ---- a12/a13/a14/a16: one evaluation of the hybrid cost function in ONE call ---------------------
  * OO_pqc.energy_from_parameters / circuit_gradient / orbital_gradient / orbital_circuit_hessian

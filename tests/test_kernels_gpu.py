@@ -714,6 +714,44 @@ def test_sector_fused_kernels_equal_the_unfused_ones(ncas, nelecas, batch):
     assert torch.equal(eng2.adjoint(th, psi_c, c1, c2), dth)
 
 
+@pytest.mark.parametrize("ncas,nelecas,ansatz", [(8, 8, "kupccd"), (4, 4, "kupccd"), (3, 4, "uccsd"), (6, 6, "uccsd")])
+def test_sector_pair_lists_equal_the_gate_sweeps(ncas, nelecas, ansatz):
+    """Round 4: the forward and the reverse sweep read every gate's determinant pairs from lists made once per
+    circuit (oovqe_sector_pairs) instead of finding them per gate and per state.  The rotations are the same
+    arithmetic on the same pairs: the state is bit-identical to the plain entry point's; the gradient's per-gate sums
+    run in another order (1e-12)."""
+    import ctypes
+    from auto_oo_amd import _lib
+    from auto_oo_amd._lib import dptr, stream_ptr, check
+    from auto_oo_amd.sector import SectorEngine
+    n = 2 * ncas
+    gates, n_theta = X.kupccd_gates(ncas, 1) if ansatz == "kupccd" else X.uccd_gates(ncas, nelecas, True)
+    hf = X.hf_state(nelecas, n)
+    gd = _gates_dev(gates)
+    eng = SectorEngine(ncas, hf, gd, len(gates), n_theta, X.basis_index(hf), torch.device(DEV))
+    rng = np.random.default_rng(5 + ncas)
+    batch = 3
+    th = torch.tensor(rng.uniform(0, 2 * np.pi, (batch, n_theta))).to(DEV)
+    c1 = torch.tensor(rng.standard_normal((ncas, ncas))).to(DEV)
+    c2 = torch.tensor(rng.standard_normal((ncas,) * 4)).to(DEV)
+    pairs, max_pairs = eng.pair_lists()
+    counts = pairs[:len(gates)].cpu().numpy()
+    assert max_pairs == counts.max() and 0 < max_pairs <= eng.Dc // 2
+    psi = eng.state(th)
+    dth = eng.adjoint(th, psi, c1, c2)
+    lib = _lib.load()
+    psi0 = torch.empty_like(psi)
+    check(lib.oovqe_sector_state(dptr(th), n_theta, dptr(gd, torch.uint8), len(gates), ncas,
+                                 ctypes.c_uint32(eng.init_index), *eng._tabs(), batch, dptr(psi0), None, stream_ptr()),
+          "oovqe_sector_state")
+    assert torch.equal(psi, psi0)
+    dth0 = torch.empty_like(dth)
+    check(lib.oovqe_sector_adjoint(dptr(th), n_theta, dptr(gd, torch.uint8), len(gates), ncas, *eng._tabs(), batch,
+                                   dptr(psi0), dptr(c1), dptr(c2), dptr(eng.work(batch)), dptr(dth0), stream_ptr()),
+          "oovqe_sector_adjoint")
+    assert (dth - dth0).abs().max() < 1e-12 * max(1.0, float(dth0.abs().max()))
+
+
 def test_batched_circuit_hessian_beyond_one_grid_of_pairs():
     """oovqe_circuit_hessian_batch puts (geometry, pair) into 16-bit grid dimensions; a stack with
     batch * 4 * n_pairs > 65535 (here 1 700 geometries x 40) goes through in chunks of geometries.  Every
