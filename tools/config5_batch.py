@@ -26,3 +26,8 @@ if len(sys.argv) > 3:
         with debug_options(sector_probe=pr):
             t, _ = T(lambda: eng.adjoint(th, psi, c1, c2))
         print(f"batch {B} k {k}: adjoint with sector_probe = {pr}: {t:9.1f} us")
+if len(sys.argv) > 3:
+    for pr in (0, 1, 2):
+        with debug_options(sector_probe=pr):
+            t, _ = T(lambda: eng.rdms(psi))
+        print(f"batch {B} k {k}: rdms with sector_probe = {pr}: {t:9.1f} us")
