@@ -134,6 +134,9 @@ SIGNATURES = {
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p,
                                             c_double_p, c_double_p, c_double_p, c_double_p, c_stream]),
     "oovqe_sector_work_size": (ctypes.c_int64, [ctypes.c_int] * 4),
+    "oovqe_sector_lambda": (ctypes.c_int, [c_double_p, ctypes.c_int, c_int32_p, c_int32_p, c_int32_p, c_int32_p,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
+                                           c_double_p, c_double_p, c_stream]),
     "oovqe_sector_pairs_size": (ctypes.c_int64, [ctypes.c_int] * 3),
     "oovqe_sector_pairs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_int32_p, c_int32_p,
                                           c_int32_p, c_int32_p, ctypes.c_int, ctypes.c_int, c_int32_p, c_stream]),

@@ -1803,6 +1803,12 @@ extern "C" int oovqe_sector_adjoint(const double* theta, int n_theta, const oovq
                                    batch, psi_c, c1, c2, nullptr, 0, work, dtheta, stream);
 }
 
+static int sector_adjoint_impl(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates, int ncas,
+                               const uint32_t* unrank_a, const uint32_t* unrank_b, const int32_t* rank_a,
+                               const int32_t* rank_b, int na, int nb, int batch, const double* psi_c,
+                               const double* c1, const double* c2, const uint32_t* pairs, int max_pairs,
+                               double* work, double* dtheta, double* lam_out, oovqe_stream_t stream);
+
 // The same with the reverse sweep from the pair lists of oovqe_sector_pairs (pairs == NULL: the gate sweep).
 extern "C" int oovqe_sector_adjoint_pl(const double* theta, int n_theta, const oovqe_gate_t* gates,
                                        int n_gates, int ncas, const uint32_t* unrank_a,
@@ -1812,12 +1818,38 @@ extern "C" int oovqe_sector_adjoint_pl(const double* theta, int n_theta, const o
                                        const uint32_t* pairs, int max_pairs, double* work, double* dtheta,
                                        oovqe_stream_t stream)
 {
-    OOVQE_REQUIRE(theta && gates && psi_c && c1 && c2 && work && dtheta, "sector_adjoint: null pointer");
+    OOVQE_REQUIRE(theta && gates && dtheta, "sector_adjoint: null pointer");
+    return sector_adjoint_impl(theta, n_theta, gates, n_gates, ncas, unrank_a, unrank_b, rank_a, rank_b, na, nb, batch,
+                               psi_c, c1, c2, pairs, max_pairs, work, dtheta, nullptr, stream);
+}
+
+// lam [batch][Dc] = (Hop + Hop^T) v for a stack of sector vectors v, Hop = sum c1e_pq E_pq + sum c2_pqrs E_pq E_rs the
+// operator whose quadratic form is c1 . gamma(v) + c2 . Gamma(v) (the first stage of oovqe_sector_adjoint on its
+// own): v^T lam(w) / 1 = the bilinear form 2 B(v, w) that second derivatives are made of.  work: oovqe_sector_work_size.
+extern "C" int oovqe_sector_lambda(const double* vecs, int ncas, const uint32_t* unrank_a, const uint32_t* unrank_b,
+                                   const int32_t* rank_a, const int32_t* rank_b, int na, int nb, int batch,
+                                   const double* c1, const double* c2, double* work, double* lam,
+                                   oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(lam, "sector_lambda: null pointer");
+    return sector_adjoint_impl(nullptr, 0, nullptr, 0, ncas, unrank_a, unrank_b, rank_a, rank_b, na, nb, batch, vecs, c1,
+                               c2, nullptr, 0, work, nullptr, lam, stream);
+}
+
+static int sector_adjoint_impl(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates, int ncas,
+                               const uint32_t* unrank_a, const uint32_t* unrank_b, const int32_t* rank_a,
+                               const int32_t* rank_b, int na, int nb, int batch, const double* psi_c,
+                               const double* c1, const double* c2, const uint32_t* pairs, int max_pairs,
+                               double* work, double* dtheta, double* lam_out, oovqe_stream_t stream)
+{
+    // lam_out: stop after the lambda stage and leave it there (theta, gates, dtheta unused)
+    OOVQE_REQUIRE(psi_c && c1 && c2 && work && unrank_a && unrank_b && rank_a && rank_b, "sector_adjoint: null pointer");
     OOVQE_REQUIRE(ncas >= 1 && ncas <= 13 && batch >= 1 && batch <= 65535, "sector_adjoint: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     const int Dc = na * nb, na2 = ncas * ncas;
     const int MT = (na2 + 1 + 15) / 16, NT = (na2 + 15) / 16;
-    const size_t lds_bytes = pairs ? adjoint_pl_lds(na * nb, n_gates) : adjoint_lds(na, nb, ncas, n_gates, n_theta);
+    const size_t lds_bytes = lam_out ? 0 : pairs ? adjoint_pl_lds(na * nb, n_gates)
+                                                 : adjoint_lds(na, nb, ncas, n_gates, n_theta);
     OOVQE_REQUIRE(lds_bytes <= 160 * 1024, "sector_adjoint: needs %zu B LDS", lds_bytes);
     OOVQE_REQUIRE(!pairs || (na * nb <= 32767 && max_pairs >= 0 && max_pairs <= 16 * SEC_PL_THREADS),
                   "sector_adjoint: pair lists for %d determinants, %d pairs", na * nb, max_pairs);
@@ -1825,8 +1857,8 @@ extern "C" int oovqe_sector_adjoint_pl(const double* theta, int n_theta, const o
     const size_t nb_ = (size_t)batch;
     double* V = work;
     double* W12 = V + nb_ * na2 * Dc;                   // [batch][2 a^2 + 1][Dc]
-    double* lam = W12 + nb_ * (2 * (size_t)na2 + 1) * Dc;
-    double* R = lam + nb_ * Dc;
+    double* lam = lam_out ? lam_out : W12 + nb_ * (2 * (size_t)na2 + 1) * Dc;
+    double* R = W12 + nb_ * (2 * (size_t)na2 + 1) * Dc + nb_ * Dc;
     double* M12 = R + 8 * nb_ * (size_t)(MT * 16) * (NT * 16);
     hipLaunchKernelGGL(sector_coeff_kernel, dim3((na2 * na2 + 255) / 256), dim3(256), 0, st, c1, c2, ncas,
                        unrank_a, unrank_b, M12);
@@ -1923,6 +1955,7 @@ extern "C" int oovqe_sector_adjoint_pl(const double* theta, int n_theta, const o
                            256 * sizeof(double) + 2 * ((size_t)1 << ncas) * sizeof(int32_t), st, W12, s, lam);
     OOVQE_CHECK_LAUNCH("sector_adjoint/lambda");
     }
+    if (lam_out) return 0;
     if (pairs) {
 #define OOVQE_SEC_APL(MP)                                                                          \
     do {                                                                                           \

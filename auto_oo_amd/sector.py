@@ -107,13 +107,24 @@ class SectorEngine:
         Gamma = torch.cat((g2[0:1], 0.5 * (g2[1:1 + nt] - g2[1 + nt:])))
         return gamma, Gamma
 
-    def circuit_hessian(self, theta, gates_host, c1, c2):
-        """d^2/dtheta^2 of E = c0 + c1 . gamma(theta) + c2 . Gamma(theta) = c0 + Q(psi), Q the quadratic form
-        of the active-space Hamiltonian (oo_pqc.py:103-111), inside the (N_alpha, N_beta) sector:
-            H_jk = 2 B(tau_jk, psi) + 2 B(tau_j, tau_k),   B(a, b) = [Q(a + b) - Q(a - b)] / 4
-        with first and second tangent states from ``oovqe_sector_state_deriv`` and Q from the plain RDM
-        kernel -- 4 n_pairs sector vectors of 4 900 amplitudes at CAS(8e,8o) instead of second tangents on
-        the dense 2^16 register."""
+    def lam(self, vecs, c1, c2):
+        """vecs [n, Dc] -> (Hop + Hop^T) vecs [n, Dc], Hop the operator whose quadratic form is
+        Q(v) = c1 . gamma(v) + c2 . Gamma(v) (oovqe_sector_lambda: the first stage of the adjoint on its own)."""
+        n = vecs.shape[0]
+        out = torch.empty((n, self.Dc), dtype=F64, device=self.device)
+        check(self.lib.oovqe_sector_lambda(dptr(vecs), self.ncas, *self._tabs(), n, dptr(c1.contiguous()),
+                                           dptr(c2.contiguous()), dptr(self.work(n)), dptr(out), stream_ptr()),
+              "oovqe_sector_lambda")
+        return out
+
+    def circuit_hessian(self, theta, gates_host, c1, c2, by_rdms=False):
+        """d^2/dtheta^2 of E = c0 + c1 . gamma(theta) + c2 . Gamma(theta) = c0 + Q(psi), Q(v) = v^T Hop v the quadratic
+        form of the active-space Hamiltonian (oo_pqc.py:103-111), inside the (N_alpha, N_beta) sector:
+            H_jk = tau_jk^T lam(psi) + tau_j^T lam(tau_k),     lam(v) = (Hop + Hop^T) v
+        with first and second tangent states from ``oovqe_sector_state_deriv`` -- 1 + n_theta applications of the
+        operator (``oovqe_sector_lambda``) and two small products, where the polarisation of Q through the plain RDM
+        kernel (``by_rdms=True``, the first form of round 4: [Q(a + b) - Q(a - b)] / 2 for every pair) took 4 n_pairs
+        RDM evaluations: 6 384 sector vectors at CAS(8e,8o), k = 1."""
         pg = self.param_gates(gates_host)
         if pg is None:
             raise NotImplementedError("sector derivatives need one gate per parameter (UCCD / UCCSD / kUpCCD)")
@@ -124,13 +135,20 @@ class SectorEngine:
         psi, tau, tau2 = st[0], st[1:1 + nt], st[1 + nt:]
         ja = torch.as_tensor([j for j, _ in pairs], device=self.device)
         ka = torch.as_tensor([k for _, k in pairs], device=self.device)
-        vecs = torch.cat((tau2 + psi, tau2 - psi, tau[ja] + tau[ka], tau[ja] - tau[ka]))
-        g1, g2 = self.rdms_chunked(vecs)
-        a = self.ncas
-        q = ((g1.reshape(-1, a * a) * c1.reshape(1, -1)).sum(dim=1)
-             + (g2.reshape(-1, a ** 4) * c2.reshape(1, -1)).sum(dim=1))
-        npair = len(pairs)
-        val = 0.5 * (q[:npair] - q[npair:2 * npair]) + 0.5 * (q[2 * npair:3 * npair] - q[3 * npair:])
+        if by_rdms:
+            vecs = torch.cat((tau2 + psi, tau2 - psi, tau[ja] + tau[ka], tau[ja] - tau[ka]))
+            g1, g2 = self.rdms_chunked(vecs)
+            a = self.ncas
+            q = ((g1.reshape(-1, a * a) * c1.reshape(1, -1)).sum(dim=1)
+                 + (g2.reshape(-1, a ** 4) * c2.reshape(1, -1)).sum(dim=1))
+            npair = len(pairs)
+            val = 0.5 * (q[:npair] - q[npair:2 * npair]) + 0.5 * (q[2 * npair:3 * npair] - q[3 * npair:])
+        else:
+            from . import ops
+            lam = self.lam(st[:1 + nt].contiguous(), c1, c2)                       # lam(psi), lam(tau_k)
+            first = ops.matmul_nn(tau2.contiguous(), lam[0].reshape(-1, 1).contiguous())[:, 0]   # tau_jk . lam(psi)
+            second = ops.matmul_nn(tau.contiguous(), lam[1:].T.contiguous())       # [j, k] = tau_j . lam(tau_k)
+            val = first + second[ja, ka]
         H = torch.zeros((nt, nt), dtype=F64, device=self.device)
         H[ja, ka] = val
         H[ka, ja] = val

@@ -416,6 +416,13 @@ int64_t oovqe_sector_work_size(int ncas, int na, int nb, int batch);
  * parity << 31 in ascending d; at most 32 767 determinants); oovqe_sector_state_pl / oovqe_sector_adjoint_pl are
  * oovqe_sector_state / oovqe_sector_adjoint sweeping the lists (max_pairs = the largest count; pairs == NULL: the
  * plain entry points).  Same results to rounding (the sums of the adjoint run in another order). */
+/* lam [batch][Dc] = (Hop + Hop^T) v for a stack of sector vectors v, Hop = sum c1e_pq E_pq + sum c2_pqrs E_pq E_rs the
+ * operator whose quadratic form is Q(v) = c1 . gamma(v) + c2 . Gamma(v) (oo_pqc.py:103-111 differentiates exactly
+ * that): the first stage of oovqe_sector_adjoint on its own.  a^T lam(b) is the symmetric bilinear form second
+ * derivatives are made of: d^2 Q / dtheta_j dtheta_k = tau_jk^T lam(psi) + tau_j^T lam(tau_k). */
+int oovqe_sector_lambda(const double* vecs, int ncas, const uint32_t* unrank_a, const uint32_t* unrank_b,
+                        const int32_t* rank_a, const int32_t* rank_b, int na, int nb, int batch, const double* c1,
+                        const double* c2, double* work, double* lam, oovqe_stream_t stream);
 int64_t oovqe_sector_pairs_size(int n_gates, int na, int nb);
 int oovqe_sector_pairs(const oovqe_gate_t* gates, int n_gates, int ncas, const uint32_t* unrank_a,
                        const uint32_t* unrank_b, const int32_t* rank_a, const int32_t* rank_b, int na, int nb,

@@ -400,8 +400,8 @@ def _kupccd_problem(N, ncas, nelecas, nelec, seed, k=1):
 
 def test_sector_second_derivatives_vs_dense_register_cas66():
     """Second derivatives inside the (N_alpha, N_beta) sector (round 4: tangent and second-tangent states from
-    oovqe_sector_state_deriv, derivative RDMs and the theta-theta block by polarisation of the plain RDM
-    kernel) against the dense-register kernels (second tangents on the 2^12 register, transition RDMs) at
+    oovqe_sector_state_deriv, derivative RDMs by polarisation of the plain RDM kernel, the theta-theta block from
+    the operator applied to psi and its first tangents) against the dense-register kernels (second tangents on the 2^12 register, transition RDMs) at
     kUpCCD CAS(6e,6o): derivative RDMs and every block of OO_pqc.full_hessian (oo_pqc.py:103-148)."""
     P, mol, pqc, oo = _kupccd_problem(18, 6, 6, 10, 660)
     assert pqc._use_sector and pqc.n_qubits == 12
@@ -422,6 +422,16 @@ def test_sector_second_derivatives_vs_dense_register_cas66():
     assert (Hs - Hd).abs().max().item() < 1e-10 * scale
     assert (Hs - Hs.T).abs().max().item() < 1e-10 * scale
     assert (gs - gd).abs().max().item() < 1e-10 * max(1.0, gd.abs().max().item())
+    # the theta-theta block two ways inside the sector: 1 + n_theta applications of the operator
+    # (oovqe_sector_lambda: H_jk = tau_jk . lam(psi) + tau_j . lam(tau_k), the default) against the polarisation of
+    # the quadratic form through 4 n_pairs RDM evaluations; random coefficients without any symmetry
+    rng = np.random.default_rng(3)
+    c1 = torch.tensor(rng.standard_normal((6, 6)), device=DEV)
+    c2 = torch.tensor(rng.standard_normal((6,) * 4), device=DEV)
+    th2 = pqc._theta2d(theta)
+    Ha = pqc._sector.circuit_hessian(th2, pqc._gates, c1, c2)
+    Hb = pqc._sector.circuit_hessian(th2, pqc._gates, c1, c2, by_rdms=True)
+    assert (Ha - Hb).abs().max().item() < 1e-10 * max(1.0, Hb.abs().max().item())
 
 
 def test_sector_second_derivatives_vs_oracle_autograd_cas44():
