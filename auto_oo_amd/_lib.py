@@ -145,6 +145,11 @@ SIGNATURES = {
                                              c_int32_p, c_int32_p, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, c_int32_p, ctypes.c_int, c_double_p, c_double_p,
                                              c_stream]),
+    "oovqe_sector_state_deriv_pl": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                                   ctypes.c_int, ctypes.c_uint32, c_int32_p, c_int32_p,
+                                                   c_int32_p, c_int32_p, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_int, c_int32_p, ctypes.c_int, c_int32_p, ctypes.c_int,
+                                                   c_double_p, c_stream]),
     "oovqe_sector_adjoint_pl": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                                ctypes.c_int, c_int32_p, c_int32_p, c_int32_p, c_int32_p,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p,

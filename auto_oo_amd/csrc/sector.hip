@@ -1415,6 +1415,89 @@ void sector_circuit_pl_kernel(const double* __restrict__ theta, int n_theta, con
     for (int d = tid; d < Dc; d += SEC_PL_THREADS) psi_c[(size_t)b * Dc + d] = st[d];
 }
 
+// sector_circuit_deriv_kernel from the pair lists: grid (batch, n_out).  A differentiated gate also annihilates
+// every amplitude it leaves alone: its pairs' new values are formed in registers, the vector is cleared, the values
+// are written (two more barriers, for at most two gates of an output).
+template <int MAXP>
+__global__ __launch_bounds__(SEC_PL_THREADS)
+void sector_circuit_deriv_pl_kernel(const double* __restrict__ theta, int n_theta,
+                                    const oovqe_gate_t* __restrict__ gates, int n_gates, Sector s,
+                                    uint32_t init_index, const uint32_t* __restrict__ pairs,
+                                    const int32_t* __restrict__ deriv, int n_out, double* __restrict__ psi_c)
+{
+    extern __shared__ double lds[];
+    const int Dc = s.na * s.nb, c0 = sec_rank(s, init_index);
+    double* st = lds;                                   // [Dc]
+    double* cs = st + Dc;                               // [n_gates][2]
+    int* cnt = reinterpret_cast<int*>(cs + 2 * n_gates);   // [n_gates], -1: not a rotation
+    const int tid = threadIdx.x, b = blockIdx.x, o = blockIdx.y;
+    const int stride = sec_pair_stride(Dc);
+    const uint32_t* lists = pairs + n_gates;
+    const double* th = theta + (size_t)b * n_theta;
+    const int ga = deriv[2 * o], gb = deriv[2 * o + 1];
+    for (int g = tid; g < n_gates; g += SEC_PL_THREADS) {
+        const int ti = gates[g].theta_idx;
+        double sn = 0.0, c = 1.0;
+        if (ti >= 0) sincos(0.5 * (double)gates[g].sign * th[ti], &sn, &c);
+        const int order = (g == ga ? 1 : 0) + (g == gb ? 1 : 0);
+        const double h = 0.5 * (double)gates[g].sign;
+        if (order == 1) { const double c1 = -h * sn, s1 = h * c; c = c1; sn = s1; }
+        if (order == 2) { c *= -0.25; sn *= -0.25; }
+        cs[2 * g] = c;
+        cs[2 * g + 1] = sn;
+        cnt[g] = ti >= 0 ? (int)pairs[g] : -1;
+    }
+    for (int d = tid; d < Dc; d += SEC_PL_THREADS) st[d] = (d == c0) ? 1.0 : 0.0;
+    __syncthreads();
+    uint32_t w[MAXP], nw[MAXP];
+    auto fetch = [&](int g, uint32_t (&dst)[MAXP]) {
+        const int n = g < n_gates ? cnt[g] : 0;
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int idx = tid + i * SEC_PL_THREADS;
+            dst[i] = idx < n ? lists[(size_t)g * stride + idx] : 0u;
+        }
+    };
+    fetch(0, w);
+    for (int g = 0; g < n_gates; ++g) {
+        fetch(g + 1, nw);
+        const int n = cnt[g];
+        if (n >= 0) {
+            const double c = cs[2 * g], sn = cs[2 * g + 1];
+            const bool differentiated = g == ga || g == gb;
+            double vd[MAXP], ve[MAXP];
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) {
+                if (tid + i * SEC_PL_THREADS < n) {
+                    const int d = w[i] & 0x7fffu, e = (w[i] >> 15) & 0x7fffu;
+                    const double pi = (w[i] >> 31) ? -sn : sn;
+                    const double ax = st[d], ay = st[e];
+                    vd[i] = c * ax + pi * ay;
+                    ve[i] = c * ay - pi * ax;
+                    if (!differentiated) { st[d] = vd[i]; st[e] = ve[i]; }
+                }
+            }
+            if (differentiated) {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                for (int d = tid; d < Dc; d += SEC_PL_THREADS) st[d] = 0.0;
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < MAXP; ++i) {
+                    if (tid + i * SEC_PL_THREADS < n) {
+                        st[w[i] & 0x7fffu] = vd[i];
+                        st[(w[i] >> 15) & 0x7fffu] = ve[i];
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) w[i] = nw[i];
+    }
+    __syncthreads();
+    for (int d = tid; d < Dc; d += SEC_PL_THREADS) psi_c[((size_t)b * n_out + o) * Dc + d] = st[d];
+}
+
 // reverse sweep from the pair lists (the arithmetic of sector_adjoint_kernel on every pair)
 template <int MAXP>
 __global__ __launch_bounds__(SEC_PL_THREADS)
@@ -1662,22 +1745,60 @@ extern "C" int oovqe_sector_state_pl(const double* theta, int n_theta, const oov
 
 // States of the circuit with up to two gates differentiated (sector_circuit_deriv_kernel): deriv [n_out][2]
 // gate indices (device, -1 = none), psi_out [batch][n_out][Dc].
+extern "C" int oovqe_sector_state_deriv_pl(const double* theta, int n_theta, const oovqe_gate_t* gates,
+                                           int n_gates, int ncas, uint32_t init_index, const uint32_t* unrank_a,
+                                           const uint32_t* unrank_b, const int32_t* rank_a, const int32_t* rank_b,
+                                           int na, int nb, int batch, const uint32_t* pairs, int max_pairs,
+                                           const int32_t* deriv, int n_out, double* psi_out, oovqe_stream_t stream);
+
 extern "C" int oovqe_sector_state_deriv(const double* theta, int n_theta, const oovqe_gate_t* gates,
                                         int n_gates, int ncas, uint32_t init_index, const uint32_t* unrank_a,
                                         const uint32_t* unrank_b, const int32_t* rank_a, const int32_t* rank_b,
                                         int na, int nb, int batch, const int32_t* deriv, int n_out,
                                         double* psi_out, oovqe_stream_t stream)
 {
+    return oovqe_sector_state_deriv_pl(theta, n_theta, gates, n_gates, ncas, init_index, unrank_a, unrank_b, rank_a,
+                                       rank_b, na, nb, batch, nullptr, 0, deriv, n_out, psi_out, stream);
+}
+
+// The same from the pair lists of oovqe_sector_pairs (pairs == NULL: the gate sweep).
+extern "C" int oovqe_sector_state_deriv_pl(const double* theta, int n_theta, const oovqe_gate_t* gates,
+                                           int n_gates, int ncas, uint32_t init_index, const uint32_t* unrank_a,
+                                           const uint32_t* unrank_b, const int32_t* rank_a, const int32_t* rank_b,
+                                           int na, int nb, int batch, const uint32_t* pairs, int max_pairs,
+                                           const int32_t* deriv, int n_out, double* psi_out, oovqe_stream_t stream)
+{
     OOVQE_REQUIRE(theta && gates && unrank_a && unrank_b && rank_a && rank_b && deriv && psi_out,
                   "sector_state_deriv: null pointer");
     OOVQE_REQUIRE(ncas >= 1 && ncas <= 13 && na >= 1 && nb >= 1 && batch >= 1 && n_gates >= 1 && n_out >= 1 &&
                   n_out <= 65535 && batch <= 65535, "sector_state_deriv: bad sizes");
     const int Dc = na * nb;
+    hipStream_t st = (hipStream_t)stream;
+    Sector s = make_sector(unrank_a, unrank_b, rank_a, rank_b, na, nb, ncas);
+    if (pairs) {
+        const size_t lb = circuit_pl_lds(Dc, n_gates);
+        OOVQE_REQUIRE(Dc <= 32767 && lb <= 160 * 1024 && max_pairs >= 0 && max_pairs <= 16 * SEC_PL_THREADS,
+                      "sector_state_deriv: pair lists for %d determinants (%zu B LDS, %d pairs)", Dc, lb, max_pairs);
+        int rc;
+#define OOVQE_SEC_DPL(MP)                                                                          \
+    do {                                                                                           \
+        if ((rc = oovqe_ensure_dynamic_lds((const void*)sector_circuit_deriv_pl_kernel<MP>, lb))) return rc; \
+        hipLaunchKernelGGL(sector_circuit_deriv_pl_kernel<MP>, dim3(batch, n_out), dim3(SEC_PL_THREADS), lb, st, \
+                           theta, n_theta, gates, n_gates, s, init_index, pairs, deriv, n_out, psi_out); \
+    } while (0)
+        const int mp = (max_pairs + SEC_PL_THREADS - 1) / SEC_PL_THREADS;
+        if (mp <= 1) OOVQE_SEC_DPL(1);
+        else if (mp <= 2) OOVQE_SEC_DPL(2);
+        else if (mp <= 4) OOVQE_SEC_DPL(4);
+        else if (mp <= 8) OOVQE_SEC_DPL(8);
+        else OOVQE_SEC_DPL(16);
+#undef OOVQE_SEC_DPL
+        OOVQE_CHECK_LAUNCH("sector_state_deriv/pairs");
+        return 0;
+    }
     const size_t lds_bytes = circuit_lds(na, nb, ncas, n_gates);
     OOVQE_REQUIRE(lds_bytes <= 160 * 1024 && Dc <= SEC_MAXIT * SEC_THREADS,
                   "sector_state_deriv: sector of %d determinants needs %zu B LDS", Dc, lds_bytes);
-    hipStream_t st = (hipStream_t)stream;
-    Sector s = make_sector(unrank_a, unrank_b, rank_a, rank_b, na, nb, ncas);
     const int nit = (Dc + SEC_THREADS - 1) / SEC_THREADS;
 #define OOVQE_SEC_CIRCD(MI)                                                                        \
     do {                                                                                           \

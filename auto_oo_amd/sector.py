@@ -74,10 +74,12 @@ class SectorEngine:
         batch = theta.shape[0]
         spec = torch.as_tensor(np.asarray(specs, dtype=np.int32).reshape(-1, 2)).to(self.device)
         out = torch.empty((batch, spec.shape[0], self.Dc), dtype=F64, device=self.device)
-        check(self.lib.oovqe_sector_state_deriv(dptr(theta), self.n_theta, dptr(self.gates_dev, torch.uint8),
-                                                self.n_gates, self.ncas, ctypes.c_uint32(self.init_index),
-                                                *self._tabs(), batch, dptr(spec, torch.int32), int(spec.shape[0]),
-                                                dptr(out), stream_ptr()), "oovqe_sector_state_deriv")
+        pairs, max_pairs = self.pair_lists()
+        check(self.lib.oovqe_sector_state_deriv_pl(dptr(theta), self.n_theta, dptr(self.gates_dev, torch.uint8),
+                                                   self.n_gates, self.ncas, ctypes.c_uint32(self.init_index),
+                                                   *self._tabs(), batch, dptr(pairs, torch.int32), max_pairs,
+                                                   dptr(spec, torch.int32), int(spec.shape[0]),
+                                                   dptr(out), stream_ptr()), "oovqe_sector_state_deriv_pl")
         return out
 
     def rdms_chunked(self, states, chunk=256):

@@ -413,8 +413,8 @@ int64_t oovqe_sector_work_size(int ncas, int na, int nb, int batch);
  * occupations match the gate's masks -- 400 of the 4 900 determinants of CAS(8e,8o) for a pair double excitation;
  * which ones depends on the gate table alone.  oovqe_sector_pairs lists them once per circuit
  * (pairs: oovqe_sector_pairs_size() 32-bit words = [n_gates] counts, then per gate its pairs d | e << 15 |
- * parity << 31 in ascending d; at most 32 767 determinants); oovqe_sector_state_pl / oovqe_sector_adjoint_pl are
- * oovqe_sector_state / oovqe_sector_adjoint sweeping the lists (max_pairs = the largest count; pairs == NULL: the
+ * parity << 31 in ascending d; at most 32 767 determinants); oovqe_sector_state_pl / _state_deriv_pl / _adjoint_pl are
+ * oovqe_sector_state / _state_deriv / _adjoint sweeping the lists (max_pairs = the largest count; pairs == NULL: the
  * plain entry points).  Same results to rounding (the sums of the adjoint run in another order). */
 /* lam [batch][Dc] = (Hop + Hop^T) v for a stack of sector vectors v, Hop = sum c1e_pq E_pq + sum c2_pqrs E_pq E_rs the
  * operator whose quadratic form is Q(v) = c1 . gamma(v) + c2 . Gamma(v) (oo_pqc.py:103-111 differentiates exactly
@@ -432,6 +432,11 @@ int oovqe_sector_state_pl(const double* theta, int n_theta, const oovqe_gate_t* 
                           const int32_t* rank_a, const int32_t* rank_b, int na, int nb, int batch,
                           const uint32_t* pairs, int max_pairs, double* psi_c, double* psi_dense,
                           oovqe_stream_t stream);
+int oovqe_sector_state_deriv_pl(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates, int ncas,
+                                uint32_t init_index, const uint32_t* unrank_a, const uint32_t* unrank_b,
+                                const int32_t* rank_a, const int32_t* rank_b, int na, int nb, int batch,
+                                const uint32_t* pairs, int max_pairs, const int32_t* deriv, int n_out,
+                                double* psi_out, oovqe_stream_t stream);
 int oovqe_sector_adjoint_pl(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates, int ncas,
                             const uint32_t* unrank_a, const uint32_t* unrank_b, const int32_t* rank_a,
                             const int32_t* rank_b, int na, int nb, int batch, const double* psi_c,

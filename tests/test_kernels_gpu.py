@@ -750,6 +750,19 @@ def test_sector_pair_lists_equal_the_gate_sweeps(ncas, nelecas, ansatz):
                                    dptr(psi0), dptr(c1), dptr(c2), dptr(eng.work(batch)), dptr(dth0), stream_ptr()),
           "oovqe_sector_adjoint")
     assert (dth - dth0).abs().max() < 1e-12 * max(1.0, float(dth0.abs().max()))
+    # first / second tangent states (a differentiated gate also annihilates what it leaves alone)
+    pg = eng.param_gates(gates)
+    if pg is not None:
+        specs = [(-1, -1), (pg[0], -1), (pg[n_theta - 1], -1), (pg[0], pg[0]), (pg[0], pg[n_theta - 1])]
+        der = eng.derivative_states(th, specs)
+        spec = torch.as_tensor(np.asarray(specs, dtype=np.int32)).to(DEV)
+        der0 = torch.empty_like(der)
+        check(lib.oovqe_sector_state_deriv(dptr(th), n_theta, dptr(gd, torch.uint8), len(gates), ncas,
+                                           ctypes.c_uint32(eng.init_index), *eng._tabs(), batch,
+                                           dptr(spec, torch.int32), len(specs), dptr(der0), stream_ptr()),
+              "oovqe_sector_state_deriv")
+        assert torch.equal(der, der0)
+        assert torch.equal(der[:, 0], psi)
 
 
 def test_batched_circuit_hessian_beyond_one_grid_of_pairs():
