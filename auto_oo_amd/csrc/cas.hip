@@ -2635,14 +2635,65 @@ void cas_column_kernel(const double* __restrict__ U, const double* __restrict__ 
         Cpart[n] = 0.0;
     }
 
-    // RDM sets, rdm_chunk at a time through LDS
-    for (int k0 = 0; k0 < nrdm; k0 += rdm_chunk) {
+    // RDM sets, rdm_chunk at a time through LDS.  gridDim.z workgroups share the chunks of one n (round 4: a
+    // kUpCCD CAS(8e,8o) derivative evaluation carries 57 sets of 33 KB, one or two fit beside U[n]; with one
+    // workgroup per n and one THREAD per (set, row) -- 16 threads busy, 512 serial terms each -- this loop took
+    // 2.8 ms of a 3.2 ms Hessian).  Large active spaces: one WAVE per (set, row), the terms dealt to its lanes
+    // and summed by a fixed shuffle tree.
+    const int zsplit = gridDim.z, zid = blockIdx.z;
+    const bool by_wave = na3 >= 128;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int k0 = zid * rdm_chunk; k0 < nrdm; k0 += zsplit * rdm_chunk) {
         const int kc = (nrdm - k0) < rdm_chunk ? (nrdm - k0) : rdm_chunk;
         __syncthreads();
         if (k0 > 0) {   // (chunk 0 was staged with the other inputs)
             for (int idx = tid; idx < kc * na2; idx += COL_THREADS) gml[idx] = gamma[(size_t)k0 * na2 + idx];
             for (int idx = tid; idx < kc * na4; idx += COL_THREADS) Gml[idx] = Gamma[(size_t)k0 * na4 + idx];
             __syncthreads();
+        }
+        if (by_wave) {
+            // items: (set kl, row m) for the Fock columns, then (set kl) for the energy pieces
+            for (int item = wave; item < kc * M + kc; item += COL_THREADS / 64) {
+                double acc = 0.0;
+                if (item < kc * M) {
+                    const int kl = item / M, m = item - kl * M;
+                    const double* gam = gml + (size_t)kl * na2;
+                    if (m < no) {
+                        for (int vw = lane; vw < na2; vw += 64) {
+                            const int v = vw / na, w = vw - v * na, V = no + v, W = no + w;
+                            acc += gam[vw] * (Gn[m * M2 + V * M + W] - 0.5 * Gn[W * M2 + V * M + m]);
+                        }
+                    } else {
+                        const int v = m - no;
+                        const double* Gv = Gml + (size_t)kl * na4 + (size_t)v * na3;
+                        if (lane < na) acc = FIn[no + lane] * gam[v * na + lane];
+                        for (int wxy = lane; wxy < na3; wxy += 64) {
+                            const int w = wxy / na2, xy = wxy - w * na2, x = xy / na, y = xy - x * na;
+                            acc += Gv[wxy] * Gn[(no + w) * M2 + (no + x) * M + no + y];
+                        }
+                    }
+                    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+                    if (lane == 0) {
+                        const int k = k0 + kl;
+                        Fcol[((size_t)k * M + m) * N + n] = m < no ? 2.0 * ((k == 0 ? FIn[m] : 0.0) + acc) : acc;
+                    }
+                } else {
+                    const int kl = item - kc * M;
+                    if (n >= no && n < M) {
+                        const int p = n - no;
+                        const double* gam = gml + (size_t)kl * na2 + (size_t)p * na;
+                        const double* Gp = Gml + (size_t)kl * na4 + (size_t)p * na3;
+                        if (lane < na) acc = FIn[no + lane] * gam[lane];
+                        for (int qrs = lane; qrs < na3; qrs += 64) {
+                            const int q = qrs / na2, rs = qrs - q * na2, r = rs / na, s2 = rs - r * na;
+                            acc += 0.5 * Gn[(no + q) * M2 + (no + r) * M + no + s2] * Gp[qrs];
+                        }
+                        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+                    }
+                    if (lane == 0) Epart[(size_t)(k0 + kl) * N + n] = acc;
+                }
+            }
+            continue;
         }
         // Fock columns: one thread per (set k, row m)
         for (int idx = tid; idx < kc * M; idx += COL_THREADS) {
@@ -4030,7 +4081,17 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
             attr_done = true;
         }
         oovqe_profile_mark_start_l(st, 3);
-        hipLaunchKernelGGL(cas_column_kernel, dim3(N, batch), dim3(COL_THREADS), lds_bytes, st, U, h_ao, C,
+        // many large RDM sets (a derivative evaluation of a big active space): their chunks are dealt to
+        // zsplit workgroups per n, about one resident round of workgroups in all
+        int zsplit = 1;
+        if (ncas * ncas * ncas >= 128 && rdm_chunk > 0) {
+            const int nchunks = (nrdm + rdm_chunk - 1) / rdm_chunk;
+            zsplit = (int)((long)device_cu_count() * 2 / ((long)N * batch));
+            if (zsplit > nchunks) zsplit = nchunks;
+            if (zsplit > 64) zsplit = 64;
+            if (zsplit < 1) zsplit = 1;
+        }
+        hipLaunchKernelGGL(cas_column_kernel, dim3(N, batch, zsplit), dim3(COL_THREADS), lds_bytes, st, U, h_ao, C,
                            gamma, Gamma, nrdm, N, n_occ, ncas, Fcol, Epart, Cpart, c1, c2, Gm, hmo,
                            out_stride, rdm_chunk);
         oovqe_profile_mark_stop(st);

@@ -54,6 +54,7 @@ class SectorEngine:
         self._work = {}
         self._param_gate = None
         self._pairs = None
+        self._hess_tables = None
 
     # ---- derivatives (round 4) --------------------------------------------------------------------
     def param_gates(self, gates_host):
@@ -72,7 +73,8 @@ class SectorEngine:
         """theta [batch, n_theta], specs: list of (gate_a, gate_b) (-1 = none) -> [batch, len(specs), Dc]:
         the circuit with those gates differentiated (oovqe_sector_state_deriv)."""
         batch = theta.shape[0]
-        spec = torch.as_tensor(np.asarray(specs, dtype=np.int32).reshape(-1, 2)).to(self.device)
+        spec = (specs if isinstance(specs, torch.Tensor)
+                else torch.as_tensor(np.asarray(specs, dtype=np.int32).reshape(-1, 2)).to(self.device))
         out = torch.empty((batch, spec.shape[0], self.Dc), dtype=F64, device=self.device)
         pairs, max_pairs = self.pair_lists()
         check(self.lib.oovqe_sector_state_deriv_pl(dptr(theta), self.n_theta, dptr(self.gates_dev, torch.uint8),
@@ -131,25 +133,28 @@ class SectorEngine:
         if pg is None:
             raise NotImplementedError("sector derivatives need one gate per parameter (UCCD / UCCSD / kUpCCD)")
         nt = self.n_theta
-        pairs = [(j, k) for j in range(nt) for k in range(j, nt)]
-        specs = [(-1, -1)] + [(pg[k], -1) for k in range(nt)] + [(pg[j], pg[k]) for j, k in pairs]
-        st = self.derivative_states(theta, specs)[0]
+        if self._hess_tables is None:      # (index tables of the pairs j <= k: once per engine, not per call)
+            pairs = [(j, k) for j in range(nt) for k in range(j, nt)]
+            specs = [(-1, -1)] + [(pg[k], -1) for k in range(nt)] + [(pg[j], pg[k]) for j, k in pairs]
+            self._hess_tables = (torch.as_tensor(np.asarray(specs, dtype=np.int32).reshape(-1, 2)).to(self.device),
+                                 torch.as_tensor([j for j, _ in pairs], device=self.device),
+                                 torch.as_tensor([k for _, k in pairs], device=self.device), len(pairs))
+        spec, ja, ka, npair = self._hess_tables
+        st = self.derivative_states(theta, spec)[0]
         psi, tau, tau2 = st[0], st[1:1 + nt], st[1 + nt:]
-        ja = torch.as_tensor([j for j, _ in pairs], device=self.device)
-        ka = torch.as_tensor([k for _, k in pairs], device=self.device)
         if by_rdms:
             vecs = torch.cat((tau2 + psi, tau2 - psi, tau[ja] + tau[ka], tau[ja] - tau[ka]))
             g1, g2 = self.rdms_chunked(vecs)
             a = self.ncas
             q = ((g1.reshape(-1, a * a) * c1.reshape(1, -1)).sum(dim=1)
                  + (g2.reshape(-1, a ** 4) * c2.reshape(1, -1)).sum(dim=1))
-            npair = len(pairs)
             val = 0.5 * (q[:npair] - q[npair:2 * npair]) + 0.5 * (q[2 * npair:3 * npair] - q[3 * npair:])
         else:
-            from . import ops
             lam = self.lam(st[:1 + nt].contiguous(), c1, c2)                       # lam(psi), lam(tau_k)
-            first = ops.matmul_nn(tau2.contiguous(), lam[0].reshape(-1, 1).contiguous())[:, 0]   # tau_jk . lam(psi)
-            second = ops.matmul_nn(tau.contiguous(), lam[1:].T.contiguous())       # [j, k] = tau_j . lam(tau_k)
+            # two sets of scalar products over the sector dimension (elementwise multiply + sum: 1 596 + 56 x 56
+            # rows of 4 900 -- the library's GEMM kernels have no shape for a few outputs of a long inner dimension)
+            first = (tau2 * lam[0]).sum(dim=1)                                     # tau_jk . lam(psi)
+            second = (tau[:, None, :] * lam[None, 1:, :]).sum(dim=2)               # [j, k] = tau_j . lam(tau_k)
             val = first + second[ja, ka]
         H = torch.zeros((nt, nt), dtype=F64, device=self.device)
         H[ja, ka] = val
