@@ -50,6 +50,7 @@ enum oovqe_option_t {
     OOVQE_OPT_NEWTON_NO_CHOL,        // oovqe_newton_direction: never the Cholesky fast path (band route for every problem)
     OOVQE_OPT_TILES_VARIANT,         // half_tiles_kernel (measurement, M in 17..32): 1 / 2 = ring of 4 / 6 tiles instead of 8, 4 = default cache policy for the loads
     OOVQE_OPT_SECTOR_LAMBDA_W,       // sector adjoint: 1 = lambda through W = Ms^T V in memory (round 3) whatever the batch, 2 = the string-driven form whatever the batch (0: by batch size)
+    OOVQE_OPT_SECTOR_RDM_R3,         // sector RDMs: 1 = the round-3 fused kernel (chunks of 128 consecutive determinants) whatever the batch, 2 = row chunks in the sigma basis whatever the batch (0: by batch size)
     OOVQE_OPT_COUNT
 };
 int oovqe_opt(int id);

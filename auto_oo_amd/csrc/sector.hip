@@ -744,6 +744,194 @@ void sector_rdm_fused_kernel(const double* __restrict__ psi_c, Sector s, int bat
     }
 }
 
+// ---- round 4: the Gram from ROW chunks in the sigma basis ----------------------------------------------------------
+// sector_rdm_fused_kernel spends 103 of its 226 us (256 CAS(8e,8o) states) building V: ~20 vector instructions per
+// element (two table words, two amplitudes, own and cross parities, two selects).  In the basis psi' = sigma psi
+// (see the string-driven lambda below: sigma^2 = 1, so the Gram and <psi| V> do not change) the cross parities
+// are gone, and with chunks of WHOLE alpha rows (all beta strings of 144 / NBp rows) a thread keeps its beta
+// string: its beta-excitation words -- source column (or a zero column), sign -- are read ONCE into registers; the
+// alpha words come from a 32-bit table that holds the byte offset of the source ROW (or of a zero row) and the
+// sign bit, so that an element of V costs two LDS reads, two XORs, four integer operations and one add.
+constexpr int SEC_RCHP = SEC_CH + 18;          // 146: V rows 36 banks apart, conflict-free Gram operand reads
+static_assert((SEC_RCHP / 2) % 2 == 1 && SEC_RCHP % 2 == 0, "pitch / 2 must be odd");
+constexpr int SEC_RCH = 144;                   // columns of a row chunk (whole alpha rows x padded nb)
+
+__device__ __forceinline__ double sec_sigma(const Sector& s, int ia, int ib)
+{
+    const uint32_t sa = s.unrank_a[ia], sb = s.unrank_b[ib];
+    uint32_t par = 0;
+    for (int i = 1; i < s.ncas; ++i)
+        if (sa & (1u << (s.ncas - 1 - i))) par ^= __popc(sb & sec_orb_mask(s.ncas, 0, i - 1)) & 1u;
+    return par ? -1.0 : 1.0;
+}
+
+__host__ __device__ inline size_t sec_rdm_rows_lds_bytes(int na, int nb, int ncas)
+{
+    const size_t na2 = (size_t)ncas * ncas, NBp = ((size_t)nb + 8) & ~(size_t)7, NRC = SEC_RCH / NBp;
+    if (NRC < 1) return (size_t)1 << 30;
+    const size_t nchunk = (na + NRC - 1) / NRC;
+    const size_t NR = nchunk * NRC > (size_t)na + 1 ? nchunk * NRC : (size_t)na + 1;
+    return (NR * NBp + na2 * SEC_RCHP) * sizeof(double) + (na2 * (size_t)na * sizeof(uint32_t) + 7) / 8 * 8;
+}
+
+template <int NT>
+__global__ __launch_bounds__(512)
+void sector_rdm_rows_kernel(const double* __restrict__ psi_c, Sector s, int batch, int MTR, double* __restrict__ R,
+                            int probe)
+{
+    extern __shared__ double lds[];
+    __shared__ double red[8][256];
+    const int na = s.na, nb = s.nb, Dc = na * nb, a = s.ncas, na2 = a * a;
+    const int NBp = (nb + 8) & ~7, NRC = SEC_RCH / NBp, CH = NRC * NBp, KSC = CH / 4;   // (>= 1 zero column behind nb)
+    const int nchunk = (na + NRC - 1) / NRC;
+    const int NR = nchunk * NRC > na + 1 ? nchunk * NRC : na + 1;     // rows >= na are zero
+    double* P = lds;                                   // [NR][NBp]  sigma psi, zero padded
+    double* Vc = P + (size_t)NR * NBp;                 // [a^2][SEC_RCHP]
+    uint32_t* tA = reinterpret_cast<uint32_t*>(Vc + (size_t)na2 * SEC_RCHP);   // [a^2][na]
+    uint16_t* tmp = reinterpret_cast<uint16_t*>(Vc);   // the 16-bit tables, before the first chunk is built
+    const size_t b = blockIdx.x;
+    const int split = blockIdx.y, nsplit = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane >> 4, lr = lane & 15;
+    for (int i = tid; i < NR * NBp; i += 512) {
+        const int r = i / NBp, c = i - r * NBp;
+        P[i] = (r < na && c < nb) ? sec_sigma(s, r, c) * psi_c[b * Dc + r * nb + c] : 0.0;
+    }
+    // this thread's column of a chunk and its share of the operators
+    constexpr int MAXOP = NT == 4 ? 24 : 8;
+    const int NP = 512 / CH < 4 ? 512 / CH : 4;
+    const int part = tid / CH, l = tid - part * CH;
+    const int ial = l / NBp, ib = l - ial * NBp;
+    const int opp = (na2 + NP - 1) / NP;
+    const int o0 = part * opp, o1 = o0 + opp < na2 ? o0 + opp : na2;
+    const bool worker = part < NP;
+    // alpha words: byte offset of the source row (row na = zeros when the operator does not apply) | sign << 31
+    sec_build_table(s.unrank_a, s.rank_a, na, a, true, tmp, 512);
+    __syncthreads();
+    for (int i = tid; i < na2 * na; i += 512) {
+        const uint32_t e = tmp[i];
+        const uint32_t row = (e & 2048u) ? (e & 2047u) : (uint32_t)na;
+        tA[i] = row * (uint32_t)(NBp * sizeof(double)) | ((e & 4096u) << 19);
+    }
+    __syncthreads();
+    // beta words of this thread's beta string, once: source column (column nb = zero) and sign mask
+    sec_build_table(s.unrank_b, s.rank_b, nb, a, false, tmp, 512);
+    __syncthreads();
+    uint32_t offB[MAXOP], sgnB[MAXOP];
+#pragma unroll
+    for (int u = 0; u < MAXOP; ++u) {
+        const uint32_t e = (worker && o0 + u < o1 && ib < nb) ? tmp[(o0 + u) * nb + ib] : 0u;
+        offB[u] = (e & 2048u) ? (e & 2047u) : (uint32_t)nb;
+        sgnB[u] = (e & 4096u) << 19;
+    }
+    // the determinant behind column 4 kk + lq of a chunk, for the k-steps of this wave (<psi| V> on the vector ALUs)
+    constexpr int MAXK = (SEC_RCH / 4 + 7) / 8;
+    int poff[MAXK];
+#pragma unroll
+    for (int i = 0; i < MAXK; ++i) {
+        const int cc = 4 * (wave + 8 * i) + lq;
+        poff[i] = cc < CH ? (cc / NBp) * NBp + (cc % NBp) : 0;      // (= cc: rows of a chunk are NBp apart in P too)
+    }
+    d4 acc[NT][NT];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = d4{0.0, 0.0, 0.0, 0.0};
+    double gpart[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) gpart[nt] = 0.0;
+    __syncthreads();                                     // (tmp is Vc: all table words are out of it)
+    for (int ch = split; ch < nchunk; ch += nsplit) {
+        const int ia = ch * NRC + ial;
+        if (worker && l < CH && !(probe == 1 && ch != split)) {
+            if (ib < nb && ia < na) {
+                const char* Pb = reinterpret_cast<const char*>(P) + (size_t)ib * sizeof(double);
+                const double* rowb = P + (size_t)ia * NBp;
+                const uint32_t* ta = tA + ia;
+#pragma unroll
+                for (int u0 = 0; u0 < MAXOP; u0 += 8) {
+                    uint32_t wa[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) wa[u] = ta[(o0 + u0 + u < o1 ? o0 + u0 + u : o0) * na];
+                    double va[8], vb[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        va[u] = *reinterpret_cast<const double*>(Pb + (wa[u] & 0x7fffffffu));
+                        vb[u] = rowb[offB[u0 + u]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const unsigned long long xa = __builtin_bit_cast(unsigned long long, va[u]) ^
+                                                      ((unsigned long long)(wa[u] & 0x80000000u) << 32);
+                        const unsigned long long xb = __builtin_bit_cast(unsigned long long, vb[u]) ^
+                                                      ((unsigned long long)sgnB[u0 + u] << 32);
+                        if (o0 + u0 + u < o1)
+                            Vc[(o0 + u0 + u) * SEC_RCHP + l] =
+                                __builtin_bit_cast(double, xa) + __builtin_bit_cast(double, xb);
+                    }
+                }
+            } else {
+                for (int o = o0; o < o1; ++o) Vc[o * SEC_RCHP + l] = 0.0;
+            }
+        }
+        __syncthreads();
+        if (probe != 2) {
+            const double* Pc = P + (size_t)ch * NRC * NBp;
+#pragma unroll
+            for (int i = 0; i < MAXK; ++i) {
+                const int kk = wave + 8 * i;
+                if (kk < KSC) {
+                    const int cc = 4 * kk + lq;
+                    double bv[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) bv[nt] = Vc[(nt * 16 + lr) * SEC_RCHP + cc];
+                    const double pv = Pc[poff[i]];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) gpart[nt] += pv * bv[nt];
+#pragma unroll
+                    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                        for (int nt = mt; nt < NT; ++nt) acc[mt][nt] = mfma_f64(bv[mt], bv[nt], acc[mt][nt]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // the 8 waves' partial tiles are summed through LDS in fixed order, tile by tile (as sector_rdm_fused_kernel)
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int nt = mt; nt < NT; ++nt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[wave][(lq + 4 * i) * 16 + lr] = acc[mt][nt][i];
+            __syncthreads();
+            if (tid < 256) {
+                double v = red[0][tid];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) v += red[w][tid];
+                const int mrow = mt * 16 + tid / 16, col = nt * 16 + (tid & 15);
+                const int row = (mrow % a) * a + mrow / a;            // product row (q,p) -> Gram row (p,q)
+                double* Rb = R + ((size_t)split * batch + b) * (MTR * 16) * (NT * 16);
+                Rb[(size_t)row * (NT * 16) + col] = v;
+                if (mt != nt) Rb[(size_t)((col % a) * a + col / a) * (NT * 16) + mrow] = v;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        red[wave][lq * 16 + lr] = gpart[nt];
+        __syncthreads();
+        if (tid < 16) {
+            double v = 0.0;
+            for (int w = 0; w < 8; ++w)
+                for (int gq = 0; gq < 4; ++gq) v += red[w][gq * 16 + tid];
+            R[(((size_t)split * batch + b) * (MTR * 16) + na2) * (NT * 16) + nt * 16 + tid] = v;
+        }
+        __syncthreads();
+    }
+}
+
 // W[b][j][c] = sum_k Ms[k][j] (E_k psi_b)[c] without V in memory.  Wave w forms the 16 x 16 tiles of W rows
 // 16 (w % NT) .. for the c-tiles (w / NT), (w / NT) + 8 / NT, ... of every chunk, its Ms fragments in registers.
 template <int NT>
@@ -1842,6 +2030,35 @@ extern "C" int oovqe_sector_rdms(const double* psi_c, int ncas, const uint32_t* 
     // a^2 a multiple of 16 and the sector vector + one chunk of E_pq vectors within a workgroup's LDS: the
     // fused kernel (V never written); nsplit workgroups per state share its chunks when the batch is small
     const size_t fused_lds = sec_fused_lds_bytes(na, nb, ncas);
+    const size_t rows_lds = sec_rdm_rows_lds_bytes(na, nb, ncas);
+    if ((na2 == 16 || na2 == 64) && rows_lds + 8 * 256 * sizeof(double) <= 160 * 1024 && na < SEC_TAB_MAXSTR &&
+        nb < SEC_TAB_MAXSTR && (size_t)(na > nb ? na : nb) * na2 * sizeof(uint16_t) <= (size_t)na2 * SEC_RCHP * 8 &&
+        oovqe_opt(OOVQE_OPT_SECTOR_UNFUSED) == 0 &&
+        (oovqe_opt(OOVQE_OPT_SECTOR_RDM_R3) == 2 || (oovqe_opt(OOVQE_OPT_SECTOR_RDM_R3) == 0 && batch >= 16))) {
+        // round 4: row chunks in the sigma basis (sector_rdm_rows_kernel); its longer prologue (two table builds, the
+        // words of the thread's beta string) costs a single state 6 us more than it saves: from 16 states on
+        const int NRC = SEC_RCH / ((nb + 8) & ~7);
+        const int nchunk = (na + NRC - 1) / NRC;
+        int nsplit = sector_cu_count() / batch;
+        if (nsplit > 8) nsplit = 8;
+        if (nsplit < 1) nsplit = 1;
+        if (nsplit > nchunk) nsplit = nchunk;
+        int rc;
+        if (na2 == 64) {
+            if ((rc = oovqe_ensure_dynamic_lds((const void*)sector_rdm_rows_kernel<4>, rows_lds))) return rc;
+            hipLaunchKernelGGL(sector_rdm_rows_kernel<4>, dim3(batch, nsplit), dim3(512), rows_lds, st, psi_c, s, batch,
+                               MT, R, oovqe_opt(OOVQE_OPT_SECTOR_PROBE));
+        } else {
+            if ((rc = oovqe_ensure_dynamic_lds((const void*)sector_rdm_rows_kernel<1>, rows_lds))) return rc;
+            hipLaunchKernelGGL(sector_rdm_rows_kernel<1>, dim3(batch, nsplit), dim3(512), rows_lds, st, psi_c, s, batch,
+                               MT, R, oovqe_opt(OOVQE_OPT_SECTOR_PROBE));
+        }
+        OOVQE_CHECK_LAUNCH("sector_rdms/rows");
+        hipLaunchKernelGGL(sector_rdm_finish_kernel, dim3((na2 * na2 + na2 + 255) / 256, batch), dim3(256),
+                           0, st, R, ncas, batch, nsplit, gamma, Gamma);
+        OOVQE_CHECK_LAUNCH("sector_rdms/finish");
+        return 0;
+    }
     if (na2 % 16 == 0 && na2 <= 64 && fused_lds <= 140 * 1024 && na < SEC_TAB_MAXSTR && nb < SEC_TAB_MAXSTR &&
         oovqe_opt(OOVQE_OPT_SECTOR_UNFUSED) == 0) {
         const int nchunk = (Dc + SEC_CH - 1) / SEC_CH;

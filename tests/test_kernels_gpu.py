@@ -541,7 +541,7 @@ def test_eri_pack_layout(N):
     out = torch.full((G, psz), float("nan"), dtype=torch.float64, device=DEV)
     _lib.check(lib.oovqe_eri_pack(_lib.dptr(gd), N, G, _lib.dptr(out), _lib.stream_ptr()), "oovqe_eri_pack")
     assert np.array_equal(out.cpu().numpy().reshape(-1), ref)
-    assert lib.oovqe_eri_packed_size(49) == 0
+    assert lib.oovqe_eri_packed_size(49) == 49 * 50 // 2 * 10 * 256      # (N > 48: the tile format, test_tile_packed_copy_layout)
 
 
 @pytest.mark.parametrize("ncas,nelecas,ansatz", [(2, 2, "np_fabric"), (3, 4, "ucc"), (3, 2, "kupccd")])
@@ -709,6 +709,11 @@ def test_sector_fused_kernels_equal_the_unfused_ones(ncas, nelecas, batch):
         with debug_options(sector_lambda_w=forced):
             dth_f = eng.adjoint(th, psi_c, c1, c2)
         assert (dth_f - dth_u).abs().max() < 1e-11 * max(1.0, float(dth_u.abs().max())), forced
+        # ... and the RDMs from chunks of 128 consecutive determinants (round 3; the default below 16 states) and
+        # from chunks of whole alpha rows in the sigma basis (round 4)
+        with debug_options(sector_rdm_r3=forced):
+            f1, f2 = eng.rdms(psi_c)
+        assert (f1 - h1).abs().max() < 1e-12 and (f2 - h2).abs().max() < 1e-12, forced
     # the adjoint no longer depends on a preceding RDM call on the same workspace
     eng2 = SectorEngine(ncas, hf, gd, len(gates), n_theta, X.basis_index(hf), torch.device(DEV))
     assert torch.equal(eng2.adjoint(th, psi_c, c1, c2), dth)
