@@ -14,6 +14,7 @@ import auto_oo_amd as aoo            # noqa: E402
 from auto_oo_amd import ops          # noqa: E402
 from oracle import cpu_ref as R      # noqa: E402
 from tests.test_api_gpu import _setup   # noqa: E402
+from tests._oracle_cache import oracle_values, pack_sym, unpack_sym   # noqa: E402
 
 
 def _reference_direction(H, g, lambda_min=1e-6, mu=1e-6, rho=1.1, aug=True):
@@ -240,17 +241,40 @@ def test_reference_property_type_b_on_device(t, max_iterations):
     assert abs(energies[-1]) < 1e-8
 
 
+def oracle_config3_n43():
+    """The oracle's side of configs[3] at N = 43 (seed 20262, theta = 0.1): full gradient, full 331 x 331 Hessian and
+    one damped Newton step -- ~5 minutes of host CPU, kept as tests/golden/oracle_cache/config3_n43_s20262.npz."""
+    def compute():
+        P = R.synthetic_problem(43, 20262)
+        omol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], 16)
+        ooo = R.OracleOOPQC(R.OraclePQC(3, 4, "ucc"), omol, 3, 4, P["oao_mo_coeff"])
+        theta = torch.full((4,), 0.1, dtype=torch.float64)
+        g_ref = ooo.full_gradient(theta)
+        h_ref = ooo.full_hessian(theta)
+        kappa = torch.zeros(ooo.n_kappa, dtype=torch.float64)
+        new_r, low_r = R.OracleNewtonStep().damped_newton_step(ooo.energy_from_parameters, (theta, kappa), g_ref, h_ref)
+        return {"gradient": g_ref.numpy(), "hessian_triu": pack_sym(h_ref.numpy()),
+                "hessian_asymmetry": np.array(float((h_ref - h_ref.T).abs().max())),
+                "new_theta": new_r[0].numpy(), "new_kappa": new_r[1].numpy(), "lowest_eigenvalue": np.array(low_r),
+                "energy": np.array(ooo.energy_from_parameters(theta).item()),
+                "new_energy": np.array(ooo.energy_from_parameters(new_r[0], new_r[1]).item())}
+    return oracle_values("config3_n43_s20262", compute)
+
+
 def test_config3_unit_of_work_at_cc_pvdz_shape():
     """BASELINE configs[3] at N = 43: energy + full gradient + full 331 x 331 Hessian (theta-theta,
     kappa-theta, kappa-kappa) + one damped Newton step, against the oracle (1e-8 abs, 1e-9 Ha)."""
     ooo, opqc, oo, pqc = _setup(43, 20262)
+    ref = oracle_config3_n43()
+    assert float(ref["hessian_asymmetry"]) < 1e-9
     theta = torch.full((pqc.theta_shape,), 0.1, dtype=torch.float64)
     grad = oo.full_gradient(theta)
     hess = oo.full_hessian(theta)
-    g_ref = ooo.full_gradient(theta)
-    h_ref = ooo.full_hessian(theta)
+    g_ref = torch.tensor(ref["gradient"])
+    h_ref = torch.tensor(unpack_sym(ref["hessian_triu"]))
     nt = pqc.theta_shape
     assert hess.shape == (331, 331) and h_ref.shape == (331, 331)
+    assert abs(oo.energy_from_parameters(theta).item() - float(ref["energy"])) < 1e-9
     assert (grad.cpu() - g_ref).abs().max() < 1e-8
     assert (hess[:nt, :nt].cpu() - h_ref[:nt, :nt]).abs().max() < 1e-8      # circuit-circuit
     assert (hess[nt:, :nt].cpu() - h_ref[nt:, :nt]).abs().max() < 1e-8      # orbital-circuit
@@ -259,14 +283,12 @@ def test_config3_unit_of_work_at_cc_pvdz_shape():
     kappa = torch.zeros(oo.n_kappa, dtype=torch.float64)
     new, low = aoo.NewtonStep(verbose=0).damped_newton_step(
         oo.energy_from_parameters, (theta.cuda(), kappa.cuda()), grad, hess)
-    new_r, low_r = R.OracleNewtonStep().damped_newton_step(ooo.energy_from_parameters, (theta, kappa),
-                                                           g_ref, h_ref)
-    assert abs(low - low_r) < 1e-9
+    assert abs(low - float(ref["lowest_eigenvalue"])) < 1e-9
     e_new = oo.energy_from_parameters(new[0], new[1]).item()
-    e_ref = ooo.energy_from_parameters(new_r[0], new_r[1]).item()
-    assert abs(e_new - e_ref) < 1e-9
+    assert abs(e_new - float(ref["new_energy"])) < 1e-9
     assert e_new < oo.energy_from_parameters(theta).item()
-    assert (new[0].cpu() - new_r[0]).abs().max() < 1e-7 and (new[1].cpu() - new_r[1]).abs().max() < 1e-7
+    assert (new[0].cpu() - torch.tensor(ref["new_theta"])).abs().max() < 1e-7
+    assert (new[1].cpu() - torch.tensor(ref["new_kappa"])).abs().max() < 1e-7
 
 
 def test_lockstep_newton_equals_sequential_on_64_geometries():
@@ -311,6 +333,25 @@ def _batch_of(N, G, seed0=20262, freeze_active=False, nelec=16):
     return pqc, batch, objs, probs
 
 
+def oracle_small_hessians(N, G, freeze):
+    """The oracle's energies, full gradients and full Hessians of the G synthetic geometries of
+    test_batched_full_hessian_vs_oracle_small (seeds 20262 + 1000 g, theta from default_rng(5)): up to two minutes of
+    host CPU, kept under tests/golden/oracle_cache/."""
+    def compute():
+        rng = np.random.default_rng(5)
+        thetas = torch.tensor(rng.uniform(0, 2 * np.pi, (G, 4)))
+        en, gr, he = [], [], []
+        for g in range(G):
+            P = R.synthetic_problem(N, 20262 + 1000 * g)
+            omol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], 16)
+            ooo = R.OracleOOPQC(R.OraclePQC(3, 4, "ucc"), omol, 3, 4, P["oao_mo_coeff"], freeze_active=freeze)
+            en.append(ooo.energy_from_parameters(thetas[g]).item())
+            gr.append(ooo.full_gradient(thetas[g]).numpy())
+            he.append(pack_sym(ooo.full_hessian(thetas[g]).numpy()))
+        return {"energy": np.array(en), "gradient": np.stack(gr), "hessian_triu": np.stack(he)}
+    return oracle_values(f"small_hessians_n{N}_g{G}_{'frozen' if freeze else 'free'}", compute)
+
+
 @pytest.mark.parametrize("N,G,freeze", [(13, 3, False), (13, 2, True), (20, 5, False)])
 def test_batched_full_hessian_vs_oracle_small(N, G, freeze):
     """OO_pqc_batch.energy_gradient_hessian (ONE call for all geometries, oovqe_oo_hessian_batch)
@@ -322,13 +363,24 @@ def test_batched_full_hessian_vs_oracle_small(N, G, freeze):
     E, grad, H = batch.energy_gradient_hessian(thetas.cuda())
     n = batch.n_theta + batch.n_kappa
     assert E.shape == (G,) and grad.shape == (G, n) and H.shape == (G, n, n)
+    ref = oracle_small_hessians(N, G, freeze)
     for g in range(G):
-        P = probs[g]
+        assert abs(E[g].item() - float(ref["energy"][g])) < 1e-9
+        assert (grad[g].cpu() - torch.tensor(ref["gradient"][g])).abs().max() < 1e-8
+        assert (H[g].cpu() - torch.tensor(unpack_sym(ref["hessian_triu"][g]))).abs().max() < 1e-8
+
+
+def oracle_hessian_n43_rng9():
+    """The oracle's full Hessian of geometry 0 (seed 20262, N = 43) at the first theta of default_rng(9).uniform --
+    minutes of host CPU, kept under tests/golden/oracle_cache/."""
+    def compute():
+        theta = torch.tensor(np.random.default_rng(9).uniform(0, 2 * np.pi, (6, 4)))[0]
+        P = R.synthetic_problem(43, 20262)
         omol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], 16)
-        ooo = R.OracleOOPQC(R.OraclePQC(3, 4, "ucc"), omol, 3, 4, P["oao_mo_coeff"], freeze_active=freeze)
-        assert abs(E[g].item() - ooo.energy_from_parameters(thetas[g]).item()) < 1e-9
-        assert (grad[g].cpu() - ooo.full_gradient(thetas[g])).abs().max() < 1e-8
-        assert (H[g].cpu() - ooo.full_hessian(thetas[g])).abs().max() < 1e-8
+        ooo = R.OracleOOPQC(R.OraclePQC(3, 4, "ucc"), omol, 3, 4, P["oao_mo_coeff"])
+        return {"theta": theta.numpy(), "hessian_triu": pack_sym(ooo.full_hessian(theta).numpy()),
+                "gradient": ooo.full_gradient(theta).numpy()}
+    return oracle_values("hessian_n43_s20262_rng9", compute)
 
 
 def test_batched_full_hessian_equals_single_geometry_path_at_cc_pvdz_shape():
@@ -349,10 +401,8 @@ def test_batched_full_hessian_equals_single_geometry_path_at_cc_pvdz_shape():
         assert (H[g][nt:, :nt] - h1[nt:, :nt]).abs().max() < 1e-10
         assert (H[g][nt:, nt:] - h1[nt:, nt:]).abs().max() < 1e-9
         assert torch.equal(H[g], H[g].T) or (H[g] - H[g].T).abs().max() < 1e-10
-    P = probs[0]
-    omol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], 16)
-    ooo = R.OracleOOPQC(R.OraclePQC(3, 4, "ucc"), omol, 3, 4, P["oao_mo_coeff"])
-    assert (H[0].cpu() - ooo.full_hessian(thetas[0].cpu())).abs().max() < 1e-8
+    ref = oracle_hessian_n43_rng9()
+    assert (H[0].cpu() - torch.tensor(unpack_sym(ref["hessian_triu"]))).abs().max() < 1e-8
     # the two convenience views
     assert torch.equal(batch.full_hessian(thetas), H)
     assert (batch.full_gradient(thetas) - grad).abs().max() < 1e-12
@@ -456,15 +506,9 @@ def test_batched_newton_step_equals_per_geometry_steps():
         assert abs(e_new[g].item() - e_s) < 1e-10
         assert (new_t[g] - new[0]).abs().max() < 1e-9
         assert e_new[g].item() < oo.energy_from_parameters(theta0[g]).item()
-    P = probs[0]
-    omol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], 16)
-    ooo = R.OracleOOPQC(R.OraclePQC(3, 4, "ucc"), omol, 3, 4, P["oao_mo_coeff"])
-    th = theta0[0].cpu()
-    kap = torch.zeros(batch.n_kappa, dtype=torch.float64)
-    new_r, low_r = R.OracleNewtonStep().damped_newton_step(ooo.energy_from_parameters, (th, kap),
-                                                           ooo.full_gradient(th), ooo.full_hessian(th))
-    assert abs(low[0].item() - low_r) < 1e-9
-    assert abs(e_new[0].item() - ooo.energy_from_parameters(new_r[0], new_r[1]).item()) < 1e-9
+    ref = oracle_config3_n43()          # (geometry 0 at theta = 0.1 is that problem: seed 20262)
+    assert abs(low[0].item() - float(ref["lowest_eigenvalue"])) < 1e-9
+    assert abs(e_new[0].item() - float(ref["new_energy"])) < 1e-9
 
 
 def test_batched_newton_step_that_gives_up_keeps_parameters_and_orbitals():

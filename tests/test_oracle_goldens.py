@@ -71,3 +71,28 @@ def test_excitation_lists():
     assert s == [[0, 4], [1, 5], [2, 4], [3, 5]]
     assert list(R.hf_state(4, 6)) == [1, 1, 1, 1, 0, 0]
     assert len(R.generalized_pair_doubles(range(16))) == 56
+
+
+@pytest.mark.parametrize("which", ["small_13_3", "small_13_2_frozen", "small_20_5", "hessian_n43_rng9", "config3_n43"])
+def test_oracle_cache_is_what_the_oracle_computes(which, monkeypatch):
+    """tests/golden/oracle_cache/*.npz (the oracle's side of the comparisons at the configs[3] shape, minutes of CPU on
+    a GPU box) against the oracle itself, recomputed here: a fixture that is stale -- the oracle, the synthetic
+    generator or a seed changed -- cannot pass.  (Deterministic on one machine; across machines the autograd
+    Hessians agree to rounding: 1e-10.)"""
+    import os
+    from tests import _oracle_cache as C
+    from tests import test_newton_gpu as T
+    fn = {"small_13_3": lambda: T.oracle_small_hessians(13, 3, False),
+          "small_13_2_frozen": lambda: T.oracle_small_hessians(13, 2, True),
+          "small_20_5": lambda: T.oracle_small_hessians(20, 5, False),
+          "hessian_n43_rng9": T.oracle_hessian_n43_rng9, "config3_n43": T.oracle_config3_n43}[which]
+    stored = fn()
+    files_before = sorted(os.listdir(C.CACHE))
+    monkeypatch.setattr(C.os.path, "exists", lambda p: False if p.startswith(C.CACHE) else os.path.lexists(p))
+    fresh = fn()                                   # (no file seen: the oracle runs; nothing is written)
+    assert sorted(os.listdir(C.CACHE)) == files_before
+    assert sorted(stored) == sorted(fresh)
+    for key in stored:
+        a, b = np.asarray(stored[key], dtype=float), np.asarray(fresh[key], dtype=float)
+        assert a.shape == b.shape, key
+        assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max()), key
