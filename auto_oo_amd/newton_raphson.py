@@ -181,10 +181,13 @@ class NewtonStep():
         new, energy, _ = self._search(objective_fn, parameters, dp, gradient)
         return new, energy
 
-    def damped_newton_step(self, objective_fn, parameters, gradient, hessian):
+    def damped_newton_step(self, objective_fn, parameters, gradient, hessian, defer_lowest=False):
         """newton_raphson.py:194-211 -> (new parameters, lowest Hessian eigenvalue).  The lowest eigenvalue of
         a positive definite Hessian is computed BESIDE the line search (side stream) and read back after it:
-        the direction does not depend on it (newton_raphson.py:105-128)."""
+        the direction does not depend on it (newton_raphson.py:105-128).  ``defer_lowest`` (an extension; ignored
+        when verbose): the eigenvalue comes back as an ``ops.PendingLowest`` (``.item()`` / ``float()`` join it) --
+        a loop of steps that only COLLECTS the eigenvalues (``hess_eig_l`` of ``OO_pqc.full_optimization``) then
+        never waits for the band route (1.1 ms at n = 331 where the step itself takes 0.4 ms)."""
         dp, low, nu, info = self._direction(gradient, hessian, defer_lowest=True)
         try:
             new, _, (shift, code) = self._search(objective_fn, parameters, dp, gradient, extra=(nu, info))
@@ -196,6 +199,8 @@ class NewtonStep():
             dp, low_t, nu = self._check_direction(gradient, hessian, dp, None, nu, [code])
             low = ops.PendingLowest(low_t, None)
             new, _, (shift,) = self._search(objective_fn, parameters, dp, gradient, extra=(nu,))
+        if defer_lowest and not self.verbose:
+            return new, low
         lowest_eigenvalue = low.result().reshape(()).item()
         if self.verbose:
             print("lowest eigval hessian =", lowest_eigenvalue)

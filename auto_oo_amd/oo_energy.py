@@ -611,8 +611,9 @@ class OO_energy:
             kappa = torch.zeros(self.n_kappa, dtype=F64, device=self.device)
             gradient = self.kappa_matrix_to_vector(self.analytic_gradient(one_rdm, two_rdm))
             hessian = self.analytic_hessian_matrix(one_rdm, two_rdm)
+            # (the reference's loop does not use the eigenvalue: it is never joined, an iteration does not wait for it)
             kappa, lowest_eigenvalue = opt.damped_newton_step(objective_fn, (kappa,), gradient,
-                                                              hessian)
+                                                              hessian, defer_lowest=True)
             self.oao_mo_coeff = ops.matmul_nn(self._t(self.oao_mo_coeff),
                                               self.kappa_to_mo_coeff(kappa))
             energy = self.energy_from_mo_coeff(self.mo_coeff, one_rdm, two_rdm).item()

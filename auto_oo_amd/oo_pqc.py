@@ -282,8 +282,10 @@ class OO_pqc(OO_energy):
             kappa = torch.zeros(self.n_kappa, dtype=F64, device=self.device)
             grad = self.full_gradient(theta)
             hess = self.full_hessian(theta)
+            # (the lowest eigenvalue is only collected: it is joined when the loop is over, so an iteration
+            # does not wait for the band route that computes it beside the line search)
             new_theta_kappa, hess_eig = opt.damped_newton_step(
-                self.energy_from_parameters, (theta, kappa), grad, hess)
+                self.energy_from_parameters, (theta, kappa), grad, hess, defer_lowest=True)
             hess_eig_l.append(hess_eig)
             theta = new_theta_kappa[0].reshape(self.pqc.theta_shape)
             kappa = new_theta_kappa[1]
@@ -302,4 +304,5 @@ class OO_pqc(OO_energy):
                         print("optimization finished.")
                         print("E_fin =", energy_l[-1])
                     break
+        hess_eig_l = [e.item() if isinstance(e, ops.PendingLowest) else e for e in hess_eig_l]
         return energy_l, theta_l, kappa_l, oao_mo_coeff_l, hess_eig_l

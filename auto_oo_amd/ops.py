@@ -549,6 +549,13 @@ class PendingLowest:
             raise _lib.OovqeError("lowest Hessian eigenvalue missing (NaN): a hand-off of the band route timed out")
         return vals
 
+    def item(self):
+        """The eigenvalue of ONE problem as a float (joins, reads back)."""
+        (v,) = self.tolist()
+        return v
+
+    __float__ = item
+
 
 def newton_direction(hessian, gradient, lambda_min=1e-6, mu=1e-6, rho=1.1, aug=True, defer_lowest=False,
                      want_info=False, max_wg=0):

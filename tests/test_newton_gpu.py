@@ -291,6 +291,32 @@ def test_config3_unit_of_work_at_cc_pvdz_shape():
     assert (new[1].cpu() - torch.tensor(ref["new_kappa"])).abs().max() < 1e-7
 
 
+def test_deferred_lowest_eigenvalue_of_single_steps():
+    """NewtonStep.damped_newton_step(defer_lowest=True): the same new parameters, the eigenvalue as an
+    ops.PendingLowest that float() joins -- for a positive definite Hessian (computed beside the line search) and for
+    an indefinite one (known before the direction: already there); OO_pqc.full_optimization collects them that way
+    and still returns plain floats (oo_pqc.py:155-207)."""
+    rng = np.random.default_rng(12)
+    n = 60
+    x0 = torch.tensor(rng.standard_normal(n)).cuda()
+    for kind in ("pd", "indefinite"):
+        Hm = torch.tensor(_sym(rng, n, kind)).cuda()
+        b = torch.tensor(rng.standard_normal(n)).cuda()
+        fn = lambda x: 0.5 * (x * (Hm @ x)).sum() + (b * x).sum() + 0.05 * (x ** 4).sum()   # noqa: E731
+        g = Hm @ x0 + b + 0.2 * x0 ** 3
+        Hx = Hm + torch.diag(0.6 * x0 ** 2)
+        opt = aoo.NewtonStep(verbose=0)
+        new0, low0 = opt.damped_newton_step(fn, (x0,), g, Hx)
+        new1, low1 = opt.damped_newton_step(fn, (x0,), g, Hx, defer_lowest=True)
+        assert isinstance(low0, float) and isinstance(low1, ops.PendingLowest)
+        assert torch.equal(new0, new1)
+        assert float(low1) == low0 and low1.item() == low0
+    ooo, opqc, oo, pqc = _setup(13, 20261)
+    theta = torch.full((pqc.theta_shape,), 0.1, dtype=torch.float64)
+    e_l, th_l, k_l, c_l, eig_l = oo.full_optimization(theta, max_iterations=4, verbose=None)
+    assert len(eig_l) == len(e_l) and all(isinstance(e, float) for e in eig_l)
+
+
 def test_lockstep_newton_equals_sequential_on_64_geometries():
     """configs[3]: 64 geometries stepped one by one (NewtonStep) and in lockstep (BatchedNewtonStep)."""
     from auto_oo_amd.synthetic import synthetic_problem
