@@ -289,6 +289,37 @@ def test_cas_eval_large_n_rs_symmetry_reads_the_tile_triangle(N, n_occ, ncas):
         ops.cas_eval(g, h, Q.contiguous(), g1, g2, 3.0, n_occ, ncas, kr, kc, eri_flags=1, g_packed=tiles)
 
 
+def test_batched_hessian_and_newton_step_beyond_n48():
+    """A stack of geometries beyond N = 48 keeps the tile-packed copy of its integrals (OO_pqc_batch: both flags); the
+    one-call energy + gradient + Hessian and the lockstep Newton step run on it and agree with the
+    single-geometry objects (which keep their own copy)."""
+    import auto_oo_amd as aoo
+    from auto_oo_amd.synthetic import synthetic_problem
+    N, G = 52, 2
+    pqc = aoo.Parameterized_circuit(3, 4, None, ansatz="ucc")
+    mols, coeffs, objs = [], [], []
+    for g in range(G):
+        P = synthetic_problem(N, 4100 + g)
+        mols.append(aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], 16))
+        coeffs.append(P["oao_mo_coeff"])
+        objs.append(aoo.OO_pqc(pqc, mols[-1], 3, 4, oao_mo_coeff=P["oao_mo_coeff"]))
+    batch = aoo.OO_pqc_batch(pqc, mols, 3, 4, oao_mo_coeffs=coeffs)
+    assert batch.eri_flags == 3 and batch._eri_packed is not None
+    assert batch._eri_packed.shape == (G, N * (N + 1) // 2 * 10 * 256)
+    th = torch.tensor(np.random.default_rng(2).uniform(0, 2 * np.pi, (G, 4)), device=DEV)
+    E, g, H = batch.energy_gradient_hessian(th)
+    for i, oo in enumerate(objs):
+        assert oo._eri_packed() is not None
+        e1, g1 = oo.energy_and_gradient(th[i])
+        h1 = oo.full_hessian(th[i])
+        assert abs(E[i].item() - e1.item()) < 1e-11 and (g[i] - g1).abs().max() < 1e-11
+        assert (H[i] - h1).abs().max() < 1e-10 * max(1.0, h1.abs().max().item())
+    e_before = batch.energy(th)
+    new_t, e_new, low = batch.damped_newton_step(th)
+    assert (e_new < e_before).all()
+    assert (batch.energy(new_t) - e_new).abs().max().item() == 0.0
+
+
 def test_tile_packed_copy_layout():
     """The format include/oovqe.h documents for N > 48: slabs p <= q; per slab the tiles (R, S), R <= S, column
     tile by column tile; per tile [k-step pair][lane][2] with lane = 16 (row mod 4) + column, k-step = row / 4;
