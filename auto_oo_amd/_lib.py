@@ -136,7 +136,11 @@ SIGNATURES = {
     "oovqe_sector_work_size": (ctypes.c_int64, [ctypes.c_int] * 4),
     "oovqe_sector_lambda": (ctypes.c_int, [c_double_p, ctypes.c_int, c_int32_p, c_int32_p, c_int32_p, c_int32_p,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
-                                           c_double_p, c_double_p, c_stream]),
+                                           ctypes.c_void_p, c_double_p, c_double_p, c_stream]),
+    "oovqe_sector_tables_size": (ctypes.c_int64, [ctypes.c_int] * 3),
+    "oovqe_sector_rdms_tb": (ctypes.c_int, [c_double_p, ctypes.c_int, c_int32_p, c_int32_p, c_int32_p,
+                                            c_int32_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                            c_double_p, c_double_p, c_double_p, c_stream]),
     "oovqe_sector_pairs_size": (ctypes.c_int64, [ctypes.c_int] * 3),
     "oovqe_sector_pairs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_int32_p, c_int32_p,
                                           c_int32_p, c_int32_p, ctypes.c_int, ctypes.c_int, c_int32_p, c_stream]),
@@ -153,8 +157,8 @@ SIGNATURES = {
     "oovqe_sector_adjoint_pl": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                                ctypes.c_int, c_int32_p, c_int32_p, c_int32_p, c_int32_p,
                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p,
-                                               c_double_p, c_double_p, c_int32_p, ctypes.c_int, c_double_p,
-                                               c_double_p, c_stream]),
+                                               c_double_p, c_double_p, c_int32_p, ctypes.c_int, ctypes.c_void_p,
+                                               c_double_p, c_double_p, c_stream]),
     "oovqe_oo_eval": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                      ctypes.c_int, ctypes.c_uint32, c_double_p, c_double_p, c_double_p,
                                      ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int,

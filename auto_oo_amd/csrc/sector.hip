@@ -607,6 +607,21 @@ __device__ void sec_build_table(const uint32_t* __restrict__ unrank, const int32
     }
 }
 
+// the two tables of a workgroup: copied from the per-circuit copy in memory (oovqe_sector_pairs leaves one behind
+// its pair lists: [a^2][na] | [a^2][nb]) when the caller holds it, built from the strings otherwise
+__device__ __forceinline__ void sec_tables(const Sector& s, const uint16_t* __restrict__ tabs_g, uint16_t* tabA,
+                                           uint16_t* tabB, int nthreads)
+{
+    const int na2 = s.ncas * s.ncas;
+    if (tabs_g) {
+        for (int i = threadIdx.x; i < s.na * na2; i += nthreads) tabA[i] = tabs_g[i];
+        for (int i = threadIdx.x; i < s.nb * na2; i += nthreads) tabB[i] = tabs_g[(size_t)s.na * na2 + i];
+    } else {
+        sec_build_table(s.unrank_a, s.rank_a, s.na, s.ncas, true, tabA, nthreads);
+        sec_build_table(s.unrank_b, s.rank_b, s.nb, s.ncas, false, tabB, nthreads);
+    }
+}
+
 // fills Vc[pq][0 .. SEC_CH) for the determinants c0 .. c0 + SEC_CH - 1 (zeros behind the sector)
 template <int SEC_CHP>
 __device__ __forceinline__ void sec_build_chunk(const double* __restrict__ src, int na, int nb, int a,
@@ -654,7 +669,7 @@ __device__ __forceinline__ void sec_build_chunk(const double* __restrict__ src, 
 template <int NT>
 __global__ __launch_bounds__(512)
 void sector_rdm_fused_kernel(const double* __restrict__ psi_c, Sector s, int batch, int MTR, double* __restrict__ R,
-                             int probe)
+                             int probe, const uint16_t* __restrict__ tabs_g)
 {
     extern __shared__ double lds[];
     __shared__ double red[8][256];
@@ -670,8 +685,7 @@ void sector_rdm_fused_kernel(const double* __restrict__ psi_c, Sector s, int bat
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane >> 4, lr = lane & 15;
     for (int i = tid; i < Dc; i += 512) src[i] = psi_c[b * Dc + i];
-    sec_build_table(s.unrank_a, s.rank_a, s.na, a, true, tabA, 512);
-    sec_build_table(s.unrank_b, s.rank_b, s.nb, a, false, tabB, 512);
+    sec_tables(s, tabs_g, tabA, tabB, 512);
     // A row m' of the product is V[m'] as well (the same conflict-free operand reads as B); it stands for
     // the pair (p,q) = (m' % a, m' / a), i.e. V[(q,p)] is row pq of the Gram: the rows are permuted when R
     // is written
@@ -777,7 +791,7 @@ __host__ __device__ inline size_t sec_rdm_rows_lds_bytes(int na, int nb, int nca
 template <int NT>
 __global__ __launch_bounds__(512)
 void sector_rdm_rows_kernel(const double* __restrict__ psi_c, Sector s, int batch, int MTR, double* __restrict__ R,
-                            int probe)
+                            int probe, const uint16_t* __restrict__ tabs_g)
 {
     extern __shared__ double lds[];
     __shared__ double red[8][256];
@@ -807,21 +821,22 @@ void sector_rdm_rows_kernel(const double* __restrict__ psi_c, Sector s, int batc
     const int o0 = part * opp, o1 = o0 + opp < na2 ? o0 + opp : na2;
     const bool worker = part < NP;
     // alpha words: byte offset of the source row (row na = zeros when the operator does not apply) | sign << 31
-    sec_build_table(s.unrank_a, s.rank_a, na, a, true, tmp, 512);
+    if (!tabs_g) sec_build_table(s.unrank_a, s.rank_a, na, a, true, tmp, 512);
     __syncthreads();
     for (int i = tid; i < na2 * na; i += 512) {
-        const uint32_t e = tmp[i];
+        const uint32_t e = tabs_g ? tabs_g[i] : tmp[i];
         const uint32_t row = (e & 2048u) ? (e & 2047u) : (uint32_t)na;
         tA[i] = row * (uint32_t)(NBp * sizeof(double)) | ((e & 4096u) << 19);
     }
     __syncthreads();
     // beta words of this thread's beta string, once: source column (column nb = zero) and sign mask
-    sec_build_table(s.unrank_b, s.rank_b, nb, a, false, tmp, 512);
+    if (!tabs_g) sec_build_table(s.unrank_b, s.rank_b, nb, a, false, tmp, 512);
     __syncthreads();
+    const uint16_t* tbb = tabs_g ? tabs_g + (size_t)na * na2 : tmp;
     uint32_t offB[MAXOP], sgnB[MAXOP];
 #pragma unroll
     for (int u = 0; u < MAXOP; ++u) {
-        const uint32_t e = (worker && o0 + u < o1 && ib < nb) ? tmp[(o0 + u) * nb + ib] : 0u;
+        const uint32_t e = (worker && o0 + u < o1 && ib < nb) ? tbb[(o0 + u) * nb + ib] : 0u;
         offB[u] = (e & 2048u) ? (e & 2047u) : (uint32_t)nb;
         sgnB[u] = (e & 4096u) << 19;
     }
@@ -937,7 +952,7 @@ void sector_rdm_rows_kernel(const double* __restrict__ psi_c, Sector s, int batc
 template <int NT>
 __global__ __launch_bounds__(512)
 void sector_w_fused_kernel(const double* __restrict__ psi_c, const double* __restrict__ Ms, Sector s,
-                           double* __restrict__ W, uint16_t* __restrict__ tab_out)
+                           double* __restrict__ W, uint16_t* __restrict__ tab_out, const uint16_t* __restrict__ tabs_g)
 {
     extern __shared__ double lds[];
     const int Dc = s.na * s.nb, a = s.ncas, na2 = a * a;
@@ -952,8 +967,7 @@ void sector_w_fused_kernel(const double* __restrict__ psi_c, const double* __res
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane >> 4, lr = lane & 15;
     for (int i = tid; i < Dc; i += 512) src[i] = psi_c[b * Dc + i];
-    sec_build_table(s.unrank_a, s.rank_a, s.na, a, true, tabA, 512);
-    sec_build_table(s.unrank_b, s.rank_b, s.nb, a, false, tabB, 512);
+    sec_tables(s, tabs_g, tabA, tabB, 512);
     if (tab_out && blockIdx.x == 0 && blockIdx.y == 0) {
         // the excitation tables for the lambda kernel that follows this launch ([a^2][na] | [a^2][nb])
         __syncthreads();
@@ -1161,9 +1175,11 @@ __host__ __device__ inline size_t sec_lambda_lds_bytes(int na, int nb, int ncas)
 // G_b; the rest: sigma of 256 determinants each.
 __global__ __launch_bounds__(256)
 void sector_gmat_kernel(const double* __restrict__ Ms, Sector s, double* __restrict__ Ga,
-                        double* __restrict__ Gb, double* __restrict__ sigma, uint16_t* __restrict__ tabs)
+                        double* __restrict__ Gb, double* __restrict__ sigma, uint16_t* __restrict__ tabs,
+                        const uint16_t* __restrict__ tabs_g)
 {
     // tabs [a^2][na] | [a^2][nb]: the excitation tables, for the kernels of the launches that follow
+    // (tabs_g: the per-circuit copy, when the caller holds one: copied instead of built)
     extern __shared__ double lds[];
     const int a = s.ncas, na2 = a * a, tid = threadIdx.x;
     int blk = blockIdx.x;
@@ -1183,7 +1199,12 @@ void sector_gmat_kernel(const double* __restrict__ Ms, Sector s, double* __restr
     const int nstr = alpha ? s.na : s.nb, row = alpha ? blk : blk - s.na;
     double* part = lds;                                                    // [a^2][nstr]
     uint16_t* tab = reinterpret_cast<uint16_t*>(part + (size_t)na2 * nstr);  // [a^2][nstr]
-    sec_build_table(alpha ? s.unrank_a : s.unrank_b, alpha ? s.rank_a : s.rank_b, nstr, a, alpha, tab, 256);
+    if (tabs_g) {
+        const uint16_t* src_t = tabs_g + (alpha ? 0 : (size_t)s.na * na2);
+        for (int i = tid; i < na2 * nstr; i += 256) tab[i] = src_t[i];
+    } else {
+        sec_build_table(alpha ? s.unrank_a : s.unrank_b, alpha ? s.rank_a : s.rank_b, nstr, a, alpha, tab, 256);
+    }
     for (int i = tid; i < na2 * nstr; i += 256) part[i] = 0.0;
     __syncthreads();
     if (row == 0) {
@@ -1501,7 +1522,7 @@ constexpr int SEC_PL_THREADS = 512;
 
 __host__ __device__ inline int sec_pair_stride(int Dc) { return ((Dc / 2 + 63) / 64) * 64 + 64; }
 
-// grid = n_gates, 1024 threads.  pairs: [n_gates] counts | [n_gates][stride] words.
+// grid = n_gates + 2, 1024 threads.  pairs: [n_gates] counts | [n_gates][stride] words | the excitation tables.
 __global__ __launch_bounds__(1024)
 void sector_pairs_kernel(const oovqe_gate_t* __restrict__ gates, int n_gates, Sector s, uint32_t* __restrict__ pairs)
 {
@@ -1509,6 +1530,13 @@ void sector_pairs_kernel(const oovqe_gate_t* __restrict__ gates, int n_gates, Se
     __shared__ int base;
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Dc = s.na * s.nb, stride = sec_pair_stride(Dc);
+    if (g >= n_gates) {
+        // the two excitation tables of the sector ([a^2][na] | [a^2][nb], 16-bit), behind the lists
+        uint16_t* tabs = reinterpret_cast<uint16_t*>(pairs + (size_t)n_gates * (1 + stride));
+        if (g == n_gates) sec_build_table(s.unrank_a, s.rank_a, s.na, s.ncas, true, tabs, 1024);
+        else sec_build_table(s.unrank_b, s.rank_b, s.nb, s.ncas, false, tabs + (size_t)s.na * s.ncas * s.ncas, 1024);
+        return;
+    }
     const oovqe_gate_t gt = gates[g];
     const uint32_t fm = gt.mask_hi | gt.mask_lo;
     uint32_t* out = pairs + n_gates + (size_t)g * stride;
@@ -1819,7 +1847,16 @@ extern "C" int oovqe_sector_state_pl(const double* theta, int n_theta, const oov
 extern "C" int64_t oovqe_sector_pairs_size(int n_gates, int na, int nb)
 {
     if (n_gates < 1 || na < 1 || nb < 1) return 0;
-    return (int64_t)n_gates * (1 + sec_pair_stride(na * nb));      // 32-bit words
+    return (int64_t)n_gates * (1 + sec_pair_stride(na * nb));      // 32-bit words (the tables: oovqe_sector_tables_size)
+}
+
+// 32-bit words of the sector's excitation tables ([a^2][na] | [a^2][nb], 16-bit entries) that oovqe_sector_pairs
+// writes behind the lists: its buffer holds oovqe_sector_pairs_size + oovqe_sector_tables_size words, the tables
+// start at word oovqe_sector_pairs_size.
+extern "C" int64_t oovqe_sector_tables_size(int ncas, int na, int nb)
+{
+    if (ncas < 1 || na < 1 || nb < 1) return 0;
+    return ((int64_t)(na + nb) * ncas * ncas + 1) / 2;
 }
 
 // The pair lists of a gate table (once per circuit): pairs [oovqe_sector_pairs_size] 32-bit words -- per gate the
@@ -1832,7 +1869,7 @@ extern "C" int oovqe_sector_pairs(const oovqe_gate_t* gates, int n_gates, int nc
     OOVQE_REQUIRE(ncas >= 1 && ncas <= 13 && na >= 1 && nb >= 1 && n_gates >= 1 && n_gates <= 65535 &&
                   (long)na * nb <= 32767, "sector_pairs: bad sizes (at most 32 767 determinants)");
     Sector s = make_sector(unrank_a, unrank_b, rank_a, rank_b, na, nb, ncas);
-    hipLaunchKernelGGL(sector_pairs_kernel, dim3(n_gates), dim3(1024), 0, (hipStream_t)stream, gates, n_gates, s,
+    hipLaunchKernelGGL(sector_pairs_kernel, dim3(n_gates + 2), dim3(1024), 0, (hipStream_t)stream, gates, n_gates, s,
                        pairs);
     OOVQE_CHECK_LAUNCH("sector_pairs");
     return 0;
@@ -2013,10 +2050,26 @@ extern "C" int64_t oovqe_sector_work_size(int ncas, int na, int nb, int batch)
     return (int64_t)batch * (3 * na2 * Dc + 2 * Dc + 8 * MT * 16 * NT * 16) + 2 * na2 * na2 + na2;
 }
 
+extern "C" int oovqe_sector_rdms_tb(const double* psi_c, int ncas, const uint32_t* unrank_a,
+                                    const uint32_t* unrank_b, const int32_t* rank_a, const int32_t* rank_b,
+                                    int na, int nb, int batch, const uint16_t* tabs, double* gamma, double* Gamma,
+                                    double* work, oovqe_stream_t stream);
+
 extern "C" int oovqe_sector_rdms(const double* psi_c, int ncas, const uint32_t* unrank_a,
                                  const uint32_t* unrank_b, const int32_t* rank_a, const int32_t* rank_b,
                                  int na, int nb, int batch, double* gamma, double* Gamma, double* work,
                                  oovqe_stream_t stream)
+{
+    return oovqe_sector_rdms_tb(psi_c, ncas, unrank_a, unrank_b, rank_a, rank_b, na, nb, batch, nullptr, gamma, Gamma,
+                                work, stream);
+}
+
+// The same with the sector's excitation tables from memory (the block oovqe_sector_pairs leaves behind its lists;
+// tabs == NULL: every workgroup builds them from the strings, as oovqe_sector_rdms does).
+extern "C" int oovqe_sector_rdms_tb(const double* psi_c, int ncas, const uint32_t* unrank_a,
+                                    const uint32_t* unrank_b, const int32_t* rank_a, const int32_t* rank_b,
+                                    int na, int nb, int batch, const uint16_t* tabs, double* gamma, double* Gamma,
+                                    double* work, oovqe_stream_t stream)
 {
     OOVQE_REQUIRE(psi_c && unrank_a && unrank_b && rank_a && rank_b && gamma && Gamma && work,
                   "sector_rdms: null pointer");
@@ -2047,11 +2100,11 @@ extern "C" int oovqe_sector_rdms(const double* psi_c, int ncas, const uint32_t* 
         if (na2 == 64) {
             if ((rc = oovqe_ensure_dynamic_lds((const void*)sector_rdm_rows_kernel<4>, rows_lds))) return rc;
             hipLaunchKernelGGL(sector_rdm_rows_kernel<4>, dim3(batch, nsplit), dim3(512), rows_lds, st, psi_c, s, batch,
-                               MT, R, oovqe_opt(OOVQE_OPT_SECTOR_PROBE));
+                               MT, R, oovqe_opt(OOVQE_OPT_SECTOR_PROBE), tabs);
         } else {
             if ((rc = oovqe_ensure_dynamic_lds((const void*)sector_rdm_rows_kernel<1>, rows_lds))) return rc;
             hipLaunchKernelGGL(sector_rdm_rows_kernel<1>, dim3(batch, nsplit), dim3(512), rows_lds, st, psi_c, s, batch,
-                               MT, R, oovqe_opt(OOVQE_OPT_SECTOR_PROBE));
+                               MT, R, oovqe_opt(OOVQE_OPT_SECTOR_PROBE), tabs);
         }
         OOVQE_CHECK_LAUNCH("sector_rdms/rows");
         hipLaunchKernelGGL(sector_rdm_finish_kernel, dim3((na2 * na2 + na2 + 255) / 256, batch), dim3(256),
@@ -2070,7 +2123,7 @@ extern "C" int oovqe_sector_rdms(const double* psi_c, int ncas, const uint32_t* 
                                                 hipFuncAttributeMaxDynamicSharedMemorySize,        \
                                                 (int)fused_lds), "sector_rdms: hipFuncSetAttribute"); \
             hipLaunchKernelGGL(sector_rdm_fused_kernel<NT_>, dim3(batch, nsplit), dim3(512), fused_lds, st, \
-                               psi_c, s, batch, MT, R, oovqe_opt(OOVQE_OPT_SECTOR_PROBE));         \
+                               psi_c, s, batch, MT, R, oovqe_opt(OOVQE_OPT_SECTOR_PROBE), tabs);   \
         } while (0)
         if (NT == 4) OOVQE_SEC_RDMF(4);
         else if (NT == 2) OOVQE_SEC_RDMF(2);
@@ -2127,8 +2180,8 @@ extern "C" int oovqe_sector_adjoint_pl(const double* theta, int n_theta, const o
                                        const uint32_t* unrank_b, const int32_t* rank_a,
                                        const int32_t* rank_b, int na, int nb, int batch,
                                        const double* psi_c, const double* c1, const double* c2,
-                                       const uint32_t* pairs, int max_pairs, double* work, double* dtheta,
-                                       oovqe_stream_t stream);
+                                       const uint32_t* pairs, int max_pairs, const uint16_t* tabs, double* work,
+                                       double* dtheta, oovqe_stream_t stream);
 
 extern "C" int oovqe_sector_adjoint(const double* theta, int n_theta, const oovqe_gate_t* gates,
                                     int n_gates, int ncas, const uint32_t* unrank_a,
@@ -2138,14 +2191,15 @@ extern "C" int oovqe_sector_adjoint(const double* theta, int n_theta, const oovq
                                     double* work, double* dtheta, oovqe_stream_t stream)
 {
     return oovqe_sector_adjoint_pl(theta, n_theta, gates, n_gates, ncas, unrank_a, unrank_b, rank_a, rank_b, na, nb,
-                                   batch, psi_c, c1, c2, nullptr, 0, work, dtheta, stream);
+                                   batch, psi_c, c1, c2, nullptr, 0, nullptr, work, dtheta, stream);
 }
 
 static int sector_adjoint_impl(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates, int ncas,
                                const uint32_t* unrank_a, const uint32_t* unrank_b, const int32_t* rank_a,
                                const int32_t* rank_b, int na, int nb, int batch, const double* psi_c,
                                const double* c1, const double* c2, const uint32_t* pairs, int max_pairs,
-                               double* work, double* dtheta, double* lam_out, oovqe_stream_t stream);
+                               const uint16_t* tabs_g, double* work, double* dtheta, double* lam_out,
+                               oovqe_stream_t stream);
 
 // The same with the reverse sweep from the pair lists of oovqe_sector_pairs (pairs == NULL: the gate sweep).
 extern "C" int oovqe_sector_adjoint_pl(const double* theta, int n_theta, const oovqe_gate_t* gates,
@@ -2153,12 +2207,12 @@ extern "C" int oovqe_sector_adjoint_pl(const double* theta, int n_theta, const o
                                        const uint32_t* unrank_b, const int32_t* rank_a,
                                        const int32_t* rank_b, int na, int nb, int batch,
                                        const double* psi_c, const double* c1, const double* c2,
-                                       const uint32_t* pairs, int max_pairs, double* work, double* dtheta,
-                                       oovqe_stream_t stream)
+                                       const uint32_t* pairs, int max_pairs, const uint16_t* tabs, double* work,
+                                       double* dtheta, oovqe_stream_t stream)
 {
     OOVQE_REQUIRE(theta && gates && dtheta, "sector_adjoint: null pointer");
     return sector_adjoint_impl(theta, n_theta, gates, n_gates, ncas, unrank_a, unrank_b, rank_a, rank_b, na, nb, batch,
-                               psi_c, c1, c2, pairs, max_pairs, work, dtheta, nullptr, stream);
+                               psi_c, c1, c2, pairs, max_pairs, tabs, work, dtheta, nullptr, stream);
 }
 
 // lam [batch][Dc] = (Hop + Hop^T) v for a stack of sector vectors v, Hop = sum c1e_pq E_pq + sum c2_pqrs E_pq E_rs the
@@ -2166,19 +2220,20 @@ extern "C" int oovqe_sector_adjoint_pl(const double* theta, int n_theta, const o
 // own): v^T lam(w) / 1 = the bilinear form 2 B(v, w) that second derivatives are made of.  work: oovqe_sector_work_size.
 extern "C" int oovqe_sector_lambda(const double* vecs, int ncas, const uint32_t* unrank_a, const uint32_t* unrank_b,
                                    const int32_t* rank_a, const int32_t* rank_b, int na, int nb, int batch,
-                                   const double* c1, const double* c2, double* work, double* lam,
-                                   oovqe_stream_t stream)
+                                   const double* c1, const double* c2, const uint16_t* tabs, double* work,
+                                   double* lam, oovqe_stream_t stream)
 {
     OOVQE_REQUIRE(lam, "sector_lambda: null pointer");
     return sector_adjoint_impl(nullptr, 0, nullptr, 0, ncas, unrank_a, unrank_b, rank_a, rank_b, na, nb, batch, vecs, c1,
-                               c2, nullptr, 0, work, nullptr, lam, stream);
+                               c2, nullptr, 0, tabs, work, nullptr, lam, stream);
 }
 
 static int sector_adjoint_impl(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates, int ncas,
                                const uint32_t* unrank_a, const uint32_t* unrank_b, const int32_t* rank_a,
                                const int32_t* rank_b, int na, int nb, int batch, const double* psi_c,
                                const double* c1, const double* c2, const uint32_t* pairs, int max_pairs,
-                               double* work, double* dtheta, double* lam_out, oovqe_stream_t stream)
+                               const uint16_t* tabs_g, double* work, double* dtheta, double* lam_out,
+                               oovqe_stream_t stream)
 {
     // lam_out: stop after the lambda stage and leave it there (theta, gates, dtheta unused)
     OOVQE_REQUIRE(psi_c && c1 && c2 && work && unrank_a && unrank_b && rank_a && rank_b, "sector_adjoint: null pointer");
@@ -2229,7 +2284,7 @@ static int sector_adjoint_impl(const double* theta, int n_theta, const oovqe_gat
         uint16_t* tabs2 = reinterpret_cast<uint16_t*>(sigma + Dc);      // [a^2][na] | [a^2][nb]
         if ((rc = oovqe_ensure_dynamic_lds((const void*)sector_gmat_kernel, gmat_lds))) return rc;
         hipLaunchKernelGGL(sector_gmat_kernel, dim3(na + nb + (Dc + 255) / 256), dim3(256), gmat_lds, st, M12, s, Ga,
-                           Gb, sigma, tabs2);
+                           Gb, sigma, tabs2, tabs_g);
         OOVQE_CHECK_LAUNCH("sector_adjoint/gmat");
         if ((rc = oovqe_ensure_dynamic_lds((const void*)sector_lambda_dense_kernel, dense_lds))) return rc;
         hipLaunchKernelGGL(sector_lambda_dense_kernel, dim3(batch), dim3(512), dense_lds, st, psi_c, Ga, Gb, sigma,
@@ -2262,7 +2317,7 @@ static int sector_adjoint_impl(const double* theta, int n_theta, const oovqe_gat
                                                 hipFuncAttributeMaxDynamicSharedMemorySize,        \
                                                 (int)fused_lds), "sector_adjoint: hipFuncSetAttribute"); \
             hipLaunchKernelGGL(sector_w_fused_kernel<NT_>, dim3(batch, nsplit), dim3(512), fused_lds, st, \
-                               psi_c, M12, s, W12, tabs);                                          \
+                               psi_c, M12, s, W12, tabs, tabs_g);                                  \
         } while (0)
         if (NT == 4) OOVQE_SEC_WF(4);
         else if (NT == 2) OOVQE_SEC_WF(2);

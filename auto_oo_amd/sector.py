@@ -54,6 +54,7 @@ class SectorEngine:
         self._work = {}
         self._param_gate = None
         self._pairs = None
+        self._tables_ptr = None
         self._hess_tables = None
 
     # ---- derivatives (round 4) --------------------------------------------------------------------
@@ -116,8 +117,10 @@ class SectorEngine:
         Q(v) = c1 . gamma(v) + c2 . Gamma(v) (oovqe_sector_lambda: the first stage of the adjoint on its own)."""
         n = vecs.shape[0]
         out = torch.empty((n, self.Dc), dtype=F64, device=self.device)
+        self.pair_lists()
         check(self.lib.oovqe_sector_lambda(dptr(vecs), self.ncas, *self._tabs(), n, dptr(c1.contiguous()),
-                                           dptr(c2.contiguous()), dptr(self.work(n)), dptr(out), stream_ptr()),
+                                           dptr(c2.contiguous()), self._tables_ptr, dptr(self.work(n)), dptr(out),
+                                           stream_ptr()),
               "oovqe_sector_lambda")
         return out
 
@@ -171,7 +174,9 @@ class SectorEngine:
                 self._pairs = (None, 0)
             else:
                 n = int(self.lib.oovqe_sector_pairs_size(self.n_gates, self.na, self.nb))
-                pairs = torch.empty(n, dtype=torch.int32, device=self.device)
+                nt = int(self.lib.oovqe_sector_tables_size(self.ncas, self.na, self.nb))
+                pairs = torch.empty(n + nt, dtype=torch.int32, device=self.device)
+                self._tables_ptr = ctypes.c_void_p(pairs.data_ptr() + 4 * n)   # the excitation tables behind the lists
                 check(self.lib.oovqe_sector_pairs(dptr(self.gates_dev, torch.uint8), self.n_gates, self.ncas,
                                                   *self._tabs(), dptr(pairs, torch.int32), stream_ptr()),
                       "oovqe_sector_pairs")
@@ -215,9 +220,10 @@ class SectorEngine:
         a = self.ncas
         gamma = torch.empty((batch, a, a), dtype=F64, device=self.device)
         Gamma = torch.empty((batch, a, a, a, a), dtype=F64, device=self.device)
-        check(self.lib.oovqe_sector_rdms(dptr(psi_c), a, *self._tabs(), batch, dptr(gamma),
-                                         dptr(Gamma), dptr(self.work(batch)), stream_ptr()),
-              "oovqe_sector_rdms")
+        self.pair_lists()          # (the per-circuit block also holds the sector's excitation tables)
+        check(self.lib.oovqe_sector_rdms_tb(dptr(psi_c), a, *self._tabs(), batch, self._tables_ptr, dptr(gamma),
+                                            dptr(Gamma), dptr(self.work(batch)), stream_ptr()),
+              "oovqe_sector_rdms_tb")
         return gamma, Gamma
 
     def adjoint(self, theta, psi_c, c1, c2):
@@ -229,7 +235,7 @@ class SectorEngine:
                                                dptr(self.gates_dev, torch.uint8), self.n_gates,
                                                self.ncas, *self._tabs(), batch, dptr(psi_c),
                                                dptr(c1.contiguous()), dptr(c2.contiguous()),
-                                               dptr(pairs, torch.int32), max_pairs,
+                                               dptr(pairs, torch.int32), max_pairs, self._tables_ptr,
                                                dptr(self.work(batch)), dptr(dth), stream_ptr()),
               "oovqe_sector_adjoint_pl")
         return dth

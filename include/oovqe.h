@@ -422,8 +422,16 @@ int64_t oovqe_sector_work_size(int ncas, int na, int nb, int batch);
  * derivatives are made of: d^2 Q / dtheta_j dtheta_k = tau_jk^T lam(psi) + tau_j^T lam(tau_k). */
 int oovqe_sector_lambda(const double* vecs, int ncas, const uint32_t* unrank_a, const uint32_t* unrank_b,
                         const int32_t* rank_a, const int32_t* rank_b, int na, int nb, int batch, const double* c1,
-                        const double* c2, double* work, double* lam, oovqe_stream_t stream);
+                        const double* c2, const uint16_t* tabs, double* work, double* lam, oovqe_stream_t stream);
 int64_t oovqe_sector_pairs_size(int n_gates, int na, int nb);
+/* oovqe_sector_pairs also leaves the sector's two excitation tables ([a^2][na] | [a^2][nb], 16-bit: source string,
+ * valid bit, parities) behind the lists -- its buffer must hold oovqe_sector_pairs_size + oovqe_sector_tables_size
+ * words, the tables start at word oovqe_sector_pairs_size.  Passed as `tabs` (NULL: every workgroup builds them from
+ * the strings) to oovqe_sector_rdms_tb / oovqe_sector_adjoint_pl / oovqe_sector_lambda. */
+int64_t oovqe_sector_tables_size(int ncas, int na, int nb);
+int oovqe_sector_rdms_tb(const double* psi_c, int ncas, const uint32_t* unrank_a, const uint32_t* unrank_b,
+                         const int32_t* rank_a, const int32_t* rank_b, int na, int nb, int batch, const uint16_t* tabs,
+                         double* gamma, double* Gamma, double* work, oovqe_stream_t stream);
 int oovqe_sector_pairs(const oovqe_gate_t* gates, int n_gates, int ncas, const uint32_t* unrank_a,
                        const uint32_t* unrank_b, const int32_t* rank_a, const int32_t* rank_b, int na, int nb,
                        uint32_t* pairs, oovqe_stream_t stream);
@@ -441,7 +449,7 @@ int oovqe_sector_adjoint_pl(const double* theta, int n_theta, const oovqe_gate_t
                             const uint32_t* unrank_a, const uint32_t* unrank_b, const int32_t* rank_a,
                             const int32_t* rank_b, int na, int nb, int batch, const double* psi_c,
                             const double* c1, const double* c2, const uint32_t* pairs, int max_pairs,
-                            double* work, double* dtheta, oovqe_stream_t stream);
+                            const uint16_t* tabs, double* work, double* dtheta, oovqe_stream_t stream);
 
 /* ---- a12/a13/a14/a16: one evaluation of the hybrid cost function in ONE call ---------------------
  * OO_pqc.energy_from_parameters / circuit_gradient / orbital_gradient / orbital_circuit_hessian
