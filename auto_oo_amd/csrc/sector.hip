@@ -1210,6 +1210,16 @@ void sector_gmat_kernel(const double* __restrict__ Ms, Sector s, double* __restr
     if (row == 0) {
         uint16_t* out = tabs + (alpha ? 0 : (size_t)s.na * na2);
         for (int i = tid; i < na2 * nstr; i += 256) out[i] = tab[i];
+        if (!alpha) {
+            // the beta words as sector_lambda_pipe_kernel consumes them: byte offset of the source ROW of the
+            // transposed Psi' (row nb = zeros when the operator does not apply) | sign << 31
+            uint32_t* out32 = reinterpret_cast<uint32_t*>(tabs + (((size_t)(s.na + s.nb) * na2 + 1) & ~(size_t)1));
+            const uint32_t rowb = (uint32_t)(((s.na + 7) & ~7) * sizeof(double));
+            for (int i = tid; i < na2 * nstr; i += 256) {
+                const uint32_t e = tab[i];
+                out32[i] = ((e & 2048u) ? (e & 2047u) : (uint32_t)s.nb) * rowb | ((e & 4096u) << 19);
+            }
+        }
     }
     if (tid < na2) {
         const int j = tid;
@@ -1421,6 +1431,203 @@ void sector_lambda_fused_kernel(const double* __restrict__ psi_c, const double* 
         // thread has passed the barrier above, and the last readers of Vc are in front of it)
     }
 }
+
+// The same mixed term with the phases of sector_lambda_fused_kernel OVERLAPPED (a^2 = 64): that kernel runs build,
+// product and gather one after the other (146 + ~50 + ~30-55 us of its 311 at 256 CAS(8e,8o) states: one workgroup per
+// CU, nothing else to fill the matrix cores while it builds).  Here waves 0-3 (one per SIMD) only multiply and waves
+// 4-7 only build and gather, on chunks of ONE beta string (all alpha strings: 70 columns in 5 tiles):
+//   interval 1 of trip t:  multipliers  Y(t) = K^T V(t) from Vbuf[t & 1] into registers
+//                          helpers      gather of Y(t-1) from Ybuf into partial sums, then build of V(t+1) into
+//                                       Vbuf[(t+1) & 1]
+//   interval 2 of trip t:  multipliers  Y(t) registers -> Ybuf;   helpers: lam of chunk t-1 = sigma (dense + sums)
+// two workgroup barriers per chunk.  MEASURED, NOT ADOPTED (option sector_lambda_w = 4 selects it): 344 us against 311.
+// The cycle counters of a workgroup (sector_probe = 9) say why: the multiplier wave of a SIMD needs 5.9 K cycles per
+// chunk for its 80 products and then WAITS 5 K cycles for the helper wave of the same SIMD, whose ~360 instructions
+// (two LDS operations and ~4 integer operations per element, the table words of the next chunk) take 10.6 K cycles
+// beside the products and 6 K alone: v_mfma_f64 runs on the SIMD's fp64 vector path, the older wave owns it, and
+// the helper gets about one instruction in per product.  Splitting the roles over SIMDs instead (two SIMDs
+// multiply, two help) would halve the matrix rate of the CU.  On gfx950 fp64 matrix work cannot be hidden behind
+// vector work of the same workgroup; the phases of sector_lambda_fused_kernel stay one after the other.
+// The excitation tables stay in memory (L1 / L2: every helper thread needs 22 + 22
+// words per chunk, the build's read one chunk ahead), so that Psi'^T (40 KB), two V buffers (2 x 41 KB) and Y (37 KB)
+// fit the LDS.
+__device__ long long g_pipe_cyc[16];        // probe 9: cycles of workgroup (0,0): [0..3] multiplier wave 0, [4..7] helper wave 4
+constexpr int SEC_PCOL = 80;                 // columns of a chunk buffer (70 alpha strings in 5 tiles), pitch of V
+constexpr int SEC_PYP = 72;                  // pitch of Y
+
+__host__ __device__ inline size_t sec_lambda_pipe_lds_bytes(int na, int nb, int ncas)
+{
+    const size_t na2 = (size_t)ncas * ncas, LA = ((size_t)na + 7) & ~(size_t)7;
+    return (((size_t)nb + 1) * LA + 2 * na2 * SEC_PCOL + na2 * SEC_PYP + 3 * SEC_PCOL) * sizeof(double);
+}
+
+__global__ __launch_bounds__(512)
+void sector_lambda_pipe_kernel(const double* __restrict__ psi_c, const double* __restrict__ Ms,
+                               const double* __restrict__ sigma, const uint16_t* __restrict__ tabs, Sector s,
+                               double* __restrict__ lam, int probe)
+{
+    // probe (timing only, wrong results): 1 no build / gather, 2 no MFMA
+    extern __shared__ double lds[];
+    constexpr int na2 = 64, KS = 16, CT = SEC_PCOL / 16;
+    const int na = s.na, nb = s.nb, Dc = na * nb;
+    const int LA = (na + 7) & ~7;
+    double* src = lds;                                   // [nb + 1][LA] sigma psi, transposed; row nb = zeros
+    double* Vb = src + (size_t)(nb + 1) * LA;            // [2][a^2][SEC_PCOL]
+    double* Yb = Vb + 2 * na2 * SEC_PCOL;                // [a^2][SEC_PYP]; columns >= na are zeros (V's are)
+    double* red = Yb + na2 * SEC_PYP;                    // [3][SEC_PCOL]
+    const uint16_t* tabA = tabs;
+    const uint32_t* tabB32 = reinterpret_cast<const uint32_t*>(tabs + (((size_t)(na + nb) * na2 + 1) & ~(size_t)1));
+    const size_t b = blockIdx.x;
+    const int split = blockIdx.y, nsplit = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane >> 4, lr = lane & 15;
+    for (int i = tid; i < (nb + 1) * LA; i += 512) {
+        const int ib2 = i / LA, ia = i - ib2 * LA;
+        src[i] = (ia < na && ib2 < nb) ? sigma[ia * nb + ib2] * psi_c[b * Dc + ia * nb + ib2] : 0.0;
+    }
+    const bool mult = wave < 4;
+    // multipliers: row tile jt = wave of Y, all CT column tiles
+    double af[KS];
+    if (mult) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = 4 * ks + lq, j = 16 * wave + lr;
+            af[ks] = Ms[(size_t)k * na2 + j] + Ms[(size_t)j * na2 + k];
+        }
+    }
+    // helpers: column (alpha string) and operator share of the thread
+    const int h = tid - 256;
+    const int part = h >= 0 ? h / SEC_PCOL : 3, col = h >= 0 ? h - part * SEC_PCOL : 0;
+    const bool helper = !mult && part < 3;
+    constexpr int MAXOP = 24, OPP = 22;
+    const int o0 = part * OPP, o1 = o0 + OPP < na2 ? o0 + OPP : na2;
+    const bool colive = helper && col < na;
+    // gather words, once: byte offset into Y of the source element (a zero column when the operator does not apply)
+    // and the sign mask -- an element of the gather is one LDS read, one XOR, one add
+    uint32_t goff[MAXOP], gsgn[MAXOP], eb[MAXOP];
+#pragma unroll
+    for (int u = 0; u < MAXOP; ++u) {
+        const int o = o0 + u < o1 ? o0 + u : o0;
+        const uint32_t e = (colive && o0 + u < o1) ? tabA[o * na + col] : 0u;
+        goff[u] = (uint32_t)((o * SEC_PYP + ((e & 2048u) ? (int)(e & 2047u) : na)) * (int)sizeof(double));
+        gsgn[u] = (e & 4096u) << 19;
+    }
+    const int nchunk = (nb - split + nsplit - 1) / nsplit;       // chunks (beta strings) of this workgroup
+    const uint32_t zero_row = (uint32_t)(nb * LA * (int)sizeof(double));
+    auto load_eb = [&](int t) {
+        const int ibn = split + t * nsplit;
+        const bool ok = colive && t < nchunk && ibn < nb;
+#pragma unroll
+        for (int u = 0; u < MAXOP; ++u) eb[u] = (ok && o0 + u < o1) ? tabB32[(o0 + u) * nb + ibn] : zero_row;
+    };
+    const char* colb = reinterpret_cast<const char*>(src) + (size_t)(col < LA ? col : 0) * sizeof(double);
+    auto build = [&](int t) {           // V(t)[k][col] = own sign * Psi'[col, src_b(k, ib)]; eb holds chunk t's words
+        double* V = Vb + (size_t)(t & 1) * na2 * SEC_PCOL;
+#pragma unroll
+        for (int u0 = 0; u0 < MAXOP; u0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double*>(colb + (eb[u0 + u] & 0x7fffffffu));
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (o0 + u0 + u < o1) {
+                    const unsigned long long x = __builtin_bit_cast(unsigned long long, v[u]) ^
+                                                 ((unsigned long long)(eb[u0 + u] & 0x80000000u) << 32);
+                    V[(o0 + u0 + u) * SEC_PCOL + col] = __builtin_bit_cast(double, x);
+                }
+        }
+    };
+    __syncthreads();
+    if (helper) {
+        load_eb(0);
+        build(0);
+        load_eb(1);
+    }
+    __syncthreads();
+    d4 acc[CT];
+    double lam_dense = 0.0, sig = 1.0;
+    long long cy[4] = {0, 0, 0, 0};
+    const bool timed = probe == 9 && blockIdx.x == 0 && blockIdx.y == 0 && (wave == 0 || wave == 4);
+    for (int t = 0; t <= nchunk; ++t) {
+        long long c0 = timed ? (long long)__builtin_readcyclecounter() : 0;
+        // ---- interval 1
+        if (mult) {
+            if (t < nchunk && probe != 2) {
+                const double* V = Vb + (size_t)(t & 1) * na2 * SEC_PCOL + lq * SEC_PCOL + lr;
+                // (one wave per SIMD multiplies: the operands of the next column tile are read before the products
+                // of this one, or every tile would start with an exposed LDS round trip)
+                double bo[2][KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) bo[0][ks] = V[4 * ks * SEC_PCOL];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    if (ct + 1 < CT) {
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) bo[(ct + 1) & 1][ks] = V[4 * ks * SEC_PCOL + 16 * (ct + 1)];
+                    }
+                    acc[ct] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) acc[ct] = mfma_f64(af[ks], bo[ct & 1][ks], acc[ct]);
+                }
+            }
+        } else if (helper && probe != 1) {
+            if (t >= 1) {
+                // gather of chunk t - 1: sum_j own sign * Y[j][src_a(j, col)]
+                const int ibp = split + (t - 1) * nsplit;
+                if (colive && part == 0) {          // (both needed in interval 2: asked for now)
+                    lam_dense = lam[b * Dc + (size_t)col * nb + ibp];
+                    sig = sigma[col * nb + ibp];
+                }
+                double sum = 0.0;
+                const char* yb = reinterpret_cast<const char*>(Yb);
+#pragma unroll
+                for (int u0 = 0; u0 < MAXOP; u0 += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double*>(yb + goff[u0 + u]);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const unsigned long long x = __builtin_bit_cast(unsigned long long, v[u]) ^
+                                                     ((unsigned long long)gsgn[u0 + u] << 32);
+                        if (o0 + u0 + u < o1) sum += __builtin_bit_cast(double, x);
+                    }
+                }
+                red[part * SEC_PCOL + col] = sum;
+            }
+            if (t + 1 < nchunk) {
+                build(t + 1);
+                load_eb(t + 2);
+            }
+        }
+        long long c1 = timed ? (long long)__builtin_readcyclecounter() : 0;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        long long c2 = timed ? (long long)__builtin_readcyclecounter() : 0;
+        // ---- interval 2
+        if (mult) {
+            if (t < nchunk) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    if (16 * ct + lr < SEC_PYP)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) Yb[(16 * wave + lq + 4 * i) * SEC_PYP + 16 * ct + lr] = acc[ct][i];
+            }
+        } else if (helper && part == 0 && colive && t >= 1) {
+            const int ibp = split + (t - 1) * nsplit;
+            const double tot = red[col] + red[SEC_PCOL + col] + red[2 * SEC_PCOL + col];
+            lam[b * Dc + (size_t)col * nb + ibp] = sig * (lam_dense + tot);
+        }
+        long long c3 = timed ? (long long)__builtin_readcyclecounter() : 0;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (timed) {
+            const long long c4 = (long long)__builtin_readcyclecounter();
+            cy[0] += c1 - c0; cy[1] += c2 - c1; cy[2] += c3 - c2; cy[3] += c4 - c3;
+        }
+    }
+    if (timed && lane == 0)
+        for (int i = 0; i < 4; ++i) g_pipe_cyc[(wave == 0 ? 0 : 4) + i] = cy[i];
+}
+
 
 // ---- adjoint sweep: grid = batch --------------------------------------------------------------------
 template <int MAXIT>
@@ -1825,6 +2032,12 @@ size_t adjoint_lds(int na, int nb, int ncas, int n_gates, int n_theta)
 }
 
 }  // namespace
+
+// (measurement hook of sector_lambda_pipe_kernel, option sector_probe = 9; not part of include/oovqe.h)
+extern "C" int oovqe_sector_pipe_cycles(long long* out16)
+{
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_pipe_cyc), 16 * sizeof(long long)) == hipSuccess ? 0 : OOVQE_ERR_HIP;
+}
 
 static int sector_cu_count()
 {
@@ -2272,10 +2485,11 @@ static int sector_adjoint_impl(const double* theta, int n_theta, const oovqe_gat
     const size_t lam_lds = sec_lambda_lds_bytes(na, nb, ncas);
     const bool string_driven = fused && (na2 == 16 || na2 == 64) && LAp <= SEC_LCH && lam_lds <= 160 * 1024 &&
                                dense_lds <= 160 * 1024 && gmat_lds <= 160 * 1024 &&
-                               (size_t)na * na + (size_t)nb * nb + Dc + ((size_t)(na + nb) * na2 + 3) / 4 <= nb_ * (2 * (size_t)na2 + 1) * Dc &&
+                               (size_t)na * na + (size_t)nb * nb + Dc + ((size_t)(na + nb) * na2 + 3) / 4 + ((size_t)nb * na2 + 1) / 2 + 2 <=
+                                   nb_ * (2 * (size_t)na2 + 1) * Dc &&
                                // (its two small extra launches cost ~55 us: CAS(8e,8o) 230 us whatever the batch up
                                // to 32 states, where W in memory takes 175 ... 230 us; 64: 264 vs 315; 256: 485 vs 603)
-                               (oovqe_opt(OOVQE_OPT_SECTOR_LAMBDA_W) == 2 ||
+                               (oovqe_opt(OOVQE_OPT_SECTOR_LAMBDA_W) >= 2 ||
                                 (oovqe_opt(OOVQE_OPT_SECTOR_LAMBDA_W) == 0 && batch >= 32));
     if (string_driven) {
         double* Ga = W12;                                   // (the W region of the workspace is free here)
@@ -2295,7 +2509,18 @@ static int sector_adjoint_impl(const double* theta, int n_theta, const oovqe_gat
         if (nsplit > 8) nsplit = 8;
         if (nsplit < 1) nsplit = 1;
         if (nsplit > nchunk) nsplit = nchunk;
-        if (na2 == 64) {
+        const size_t pipe_lds = sec_lambda_pipe_lds_bytes(na, nb, ncas);
+        if (na2 == 64 && na <= 72 && pipe_lds <= 160 * 1024 && oovqe_opt(OOVQE_OPT_SECTOR_LAMBDA_W) == 4) {
+            // the phases overlapped: multiplier and helper waves, one beta string per chunk -- measured and NOT the
+            // default (344 us against 311 at 256 states: see the kernel's header)
+            int nsp = sector_cu_count() / batch;
+            if (nsp > 8) nsp = 8;
+            if (nsp < 1) nsp = 1;
+            if (nsp > nb) nsp = nb;
+            if ((rc = oovqe_ensure_dynamic_lds((const void*)sector_lambda_pipe_kernel, pipe_lds))) return rc;
+            hipLaunchKernelGGL(sector_lambda_pipe_kernel, dim3(batch, nsp), dim3(512), pipe_lds, st, psi_c, M12, sigma,
+                               tabs2, s, lam, oovqe_opt(OOVQE_OPT_SECTOR_PROBE));
+        } else if (na2 == 64) {
             if ((rc = oovqe_ensure_dynamic_lds((const void*)sector_lambda_fused_kernel<4>, lam_lds))) return rc;
             hipLaunchKernelGGL(sector_lambda_fused_kernel<4>, dim3(batch, nsplit), dim3(512), lam_lds, st, psi_c,
                                M12, sigma, tabs2, s, lam, oovqe_opt(OOVQE_OPT_SECTOR_PROBE));

@@ -705,12 +705,14 @@ def test_sector_fused_kernels_equal_the_unfused_ones(ncas, nelecas, batch):
     assert (dth - dth_u).abs().max() < 1e-11 * max(1.0, float(dth_u.abs().max()))
     # round 4: lambda in the string-driven form (G_a Psi + Psi G_b^T + the mixed term inside LDS; the default from
     # 32 states on) and through W = Ms^T V in memory (the default below), each forced, against the round-2 kernels
-    for forced in (1, 2):
+    for forced in (1, 2, 4):      # (4: the multiplier / helper-wave variant of the string-driven form, a^2 = 64 only)
         with debug_options(sector_lambda_w=forced):
             dth_f = eng.adjoint(th, psi_c, c1, c2)
         assert (dth_f - dth_u).abs().max() < 1e-11 * max(1.0, float(dth_u.abs().max())), forced
         # ... and the RDMs from chunks of 128 consecutive determinants (round 3; the default below 16 states) and
         # from chunks of whole alpha rows in the sigma basis (round 4)
+        if forced == 4:
+            continue
         with debug_options(sector_rdm_r3=forced):
             f1, f2 = eng.rdms(psi_c)
         assert (f1 - h1).abs().max() < 1e-12 and (f2 - h2).abs().max() < 1e-12, forced

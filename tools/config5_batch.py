@@ -31,3 +31,14 @@ if len(sys.argv) > 3:
         with debug_options(sector_probe=pr):
             t, _ = T(lambda: eng.rdms(psi))
         print(f"batch {B} k {k}: rdms with sector_probe = {pr}: {t:9.1f} us")
+if len(sys.argv) > 3:
+    import ctypes
+    from auto_oo_amd import _lib
+    lib = _lib.load()
+    if hasattr(lib, "oovqe_sector_pipe_cycles"):
+        with debug_options(sector_probe=9):
+            eng.adjoint(th, psi, c1, c2); torch.cuda.synchronize()
+        buf = (ctypes.c_longlong * 16)()
+        lib.oovqe_sector_pipe_cycles(buf)
+        v = list(buf)
+        print("pipe kernel, workgroup 0, cycles [work 1 | barrier 1 | work 2 | barrier 2]: multiplier wave 0", v[0:4], " helper wave 4", v[4:8])
