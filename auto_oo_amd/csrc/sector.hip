@@ -1164,10 +1164,8 @@ static_assert(SEC_LCHP % 32 == 16, "k-step rows lq, lq + 1 of an MFMA operand re
 __host__ __device__ inline size_t sec_lambda_lds_bytes(int na, int nb, int ncas)
 {
     const size_t na2 = (size_t)ncas * ncas;
-    const size_t Dt = (size_t)nb * ((na + 7) & ~7);            // Psi' transposed, rows padded to LA
-    size_t bytes = (Dt + na2 * SEC_LCHP + 4 * SEC_LCH) * sizeof(double);
-    bytes += (((size_t)na + nb) * na2 * sizeof(uint16_t) + 7) & ~(size_t)7;
-    return bytes;
+    const size_t Dt = ((size_t)nb + 1) * ((na + 8) & ~7);      // Psi' transposed, rows padded to LA (>= 1 zero column), + a zero row
+    return (Dt + na2 * SEC_LCHP + 4 * SEC_LCH) * sizeof(double);
 }
 
 // grid: na + nb + ceil(Dc / 256) workgroups of 256 threads.  Workgroup r < na: row r of G_a (thread j < a^2: the
@@ -1214,7 +1212,7 @@ void sector_gmat_kernel(const double* __restrict__ Ms, Sector s, double* __restr
             // the beta words as sector_lambda_pipe_kernel consumes them: byte offset of the source ROW of the
             // transposed Psi' (row nb = zeros when the operator does not apply) | sign << 31
             uint32_t* out32 = reinterpret_cast<uint32_t*>(tabs + (((size_t)(s.na + s.nb) * na2 + 1) & ~(size_t)1));
-            const uint32_t rowb = (uint32_t)(((s.na + 7) & ~7) * sizeof(double));
+            const uint32_t rowb = (uint32_t)(((s.na + 8) & ~7) * sizeof(double));
             for (int i = tid; i < na2 * nstr; i += 256) {
                 const uint32_t e = tab[i];
                 out32[i] = ((e & 2048u) ? (e & 2047u) : (uint32_t)s.nb) * rowb | ((e & 4096u) << 19);
@@ -1305,27 +1303,30 @@ void sector_lambda_fused_kernel(const double* __restrict__ psi_c, const double* 
     // probe (timing only, wrong results): 1 no chunk build after the first, 2 no MFMA, 3 no gather
     extern __shared__ double lds[];
     const int na = s.na, nb = s.nb, Dc = na * nb, a = s.ncas, na2 = a * a;
-    const int LA = (na + 7) & ~7;                        // columns of one beta string inside a chunk
+    const int LA = (na + 8) & ~7;                        // columns of one beta string inside a chunk (>= 1 zero column)
     const int NBC = SEC_LCH / LA;                        // beta strings per chunk (>= 1: checked by the host)
     const int CH = NBC * LA, CT = (CH + 15) / 16;
     // Psi' TRANSPOSED, [nb][LA]: the lanes of a wave hold consecutive alpha strings of one beta string, so the
     // amplitude reads of the build are consecutive words (row-major, 70 doubles apart, they were 4-way bank
     // conflicts: the build was LDS-bandwidth bound)
-    double* src = lds;
-    double* Vc = src + (size_t)nb * LA;                  // [a^2][SEC_LCHP]: B_k Psi' of the chunk, then Y
+    // An element of the build or of the gather is one LDS read, one XOR (the sign, bit 63) and the store / add:
+    // the table words are byte offsets (a ZERO row of Psi'^T, a zero column of Y when the operator does not apply)
+    // and sign masks -- the beta ones from the 32-bit table sector_gmat_kernel leaves in memory, read one chunk
+    // ahead; the alpha ones made once from the thread's alpha string.
+    double* src = lds;                                   // [nb + 1][LA], row nb = zeros
+    double* Vc = src + (size_t)(nb + 1) * LA;            // [a^2][SEC_LCHP]: B_k Psi' of the chunk, then Y
     double* red = Vc + (size_t)na2 * SEC_LCHP;           // [4][SEC_LCH]
-    uint16_t* tabA = reinterpret_cast<uint16_t*>(red + 4 * SEC_LCH);
-    uint16_t* tabB = tabA + (size_t)na * na2;
+    const uint16_t* tabA = tabs;
+    const uint32_t* tabB32 = reinterpret_cast<const uint32_t*>(tabs + (((size_t)(na + nb) * na2 + 1) & ~(size_t)1));
     const size_t b = blockIdx.x;
     const int split = blockIdx.y, nsplit = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane >> 4, lr = lane & 15;
-    for (int i = tid; i < Dc; i += 512) {
-        const int ia = i / nb, ib2 = i - ia * nb;
-        src[ib2 * LA + ia] = sigma[i] * psi_c[b * Dc + i];
+    for (int i = tid; i < (nb + 1) * LA; i += 512) {
+        const int ib2 = i / LA, ia = i - ib2 * LA;
+        src[i] = (ia < na && ib2 < nb) ? sigma[ia * nb + ib2] * psi_c[b * Dc + ia * nb + ib2] : 0.0;
     }
-    for (int i = tid; i < (na + nb) * na2; i += 512) tabA[i] = tabs[i];      // (tabB follows tabA in both)
     constexpr int KS = NT * 4;
     const int jt = wave % NT, ct0 = wave / NT;
     constexpr int CSTEP = 8 / NT;
@@ -1350,16 +1351,24 @@ void sector_lambda_fused_kernel(const double* __restrict__ psi_c, const double* 
     __syncthreads();
     // table words in registers: the gather's (they depend on the alpha string of the thread's column only: the same
     // for every chunk) and the build's, read one chunk ahead
-    uint32_t ea[MAXOP], eb[MAXOP];
+    uint32_t goff[MAXOP], gsgn[MAXOP], eb[MAXOP];
+    const bool colive = worker && l < CH && ial < na;
 #pragma unroll
-    for (int u = 0; u < MAXOP; ++u)
-        ea[u] = (worker && o0 + u < o1 && l < CH && ial < na) ? tabA[(o0 + u) * na + ial] : 0u;
+    for (int u = 0; u < MAXOP; ++u) {
+        const int o = o0 + u < o1 ? o0 + u : o0;
+        const uint32_t e = (colive && o0 + u < o1) ? tabA[o * na + ial] : 0u;
+        // (columns ial >= na of a beta string's block are zeros in Y: V's are)
+        goff[u] = (uint32_t)((o * SEC_LCHP + ibl * LA + ((e & 2048u) ? (int)(e & 2047u) : na)) * (int)sizeof(double));
+        gsgn[u] = (e & 4096u) << 19;
+    }
+    const uint32_t zero_row = (uint32_t)(nb * LA * (int)sizeof(double));
     auto load_eb = [&](int chn) {
         const int ibn = chn * NBC + ibl;
-        const bool ok = worker && l < CH && ial < na && chn < nchunk && ibn < nb;
+        const bool ok = colive && chn < nchunk && ibn < nb;
 #pragma unroll
-        for (int u = 0; u < MAXOP; ++u) eb[u] = (ok && o0 + u < o1) ? tabB[(o0 + u) * nb + ibn] : 0u;
+        for (int u = 0; u < MAXOP; ++u) eb[u] = (ok && o0 + u < o1) ? tabB32[(o0 + u) * nb + ibn] : zero_row;
     };
+    const char* colb = reinterpret_cast<const char*>(src) + (size_t)(colive ? ial : 0) * sizeof(double);
     load_eb(split);
     for (int ch = split; ch < nchunk; ch += nsplit) {
         const int ib = ch * NBC + ibl;
@@ -1367,19 +1376,20 @@ void sector_lambda_fused_kernel(const double* __restrict__ psi_c, const double* 
         // lam' of this thread's determinant: needed at the end of the trip, asked for now
         double lam_dense = 0.0;
         if (live && part == 0) lam_dense = lam[b * Dc + (size_t)ial * nb + ib];
-        // 1. Vc[k][l] = (B_k Psi')[ial, ib] = own sign * Psi'[ial, src_b(k, ib)]  (eb = 0: not valid -> 0)
+        // 1. Vc[k][l] = (B_k Psi')[ial, ib] = own sign * Psi'[ial, src_b(k, ib)]  (columns that are not live: zero row)
         if (worker && !(probe == 1 && ch != split)) {
-            const double* cola = src + (live ? ial : 0);
 #pragma unroll
             for (int u0 = 0; u0 < MAXOP; u0 += 8) {
                 double v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = cola[(eb[u0 + u] & 2047u) * LA];
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double*>(colb + (eb[u0 + u] & 0x7fffffffu));
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (o0 + u0 + u < o1)
-                        Vc[(o0 + u0 + u) * SEC_LCHP + l] =
-                            (eb[u0 + u] & 2048u) ? ((eb[u0 + u] & 4096u) ? -v[u] : v[u]) : 0.0;
+                    if (o0 + u0 + u < o1) {
+                        const unsigned long long x = __builtin_bit_cast(unsigned long long, v[u]) ^
+                                                     ((unsigned long long)(eb[u0 + u] & 0x80000000u) << 32);
+                        Vc[(o0 + u0 + u) * SEC_LCHP + l] = __builtin_bit_cast(double, x);
+                    }
             }
         }
         load_eb(ch + nsplit);
@@ -1408,16 +1418,18 @@ void sector_lambda_fused_kernel(const double* __restrict__ psi_c, const double* 
         // 3. sum_j (A_j Y_j)[ial, ib] = sum_j own sign * Y[j][(ibl, src_a(j, ial))]
         double sum = 0.0;
         if (live && probe != 3) {
-            const double* yb = Vc + ibl * LA;
+            const char* yb = reinterpret_cast<const char*>(Vc);
 #pragma unroll
             for (int u0 = 0; u0 < MAXOP; u0 += 8) {
                 double v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    v[u] = yb[(o0 + u0 + u < o1 ? o0 + u0 + u : o0) * SEC_LCHP + (ea[u0 + u] & 2047u)];
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double*>(yb + goff[u0 + u]);
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (ea[u0 + u] & 2048u) sum += (ea[u0 + u] & 4096u) ? -v[u] : v[u];
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned long long x = __builtin_bit_cast(unsigned long long, v[u]) ^
+                                                 ((unsigned long long)gsgn[u0 + u] << 32);
+                    if (o0 + u0 + u < o1) sum += __builtin_bit_cast(double, x);
+                }
             }
         }
         if (worker && l < SEC_LCH) red[part * SEC_LCH + l] = sum;
@@ -1457,7 +1469,7 @@ constexpr int SEC_PYP = 72;                  // pitch of Y
 
 __host__ __device__ inline size_t sec_lambda_pipe_lds_bytes(int na, int nb, int ncas)
 {
-    const size_t na2 = (size_t)ncas * ncas, LA = ((size_t)na + 7) & ~(size_t)7;
+    const size_t na2 = (size_t)ncas * ncas, LA = ((size_t)na + 8) & ~(size_t)7;
     return (((size_t)nb + 1) * LA + 2 * na2 * SEC_PCOL + na2 * SEC_PYP + 3 * SEC_PCOL) * sizeof(double);
 }
 
@@ -1470,7 +1482,7 @@ void sector_lambda_pipe_kernel(const double* __restrict__ psi_c, const double* _
     extern __shared__ double lds[];
     constexpr int na2 = 64, KS = 16, CT = SEC_PCOL / 16;
     const int na = s.na, nb = s.nb, Dc = na * nb;
-    const int LA = (na + 7) & ~7;
+    const int LA = (na + 8) & ~7;
     double* src = lds;                                   // [nb + 1][LA] sigma psi, transposed; row nb = zeros
     double* Vb = src + (size_t)(nb + 1) * LA;            // [2][a^2][SEC_PCOL]
     double* Yb = Vb + 2 * na2 * SEC_PCOL;                // [a^2][SEC_PYP]; columns >= na are zeros (V's are)
@@ -2476,7 +2488,7 @@ static int sector_adjoint_impl(const double* theta, int n_theta, const oovqe_gat
                        nb < SEC_TAB_MAXSTR &&
                        oovqe_opt(OOVQE_OPT_SECTOR_UNFUSED) == 0;
     // round 4: lambda from the string-driven form (G_a Psi' + Psi' G_b^T + the mixed term in LDS): no W
-    const int LAp = (na + 7) & ~7;
+    const int LAp = (na + 8) & ~7;
     const int ta16 = (na + 15) / 16 * 16, tb16 = (nb + 15) / 16 * 16;
     const size_t dense_lds = (size_t)(ta16 > (na + 3) / 4 * 4 ? ta16 : (na + 3) / 4 * 4) *
                              ((tb16 > (nb + 3) / 4 * 4 ? tb16 : (nb + 3) / 4 * 4) + 4) * sizeof(double) +
@@ -2510,7 +2522,7 @@ static int sector_adjoint_impl(const double* theta, int n_theta, const oovqe_gat
         if (nsplit < 1) nsplit = 1;
         if (nsplit > nchunk) nsplit = nchunk;
         const size_t pipe_lds = sec_lambda_pipe_lds_bytes(na, nb, ncas);
-        if (na2 == 64 && na <= 72 && pipe_lds <= 160 * 1024 && oovqe_opt(OOVQE_OPT_SECTOR_LAMBDA_W) == 4) {
+        if (na2 == 64 && na <= 70 && pipe_lds <= 160 * 1024 && oovqe_opt(OOVQE_OPT_SECTOR_LAMBDA_W) == 4) {
             // the phases overlapped: multiplier and helper waves, one beta string per chunk -- measured and NOT the
             // default (344 us against 311 at 256 states: see the kernel's header)
             int nsp = sector_cu_count() / batch;
