@@ -1374,8 +1374,11 @@ void sector_lambda_fused_kernel(const double* __restrict__ psi_c, const double* 
         const int ib = ch * NBC + ibl;
         const bool live = worker && l < CH && ial < na && ib < nb;
         // lam' of this thread's determinant: needed at the end of the trip, asked for now
-        double lam_dense = 0.0;
-        if (live && part == 0) lam_dense = lam[b * Dc + (size_t)ial * nb + ib];
+        double lam_dense = 0.0, sig = 1.0;
+        if (live && part == 0) {
+            lam_dense = lam[b * Dc + (size_t)ial * nb + ib];
+            sig = sigma[ial * nb + ib];
+        }
         // 1. Vc[k][l] = (B_k Psi')[ial, ib] = own sign * Psi'[ial, src_b(k, ib)]  (columns that are not live: zero row)
         if (worker && !(probe == 1 && ch != split)) {
 #pragma unroll
@@ -1437,7 +1440,7 @@ void sector_lambda_fused_kernel(const double* __restrict__ psi_c, const double* 
         if (live && part == 0) {
             double t = red[l];
             for (int pp = 1; pp < NP; ++pp) t += red[pp * SEC_LCH + l];
-            lam[b * Dc + (size_t)ial * nb + ib] = sigma[ial * nb + ib] * (lam_dense + t);
+            lam[b * Dc + (size_t)ial * nb + ib] = sig * (lam_dense + t);
         }
         // (the next chunk's build writes Vc and, three barriers later, red: both are free by then -- every
         // thread has passed the barrier above, and the last readers of Vc are in front of it)
