@@ -32,6 +32,21 @@ class GateT(ctypes.Structure):
 
 GATE_NBYTES = ctypes.sizeof(GateT)
 
+
+class NewtonStepT(ctypes.Structure):
+    """Mirror of oovqe_newton_step_t (include/oovqe.h): the argument block of oovqe_oo_newton_step_batch."""
+    _POINTERS = ("theta", "gates", "g_ao", "h_ao", "nuc", "g_packed", "oao_coeff", "oao_mo_coeff", "mo_coeff",
+                 "kap_row", "kap_col", "pairs", "work_hessian", "work_eval", "work_pd", "work_rest",
+                 "work_rest_side", "work_rotate", "out", "hessian", "grad", "energy", "flat", "dp", "lowest",
+                 "shift", "info", "t", "state", "flags", "points_a", "points_b", "trial_oao", "trial_mo",
+                 "trial_out")
+    _DOUBLES = ("lambda_min", "mu", "rho", "alpha", "beta")
+    _INTS = ("n_theta", "n_gates", "n_qubits", "N", "n_occ", "ncas", "n_kappa", "n_pairs", "batch", "aug",
+             "speculate", "side_wg")
+    _fields_ = ([(k, ctypes.c_void_p) for k in _POINTERS] + [(k, ctypes.c_double) for k in _DOUBLES] +
+                [(k, ctypes.c_int32) for k in _INTS] + [("init_index", ctypes.c_uint32),
+                                                        ("eri_flags", ctypes.c_uint32)])
+
 # name -> (restype, argtypes)   -- must list every symbol of include/oovqe.h
 SIGNATURES = {
     "oovqe_version": (ctypes.c_int, []),
@@ -220,6 +235,7 @@ SIGNATURES = {
     "oovqe_rotate_orbitals_batch": (ctypes.c_int, [c_double_p, c_int32_p, c_int32_p, ctypes.c_int,
                                                    ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
                                                    c_double_p, c_double_p, c_stream]),
+    "oovqe_oo_newton_step_batch": (ctypes.c_int, [ctypes.POINTER(NewtonStepT), c_stream, c_stream]),
 }
 
 _lib = None

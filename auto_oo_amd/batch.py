@@ -79,6 +79,9 @@ class OO_pqc_batch:
         self._plans = {}
         self._flat0 = None
         self._trial_orbitals = None
+        self._step_args = None
+        self._all_pd_last_step = False
+        self.step_by_calls = False
 
     def set_oao_mo_coeff(self, g, oao_mo_coeff):
         """Replace the orbitals of geometry g and refresh mo_coeff[g] = S^-1/2 C_oao
@@ -272,22 +275,23 @@ class OO_pqc_batch:
     def damped_newton_step(self, thetas, opt=None, defer_lowest=False):
         """One damped Newton step on (theta, kappa) of EVERY geometry in lockstep -- the body of
         OO_pqc.full_optimization / of the Berry-phase loop (oo_pqc.py:172-196), per geometry the
-        arithmetic of NewtonStep.damped_newton_step: gradient + Hessian (one call), the G directions
-        (one launch), a line search whose trials evaluate all geometries at once, then the orbitals
-        of every geometry rotated in place.  Returns (new thetas [G, n_theta], energies at the new
-        parameters [G], lowest Hessian eigenvalues [G]).  ``defer_lowest``: the eigenvalues come as an
-        ``ops.PendingLowest`` -- they are a diagnostic (hess_eig_l of the reference's loops) computed on a side
-        stream beside the line search; ``.result()`` joins them."""
+        arithmetic of NewtonStep.damped_newton_step: gradient + Hessian, the G directions, a line search
+        whose trials evaluate all geometries at once, then the orbitals of every geometry rotated.
+        Returns (new thetas [G, n_theta], energies at the new parameters [G], lowest Hessian eigenvalues [G]).
+        ``defer_lowest``: the eigenvalues come as an ``ops.PendingLowest`` -- they are a diagnostic
+        (hess_eig_l of the reference's loops) computed on a side stream beside the line search; ``.result()``
+        joins them.
+
+        The whole step up to the first verdict of the line search is ONE library call
+        (``oovqe_oo_newton_step_batch``: ~45 launches back to back) and one 32-byte readback; only further trials
+        (rare) are driven from here.  ``step_by_calls=True`` (attribute; for tests and measurements) drives every
+        stage through its own entry point instead -- the same launches, the same bits."""
         from .newton_raphson import BatchedNewtonStep
         if opt is None:
             opt = BatchedNewtonStep(verbose=0)
         nt = self.n_theta
         thetas = ops.as_device(thetas, self.device).reshape(self.G, nt)
-        E, grad, H = self.energy_gradient_hessian(thetas)
-        flat = self._flat0
-        if flat is None:
-            flat = self._flat0 = torch.zeros((self.G, nt + self.n_kappa), dtype=F64, device=self.device)
-        flat[:, :nt] = thetas                        # (the kappa part stays zero: steps start at the current orbitals)
+        thetas = thetas if thetas.is_contiguous() else thetas.contiguous()
         if self._trial_orbitals is None:
             self._trial_orbitals = (torch.empty_like(self.oao_mo_coeff), torch.empty_like(self.mo_coeff))
 
@@ -300,10 +304,19 @@ class OO_pqc_batch:
             ops.matmul_nn_batch(self.oao_coeff, t_oao, out=t_mo)
             return self.evaluate(pa, derivatives=False, mo_coeff=t_mo)[:, 1]
 
-        # the energy at the accepted trial point IS the energy at the new parameters, so the loop body's closing
-        # evaluation (oo_pqc.py:195) is not repeated
-        (new_thetas, new_kappas), low, energies = opt.damped_newton_steps_flat(
-            trial, flat, grad, H, energy0=E, defer_lowest=True, split=nt, return_energy=True)
+        n = nt + self.n_kappa
+        if self.step_by_calls or n > self.lib.oovqe_newton_direction_max_n() or self.G > 32767:
+            E, grad, H = self.energy_gradient_hessian(thetas)
+            flat = self._flat0
+            if flat is None:
+                flat = self._flat0 = torch.zeros((self.G, n), dtype=F64, device=self.device)
+            flat[:, :nt] = thetas                    # (the kappa part stays zero: steps start at the current orbitals)
+            # the energy at the accepted trial point IS the energy at the new parameters, so the loop body's closing
+            # evaluation (oo_pqc.py:195) is not repeated
+            (new_thetas, new_kappas), low, energies = opt.damped_newton_steps_flat(
+                trial, flat, grad, H, energy0=E, defer_lowest=True, split=nt, return_energy=True)
+        else:
+            new_thetas, new_kappas, low, energies = self._newton_step_one_call(thetas, opt, trial)
         if opt.last_search_gave_up:
             self.rotate_(new_kappas)                 # (some problems went back to their old parameters)
         else:
@@ -314,3 +327,114 @@ class OO_pqc_batch:
             self._trial_orbitals = (self.oao_mo_coeff, self.mo_coeff)
             self.oao_mo_coeff, self.mo_coeff = t_oao, t_mo
         return new_thetas, energies, (low if defer_lowest else low.result())
+
+    def _step_block(self):
+        """The argument block of oovqe_oo_newton_step_batch with everything that does not change from step to
+        step filled in (made once per batch object)."""
+        if self._step_args is not None:
+            return self._step_args
+        lib, pqc, G, N = self.lib, self.pqc, self.G, self.nao
+        nt, nk = self.n_theta, self.n_kappa
+        n = nt + nk
+        pairs_dev, _, _ = ops._hessian_pair_tables(nt, self.device)
+        n_pairs = int(pairs_dev.shape[0])
+        osz1 = int(lib.oovqe_oo_eval_out_size(nt, nk, self.ncas, 1))
+        osz0 = int(lib.oovqe_oo_eval_out_size(nt, nk, self.ncas, 0))
+        key = ("hessian", 0)
+        if key not in self._plans:
+            wsz = lib.oovqe_oo_hessian_work_size(nt, pqc._n_gates, pqc.n_qubits, N, self._n_occ, self.ncas, n_pairs)
+            self._plans[key] = (torch.empty(G * wsz, dtype=F64, device=self.device), osz1)
+        work_eval, _ = self._plan(False, 0)
+        b = _lib.NewtonStepT()
+        keep = {"pairs": pairs_dev, "trial_out": torch.empty((G, osz0), dtype=F64, device=self.device),
+                "flat": torch.empty((G, n), dtype=F64, device=self.device)}
+        has_pd = bool(lib.oovqe_newton_direction_has_pd(n, 1))
+        if has_pd:
+            keep["work_pd"] = torch.empty(int(lib.oovqe_newton_direction_pd_work_size(n, G)), dtype=F64,
+                                          device=self.device)
+        rest = int(lib.oovqe_newton_direction_rest_work_size(n, G))
+        keep["work_rest"] = torch.empty(rest, dtype=F64, device=self.device)
+        # one workspace per side stream: the eigenvalue routes of consecutive steps run beside each other
+        keep["work_side"] = [torch.empty(rest, dtype=F64, device=self.device) for _ in range(2)]
+        if N > 48:
+            keep["work_rotate"] = torch.empty((G + 7) * N * N, dtype=F64, device=self.device)
+        b.gates = pqc._gates_dev.data_ptr()
+        b.kap_row, b.kap_col = self._kap_row.data_ptr(), self._kap_col.data_ptr()
+        b.pairs = pairs_dev.data_ptr()
+        b.work_hessian = self._plans[key][0].data_ptr()
+        b.work_eval = work_eval.data_ptr()
+        b.work_pd = keep["work_pd"].data_ptr() if has_pd else None
+        b.work_rest = keep["work_rest"].data_ptr()
+        b.work_rotate = keep["work_rotate"].data_ptr() if N > 48 else None
+        b.flat = keep["flat"].data_ptr()
+        b.trial_out = keep["trial_out"].data_ptr()
+        b.n_theta, b.n_gates, b.n_qubits, b.N, b.n_occ, b.ncas = nt, pqc._n_gates, pqc.n_qubits, N, self._n_occ, self.ncas
+        b.n_kappa, b.n_pairs, b.batch = nk, n_pairs, G
+        b.init_index = pqc._init_index
+        # the eigenvalue route beside the line search keeps to a quarter of the chip (half for larger stacks):
+        # ops.newton_direction
+        b.side_wg = max(1, 64 // G) if G <= 16 else max(1, 128 // G)
+        # per-step slab (doubles): out | H | grad | energy | dp | low | nu | info | t | state | flags | pa | pb
+        sizes = [("out", G * osz1), ("hessian", G * n * n), ("grad", G * n), ("energy", G), ("dp", G * n),
+                 ("lowest", G), ("shift", G), ("info", G), ("t", G), ("state", 3 * G), ("flags", 4),
+                 ("points_a", G * nt), ("points_b", G * nk)]
+        offs, o = {}, 0
+        for k, sz in sizes:
+            offs[k] = (o, sz)
+            o += (sz + 1) & ~1                      # (16-byte aligned pieces)
+        self._step_args = (b, keep, offs, o, osz0)
+        return self._step_args
+
+    def _newton_step_one_call(self, thetas, opt, trial):
+        from .newton_raphson import LockstepSearch
+        b, keep, offs, total, osz0 = self._step_block()
+        G, nt, nk = self.G, self.n_theta, self.n_kappa
+        n = nt + nk
+        slab = torch.empty(total, dtype=F64, device=self.device)
+        base = slab.data_ptr()
+        for k, (o, _) in offs.items():
+            setattr(b, k, base + 8 * o)
+
+        def view(k, *shape):
+            o, sz = offs[k]
+            return slab[o:o + sz].view(*shape)
+
+        t_oao, t_mo = self._trial_orbitals
+        b.theta = thetas.data_ptr()
+        b.g_ao, b.h_ao, b.nuc = self.int2e_ao.data_ptr(), self.int1e_ao.data_ptr(), self.nuc.data_ptr()
+        b.g_packed = self._eri_packed.data_ptr() if self.eri_flags == 3 else None
+        b.eri_flags = int(self.eri_flags)
+        b.oao_coeff, b.oao_mo_coeff, b.mo_coeff = (self.oao_coeff.data_ptr(), self.oao_mo_coeff.data_ptr(),
+                                                   self.mo_coeff.data_ptr())
+        b.trial_oao, b.trial_mo = t_oao.data_ptr(), t_mo.data_ptr()
+        b.lambda_min, b.mu, b.rho, b.alpha, b.beta = opt.lambda_min, opt.mu, opt.rho, opt.alpha, opt.beta
+        b.aug = int(bool(opt.aug))
+        # when the previous step of this stack found every Hessian positive definite, the band route of "the
+        # others" is not waited for (it runs beside the trial; flags[1] says whether that was right)
+        spec = bool(self._all_pd_last_step)
+        b.speculate = int(spec)
+        side = ops._side_stream(self.device)
+        b.work_rest_side = keep["work_side"][ops.side_streams(self.device).index(side)].data_ptr()
+        check(self.lib.oovqe_oo_newton_step_batch(ctypes.byref(b), stream_ptr(), ctypes.c_void_p(side.cuda_stream)),
+              "oovqe_oo_newton_step_batch")
+        event = torch.cuda.Event()
+        event.record(side)
+        slab.record_stream(side)
+        # (the views are made while the device works through the step, the readback comes last)
+        state = view("state", 3, G)
+        s = LockstepSearch(flat=keep["flat"], g=view("grad", G, n), H=view("hessian", G, n, n), dp=view("dp", G, n),
+                           low=ops.PendingLowest(view("lowest", G), event), nu=view("shift", G),
+                           info=view("info", G), energy=view("energy", G), t=view("t", G), active=state[0],
+                           best=state[1], slope=state[2], flags=view("flags", 4), pa=view("points_a", G, nt),
+                           pb=view("points_b", G, nk))
+        fl = s.flags.tolist()                        # the one readback of the common case
+        self._all_pd_last_step = fl[1] >= 1.0
+        if spec and fl[1] < 1.0:
+            # some Hessian was not positive definite after all: its direction is still on the side stream.  Join it
+            # and search from the start.
+            torch.cuda.current_stream().wait_event(event)
+            s.t.fill_(1.0)
+            fl = None
+        opt.run_search(s, trial, split=nt, first_flags=fl)
+        return s.pa, s.pb, s.low, s.best
+

@@ -270,49 +270,65 @@ class BatchedNewtonStep(NewtonStep):
         if energy0 is None:
             energy0 = (objective(flat) if split is None
                        else objective(flat[:, :n_a].contiguous(), flat[:, n_a:].contiguous()))
-        energy = energy0 if energy0.is_contiguous() else energy0.contiguous()
         kw = dict(dtype=flat.dtype, device=dev)
-        t = torch.ones(G, **kw)
         state = torch.empty((3, G), **kw)            # active | best energy | slope
-        active, best, slope = state[0], state[1], state[2]
-        flags = torch.empty(4, **kw)
-        pa = torch.empty((G, n_a), **kw)
-        pb = torch.empty((G, n - n_a), **kw) if n_a < n else None
+        s = LockstepSearch(flat=flat, g=g, H=H, dp=dp, low=low, nu=nu, info=info,
+                           energy=energy0 if energy0.is_contiguous() else energy0.contiguous(),
+                           t=torch.ones(G, **kw), active=state[0], best=state[1], slope=state[2],
+                           flags=torch.empty(4, **kw), pa=torch.empty((G, n_a), **kw),
+                           pb=torch.empty((G, n - n_a), **kw) if n_a < n else None)
+        self.run_search(s, objective, split)
+        new = s.pa if split is None else (s.pa, s.pb)
+        out = (new, s.low if defer_lowest else s.low.result())
+        return out + (s.best,) if return_energy else out
+
+    def run_search(self, s, objective, split=None, first_flags=None):
+        """The backtracking line search of G problems in lockstep on the state ``s`` (a ``LockstepSearch``: the
+        directions are in it).  ``first_flags``: the host values of ``s.flags`` after a first trial (t = 1 for every
+        problem) that has been made already -- by ``oovqe_oo_newton_step_batch``, which enqueues a whole step up to
+        that verdict; None: the first trial is made here.  On return s.pa / s.pb are the new parameters, s.best the
+        energies there."""
+        lib = _lib.load()
+        G, n = s.flat.shape
+        n_a = s.pa.shape[1]
         sp = ops.stream_ptr
 
         def points(with_slope):
-            ops.check(lib.oovqe_linesearch_points(ops.dptr(flat), ops.dptr(dp), ops.dptr(t), ops.dptr(g),
-                                                  float(self.alpha), n, n_a, G, ops.dptr(pa),
-                                                  ops.dptr(pb) if pb is not None else None,
-                                                  ops.dptr(slope) if with_slope else None, sp()),
+            ops.check(lib.oovqe_linesearch_points(ops.dptr(s.flat), ops.dptr(s.dp), ops.dptr(s.t), ops.dptr(s.g),
+                                                  float(self.alpha), n, n_a, G, ops.dptr(s.pa),
+                                                  ops.dptr(s.pb) if s.pb is not None else None,
+                                                  ops.dptr(s.slope) if with_slope else None, sp()),
                       "oovqe_linesearch_points")
 
         def update(trial, first, give_up, with_info):
-            if trial is not None and (trial.dtype != flat.dtype or trial.device != flat.device or trial.dim() != 1):
+            if trial is not None and (trial.dtype != s.flat.dtype or trial.device != s.flat.device or trial.dim() != 1):
                 raise _lib.OovqeError("the objective must return a 1-d fp64 device tensor of energies")
             ops.check(lib.oovqe_linesearch_update(
                 # (a strided view is fine: e.g. column 1 of the packed outputs of a batched evaluation)
                 ctypes.c_void_p(trial.data_ptr()) if trial is not None else None,
                 trial.stride(0) if trial is not None else 1,
-                ops.dptr(energy), ops.dptr(slope), ops.dptr(info) if (with_info and info is not None) else None,
-                float(self.beta), int(first), int(give_up), G, ops.dptr(t), ops.dptr(active), ops.dptr(best),
-                ops.dptr(flags), sp()), "oovqe_linesearch_update")
-            return flags.tolist()                     # the one readback of a trial
+                ops.dptr(s.energy), ops.dptr(s.slope),
+                ops.dptr(s.info) if (with_info and s.info is not None) else None,
+                float(self.beta), int(first), int(give_up), G, ops.dptr(s.t), ops.dptr(s.active), ops.dptr(s.best),
+                ops.dptr(s.flags), sp()), "oovqe_linesearch_update")
+            return s.flags.tolist()                   # the one readback of a trial
 
         def trial_energies():
-            e = objective(pa) if split is None else objective(pa, pb)
+            e = objective(s.pa) if split is None else objective(s.pa, s.pb)
             return e.reshape(G)
 
         self.last_search_gave_up = False
-        points(True)
-        fl = update(trial_energies(), 1, 0, True)
+        fl = first_flags
+        if fl is None:
+            points(True)
+            fl = update(trial_energies(), 1, 0, True)
         if fl[1] < 0:
             # the library refused a problem loudly: repeat without inter-workgroup waits / eigh fallback (or
             # raise), then search from scratch
-            dp, low_t, nu = self._check_direction(g, H, dp, None, nu, info.tolist(), batched=True)
-            dp = dp if dp.is_contiguous() else dp.contiguous()
-            low = ops.PendingLowest(low_t, None)
-            t.fill_(1.0)
+            dp, low_t, s.nu = self._check_direction(s.g, s.H, s.dp, None, s.nu, s.info.tolist(), batched=True)
+            s.dp = dp if dp.is_contiguous() else dp.contiguous()
+            s.low = ops.PendingLowest(low_t, None)
+            s.t.fill_(1.0)
             points(True)
             fl = update(trial_energies(), 1, 0, False)
         if fl[2] != 0.0:
@@ -332,6 +348,16 @@ class BatchedNewtonStep(NewtonStep):
                 break
             points(False)
             fl = update(trial_energies(), 0, 0, False)
-        new = pa if split is None else (pa, pb)
-        out = (new, low if defer_lowest else low.result())
-        return out + (best,) if return_energy else out
+        return fl
+
+
+class LockstepSearch:
+    """State of the line search of G problems in lockstep (device tensors): flat [G, n] current parameters,
+    g [G, n], H [G, n, n], dp [G, n], low (``ops.PendingLowest``), nu [G], info [G] or None, energy [G] at flat,
+    t [G] step lengths, active / best / slope [G], flags [4], pa [G, n_a] / pb [G, n - n_a] trial points."""
+    __slots__ = ("flat", "g", "H", "dp", "low", "nu", "info", "energy", "t", "active", "best", "slope", "flags",
+                 "pa", "pb")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw[k])

@@ -506,6 +506,73 @@ int64_t oovqe_oo_hessian_work_size(int n_theta, int n_gates, int n_qubits, int N
 int oovqe_rotate_orbitals_batch(const double* kappa, const int32_t* kap_row, const int32_t* kap_col,
                                 int n_kappa, int N, int batch, const double* C, double* C_out, double* U,
                                 double* work, oovqe_stream_t stream);
+/* ---- (e)/(f1): one damped Newton step of a stack of geometries in lockstep, enqueued by ONE call -------------
+ * The body of OO_pqc.full_optimization / of the Berry-phase loop (src/auto_oo/oo_pqc.py:172-196,
+ * examples/Tutorial_Berry_phase.ipynb raw 408-441) per geometry, with NewtonStep.damped_newton_step
+ * (src/auto_oo/utils/newton_raphson.py:194-211) up to the FIRST verdict of its line search: E + full gradient + full
+ * Hessian (oovqe_oo_hessian_batch), the directions (Cholesky fast path, band route for the others), the trial
+ * points flat + dp with their orbitals C_oao expm(-K), S^-1/2 (C_oao U) (oo_pqc.py:191, oo_energy.py:173-176), the
+ * trial energies and the acceptance rule (newton_raphson.py:146-177) -- the launches of the single entry points,
+ * back to back on `stream` with no host work between them (at the 8 geometries per rank of an 8-GPU job the host's
+ * share of a step driven call by call was a fifth of it).  The host then reads flags [4] (oovqe_linesearch_update):
+ * flags[0] == 0: every problem accepted its first trial -- new parameters = points_a / points_b, new orbitals =
+ * trial_oao / trial_mo, new energies = state[batch .. 2 batch).  Otherwise it continues with the single entry points.
+ * side_stream (may be NULL): the lowest eigenvalues of positive definite Hessians -- a reported number no step reads
+ * (newton_raphson.py:105-128) -- are computed there with at most side_wg workgroups per problem (0: no bound).
+ * speculate != 0: the band route of the problems the fast path did NOT serve runs on the side stream too, and the
+ * trial is formed without waiting for it: when flags[1] (min of info) comes back <= 0 the caller must join the side
+ * stream and repeat the trial (for loops whose Hessians stay positive definite: nothing but the fast path is then
+ * on the calling stream).
+ * All arrays on the device, stacked over the batch; sizes from the *_work_size / *_out_size functions of the entry
+ * points named above. */
+typedef struct oovqe_newton_step_t {
+    /* circuit and integrals, as oovqe_oo_hessian_batch */
+    const double* theta;            /* [batch][n_theta] */
+    const oovqe_gate_t* gates;
+    const double* g_ao;
+    const double* h_ao;
+    const double* nuc;              /* [batch] */
+    const double* g_packed;         /* or NULL */
+    /* orbitals: S^-1/2 [batch][N][N], C_oao [batch][N][N], mo_coeff = S^-1/2 C_oao [batch][N][N] */
+    const double* oao_coeff;
+    const double* oao_mo_coeff;
+    const double* mo_coeff;
+    const int32_t* kap_row;
+    const int32_t* kap_col;
+    const int32_t* pairs;           /* [n_pairs][2], every j <= k */
+    /* workspaces */
+    double* work_hessian;           /* batch * oovqe_oo_hessian_work_size() */
+    double* work_eval;              /* batch * oovqe_oo_eval_work_size(derivatives = 0) */
+    double* work_pd;                /* oovqe_newton_direction_pd_work_size(n, batch), or NULL: band route only */
+    double* work_rest;              /* oovqe_newton_direction_rest_work_size(n, batch) */
+    double* work_rest_side;         /* the same size, for the side stream (NULL without one) */
+    double* work_rotate;            /* NULL for N <= 48, else (batch + 7) N^2 */
+    /* results */
+    double* out;                    /* [batch][oovqe_oo_eval_out_size(derivatives = 1)] */
+    double* hessian;                /* [batch][n][n], n = n_theta + n_kappa */
+    double* grad;                   /* [batch][n] */
+    double* energy;                 /* [batch] */
+    double* flat;                   /* [batch][n] = [theta | 0] */
+    double* dp;                     /* [batch][n] */
+    double* lowest;                 /* [batch] (side stream) */
+    double* shift;                  /* [batch] */
+    double* info;                   /* [batch], as oovqe_newton_direction_rest */
+    double* t;                      /* [batch] step lengths */
+    double* state;                  /* [3][batch]: still searching | energy at the accepted point | Armijo slope */
+    double* flags;                  /* [4], as oovqe_linesearch_update */
+    double* points_a;               /* [batch][n_theta] */
+    double* points_b;               /* [batch][n_kappa] */
+    double* trial_oao;              /* [batch][N][N] */
+    double* trial_mo;               /* [batch][N][N] */
+    double* trial_out;              /* [batch][oovqe_oo_eval_out_size(derivatives = 0)] */
+    /* reference defaults: newton_raphson.py:47-61 */
+    double lambda_min, mu, rho, alpha, beta;
+    int32_t n_theta, n_gates, n_qubits, N, n_occ, ncas, n_kappa, n_pairs, batch, aug, speculate, side_wg;
+    uint32_t init_index, eri_flags;
+} oovqe_newton_step_t;
+int oovqe_oo_newton_step_batch(const oovqe_newton_step_t* step, oovqe_stream_t stream,
+                               oovqe_stream_t side_stream);
+
 /* 1 when oovqe_circuit_rdms takes its one-workgroup LDS path for these sizes */
 int oovqe_circuit_rdms_is_small(int n_qubits, int ncas, int nvec, int n_gates);
 

@@ -557,6 +557,49 @@ def test_batched_newton_step_that_gives_up_keeps_parameters_and_orbitals():
     assert (e_new < e_before).all()
 
 
+def test_one_call_newton_step_equals_the_step_driven_call_by_call():
+    """oovqe_oo_newton_step_batch (the whole lockstep step up to the line search's first verdict enqueued by one
+    call) against the same step driven through the single entry points (``step_by_calls``): the same launches, so
+    the same bits -- thetas, energies, orbitals at every step of a short optimisation that starts with
+    indefinite Hessians (band route, backtracking) and ends with positive definite ones, where the one-call form
+    stops waiting for the band route (``speculate``).  A speculation that turns out wrong (forced here) is
+    repaired: the band route's directions then come from the side stream with another workgroup count, so
+    rounding-level agreement."""
+    N, G, steps = 20, 3, 40
+    runs = []
+    for by_calls in (False, True):
+        pqc, batch, objs, probs = _batch_of(N, G, freeze_active=True)
+        batch.step_by_calls = by_calls
+        th = torch.full((G, pqc.theta_shape), 0.1, dtype=torch.float64, device="cuda")
+        traj, spec = [], []
+        for it in range(steps):
+            spec.append(batch._all_pd_last_step)
+            th, e, low = batch.damped_newton_step(th, defer_lowest=True)
+            traj.append((th.clone(), e.clone(), batch.oao_mo_coeff.clone(), batch.mo_coeff.clone(),
+                         low.result().clone()))
+            if not by_calls and sum(spec) >= 3:
+                steps = it + 1                  # (three speculative steps seen: the other run makes as many)
+                break
+        runs.append((traj, spec))
+    (tb, spec_b), (ta, _) = runs
+    for it, (a, b) in enumerate(zip(ta, tb)):
+        for x, y in zip(a[:4], b[:4]):
+            assert torch.equal(x, y), f"step {it}"
+        assert (a[4] - b[4]).abs().max() < 1e-10, f"lowest eigenvalues, step {it}"
+    assert (ta[-1][1] < ta[0][1]).all()
+    # the optimisation reached positive definite Hessians and the one-call form speculated there
+    assert any(spec_b), "no step ran with speculate = 1 (the trajectory never became positive definite)"
+    # a wrong speculation: indefinite Hessians (the start point) with the flag forced on
+    pqc, batch, objs, probs = _batch_of(N, G, freeze_active=True)
+    th0 = torch.full((G, pqc.theta_shape), 0.1, dtype=torch.float64, device="cuda")
+    batch._all_pd_last_step = True
+    th1, e1, low1 = batch.damped_newton_step(th0)
+    assert batch._all_pd_last_step is False
+    assert (th1 - ta[0][0]).abs().max() < 1e-9 and (e1 - ta[0][1]).abs().max() < 1e-9
+    assert (batch.oao_mo_coeff - ta[0][2]).abs().max() < 1e-9
+    assert (low1 - ta[0][4]).abs().max() < 1e-9
+
+
 def _pd_stack(rng, n, G, low=0.05):
     out = []
     for k in range(G):
