@@ -30,6 +30,14 @@
 //     the straight-line code that issued it, where it is counted exactly.
 //   INNER contractions with even B and many strips run on contract_pair.hip (two strips per wave).
 #include "common.h"
+
+// cache policy of the result stores / the T loads (buffer aux bits; 2 = nt: streaming)
+#ifndef K1_AUX_ST
+#define K1_AUX_ST 0
+#endif
+#ifndef K1_AUX_LD
+#define K1_AUX_LD 0
+#endif
 #include "circuit_small.h"
 
 // tools/k1_standalone.hip ablations (bit mask): 1 no T loads, 2 no stores, 4 no Cm staging,
@@ -215,7 +223,7 @@ void contract_body(const double* __restrict__ T, const double* __restrict__ Cm,
                 unsigned so = (unsigned)s2 * step_bytes;
                 so = so < (unsigned)rem ? so : (unsigned)rem;
                 const unsigned tvo = (!LAST || kbase + 4 * s2 + lq < K) ? st.tvo : OOB;
-                dst[s2] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, tvo, so, 0));
+                dst[s2] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, tvo, so, K1_AUX_LD));
             }
         } else {
 #pragma unroll
@@ -225,7 +233,7 @@ void contract_body(const double* __restrict__ T, const double* __restrict__ Cm,
                 rem1 = clamp_u32(rem1);
                 const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<double*>(T) + e1, 0, (int)(unsigned)rem1, 0x00020000);
-                dst[s2] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, st.tvo, 0, 0));
+                dst[s2] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, st.tvo, 0, K1_AUX_LD));
             }
         }
     };
@@ -297,7 +305,7 @@ void contract_body(const double* __restrict__ T, const double* __restrict__ Cm,
                 so = so < pf_rem ? so : pf_rem;
                 // LAST: a row of T is followed by the next row, so the k-steps past K are masked per lane
                 const unsigned tvo = (!LAST || pf_kn + 4 * s2 + lq < K) ? stn.tvo : OOB;
-                tnext[s2] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(pf_tr, tvo, so, 0));
+                tnext[s2] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(pf_tr, tvo, so, K1_AUX_LD));
 #if OOVQE_K1_PROBE & 512
                 if (s2 == KSTEPS - 1) K1_MARK(52);
 #endif
@@ -347,7 +355,7 @@ void contract_body(const double* __restrict__ T, const double* __restrict__ Cm,
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const double v = acc[t][i];   // (bit_cast of the vector-element expression itself reads element 0)
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, vo, (unsigned)i * ostep_bytes, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, vo, (unsigned)i * ostep_bytes, K1_AUX_ST);
         }
     };
 

@@ -22,6 +22,14 @@
 // between groups of MFMAs, the last chunk of a strip tile-outer with its stores between the MFMAs.
 #include "common.h"
 
+// cache policy of the result stores / the T loads (buffer aux bits; 2 = nt: streaming)
+#ifndef K1_AUX_ST
+#define K1_AUX_ST 0
+#endif
+#ifndef K1_AUX_LD
+#define K1_AUX_LD 0
+#endif
+
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -154,7 +162,7 @@ void contract_pair_kernel(const double* __restrict__ T, const double* __restrict
     auto prefetch_t = [&](const Strip& stn, int s2, d2& dst) {
         unsigned so = (unsigned)s2 * step_bytes;
         so = so < pf_rem ? so : pf_rem;
-        dst = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(pf_tr, stn.vo, so, 0));
+        dst = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(pf_tr, stn.vo, so, K1_AUX_LD));
     };
     // Cm and T together in np parts (prologue and last chunk of a strip: T goes to tnext)
     auto prefetch_part = [&](const Strip& stn, int knext, int part, int np) {
@@ -204,7 +212,7 @@ void contract_pair_kernel(const double* __restrict__ T, const double* __restrict
         for (int i = 0; i < 4; ++i) {
             const double v0 = acc[0][t][i], v1 = acc[1][t][i];
             const d2 v = {v0, v1};
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, st.vo, (unsigned)i * step_bytes, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, st.vo, (unsigned)i * step_bytes, K1_AUX_ST);
         }
     };
 
