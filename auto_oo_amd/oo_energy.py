@@ -315,6 +315,7 @@ class OO_energy:
         else:
             self.oao_mo_coeff = ops.as_device(oao_mo_coeff, self.device)
         self.interface = interface
+        self._freeze_active = bool(freeze_active)
 
         # molecular data, resident in HBM
         self.int1e_ao = ops.as_device(mol.int1e_ao, self.device)

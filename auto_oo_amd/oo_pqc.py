@@ -266,6 +266,36 @@ class OO_pqc(OO_energy):
         size = self._n_theta()
         return full_circuit_hessian.reshape(size, size)
 
+    def _one_geometry_stack(self):
+        """This geometry as an ``OO_pqc_batch`` of one (its own resident copy of the integrals, kept per state of
+        ``int2e_ao`` / ``int1e_ao``), for the one-call Newton iteration of ``full_optimization`` -- or None where that
+        path does not apply (sector circuits, N > 64 [the copy], more parameters than the direction kernels
+        take)."""
+        from .batch import OO_pqc_batch
+        pqc = self.pqc
+        n = int(np.prod(pqc.theta_shape)) + self.n_kappa
+        if (getattr(pqc, "_use_sector", False) or self.nao > 64 or self.n_kappa < 1
+                or n > ops._lib.load().oovqe_newton_direction_max_n()):
+            return None
+        g, h = self.int2e_ao, self.int1e_ao
+        key = (id(g), g._version, id(h), h._version, id(self.oao_coeff))
+        hit = self.__dict__.get("_stack1")
+        if hit is None or hit[0] != key:
+            oo = self
+
+            class _Mol:                      # what OO_pqc_batch reads of a Moldata
+                nao, nuc = oo.nao, oo.nuc
+                nelectron = 2 * oo._n_occ + oo.nelecas
+                int1e_ao, int2e_ao, oao_coeff = h, g, oo.oao_coeff
+
+                @staticmethod
+                def get_active_space_idx(ncas, nelecas):
+                    return oo.occ_idx, oo.act_idx, oo.virt_idx
+            stack = OO_pqc_batch(pqc, [_Mol], self.ncas, self.nelecas, oao_mo_coeffs=[self._t(self.oao_mo_coeff)],
+                                 freeze_active=self._freeze_active)
+            hit = self.__dict__["_stack1"] = (key, stack)
+        return hit[1]
+
     def full_optimization(self, theta_init, max_iterations=50, conv_tol=1e-10, verbose=0,
                           flush=True, **kwargs):
         """oo_pqc.py:155-207: Newton-Raphson on circuit and orbital parameters together.  The
@@ -278,6 +308,37 @@ class OO_pqc(OO_energy):
             print(f"iter = 000, energy = {energy_init:.12f}", flush=flush)
         theta_l, kappa_l, oao_mo_coeff_l, energy_l, hess_eig_l = [], [], [], [], []
         theta = theta_init
+        # (`optimization_by_calls = True` on the object keeps the loop below: tests and measurements)
+        stack = None if (verbose or getattr(self, "optimization_by_calls", False)) else self._one_geometry_stack()
+        if stack is not None:
+            # One library call per iteration (oovqe_oo_newton_step_batch on a stack of one geometry: gradient,
+            # Hessian, direction, the line search's first trial and its verdict back to back) instead of a
+            # dozen calls with host work between them; the accepted trial's energy IS the closing energy of
+            # oo_pqc.py:195.  Same arithmetic per geometry (tests: lockstep == sequential).
+            from .newton_raphson import BatchedNewtonStep
+            bopt = BatchedNewtonStep(verbose=0, **kwargs)
+            stack.oao_mo_coeff[0].copy_(self._t(self.oao_mo_coeff))
+            stack.refresh_mo_coeff()
+            th = theta.reshape(1, -1)
+            for n in range(max_iterations):
+                th, e_new, low = stack.damped_newton_step(th, bopt, defer_lowest=True)
+                hess_eig_l.append(low)
+                theta = th[0].reshape(self.pqc.theta_shape)
+                theta_l.append(theta)
+                kappa_l.append(theta)
+                self.oao_mo_coeff = stack.oao_mo_coeff[0].clone()
+                oao_mo_coeff_l.append(self.oao_mo_coeff)
+                energy = e_new[0].item()
+                energy_l.append(energy)
+                if verbose is not None:
+                    print(f"iter = {n+1:03}, energy = {energy:.12f}")
+                if n > 1:
+                    if abs(energy_l[-1] - energy_l[-2]) < conv_tol:
+                        if verbose is not None:
+                            print("optimization finished.")
+                            print("E_fin =", energy_l[-1])
+                        break
+            max_iterations = 0
         for n in range(max_iterations):
             kappa = torch.zeros(self.n_kappa, dtype=F64, device=self.device)
             grad = self.full_gradient(theta)

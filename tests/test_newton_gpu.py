@@ -317,6 +317,30 @@ def test_deferred_lowest_eigenvalue_of_single_steps():
     assert len(eig_l) == len(e_l) and all(isinstance(e, float) for e in eig_l)
 
 
+def test_full_optimization_one_call_iterations_equal_the_loop_of_calls():
+    """OO_pqc.full_optimization (oo_pqc.py:155-207) runs every iteration as one library call on a stack of one
+    geometry; ``optimization_by_calls`` keeps the reference's sequence of calls (gradient, Hessian, damped Newton
+    step, rotation, closing energy).  Same energies, parameters, orbitals and eigenvalues to rounding, the same
+    number of iterations, the reference's list quirks."""
+    outs = []
+    for by_calls in (True, False):
+        ooo, opqc, oo, pqc = _setup(13, 20261, freeze_active=True)
+        oo.optimization_by_calls = by_calls
+        theta0 = torch.full((pqc.theta_shape,), 0.1, dtype=torch.float64)
+        outs.append((oo.full_optimization(theta0, max_iterations=60, conv_tol=1e-11, verbose=None), oo))
+        assert ("_stack1" in oo.__dict__) == (not by_calls)
+    (a, oo_a), (b, oo_b) = outs
+    assert len(a[0]) == len(b[0]) < 60
+    assert np.abs(np.array(a[0]) - np.array(b[0])).max() < 1e-10
+    assert np.abs(np.array(a[4]) - np.array(b[4])).max() < 1e-9 and all(isinstance(e, float) for e in b[4])
+    for ta, tb, ca, cb in zip(a[1], b[1], a[3], b[3]):
+        assert (ta - tb).abs().max() < 1e-8 and (ca - cb).abs().max() < 1e-8
+        assert tb.shape == ta.shape
+    assert b[2][-1] is b[1][-1]
+    assert (oo_a.oao_mo_coeff - oo_b.oao_mo_coeff).abs().max() < 1e-8
+    assert abs(oo_b.energy_from_parameters(b[1][-1]).item() - b[0][-1]) < 1e-11
+
+
 def test_lockstep_newton_equals_sequential_on_64_geometries():
     """configs[3]: 64 geometries stepped one by one (NewtonStep) and in lockstep (BatchedNewtonStep)."""
     from auto_oo_amd.synthetic import synthetic_problem
