@@ -939,7 +939,7 @@ void sym_gm_kernel(const double* __restrict__ J, const double* __restrict__ C,
             af[ks] = __builtin_bit_cast(double, v);
         }
         // PB rows of the wave at a time: PB * KS loads of a lane in flight, then their MFMA chains
-        constexpr int PB = WPE >= 4 ? 2 : PW;
+        constexpr int PB = WPE >= 6 ? 1 : WPE >= 4 ? 2 : PW;
 #pragma unroll
         for (int h = 0; h < PW; h += PB) {
             double bf[PB][KS];
@@ -3377,9 +3377,16 @@ static int sym_gm_batched(const double* J, const double* C, double* Gm, int N, i
 {
     OOVQE_REQUIRE(M >= 1 && M <= 16 && N >= 1 && N <= 48, "sym_gm: N=%d M=%d", N, M);
     const int ksteps = (N + 3) / 4;
-    const int KSr = ksteps <= 4 ? 4 : ksteps <= 8 ? 8 : 12;
+    int KSr = ksteps <= 4 ? 4 : ksteps <= 8 ? 8 : 12;
     size_t lds_bytes = (size_t)4 * KSr * (M * 16 + 8) * sizeof(double);
     if (cj && cj->lds_bytes > lds_bytes) lds_bytes = cj->lds_bytes;
+    // N = 41 ... 44 (cc-pVDZ formaldimine: 43): T3 in exactly 44 rows leaves room for a THIRD workgroup per CU (3 x
+    // 53.5 KB), built for 80 VGPRs with one row of J in flight per wave.  Measured (round 4, 256 geometries): 86 us
+    // against 58 us for two workgroups per CU with two rows in flight -- 24 registers spilled and half the loads in
+    // flight per wave cost more than the third workgroup hides.  Kept behind the option gm_three_per_cu = 1.
+    const size_t lds11 = (size_t)44 * (M * 16 + 8) * sizeof(double);
+    const bool three_per_cu = ksteps == 11 && (!cj || cj->lds_bytes <= lds11) && 3 * lds11 <= 160 * 1024 &&
+                              oovqe_opt(OOVQE_OPT_GM_THREE_PER_CU) == 1;
     const unsigned nty = (unsigned)(((packed ? M * (M + 1) / 2 : M * M) + 15) / 16);
     oovqe_circuit_job_t job;
     memset(&job, 0, sizeof(job));
@@ -3409,7 +3416,11 @@ static int sym_gm_batched(const double* J, const double* C, double* Gm, int N, i
         else OOVQE_LAUNCH_GM2(KS_, 2);                                                            \
     } while (0)
     oovqe_profile_mark_start_l(st, 2);
-    if (KSr == 4) OOVQE_LAUNCH_GM(4);
+    if (three_per_cu) {
+        KSr = 11;
+        lds_bytes = lds11;
+        OOVQE_LAUNCH_GM2(11, 6);
+    } else if (KSr == 4) OOVQE_LAUNCH_GM(4);
     else if (KSr == 8) OOVQE_LAUNCH_GM(8);
     else OOVQE_LAUNCH_GM(12);
     oovqe_profile_mark_stop(st);

@@ -188,15 +188,28 @@ def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl", mode="weak",
         base, loop = synthetic_loop(NAO, 20263, n_geom, eps=0.01)
         bmol = aoo.Moldata(base["int1e_ao"], base["int2e_ao"], base["overlap"], base["nuc"], NELEC)
         boo = aoo.OO_pqc(pqc, bmol, NCAS, NELECAS, oao_mo_coeff=base["oao_mo_coeff"], freeze_active=True)
-        with contextlib.redirect_stdout(sys.stderr):
-            e_l, th_l, _, _, eig_l = boo.full_optimization(
-                torch.full((pqc.theta_shape,), 0.1, dtype=torch.float64, device="cuda"), max_iterations=80,
-                conv_tol=1e-11, verbose=None)
+        th_start = torch.full((pqc.theta_shape,), 0.1, dtype=torch.float64, device="cuda")
+        c_start = boo.oao_mo_coeff.detach().clone()
+        per_iter = {}
+        # OO_pqc.full_optimization (oo_pqc.py:155-207) of the base problem, timed both ways (second run of each):
+        # the reference's sequence of calls per iteration, and one library call per iteration (the default)
+        for by_calls in (True, False):
+            boo.optimization_by_calls = by_calls
+            for rep in range(2):
+                boo.oao_mo_coeff = c_start.clone()
+                torch.cuda.synchronize()
+                t_opt = time.perf_counter()
+                with contextlib.redirect_stdout(sys.stderr):
+                    e_l, th_l, _, _, eig_l = boo.full_optimization(th_start, max_iterations=80, conv_tol=1e-11,
+                                                                   verbose=None)
+                torch.cuda.synchronize()
+                t_opt = time.perf_counter() - t_opt
+            per_iter["by_calls" if by_calls else "one_call"] = t_opt / len(e_l) * 1e3
         theta0 = th_l[-1].detach().clone()
         c_star = boo.oao_mo_coeff.detach().clone()
         setup = {"base_optimisation_iterations": len(e_l), "base_energy": float(e_l[-1]),
                  "base_lowest_hessian_eigenvalue": float(eig_l[-1]), "displacement_eps": 0.01,
-                 "freeze_active": True}
+                 "freeze_active": True, "full_optimization_ms_per_iteration": per_iter}
         for g in my_geoms:
             P = loop[g]
             mol = aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], NELEC)

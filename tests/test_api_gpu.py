@@ -483,6 +483,13 @@ def test_packed_stage1_realisations_agree(N, G, lib_options):
     # every mode runs the first products as single accumulator chains in the same order: bit-identical
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+    # the builds of the q -> x, p -> n kernel behind it (one / two workgroups per CU; at N = 41 ... 44 the measured
+    # and not adopted three-per-CU build): the same chains of products with more or fewer zero k-steps
+    lib_options(tri_mode=0)
+    for opt in ("gm_one_per_cu", "gm_two_per_cu", "gm_three_per_cu", "gm_plain_grid"):
+        lib_options(**{opt: 1})
+        assert torch.equal(batch.energy_and_gradient(thetas), outs[0]), opt
+        lib_options(**{opt: 0})
     omol = R.OracleMol(mols[0].int1e_ao, mols[0].int2e_ao, mols[0].overlap, mols[0].nuc, nelec)
     ooo = R.OracleOOPQC(R.OraclePQC(ncas, nelecas, "ucc"), omol, ncas, nelecas, coeffs[0])
     assert abs(outs[0][0, 0].item() - ooo.energy_from_parameters(thetas[0]).item()) < 1e-9
