@@ -674,6 +674,11 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # a multi-rank job has RCCL's streams next to the library's side streams: give each of them a hardware
+        # queue of its own (HIP's default of four would make two of them run one after the other).  Read by the
+        # HIP runtime when it initialises, i.e. below; one rank alone stays on the default.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
