@@ -236,6 +236,7 @@ SIGNATURES = {
                                                    ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
                                                    c_double_p, c_double_p, c_stream]),
     "oovqe_oo_newton_step_batch": (ctypes.c_int, [ctypes.POINTER(NewtonStepT), c_stream, c_stream]),
+    "oovqe_newton_step_size": (ctypes.c_int, []),
 }
 
 _lib = None
@@ -255,6 +256,9 @@ def load():
         fn = getattr(lib, name)     # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.oovqe_newton_step_size() != ctypes.sizeof(NewtonStepT):
+        raise OovqeError(f"oovqe_newton_step_t is {lib.oovqe_newton_step_size()} bytes in {LIB_PATH}, "
+                         f"{ctypes.sizeof(NewtonStepT)} in _lib.NewtonStepT: rebuild the library")
     _lib = lib
     return lib
 

@@ -59,6 +59,9 @@ hipEvent_t fork_event()
 
 }  // namespace
 
+// sizeof(oovqe_newton_step_t) as this library was built: a binding checks its mirror of the block against it
+extern "C" int oovqe_newton_step_size(void) { return (int)sizeof(oovqe_newton_step_t); }
+
 extern "C" int oovqe_oo_newton_step_batch(const oovqe_newton_step_t* s, oovqe_stream_t stream,
                                           oovqe_stream_t side_stream)
 {

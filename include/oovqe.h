@@ -572,6 +572,8 @@ typedef struct oovqe_newton_step_t {
 } oovqe_newton_step_t;
 int oovqe_oo_newton_step_batch(const oovqe_newton_step_t* step, oovqe_stream_t stream,
                                oovqe_stream_t side_stream);
+/* sizeof(oovqe_newton_step_t) in the library as built (a binding compares its mirror of the block with it) */
+int oovqe_newton_step_size(void);
 
 /* 1 when oovqe_circuit_rdms takes its one-workgroup LDS path for these sizes */
 int oovqe_circuit_rdms_is_small(int n_qubits, int ncas, int nvec, int n_gates);

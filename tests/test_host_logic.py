@@ -37,6 +37,25 @@ def test_gate_struct_layout():
     assert _lib.GATE_NBYTES == 40
 
 
+def test_newton_step_block_layout():
+    """The ctypes mirror of oovqe_newton_step_t (include/oovqe.h) against the header, field by field in order, and its
+    size against the library's."""
+    import ctypes
+    with open(os.path.join(ROOT, "include", "oovqe.h")) as fh:
+        hdr = fh.read()
+    body = hdr[hdr.index("typedef struct oovqe_newton_step_t {"):hdr.index("} oovqe_newton_step_t;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for piece in decl.split(","):
+            names.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", piece)[-1])
+    assert names == [f[0] for f in _lib.NewtonStepT._fields_]
+    assert _lib.load().oovqe_newton_step_size() == ctypes.sizeof(_lib.NewtonStepT)
+
+
 @pytest.mark.parametrize("case", [c for c in _load("pqc_states.json") if c["ansatz"] == "ucc"],
                          ids=lambda c: c["source"])
 def test_gate_table_reproduces_reference_states(case):
