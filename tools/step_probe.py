@@ -1,6 +1,6 @@
 """The lockstep Berry-loop step (tracking regime: positive definite Hessians) driven call by call and as ONE
 library call (oovqe_oo_newton_step_batch), at several batch sizes; time until the step's outputs are complete.
-    python tools/step_probe.py [G ...]"""
+    python tools/step_probe.py [G ...] [option=value ...]"""
 import contextlib
 import os
 import sys
@@ -13,7 +13,13 @@ import auto_oo_amd as aoo                               # noqa: E402
 from auto_oo_amd.synthetic import synthetic_loop        # noqa: E402
 import bench                                            # noqa: E402
 
-sizes = [int(a) for a in sys.argv[1:]] or [8, 16, 32, 64]
+opts = dict((a.split("=")[0], int(a.split("=")[1])) for a in sys.argv[1:] if "=" in a)   # library options name=value
+sizes = [int(a) for a in sys.argv[1:] if "=" not in a] or [8, 16, 32, 64]
+if opts:
+    from auto_oo_amd import _lib
+    _ctx = _lib.debug_options(**opts)
+    _ctx.__enter__()
+    print("library options:", opts)
 pqc = aoo.Parameterized_circuit(bench.NCAS, bench.NELECAS, None, ansatz="ucc")
 base, loop = synthetic_loop(bench.NAO, 20263, max(sizes), eps=0.01)
 bmol = aoo.Moldata(base["int1e_ao"], base["int2e_ao"], base["overlap"], base["nuc"], bench.NELEC)
