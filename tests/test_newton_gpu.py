@@ -624,6 +624,26 @@ def test_one_call_newton_step_equals_the_step_driven_call_by_call():
     assert (low1 - ta[0][4]).abs().max() < 1e-9
 
 
+def test_one_call_newton_step_beyond_the_cholesky_kernel():
+    """N = 64: n_theta + n_kappa = 520 is beyond the one-workgroup Cholesky (495), so every direction of the
+    one-call step comes from the band route on the calling stream (no fast path, nothing on the side stream) --
+    the same launches as the step driven call by call, the same bits; and the tile-packed integrals (N > 48)
+    with the rotation's workspace."""
+    N, G = 64, 2
+    outs = []
+    for by_calls in (True, False):
+        pqc, batch, objs, probs = _batch_of(N, G, seed0=515)
+        assert batch.n_theta + batch.n_kappa > aoo._lib.load().oovqe_newton_direction_pd_max_n()
+        batch.step_by_calls = by_calls
+        th = torch.full((G, pqc.theta_shape), 0.1, dtype=torch.float64, device="cuda")
+        e0 = batch.energy(th)
+        new_t, e_new, low = batch.damped_newton_step(th)
+        assert (e_new < e0).all()
+        outs.append((new_t.clone(), e_new.clone(), low.clone(), batch.oao_mo_coeff.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def _pd_stack(rng, n, G, low=0.05):
     out = []
     for k in range(G):
