@@ -4206,7 +4206,7 @@ static int oo_eval_batched(const double* theta, int n_theta, const oovqe_gate_t*
     // evaluation); otherwise it is launched here.  OOVQE_NO_RIDE=1 forces the separate launch.
     oovqe_circuit_job_t cj;
     bool ride = false;
-    if (oovqe_circuit_rdms_is_small(n_qubits, ncas, nvec, n_gates) && oovqe_opt(OOVQE_OPT_NO_RIDE) == 0) {
+    if (oovqe_circuit_rdms_is_small(n_qubits, ncas, nvec, n_gates) && oovqe_opt(OOVQE_OPT_NO_RIDE) != 1) {
         const int M = n_occ + ncas;
         const long m2 = (long)M * M, m3 = m2 * M;
         cj.theta = theta;
@@ -4226,6 +4226,17 @@ static int oo_eval_batched(const double* theta, int n_theta, const oovqe_gate_t*
         const long K = fused ? (long)fp.nchunk * N : N, B = fused ? m3 : (long)N * m2;
         ride = cj.lds_bytes <= 64 * 1024 && K <= 0x7fffffffL &&
                oovqe_contract_hosts_circuit(1, (int)K, N, B, 0, batch);
+        // On the packed-triangle path the host launch is sym_gm_kernel, two workgroups per CU: the circuit
+        // workgroups are its longest (a latency chain through the gates and the RDM products, slowed further by the
+        // matrix-core workgroups they share a CU with), and once the grid is beyond 1.5 resident rounds they end
+        // the launch alone.  Measured per call (tools/ride_probe.py, riding / own launch): 192 geometries 363.9 /
+        // 370.2 us, 224: 427.8 / 420.6, 256: 471.4 / 464.5, 384: 734.6 / 705.0, 512: 983.4 / 946.9.
+        if (ride && fused && (eri_flags & OOVQE_ERI_PQ_SYMMETRIC) != 0 && oovqe_opt(OOVQE_OPT_SYM_MIRROR) == 0 &&
+            oovqe_opt(OOVQE_OPT_NO_RIDE) != 2) {
+            const bool rs = (eri_flags & OOVQE_ERI_RS_SYMMETRIC) != 0 && oovqe_opt(OOVQE_OPT_SYM_NO_RS) == 0;
+            const long ntile = ((rs ? (long)M * (M + 1) / 2 : m2) + 15) / 16;
+            if ((ntile + 1) * batch > 3L * device_cu_count()) ride = false;
+        }
     }
     if (!ride) {
         oovqe_profile_mark_start_l((hipStream_t)stream, 1);

@@ -35,7 +35,7 @@ enum oovqe_option_t {
     OOVQE_OPT_SYM_MIRROR,            // mirrored T2 instead of the packed triangle
     OOVQE_OPT_SYM_SIMPLE,            // one-slab-per-wave triangle kernel
     OOVQE_OPT_SYM_TWO_STEP,          // q->x kernel + K1 instead of the one-launch kernel
-    OOVQE_OPT_NO_RIDE,               // circuit + RDM step as its own launch
+    OOVQE_OPT_NO_RIDE,               // 1: circuit + RDM step as its own launch whatever the batch; 2: riding whatever the batch
     OOVQE_OPT_TRI_MODE,              // packed-triangle stage 1: 1 operand loads, 2 LDS-DMA, 3/4 contiguous loads
     OOVQE_OPT_K1_NO_PAIR,            // K1: never the two-strips-per-wave kernel
     OOVQE_OPT_K1_FORCE_WIDE,         // K1: INNER contractions on the long-stride kernels (one descriptor per k-step)
