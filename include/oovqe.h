@@ -69,7 +69,10 @@ typedef struct {
  * variant a call takes): "half_stream_old", "gm_two_per_cu", "gm_one_per_cu", "fused_chunks" (int),
  * "tri_plain_w", "cas_unfused", "sym_no_rs", "sym_mirror", "sym_simple", "sym_two_step", "no_ride",
  * "tri_mode" (int), "k1_no_pair", "k1_force_wide", "gm_plain_grid", "newton_one_wg", "sector_unfused",
- * "sector_probe" (int; timing only), "hess_vk_pass", "hess_own_stage1", "panel_rows" (int).
+ * "sector_probe" (int; timing only), "hess_vk_pass", "hess_own_stage1", "panel_rows" (int), "k1_force_nt" (int),
+ * "newton_no_chol", "tiles_variant" (int), "sector_lambda_w" (int), "sector_rdm_r3" (int), "gm_three_per_cu";
+ * "no_ride": 1 = the circuit + RDM step as a launch of its own, 2 = riding on the launch in front of the Fock stage
+ * whatever the batch (0: the library decides by the grid of that launch).
  * All 0 by default; the library never reads environment variables.  tests/ and tools/ only. */
 int oovqe_debug_set_option(const char* name, int value);
 int oovqe_debug_get_option(const char* name);
