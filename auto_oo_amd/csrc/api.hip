@@ -59,7 +59,7 @@ static const char* const g_opt_names[OOVQE_OPT_COUNT] = {
     "half_stream_old", "gm_two_per_cu", "gm_one_per_cu", "fused_chunks", "tri_plain_w", "cas_unfused",
     "sym_no_rs", "sym_mirror", "sym_simple", "sym_two_step", "no_ride", "tri_mode", "k1_no_pair", "k1_force_wide", "gm_plain_grid",
     "newton_one_wg", "sector_unfused", "sector_probe", "hess_vk_pass", "hess_own_stage1", "panel_rows",
-    "k1_force_nt", "newton_no_chol", "tiles_variant", "sector_lambda_w", "sector_rdm_r3", "gm_three_per_cu"};
+    "k1_force_nt", "newton_no_chol", "tiles_variant", "sector_lambda_w", "sector_rdm_r3", "gm_three_per_cu", "panel_no_w"};
 static_assert(sizeof(g_opt_names) / sizeof(g_opt_names[0]) == OOVQE_OPT_COUNT, "option name table out of step with oovqe_option_t");
 
 int oovqe_opt(int id) { return (id >= 0 && id < OOVQE_OPT_COUNT) ? g_opts[id] : 0; }

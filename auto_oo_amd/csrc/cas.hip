@@ -32,6 +32,10 @@ int oovqe_mode_contract_batched_circ(const double* T, const double* Cm, double* 
                                      long B, int ldc, int last, int batch, long t_bs, long c_bs,
                                      long o_bs, hipStream_t st, const oovqe_circuit_job_t* cj);
 int oovqe_contract_hosts_circuit(long A, int K, int J, long B, int last, int batch);
+int oovqe_circuit_rdms_w(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates, int n_qubits,
+                         int ncas, uint32_t init_index, int want_tangents, int batch, double* psi, double* dpsi,
+                         double* gamma, double* Gamma, double* work, const double* h_ao, const double* C, int N,
+                         double* Wpre, oovqe_stream_t stream);
 extern "C" int oovqe_circuit_rdms(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
                                   int n_qubits, int ncas, uint32_t init_index, int want_tangents, int batch,
                                   double* psi, double* dpsi, double* gamma, double* Gamma, double* work,
@@ -2756,16 +2760,18 @@ void cas_panel_kernel(const double* __restrict__ Gm_in, const double* __restrict
                       double* __restrict__ Fcol, double* __restrict__ Epart,
                       double* __restrict__ Cpart, double* __restrict__ c1, double* __restrict__ c2,
                       double* __restrict__ Gm_out, double* __restrict__ hmo_out, size_t out_stride,
-                      int rdm_chunk, int batch_1d)
+                      int rdm_chunk, int batch_1d, const double* __restrict__ Wpre)
 {
     extern __shared__ double lds[];
     const int M = no + na, M2 = M * M, M3 = M2 * M;
     const int na2 = na * na, na3 = na2 * na, na4 = na2 * na2;
+    // Wpre [G][N][N]: W = C^T h_ao formed once per geometry by the launch of the circuit workgroups
+    // (circuit.hip); h_ao and the panel's columns of C are then not staged here
     double* Gp = lds;                          // [npan][M3]   g_mo[n0+nl, x, y, z]
     double* Cl = Gp + (size_t)npan * M3;       // [N][M]       C[:, :M]
-    double* hl = Cl + (size_t)N * M;           // [N][N]       h_ao
-    double* cn = hl + (size_t)N * N;           // [npan][N]    C[:, n]
-    double* Wn = cn + (size_t)npan * N;        // [npan][N]    (C^T h)[n, :]
+    double* hl = Cl + (size_t)N * M;           // [N][N]       h_ao                       (not with Wpre)
+    double* cn = hl + (Wpre ? 0 : (size_t)N * N);           // [npan][N]    C[:, n]       (not with Wpre)
+    double* Wn = cn + (Wpre ? 0 : (size_t)npan * N);        // [npan][N]    (C^T h)[n, :]
     double* hn = Wn + (size_t)npan * N;        // [npan][M]
     double* FIn = hn + (size_t)npan * M;       // [npan][M]
     double* gml = FIn + (size_t)npan * M;      // [rdm_chunk][na2]
@@ -2797,6 +2803,7 @@ void cas_panel_kernel(const double* __restrict__ Gm_in, const double* __restrict
         c2 += gi * out_stride;
         if (Gm_out) Gm_out += gi * (size_t)N * M3;
         if (hmo_out) hmo_out += gi * (size_t)N * M;
+        if (Wpre) Wpre += gi * (size_t)N * N;
     }
 
     // every global load first (straight-line, into registers), then every LDS store: a load/store
@@ -2813,12 +2820,13 @@ void cas_panel_kernel(const double* __restrict__ Gm_in, const double* __restrict
 #pragma unroll
         for (int it = 0; it < IT_H; ++it) {
             const int idx = tid + it * PAN_THREADS;
-            rh[it] = idx < N * N ? h_ao[idx] : 0.0;
+            rh[it] = (!Wpre && idx < N * N) ? h_ao[idx] : 0.0;
         }
 #pragma unroll
         for (int it = 0; it < IT_N; ++it) {
             const int idx = tid + it * PAN_THREADS, nl = idx / N, p = idx - nl * N;
-            rn[it] = idx < nn * N ? C[(size_t)p * N + n0 + nl] : 0.0;
+            // (with Wpre: the panel's rows of W, contiguous)
+            rn[it] = idx < nn * N ? (Wpre ? Wpre[(size_t)n0 * N + idx] : C[(size_t)p * N + n0 + nl]) : 0.0;
         }
         // first RDM chunk (one element of gamma and of Gamma per thread here, the rest in the loop)
         const int kc0 = nrdm < rdm_chunk ? nrdm : rdm_chunk;
@@ -2854,17 +2862,17 @@ void cas_panel_kernel(const double* __restrict__ Gm_in, const double* __restrict
 #pragma unroll
         for (int it = 0; it < IT_H; ++it) {
             const int idx = tid + it * PAN_THREADS;
-            if (idx < N * N) hl[idx] = rh[it];
+            if (!Wpre && idx < N * N) hl[idx] = rh[it];
         }
 #pragma unroll
         for (int it = 0; it < IT_N; ++it) {
             const int idx = tid + it * PAN_THREADS;
-            if (idx < nn * N) cn[idx] = rn[it];
+            if (idx < nn * N) (Wpre ? Wn : cn)[idx] = rn[it];
         }
     }
     __syncthreads();
     // W[n,q] = sum_p C[p,n] h[p,q]
-    for (int idx = tid; idx < nn * N; idx += PAN_THREADS) {
+    for (int idx = tid; !Wpre && idx < nn * N; idx += PAN_THREADS) {
         const int nl = idx / N, q = idx - nl * N;
         const double* cv = cn + (size_t)nl * N;
         double a0 = 0.0, a1 = 0.0;
@@ -3870,6 +3878,25 @@ static bool column_fits(int N, int M, int ncas)
 
 // Batched CAS path: `batch` geometries of identical shape, every per-geometry array stacked.
 // Outputs c0/c1/c2/E/gvec/dE of geometry g live at pointer + g * out_stride (doubles).
+// Where the circuit launch of an evaluation may leave W = C^T h_ao [G][N][N] for the panel kernel: the T3 block of
+// the packed-triangle path's workspace, which its one-launch q -> x / p -> n kernel does not use.  False when the
+// call will not take that path (the decision tree of cas_eval_batched below).
+static bool cas_w_block(int N, int M, int batch, unsigned eri_flags, double* work, double** W)
+{
+    if (N > 48 || oovqe_opt(OOVQE_OPT_CAS_UNFUSED) != 0 || oovqe_opt(OOVQE_OPT_SYM_MIRROR) != 0 ||
+        oovqe_opt(OOVQE_OPT_SYM_SIMPLE) != 0 || oovqe_opt(OOVQE_OPT_SYM_TWO_STEP) != 0 ||
+        oovqe_opt(OOVQE_OPT_PANEL_NO_W) != 0 || (eri_flags & OOVQE_ERI_PQ_SYMMETRIC) == 0)
+        return false;
+    FusedPlan fp;
+    if (!fused_plan(N, M, batch, &fp)) return false;
+    const long m2 = (long)M * M, m3 = m2 * M;
+    const long tri = (long)N * (N + 1) / 2;
+    const long nty16 = (m2 + 15) / 16 * 16;
+    if (tri * nty16 + 2 * (long)N * m3 > 2 * (long)N * N * m2) return false;
+    *W = work + (size_t)batch * tri * nty16;
+    return true;
+}
+
 static int cas_eval_batched(const double* g_ao, const double* h_ao, const double* C,
                             const double* gamma, const double* Gamma, int nrdm, double nuc,
                             const double* nuc_arr, int N, int n_occ, int ncas, const int32_t* kap_row,
@@ -3878,8 +3905,10 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
                             double* gmat, double* Gm, double* hmo, int batch, size_t out_stride,
                             oovqe_stream_t stream, const oovqe_circuit_job_t* cj = nullptr,
                             unsigned eri_flags = 0, const double* g_packed = nullptr,
-                            const double* T2_ready = nullptr)
+                            const double* T2_ready = nullptr, bool w_ready = false)
 {
+    // w_ready: the caller's circuit launch has left W = C^T h_ao [G][N][N] in this workspace's T3 block
+    // (cas_w_block: packed-triangle path, one-launch q -> x / p -> n kernel)
     // T2_ready [G][N][N][M][M]: the caller has stage 1's result in memory (the Hessian call); the
     // packed-triangle path then builds its J from it instead of reading the integrals again
     // cj: circuit + RDM evaluations that produce gamma / Gamma; they ride along the p -> n
@@ -3908,6 +3937,7 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
     FusedPlan fp;
     const bool fused = !unfused_env && fused_plan(N, M, batch, &fp);
     const double* Gm_in = nullptr;
+    const double* Wpre = nullptr;
     // p <-> q symmetric integrals (verified by the caller): only the slabs p <= q are read
     const bool pq_sym = (eri_flags & OOVQE_ERI_PQ_SYMMETRIC) != 0;
     // r <-> s symmetric as well: J[p,q,y,z] == J[p,q,z,y], the packed path keeps the columns y <= z
@@ -3946,6 +3976,12 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
         }
         if (!two_step) {
             if ((rc = sym_gm_batched(Jp, C, Gmw, N, M, batch, st, cj, rs_sym))) return rc;
+            if (w_ready) {                                       // (the block this path leaves unused)
+                double* wchk = nullptr;
+                OOVQE_REQUIRE(cas_w_block(N, M, batch, eri_flags, work, &wchk) && wchk == T3,
+                              "cas_eval: W = C^T h was promised for another path");
+                Wpre = T3;
+            }
         } else {
             if ((rc = sym_q_contract_batched(Jp, C, T3, N, M, batch, st))) return rc;
             oovqe_profile_mark_start_l(st, 2);
@@ -4040,14 +4076,20 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
     const size_t lds_cap = 160 * 1024;
     if (fused || sym_packed) {
         // panel kernel: npan general indices per workgroup, about one resident round of workgroups
-        const size_t fixed_bytes = ((size_t)N * M + (size_t)N * N) * sizeof(double);
-        const size_t per_n = ((size_t)m3 + 2 * (size_t)N + 2 * (size_t)M) * sizeof(double);
+        const size_t fixed_bytes = ((size_t)N * M + (Wpre ? 0 : (size_t)N * N)) * sizeof(double);
+        const size_t per_n = ((size_t)m3 + (Wpre ? 1 : 2) * (size_t)N + 2 * (size_t)M) * sizeof(double);
         OOVQE_REQUIRE(fixed_bytes + per_n + set_bytes <= lds_cap, "cas_eval: N=%d M=%d needs %zu B of LDS",
                       N, M, fixed_bytes + per_n + set_bytes);
         long npan = ((long)N * batch + 383) / 384;
         const long npan_max = (long)((lds_cap - fixed_bytes - set_bytes) / per_n);
         if (npan > npan_max) npan = npan_max;
         if (npan > 8) npan = 8;   // (two workgroups per CU: 40 us against 47 us with panels of 16 at 256 geometries)
+        if (Wpre) {
+            // without h_ao in LDS a panel of this many general indices leaves room for THREE workgroups per CU
+            // (N = 43, M = 9: 7 indices, 51 KB; 39 -> 31 us at 256 geometries)
+            const long n3 = (long)((lds_cap / 3 - fixed_bytes - set_bytes) / per_n);
+            if (n3 >= 4 && n3 < npan) npan = n3;
+        }
         if (oovqe_opt(OOVQE_OPT_PANEL_ROWS) > 0) npan = oovqe_opt(OOVQE_OPT_PANEL_ROWS);   // measurement hook
         if (npan < 1) npan = 1;
         int rdm_chunk = (int)((lds_cap - fixed_bytes - (size_t)npan * per_n) / set_bytes);
@@ -4070,7 +4112,7 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
                            xcd_grid ? dim3(npanels * (unsigned)((batch + 7) / 8 * 8)) : dim3(npanels, batch),
                            dim3(PAN_THREADS), lds_bytes, st, Gm_in, h_ao, C, gamma, Gamma, nrdm, N, n_occ,
                            ncas, (int)npan, Fcol, Epart, Cpart, c1, c2, Gm, hmo, out_stride, rdm_chunk,
-                           xcd_grid ? batch : 0);
+                           xcd_grid ? batch : 0, Wpre);
         oovqe_profile_mark_stop(st);
         OOVQE_CHECK_LAUNCH("cas_eval/panel");
     } else {
@@ -4238,11 +4280,18 @@ static int oo_eval_batched(const double* theta, int n_theta, const oovqe_gate_t*
             if ((ntile + 1) * batch > 3L * device_cu_count()) ride = false;
         }
     }
+    bool w_ready = false;
     if (!ride) {
+        // the circuit as a launch of its own: W = C^T h_ao of every geometry comes from extra workgroups of that
+        // launch when the panel kernel will take it (packed-triangle path, small circuit, T2 not from a caller)
+        double* Wpre = nullptr;
+        if (oovqe_circuit_rdms_is_small(n_qubits, ncas, nvec, n_gates) && batch <= 32767)
+            w_ready = cas_w_block(N, n_occ + ncas, batch, eri_flags, cas_work, &Wpre);
         oovqe_profile_mark_start_l((hipStream_t)stream, 1);
-        int rc = oovqe_circuit_rdms(theta, n_theta, gates, n_gates, n_qubits, ncas, init_index,
-                                    derivatives, batch, psi, derivatives ? dpsi : nullptr, gamma, Gamma,
-                                    rwork, stream);
+        int rc = oovqe_circuit_rdms_w(theta, n_theta, gates, n_gates, n_qubits, ncas, init_index,
+                                      derivatives, batch, psi, derivatives ? dpsi : nullptr, gamma, Gamma,
+                                      rwork, w_ready ? h_ao : nullptr, w_ready ? C : nullptr, N,
+                                      w_ready ? Wpre : nullptr, stream);
         if (rc) return rc;
         oovqe_profile_mark_stop((hipStream_t)stream);
     }
@@ -4258,7 +4307,7 @@ static int oo_eval_batched(const double* theta, int n_theta, const oovqe_gate_t*
     return cas_eval_batched(g_ao, h_ao, C, gamma, Gamma, nvec, nuc, nuc_arr, N, n_occ, ncas, kap_row,
                             kap_col, n_kappa, cas_work, c0, c1, c2, E, gvec, dE, fock, nullptr,
                             nullptr, nullptr, batch, out_stride, stream, ride ? &cj : nullptr, eri_flags,
-                            g_packed, T2_ready);
+                            g_packed, T2_ready, w_ready);
 }
 
 // hessian.hip (oovqe_oo_hessian_batch): the batched evaluation with the generalized Fock matrices

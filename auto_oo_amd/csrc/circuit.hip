@@ -382,9 +382,49 @@ void circuit_rdm_small_kernel(const double* __restrict__ theta, int n_theta,
                               const oovqe_gate_t* __restrict__ gates, int n_gates, int n_qubits,
                               int ncas, uint32_t init_index, int n_tan, double* __restrict__ psi_out,
                               double* __restrict__ dpsi_out, double* __restrict__ gamma,
-                              double* __restrict__ Gamma)
+                              double* __restrict__ Gamma, int batch, const double* __restrict__ h_ao,
+                              const double* __restrict__ C, int N, double* __restrict__ Wpre)
 {
     extern __shared__ double lds[];
+    if ((int)blockIdx.x >= batch) {
+        // Extra workgroups of this launch (they run beside the circuit workgroups: the launch is one short
+        // resident round): W = C^T h_ao of geometry blockIdx.x - batch for the Fock stage's panel kernel, which
+        // otherwise stages all of h_ao in EVERY panel workgroup to form its own rows.  The same two-accumulator
+        // sums as there: the same bits.  h_ao and C through LDS (2 N^2 doubles, N <= 48).
+        const int g = (int)blockIdx.x - batch;
+        const double* __restrict__ hg = h_ao + (size_t)g * N * N;
+        const double* __restrict__ Cg = C + (size_t)g * N * N;
+        double* __restrict__ Wg = Wpre + (size_t)g * N * N;
+        double* hs = lds;
+        double* cs = lds + (size_t)N * N;
+        constexpr int IT = (48 * 48 + SMALL_THREADS - 1) / SMALL_THREADS;
+        double rh[IT], rc[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int idx = threadIdx.x + it * SMALL_THREADS;
+            const int ic = idx < N * N ? idx : 0;
+            rh[it] = hg[ic];
+            rc[it] = Cg[ic];
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int idx = threadIdx.x + it * SMALL_THREADS;
+            if (idx < N * N) { hs[idx] = rh[it]; cs[idx] = rc[it]; }
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < N * N; idx += SMALL_THREADS) {
+            const int n = idx / N, q = idx - n * N;
+            double a0 = 0.0, a1 = 0.0;
+            int p = 0;
+            for (; p + 1 < N; p += 2) {
+                a0 += cs[p * N + n] * hs[p * N + q];
+                a1 += cs[(p + 1) * N + n] * hs[(p + 1) * N + q];
+            }
+            if (p < N) a0 += cs[p * N + n] * hs[p * N + q];
+            Wg[idx] = a0 + a1;
+        }
+        return;
+    }
     circuit_rdm_small_body(theta, n_theta, gates, n_gates, n_qubits, ncas, init_index, n_tan, psi_out,
                            dpsi_out, gamma, Gamma, (int)blockIdx.x, lds);
 }
@@ -615,17 +655,37 @@ extern "C" int oovqe_circuit_rdms_is_small(int n_qubits, int ncas, int nvec, int
     return n_qubits <= 10 && small_lds_bytes(n_qubits, ncas, nvec, n_gates) <= 150 * 1024;
 }
 
+// cas.hip: the same with W = C^T h_ao [batch][N][N] of every geometry formed by extra workgroups of the launch
+// (small circuits only: the caller has checked oovqe_circuit_rdms_is_small; N <= 48)
+int oovqe_circuit_rdms_w(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates, int n_qubits,
+                         int ncas, uint32_t init_index, int want_tangents, int batch, double* psi, double* dpsi,
+                         double* gamma, double* Gamma, double* work, const double* h_ao, const double* C, int N,
+                         double* Wpre, oovqe_stream_t stream);
+
 extern "C" int oovqe_circuit_rdms(const double* theta, int n_theta, const oovqe_gate_t* gates,
                                   int n_gates, int n_qubits, int ncas, uint32_t init_index,
                                   int want_tangents, int batch, double* psi, double* dpsi,
                                   double* gamma, double* Gamma, double* work, oovqe_stream_t stream)
+{
+    return oovqe_circuit_rdms_w(theta, n_theta, gates, n_gates, n_qubits, ncas, init_index, want_tangents, batch, psi,
+                                dpsi, gamma, Gamma, work, nullptr, nullptr, 0, nullptr, stream);
+}
+
+int oovqe_circuit_rdms_w(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates, int n_qubits,
+                         int ncas, uint32_t init_index, int want_tangents, int batch, double* psi, double* dpsi,
+                         double* gamma, double* Gamma, double* work, const double* h_ao, const double* C, int N,
+                         double* Wpre, oovqe_stream_t stream)
 {
     OOVQE_REQUIRE(theta && gates && gamma && Gamma, "circuit_rdms: null pointer");
     OOVQE_REQUIRE(n_qubits == 2 * ncas && ncas >= 1 && ncas <= 13, "circuit_rdms: bad sizes");
     OOVQE_REQUIRE(n_theta >= 1 && n_gates >= 1 && batch >= 1, "circuit_rdms: bad sizes");
     const int n_tan = want_tangents ? n_theta : 0;
     const int nvec = 1 + n_tan;
-    const size_t lds_bytes = small_lds_bytes(n_qubits, ncas, nvec, n_gates);
+    size_t lds_bytes = small_lds_bytes(n_qubits, ncas, nvec, n_gates);
+    OOVQE_REQUIRE(!Wpre || (h_ao && C && N >= 1 && N <= 48 && oovqe_circuit_rdms_is_small(n_qubits, ncas, nvec, n_gates) &&
+                            batch <= 32767),
+                  "circuit_rdms: W = C^T h rides with the one-workgroup circuit kernel (N <= 48)");
+    if (Wpre && (size_t)2 * N * N * sizeof(double) > lds_bytes) lds_bytes = (size_t)2 * N * N * sizeof(double);
     if (oovqe_circuit_rdms_is_small(n_qubits, ncas, nvec, n_gates)) {
         static bool attr_done = false;
         if (!attr_done) {
@@ -638,9 +698,9 @@ extern "C" int oovqe_circuit_rdms(const double* theta, int n_theta, const oovqe_
             }
             attr_done = true;
         }
-        hipLaunchKernelGGL(circuit_rdm_small_kernel, dim3(batch), dim3(SMALL_THREADS), lds_bytes,
+        hipLaunchKernelGGL(circuit_rdm_small_kernel, dim3(Wpre ? 2 * batch : batch), dim3(SMALL_THREADS), lds_bytes,
                            (hipStream_t)stream, theta, n_theta, gates, n_gates, n_qubits, ncas,
-                           init_index, n_tan, psi, dpsi, gamma, Gamma);
+                           init_index, n_tan, psi, dpsi, gamma, Gamma, batch, h_ao, C, N, Wpre);
         OOVQE_CHECK_LAUNCH("circuit_rdms/small");
         return 0;
     }

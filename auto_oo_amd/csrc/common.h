@@ -52,6 +52,7 @@ enum oovqe_option_t {
     OOVQE_OPT_SECTOR_LAMBDA_W,       // sector adjoint: 1 = lambda through W = Ms^T V in memory (round 3) whatever the batch, 2 = the string-driven form whatever the batch, 3 = the same (kept for the tools), 4 = that with multiplier / helper waves (sector_lambda_pipe_kernel: measured, slower) (0: by batch size)
     OOVQE_OPT_SECTOR_RDM_R3,         // sector RDMs: 1 = the round-3 fused kernel (chunks of 128 consecutive determinants) whatever the batch, 2 = row chunks in the sigma basis whatever the batch (0: by batch size)
     OOVQE_OPT_GM_THREE_PER_CU,       // sym_gm_kernel at N = 41 ... 44: 1 = the three-workgroups-per-CU build (measured: slower)
+    OOVQE_OPT_PANEL_NO_W,            // cas_panel_kernel always stages h_ao and forms its rows of C^T h itself (no W from the circuit launch)
     OOVQE_OPT_COUNT
 };
 int oovqe_opt(int id);
