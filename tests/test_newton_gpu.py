@@ -624,6 +624,22 @@ def test_one_call_newton_step_equals_the_step_driven_call_by_call():
     assert (low1 - ta[0][4]).abs().max() < 1e-9
 
 
+@pytest.mark.parametrize("N,freeze", [(13, False), (43, True), (52, False)])
+def test_full_hessian_one_call_equals_the_three_blocks(N, freeze):
+    """OO_pqc.full_hessian (oo_pqc.py:136-148) as ONE library call (the batched entry point on a stack of one
+    geometry, on the object's own tensors) against the three calls + concatenations it replaces
+    (``hessian_by_blocks``): the same launches, the same bits; beyond N = 48 the three calls stay."""
+    ooo, opqc, oo, pqc = _setup(N, 20261 + N, freeze_active=freeze)
+    theta = torch.tensor(np.random.default_rng(N).uniform(0, 2 * np.pi, pqc.theta_shape))
+    H1 = oo.full_hessian(theta)
+    assert ("_hess1_plans" in oo.__dict__) == (N <= 48)          # (beyond N = 48 the three calls stay)
+    oo.hessian_by_blocks = True
+    H3 = oo.full_hessian(theta)
+    assert H1.shape == H3.shape and torch.equal(H1, H3)
+    oo.hessian_by_blocks = False
+    assert torch.equal(oo.full_hessian(theta.cuda()), H1)
+
+
 def test_one_call_newton_step_beyond_the_cholesky_kernel():
     """N = 64: n_theta + n_kappa = 520 is beyond the one-workgroup Cholesky (495), so every direction of the
     one-call step comes from the band route on the calling stream (no fast path, nothing on the side stream) --
