@@ -638,6 +638,14 @@ def test_full_hessian_one_call_equals_the_three_blocks(N, freeze):
     assert H1.shape == H3.shape and torch.equal(H1, H3)
     oo.hessian_by_blocks = False
     assert torch.equal(oo.full_hessian(theta.cuda()), H1)
+    if N == 13:
+        # integrals without the p <-> q / r <-> s symmetries (an in-place edit: the flags are re-verified): the
+        # general-tensor kernels behind both forms
+        oo.int2e_ao[0, 1, 2, 3] += 0.25
+        assert oo._eri_flags() == 0
+        Hg1 = oo.full_hessian(theta)
+        oo.hessian_by_blocks = True
+        assert torch.equal(oo.full_hessian(theta), Hg1) and not torch.equal(Hg1, H1)
 
 
 def test_one_call_newton_step_beyond_the_cholesky_kernel():
