@@ -189,6 +189,8 @@ SIGNATURES = {
                                            ctypes.c_uint, c_double_p, c_stream]),
     "oovqe_eri_packed_size": (ctypes.c_int64, [ctypes.c_int]),
     "oovqe_eri_pack": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, c_stream]),
+    "oovqe_eri_ingest": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_int, c_double_p,
+                                        ctypes.POINTER(ctypes.c_uint), c_stream]),
     "oovqe_circuit_rdms_is_small": (ctypes.c_int, [ctypes.c_int] * 4),
     "oovqe_spin_rdms": (ctypes.c_int, [c_double_p, c_double_p, ctypes.c_int, ctypes.c_int, c_double_p,
                                        c_double_p, c_stream]),

@@ -71,11 +71,11 @@ class OO_pqc_batch:
             nuc_host[g] = m.nuc
         self.nuc.copy_(torch.as_tensor(nuc_host))
         # exact p<->q / r<->s symmetry of every geometry's integrals (true for PySCF's int2e), verified
-        # bit for bit per geometry: the batch runs on the flags ALL its geometries share.  int2e_ao must
+        # bit for bit per geometry, and the packed resident copy the batched N^4 pass streams: ONE pass over the
+        # stack (oovqe_eri_ingest).  The batch runs on the flags ALL its geometries share.  int2e_ao must
         # not be modified in place afterwards (set_molecule / reverify_integrals are the ways in).
-        self._flags_g = self._stack_flags()
         self._eri_packed = None
-        self._refresh_flags(repack=range(self.G))
+        self._ingest()
         self._plans = {}
         self._flat0 = None
         self._trial_orbitals = None
@@ -94,16 +94,15 @@ class OO_pqc_batch:
         """Call after writing into ``int2e_ao`` (or ``int1e_ao`` / ``oao_coeff`` / ``nuc``) in place,
         e.g. when the integrals of many geometries are produced on the device: re-checks the
         symmetry flags of the whole stack bit for bit, rebuilds the packed resident copy (or drops
-        it) and refreshes ``mo_coeff = S^-1/2 C_oao`` of every geometry."""
-        self._flags_g = self._stack_flags()
-        self._refresh_flags(repack=range(self.G))
+        it) -- one pass over the stack -- and refreshes ``mo_coeff = S^-1/2 C_oao`` of every geometry."""
+        self._ingest()
         self.refresh_mo_coeff()
 
     def set_molecule(self, g, mol, oao_mo_coeff=None):
         """Replace geometry g of the batch (the next point of a Berry-phase loop, say): integrals,
         OAO basis, nuclear repulsion and orbitals.  The symmetry flags of the batch are re-verified
-        for the new integrals and its slice of the packed copy is rebuilt -- never write into
-        ``int2e_ao`` directly, the flags and the packed copy would go stale."""
+        for the new integrals and its slice of the packed copy is rebuilt (one pass over the new tensor) -- never
+        write into ``int2e_ao`` directly, the flags and the packed copy would go stale."""
         if mol.nao != self.nao:
             raise ValueError("all geometries of a batch must share nao")
         self.int2e_ao[g].copy_(ops.as_device(mol.int2e_ao, self.device))
@@ -114,43 +113,34 @@ class OO_pqc_batch:
             mol.run_rhf()
             oao_mo_coeff = mo_ao_to_mo_oao(mol.hf.mo_coeff, mol.overlap)
         self.set_oao_mo_coeff(g, oao_mo_coeff)
-        self._flags_g[g] = ops.eri_flags(self.int2e_ao[g])
-        self._refresh_flags(repack=[g])
+        self._ingest(g)
 
-    def _stack_flags(self):
-        """Per-geometry symmetry flags of the whole stack: one pass when every geometry carries both
-        symmetries (the common case), a pass per geometry otherwise."""
+    def _ingest(self, g=None):
+        """Symmetry flags and packed copy of geometry ``g`` (None: of the whole stack) from one pass over the
+        integrals (``ops.eri_ingest``).  eri_flags = the symmetries every geometry of the stack has (a geometry
+        replaced by a symmetric one can RESTORE a flag, not only drop it); the packed copy (slabs p <= q, upper
+        triangle of each slab: about a quarter of the tensor) exists while every geometry carries both."""
         both = ops.ERI_PQ_SYMMETRIC | ops.ERI_RS_SYMMETRIC
-        if ops.eri_flags(self.int2e_ao) == both:
-            return [both] * self.G
-        return [ops.eri_flags(self.int2e_ao[g]) for g in range(self.G)]
-
-    def _refresh_flags(self, repack):
-        """eri_flags = the symmetries every geometry of the stack has (a geometry replaced by a
-        symmetric one can RESTORE a flag, not only drop it); with both of them the packed resident
-        copy (slabs p <= q, upper triangle of each slab: about a quarter of the tensor) that the batched
-        N^4 pass streams is kept up to date: the geometries in ``repack``, or all of them when the copy
-        did not exist."""
-        flags = ops.ERI_PQ_SYMMETRIC | ops.ERI_RS_SYMMETRIC
+        psz = int(self.lib.oovqe_eri_packed_size(self.nao))
+        want = psz > 0 and not (self.nao <= 48 and self._n_occ + self.ncas > 16)
+        had = self._eri_packed is not None
+        if want and not had:
+            self._eri_packed = torch.empty((self.G, psz), dtype=F64, device=self.device)
+        if g is None:
+            self._flags_g, _ = ops.eri_ingest(self.int2e_ao, pack=want, out=self._eri_packed)
+        else:
+            (self._flags_g[g],), _ = ops.eri_ingest(self.int2e_ao[g], pack=want,
+                                                    out=self._eri_packed[g] if want else None)
+        flags = both
         for f in self._flags_g:
             flags &= f
         self.eri_flags = flags
-        both = ops.ERI_PQ_SYMMETRIC | ops.ERI_RS_SYMMETRIC
-        psz = self.lib.oovqe_eri_packed_size(self.nao)
-        if flags != both or psz <= 0 or (self.nao <= 48 and self._n_occ + self.ncas > 16):
+        if flags != both:
             self._eri_packed = None
-            return
-        repack = list(repack)
-        if self._eri_packed is None:
-            self._eri_packed = torch.empty((self.G, psz), dtype=F64, device=self.device)
-            repack = list(range(self.G))
-        if len(repack) == self.G:
+        elif want and not had and g is not None:
+            # the new geometry restored the last missing flag: the other slices of the copy are made now
             check(self.lib.oovqe_eri_pack(dptr(self.int2e_ao), self.nao, self.G, dptr(self._eri_packed),
                                           stream_ptr()), "oovqe_eri_pack")
-        else:
-            for g in repack:
-                check(self.lib.oovqe_eri_pack(dptr(self.int2e_ao[g]), self.nao, 1, dptr(self._eri_packed[g]),
-                                              stream_ptr()), "oovqe_eri_pack")
 
     def refresh_mo_coeff(self):
         """mo_coeff[g] = S^-1/2[g] C_oao[g] for the whole stack (oo_energy.py:173-176), one launch."""
@@ -194,10 +184,36 @@ class OO_pqc_batch:
             "oovqe_oo_eval_batch")
         return out
 
-    def energy_and_gradient(self, thetas, count=None, slot=0):
-        """-> [G, 1 + n_theta + n_kappa]: column 0 = E, then dE/dtheta, then dE/dkappa."""
+    def evaluate_deferred(self, thetas, derivatives=True, count=None, mo_coeff=None, view=None):
+        """``evaluate`` enqueued on one of the library's two side streams (taken in turn, each with a workspace of its
+        own) -> ``ops.PendingTensor``; ``.result()`` joins it to the stream that is current then.  For INDEPENDENT calls
+        issued back to back (a scan over parameter sets, the points of several loops, a benchmark's steps): the
+        latency-bound tail of one call (q -> x / p -> n, Fock panels, assembly: a quarter of a 256-geometry call,
+        during which HBM idles) runs under the N^4 sweep of the next call instead of in front of it.  The inputs
+        must be complete on the current stream when this is called (the side stream is forked from it here);
+        per call the launches and the arithmetic are those of ``evaluate``: the same bits."""
+        side_streams = ops.side_streams(self.device)
+        k = self._defer_next = (getattr(self, "_defer_next", 1) + 1) & 1
+        side = side_streams[k]
+        side.wait_stream(torch.cuda.current_stream())
+        thetas = ops.as_device(thetas, self.device)
+        with torch.cuda.stream(side):
+            out = self.evaluate(thetas, derivatives=derivatives, count=count, slot=1 + k, mo_coeff=mo_coeff)
+            event = torch.cuda.Event()
+            event.record(side)
+        thetas.record_stream(side)
+        if mo_coeff is not None:
+            mo_coeff.record_stream(side)
+        return ops.PendingTensor(out, event, view)
+
+    def energy_and_gradient(self, thetas, count=None, slot=0, defer=False):
+        """-> [G, 1 + n_theta + n_kappa]: column 0 = E, then dE/dtheta, then dE/dkappa.
+        ``defer``: -> ``ops.PendingTensor`` of the same (``evaluate_deferred``)."""
+        n_out = 2 + self.n_theta + self.n_kappa
+        if defer:
+            return self.evaluate_deferred(thetas, derivatives=True, count=count, view=lambda o: o[:, 1:n_out])
         out = self.evaluate(thetas, derivatives=True, count=count, slot=slot)
-        return out[:, 1:2 + self.n_theta + self.n_kappa]
+        return out[:, 1:n_out]
 
     def energy(self, thetas, kappas=None):
         """-> [G] energies (OO_pqc.energy_from_parameters(theta, kappa) per geometry, oo_pqc.py:64-84).
@@ -326,7 +342,7 @@ class OO_pqc_batch:
             t_oao, t_mo = self._trial_orbitals
             self._trial_orbitals = (self.oao_mo_coeff, self.mo_coeff)
             self.oao_mo_coeff, self.mo_coeff = t_oao, t_mo
-        return new_thetas, energies, (low if defer_lowest else low.result())
+        return new_thetas, energies, (low if defer_lowest else low.checked())
 
     def _step_block(self):
         """The argument block of oovqe_oo_newton_step_batch with everything that does not change from step to
@@ -402,7 +418,8 @@ class OO_pqc_batch:
         t_oao, t_mo = self._trial_orbitals
         b.theta = thetas.data_ptr()
         b.g_ao, b.h_ao, b.nuc = self.int2e_ao.data_ptr(), self.int1e_ao.data_ptr(), self.nuc.data_ptr()
-        b.g_packed = self._eri_packed.data_ptr() if self.eri_flags == 3 else None
+        b.g_packed = (self._eri_packed.data_ptr() if (self.eri_flags == 3 and self._eri_packed is not None)
+                      else None)        # (no packed copy exists for M > 16 at N <= 48: _refresh_flags)
         b.eri_flags = int(self.eri_flags)
         b.oao_coeff, b.oao_mo_coeff, b.mo_coeff = (self.oao_coeff.data_ptr(), self.oao_mo_coeff.data_ptr(),
                                                    self.mo_coeff.data_ptr())
@@ -415,21 +432,42 @@ class OO_pqc_batch:
         b.speculate = int(spec)
         side = ops._side_stream(self.device)
         b.work_rest_side = keep["work_side"][ops.side_streams(self.device).index(side)].data_ptr()
-        check(self.lib.oovqe_oo_newton_step_batch(ctypes.byref(b), stream_ptr(), ctypes.c_void_p(side.cuda_stream)),
-              "oovqe_oo_newton_step_batch")
+        refused = False
+        try:
+            check(self.lib.oovqe_oo_newton_step_batch(ctypes.byref(b), stream_ptr(), ctypes.c_void_p(side.cuda_stream)),
+                  "oovqe_oo_newton_step_batch")
+        except _lib.OovqeError:
+            # beyond N = 48 the trial's orbital rotation fails loudly on a direction the library refused (dp = NaN):
+            # the search below repeats that direction without inter-workgroup waits / through eigh, or raises
+            torch.cuda.current_stream().wait_stream(side)
+            if min(slab[offs["info"][0]:offs["info"][0] + G].tolist()) >= 0:
+                raise
+            refused = True
         event = torch.cuda.Event()
         event.record(side)
         slab.record_stream(side)
         # (the views are made while the device works through the step, the readback comes last)
         state = view("state", 3, G)
+        lam_args = (float(opt.lambda_min), float(opt.mu), float(opt.rho), int(bool(opt.aug)))
+
+        def retry_lowest():
+            # eigenvalues the side route could not deliver: again on the calling stream, one workgroup per problem
+            check(self.lib.oovqe_newton_direction_rest(
+                dptr(view("hessian", G, n, n)), dptr(view("grad", G, n)), n, G, *lam_args, dptr(view("info", G)), 2, 1,
+                dptr(keep["work_rest"]), dptr(view("dp", G, n)), dptr(view("lowest", G)), dptr(view("shift", G)),
+                stream_ptr()), "oovqe_newton_direction_rest")
+
         s = LockstepSearch(flat=keep["flat"], g=view("grad", G, n), H=view("hessian", G, n, n), dp=view("dp", G, n),
-                           low=ops.PendingLowest(view("lowest", G), event), nu=view("shift", G),
+                           low=ops.PendingLowest(view("lowest", G), event, retry_lowest), nu=view("shift", G),
                            info=view("info", G), energy=view("energy", G), t=view("t", G), active=state[0],
                            best=state[1], slope=state[2], flags=view("flags", 4), pa=view("points_a", G, nt),
                            pb=view("points_b", G, nk))
-        fl = s.flags.tolist()                        # the one readback of the common case
+        fl = [1.0, -1.0, 0.0, 0.0] if refused else s.flags.tolist()    # the one readback of the common case
         self._all_pd_last_step = fl[1] >= 1.0
-        if spec and fl[1] < 1.0:
+        if refused:
+            s.t.fill_(1.0)
+            fl = None
+        elif spec and fl[1] < 1.0:
             # some Hessian was not positive definite after all: its direction is still on the side stream.  Join it
             # and search from the start.
             torch.cuda.current_stream().wait_event(event)

@@ -59,7 +59,8 @@ static const char* const g_opt_names[OOVQE_OPT_COUNT] = {
     "half_stream_old", "gm_two_per_cu", "gm_one_per_cu", "fused_chunks", "tri_plain_w", "cas_unfused",
     "sym_no_rs", "sym_mirror", "sym_simple", "sym_two_step", "no_ride", "tri_mode", "k1_no_pair", "k1_force_wide", "gm_plain_grid",
     "newton_one_wg", "sector_unfused", "sector_probe", "hess_vk_pass", "hess_own_stage1", "panel_rows",
-    "k1_force_nt", "newton_no_chol", "tiles_variant", "sector_lambda_w", "sector_rdm_r3", "gm_three_per_cu", "panel_no_w"};
+    "k1_force_nt", "newton_no_chol", "tiles_variant", "sector_lambda_w", "sector_rdm_r3", "gm_three_per_cu", "panel_no_w",
+    "stage1_free_run", "one_stream"};
 static_assert(sizeof(g_opt_names) / sizeof(g_opt_names[0]) == OOVQE_OPT_COUNT, "option name table out of step with oovqe_option_t");
 
 int oovqe_opt(int id) { return (id >= 0 && id < OOVQE_OPT_COUNT) ? g_opts[id] : 0; }
@@ -89,6 +90,83 @@ extern "C" int oovqe_debug_get_option(const char* name)
     for (int i = 0; name && i < OOVQE_OPT_COUNT; ++i)
         if (strcmp(name, g_opt_names[i]) == 0) return g_opts[i];
     return -1;
+}
+
+// ---- a ring of events and two internal streams per device (common.h) --------------------------------
+namespace {
+struct Internals {
+    hipEvent_t ev[64] = {};
+    hipStream_t st[2] = {nullptr, nullptr};
+    unsigned next = 0;
+    bool tried = false;
+};
+Internals g_int[16];
+std::mutex g_int_mu;
+
+Internals* internals()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    Internals& I = g_int[dev];
+    if (!I.tried) {
+        I.tried = true;
+        for (int i = 0; i < 64; ++i)
+            if (hipEventCreateWithFlags(&I.ev[i], hipEventDisableTiming) != hipSuccess) I.ev[i] = nullptr;
+        for (int i = 0; i < 2; ++i)
+            if (hipStreamCreateWithFlags(&I.st[i], hipStreamNonBlocking) != hipSuccess) I.st[i] = nullptr;
+    }
+    return &I;
+}
+}  // namespace
+
+hipEvent_t oovqe_internal_event()
+{
+    std::lock_guard<std::mutex> lock(g_int_mu);
+    Internals* I = internals();
+    // (a wait enqueued on an event refers to the record that preceded it: re-recording the event later, 64 uses
+    // on, does not disturb it)
+    return I ? I->ev[I->next++ & 63] : nullptr;
+}
+
+hipStream_t oovqe_internal_stream(int k)
+{
+    if (oovqe_opt(OOVQE_OPT_ONE_STREAM) != 0 || k < 0 || k > 1) return nullptr;
+    std::lock_guard<std::mutex> lock(g_int_mu);
+    Internals* I = internals();
+    return I ? I->st[k] : nullptr;
+}
+
+static hipStream_t g_s1_stream[16];
+static hipEvent_t g_s1_event[16];
+
+int oovqe_stage1_enter(hipStream_t st)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+    if (oovqe_opt(OOVQE_OPT_STAGE1_FREE_RUN) != 0) return 0;
+    hipEvent_t ev;
+    hipStream_t last;
+    {
+        std::lock_guard<std::mutex> lock(g_int_mu);
+        ev = g_s1_event[dev];
+        last = g_s1_stream[dev];
+    }
+    if (ev && last != st) OOVQE_CHECK_HIP(hipStreamWaitEvent(st, ev, 0), "stage 1: hipStreamWaitEvent");
+    return 0;
+}
+
+int oovqe_stage1_leave(hipStream_t st)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+    if (oovqe_opt(OOVQE_OPT_STAGE1_FREE_RUN) != 0) return 0;
+    hipEvent_t ev = oovqe_internal_event();
+    if (!ev) return 0;
+    OOVQE_CHECK_HIP(hipEventRecord(ev, st), "stage 1: hipEventRecord");
+    std::lock_guard<std::mutex> lock(g_int_mu);
+    g_s1_event[dev] = ev;
+    g_s1_stream[dev] = st;
+    return 0;
 }
 
 // ---- optional HIP-event timing of the evaluation kernels (bench.py: roofline + breakdown) -------

@@ -1444,6 +1444,81 @@ void eri_pack_kernel(const double* __restrict__ g, double* __restrict__ out, int
     }
 }
 
+// Ingest of a stack of AO tensors in ONE pass over them (N <= 48): the bitwise symmetry tests of
+// eri_symmetry_check_kernel AND the packed copy of eri_pack_kernel.  One workgroup per (pair p <= q, geometry):
+// slab (p,q) and its mirror (q,p) are read once each -- every slab of the tensor by exactly one workgroup --,
+// compared word for word, slab (p,q) goes through LDS for the r <-> s test (the transposed element from LDS: the
+// row length N is what it is, no 8-byte gathers from memory as in the two-pass check) and straight into the packed
+// copy.  When the mirror differs, ITS r <-> s symmetry is tested as well (the flags are exact whatever the tensor).
+// HBM traffic: the tensor read once + the copy written (27 % of it at N = 43); the two passes it replaces read the
+// tensor 1.5 x for the check, the slabs p <= q again for the copy.  mismatch[g]: bit 0 = some slab differs from its
+// mirror, bit 1 = some slab is not symmetric in (r, s).  `out` may be null (flags only).
+__global__ __launch_bounds__(256)
+void eri_ingest_kernel(const unsigned long long* __restrict__ g, double* __restrict__ out, int N, unsigned slab_pk,
+                       int* __restrict__ mismatch)
+{
+    __shared__ unsigned long long sl[48 * 48];
+    const long t = blockIdx.x;
+    const long tri = (long)N * (N + 1) / 2;
+    int p, q;
+    tri_decode(t, N, p, q);
+    const int n2 = N * N;
+    const size_t geo = (size_t)blockIdx.y * n2 * n2;
+    const unsigned long long* a = g + geo + ((size_t)p * N + q) * n2;
+    const unsigned long long* b = g + geo + ((size_t)q * N + p) * n2;
+    constexpr int PER = (48 * 48 + 255) / 256;          // 9 elements per thread at most
+    unsigned long long va[PER];
+    bool bad_pq = false;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int idx = threadIdx.x + 256 * j;
+        va[j] = idx < n2 ? a[idx] : 0ull;
+    }
+    if (p < q) {
+        unsigned long long vb[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int idx = threadIdx.x + 256 * j;
+            vb[j] = idx < n2 ? b[idx] : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) bad_pq |= va[j] != vb[j];
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int idx = threadIdx.x + 256 * j;
+        if (idx < n2) sl[idx] = va[j];
+    }
+    const int any_pq = __syncthreads_or(bad_pq);
+    bool bad_rs = false;
+    double* dst = out ? out + ((size_t)blockIdx.y * tri + t) * slab_pk : nullptr;
+    if (dst && threadIdx.x == 0 && slab_pk > eri_tri_row_start(N, N)) dst[slab_pk - 1] = 0.0;   // the pad element
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int idx = threadIdx.x + 256 * j;
+        if (idx >= n2) continue;
+        const int r = idx / N, c = idx - r * N;
+        if (r < c) bad_rs |= va[j] != sl[c * N + r];
+        const int e = r & ~1;
+        if (dst && c >= e) {
+            const double v = __longlong_as_double((long long)va[j]);
+            dst[eri_tri_row_start(r, N) + (c - e)] = c < r ? 0.0 : (c == r ? 0.5 * v : v);
+        }
+    }
+    if (any_pq) {
+        // the mirror slab is a different matrix: its own r <-> s symmetry
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < n2; idx += 256) sl[idx] = b[idx];
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < n2; idx += 256) {
+            const int r = idx / N, c = idx - r * N;
+            if (r < c) bad_rs |= sl[idx] != sl[c * N + r];
+        }
+    }
+    if (bad_pq) atomicOr(mismatch + blockIdx.y, 1);
+    if (bad_rs) atomicOr(mismatch + blockIdx.y, 2);
+}
+
 // ------------------------------------------------------------------------------------------
 // Stage 1 over the upper triangle of slabs (p <-> q symmetric integrals; M <= 16, N <= 48),
 // persistent and software-pipelined like half_transform_fused_kernel, whose load path it shares:
@@ -3361,6 +3436,43 @@ extern "C" int oovqe_eri_symmetry_flags(const double* g_ao, int N, int batch, un
     return 0;
 }
 
+// Ingest of a stack of AO tensors: per-geometry symmetry flags (host array [batch]) and, when `packed` is given,
+// the packed resident copy of EVERY geometry (meaningful for those whose flags carry both bits) -- one pass over
+// g_ao for N <= 48 (eri_ingest_kernel), the check pass + the tile pack beyond.  Synchronises `stream`.
+extern "C" int oovqe_eri_ingest(const double* g_ao, int N, int batch, double* packed, unsigned* eri_flags,
+                                oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(g_ao && eri_flags, "eri_ingest: null pointer");
+    OOVQE_REQUIRE(N >= 1 && N <= 4096 && batch >= 1 && batch <= 65535, "eri_ingest: N=%d batch=%d", N, batch);
+    hipStream_t st = (hipStream_t)stream;
+    if (N > 48) {
+        for (int gi = 0; gi < batch; ++gi) {
+            int rc = oovqe_eri_symmetry_flags(g_ao + (size_t)gi * N * N * N * N, N, 1, eri_flags + gi, stream);
+            if (rc) return rc;
+        }
+        return packed ? oovqe_eri_pack(g_ao, N, batch, packed, stream) : 0;
+    }
+    int* flag = nullptr;
+    OOVQE_CHECK_HIP(hipMalloc(&flag, sizeof(int) * (size_t)batch), "eri_ingest");
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int) * (size_t)batch, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(eri_ingest_kernel, dim3((unsigned)(N * (N + 1) / 2), batch), dim3(256), 0, st,
+                           reinterpret_cast<const unsigned long long*>(g_ao), packed, N, eri_slab_pitch(N), flag);
+        e = hipGetLastError();
+    }
+    int* bad = (int*)malloc(sizeof(int) * (size_t)batch);
+    if (!bad) e = hipErrorOutOfMemory;
+    if (e == hipSuccess) e = hipMemcpyAsync(bad, flag, sizeof(int) * (size_t)batch, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(flag);
+    if (e == hipSuccess)
+        for (int gi = 0; gi < batch; ++gi)
+            eri_flags[gi] = ((bad[gi] & 1) ? 0u : OOVQE_ERI_PQ_SYMMETRIC) | ((bad[gi] & 2) ? 0u : OOVQE_ERI_RS_SYMMETRIC);
+    free(bad);
+    OOVQE_CHECK_HIP(e, "eri_ingest");
+    return 0;
+}
+
 static int sym_q_contract_batched(const double* J, const double* C, double* T3, int N, int M, int batch,
                                   hipStream_t st)
 {
@@ -3676,6 +3788,7 @@ static int half_tri_batched(const double* g_ao, const double* C, int N, int M, d
         if (R == 3) OOVQE_LAUNCH_TRI_REG(KC_, NS_, NPC_, 3);                                      \
         else OOVQE_LAUNCH_TRI_REG(KC_, NS_, NPC_, 4);                                             \
     } while (0)
+        if (int rc_s1 = oovqe_stage1_enter(st)) return rc_s1;
         oovqe_profile_mark_start(st);
         if (kch == 4 && nrb == 1) OOVQE_LAUNCH_TRI_REG_R(4, 1, 2);
         else if (kch == 8 && nrb == 2) OOVQE_LAUNCH_TRI_REG_R(8, 2, 5);
@@ -3689,7 +3802,7 @@ static int half_tri_batched(const double* g_ao, const double* C, int N, int M, d
 #undef OOVQE_LAUNCH_TRI_REG_R
 #undef OOVQE_LAUNCH_TRI_REG
         OOVQE_CHECK_LAUNCH("cas_eval/half_tri_reg");
-        return 0;
+        return oovqe_stage1_leave(st);
     }
     long phase = (long)((160 * 1024 - fixed_bytes) / round_bytes) & ~1L;   // even
     OOVQE_REQUIRE(phase >= 2, "cas_eval: half_tri staging does not fit LDS (M=%d)", M);

@@ -53,12 +53,25 @@ enum oovqe_option_t {
     OOVQE_OPT_SECTOR_RDM_R3,         // sector RDMs: 1 = the round-3 fused kernel (chunks of 128 consecutive determinants) whatever the batch, 2 = row chunks in the sigma basis whatever the batch (0: by batch size)
     OOVQE_OPT_GM_THREE_PER_CU,       // sym_gm_kernel at N = 41 ... 44: 1 = the three-workgroups-per-CU build (measured: slower)
     OOVQE_OPT_PANEL_NO_W,            // cas_panel_kernel always stages h_ao and forms its rows of C^T h itself (no W from the circuit launch)
+    OOVQE_OPT_STAGE1_FREE_RUN,       // 1: N^4 sweeps enqueued on different streams are not ordered one after the other
+    OOVQE_OPT_ONE_STREAM,            // 1: every launch of a call on the caller's stream (no chain of a call on the library's internal streams)
     OOVQE_OPT_COUNT
 };
 int oovqe_opt(int id);
 // raise a kernel's dynamic-LDS limit to `bytes` (cached per kernel AND device, thread-safe); 0 or OOVQE_ERR_HIP
 int oovqe_ensure_dynamic_lds(const void* kernel, size_t bytes);
 void oovqe_note_stage1(const char* fmt, ...);
+// the next event of a small per-device ring (timing disabled; nullptr on failure), and the library's internal
+// streams of the current device (k = 0, 1; made once, non-blocking; nullptr on failure or with option
+// one_stream): independent chains of ONE library call run beside each other, forked from and joined to the
+// caller's stream inside the call -- the caller sees in-order stream semantics.
+hipEvent_t oovqe_internal_event();
+hipStream_t oovqe_internal_stream(int k);
+// Around every launch of the packed N^4 sweep: sweeps enqueued on DIFFERENT streams (calls in flight on two streams:
+// OO_pqc_batch.evaluate_deferred) run one after the other -- each is sized to fill the chip, and the HIP events that
+// bracket a launch for the roofline then time the sweep, not its wait for the CUs of the previous one.
+int oovqe_stage1_enter(hipStream_t st);
+int oovqe_stage1_leave(hipStream_t st);
 
 #define OOVQE_CHECK_LAUNCH(name)                                                          \
     do {                                                                                  \

@@ -222,12 +222,22 @@ int oovqe_mode_contract_batched(const double* T, const double* Cm, double* out, 
 // leading batch axis with the given strides (doubles), every intermediate stacked in `work`
 // (batch * oovqe_orbital_hessian_work_size() doubles); the geometry index is a grid dimension of
 // every launch.  H_matrix element (t1,t2) of geometry b -> H_matrix[b * h_bs + t1 * ldh + t2].
+// The chains of stage 2 that do not depend on each other, beside each other (oovqe_oo_hessian_batch): the K-type
+// integrals and the assembly on sK, the one-electron and J-type integrals on sJ.  Both streams must already wait for
+// stage 1 (T2 / Vk); rdm_ready: recorded by the caller where gamma / Gamma / fock are final; done: recorded on sK
+// behind the last launch (the caller's stream waits for it when it needs the block).
+struct HessFork {
+    hipStream_t sK, sJ;
+    hipEvent_t rdm_ready, done;
+};
+
 static int orbital_hessian_batched(const double* g_ao, const double* h_ao, const double* C,
                                    const double* gamma, long gamma_bs, const double* Gamma, long Gamma_bs,
                                    const double* fock, int N, int n_occ, int ncas, const int32_t* kap_row,
                                    const int32_t* kap_col, int n_kappa, int batch, double* work,
                                    double* H_matrix, long ldh, long h_bs, double* H_full,
-                                   unsigned eri_flags, oovqe_stream_t stream, int stage = 0)
+                                   unsigned eri_flags, oovqe_stream_t stream, int stage = 0,
+                                   HessFork* fork = nullptr)
 {
     // stage 0: everything; 1: stage 1 of the integrals only (T2 and, when available, Vk: needs neither
     // the RDMs nor the Fock matrices); 2: the rest, on the T2 / Vk a stage-1 call left in `work`
@@ -257,8 +267,19 @@ static int orbital_hessian_batched(const double* g_ao, const double* h_ao, const
     double* YjT = YkT + nb * n2 * m2;       // [G][N][N][M*M]
     int rc;
     const long t4 = n2 * n2, y = n2 * m2;
+    // sj / sk: the streams of the J-type (+ one-electron) chain and of the K-type chain + assembly
+    hipStream_t sj = st, sk = st;
+    hipEvent_t ev_ab = nullptr, ev_yj = nullptr;
+    if (fork && stage == 2) {
+        sj = fork->sJ;
+        sk = fork->sK;
+        ev_ab = oovqe_internal_event();
+        ev_yj = oovqe_internal_event();
+        OOVQE_REQUIRE(sj && sk && ev_ab && ev_yj && fork->rdm_ready && fork->done, "orbital_hessian: fork without streams / events");
+    }
+    hipStream_t ms = st;           // the stream the MC macro launches on
 #define MC(T_, tb, C_, cb, O_, ob, ...) \
-    if ((rc = oovqe_mode_contract_batched(T_, C_, O_, __VA_ARGS__, batch, tb, cb, ob, st))) return rc
+    if ((rc = oovqe_mode_contract_batched(T_, C_, O_, __VA_ARGS__, batch, tb, cb, ob, ms))) return rc
     // ---- J-type integrals: g_mo[q,s,m,n] ---------------------------------------------------------
     // p <-> q symmetric integrals, N <= 48: stage 1 also leaves its first products Vk[tri(p,q)][s][n]
     // (the quarter transform of the K-type path), so the AO tensor is read once instead of twice
@@ -268,8 +289,13 @@ static int orbital_hessian_batched(const double* g_ao, const double* h_ao, const
         (rc = oovqe_half_transform_batched_impl(g_ao, C, N, M, T2, batch, eri_flags, stream, vk_tri ? Vk : nullptr)))
         return rc;
     if (stage == 1) return 0;
+    ms = sj;
     MC(T2, y, C, n2, Uj, y, 1, N, N, n * m2, N, 0);          // Uj[q',q,yz]  = sum_p C[p,q'] T2[p,q,yz]
     MC(Uj, y, C, n2, Jint, y, n, N, N, m2, N, 0);            // Jint[q',s',yz] = sum_q C[q,s'] Uj[q',q,yz]
+    // ---- one-electron integrals ------------------------------------------------------------------
+    MC(h_ao, n2, C, n2, X1, n2, 1, N, N, n, N, 0);           // X1 = C^T h
+    MC(X1, n2, C, n2, hmo, n2, n, N, N, 1, N, 1);            // hmo = X1 C
+    ms = sk;
     // ---- K-type integrals: g_mo[q,m,n,s] ---------------------------------------------------------
     if (vk_tri) {
         const size_t lds_bytes = (size_t)m2 * N * sizeof(double);
@@ -279,7 +305,7 @@ static int orbital_hessian_batched(const double* g_ao, const double* h_ao, const
             int rc_lds = oovqe_ensure_dynamic_lds((const void*)t2k_tri_kernel<MT_>, lds_bytes);           \
             if (rc_lds) return rc_lds;                                                                    \
         }                                                                                                 \
-        t2k_tri_kernel<MT_><<<dim3(N, batch), 512, lds_bytes, st>>>(Vk, C, T2K, N, M); /* T2K[p,m,n,s] */  \
+        t2k_tri_kernel<MT_><<<dim3(N, batch), 512, lds_bytes, sk>>>(Vk, C, T2K, N, M); /* T2K[p,m,n,s] */  \
     } while (0)
         if (M <= 4) OOVQE_LAUNCH_T2K(4);
         else if (M <= 8) OOVQE_LAUNCH_T2K(8);
@@ -293,28 +319,34 @@ static int orbital_hessian_batched(const double* g_ao, const double* h_ao, const
     }
     MC(T2K, y, C, n2, W, y, n * m2, N, N, 1, N, 1);          // W[p,m,n,s']  = sum_s T2K[p,m,n,s] C[s,s']
     MC(W, y, C, n2, Kint, y, 1, N, N, m2 * n, N, 0);         // Kint[q',m,n,s'] = sum_p C[p,q'] W[p,m,n,s']
-    // ---- one-electron integrals ------------------------------------------------------------------
-    MC(h_ao, n2, C, n2, X1, n2, 1, N, N, n, N, 0);           // X1 = C^T h
-    MC(X1, n2, C, n2, hmo, n2, n, N, N, 1, N, 1);            // hmo = X1 C
     // ---- Y ------------------------------------------------------------------------------------------
-    hess_ab_kernel<<<dim3(64, batch), 256, 0, st>>>(gamma, Gamma, n_occ, ncas, At, Bt, gamma_bs, Gamma_bs);
+    if (ev_ab) OOVQE_CHECK_HIP(hipStreamWaitEvent(sk, fork->rdm_ready, 0), "orbital_hessian: hipStreamWaitEvent");
+    hess_ab_kernel<<<dim3(64, batch), 256, 0, sk>>>(gamma, Gamma, n_occ, ncas, At, Bt, gamma_bs, Gamma_bs);
+    if (ev_ab) OOVQE_CHECK_HIP(hipEventRecord(ev_ab, sk), "orbital_hessian: hipEventRecord");
     // YkT[q,(pr),s] = sum_(mn) At[(mn),(pr)] Kint[q,(mn),s]
     MC(Kint, y, At, m2 * m2, YkT, y, n, (int)m2, (int)m2, n, (int)m2, 0);
     // YjT[(qs),(pr)] = sum_(mn) Jint[(qs),(mn)] Bt[(mn),(pr)]
+    ms = sj;
+    if (ev_ab) OOVQE_CHECK_HIP(hipStreamWaitEvent(sj, ev_ab, 0), "orbital_hessian: hipStreamWaitEvent");
     MC(Jint, y, Bt, m2 * m2, YjT, y, n2, (int)m2, (int)m2, 1, (int)m2, 1);
+    if (ev_ab) {
+        OOVQE_CHECK_HIP(hipEventRecord(ev_yj, sj), "orbital_hessian: hipEventRecord");
+        OOVQE_CHECK_HIP(hipStreamWaitEvent(sk, ev_yj, 0), "orbital_hessian: hipStreamWaitEvent");
+    }
 #undef MC
     HessArgs a{YkT, YjT, hmo, fock, gamma, N, n_occ, ncas, y, n2, n2, gamma_bs};
     if (H_matrix) {
         const long total = (long)n_kappa * n_kappa;
         const unsigned nbk = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hess_matrix_kernel<<<dim3(nbk, batch), 256, 0, st>>>(a, kap_row, kap_col, n_kappa, H_matrix, ldh, h_bs);
+        hess_matrix_kernel<<<dim3(nbk, batch), 256, 0, sk>>>(a, kap_row, kap_col, n_kappa, H_matrix, ldh, h_bs);
     }
     if (H_full) {
         const long total = n2 * n2;
         const unsigned nbk = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-        hess_full_kernel<<<nbk, 256, 0, st>>>(a, H_full);
+        hess_full_kernel<<<nbk, 256, 0, sk>>>(a, H_full);
     }
     OOVQE_CHECK_LAUNCH("orbital_hessian");
+    if (ev_ab) OOVQE_CHECK_HIP(hipEventRecord(fork->done, sk), "orbital_hessian: hipEventRecord");
     return 0;
 }
 
@@ -358,6 +390,8 @@ int oovqe_circuit_hessian_batched_impl(const double* theta, int n_theta, const o
                                        const int32_t* pairs, int n_pairs, int batch, double* work, double* H,
                                        long ldh, long h_bs, oovqe_stream_t stream);
 
+static bool hess_circuit_own_block(int n_qubits) { return n_qubits <= 10; }
+
 extern "C" int64_t oovqe_oo_hessian_work_size(int n_theta, int n_gates, int n_qubits, int N, int n_occ,
                                               int ncas, int n_pairs)
 {
@@ -365,7 +399,9 @@ extern "C" int64_t oovqe_oo_hessian_work_size(int n_theta, int n_gates, int n_qu
     const int64_t ev = oovqe_oo_eval_work_size(n_theta, n_gates, n_qubits, N, n_occ, ncas, 1);
     const int64_t ch = oovqe_circuit_hessian_work_size(n_theta, n_qubits, ncas, n_pairs);
     const int64_t oh = oovqe_orbital_hessian_work_size(N, n_occ, ncas);
-    return ev + (int64_t)N * N + (ch > oh ? ch : oh);
+    // (small circuits: the circuit Hessian has a block of its own behind the shared one -- it runs BESIDE the
+    // orbital Hessian's chains, oovqe_oo_hessian_batch)
+    return ev + (int64_t)N * N + (ch > oh ? ch : oh) + (hess_circuit_own_block(n_qubits) ? ch : 0);
 }
 
 extern "C" int oovqe_oo_hessian_batch(const double* theta, int n_theta, const oovqe_gate_t* gates,
@@ -399,6 +435,28 @@ extern "C" int oovqe_oo_hessian_batch(const double* theta, int n_theta, const oo
                                                kap_row, kap_col, n_kappa, batch, hs_work, nullptr, 0, 0, nullptr,
                                                eri_flags, stream, 1)))
         return rc;
+    // The call is a graph, not a chain: behind stage 1 the evaluation (j_from_t2 -> q -> x / p -> n -> panels ->
+    // assembly, then the circuit Hessian and the cross block: this stream), the K-type integrals + the assembly of
+    // the orbital block (internal stream 0) and the one-electron + J-type integrals (internal stream 1) do not depend
+    // on each other.  Run one after the other they are 22 launches of 5-37 us at 8 geometries, 230 us; the longest
+    // path through the graph is stage 1 -> K-type chain -> Y -> matrix, ~110 us.  Forked from and joined to the
+    // caller's stream in here.
+    hipStream_t st = (hipStream_t)stream;
+    HessFork fork{nullptr, nullptr, nullptr, nullptr};
+    bool forked = false;
+    if (share && hess_circuit_own_block(n_qubits)) {
+        fork.sK = oovqe_internal_stream(0);
+        fork.sJ = oovqe_internal_stream(1);
+        hipEvent_t ev_a = oovqe_internal_event();
+        fork.rdm_ready = oovqe_internal_event();
+        fork.done = oovqe_internal_event();
+        if (fork.sK && fork.sJ && ev_a && fork.rdm_ready && fork.done) {
+            OOVQE_CHECK_HIP(hipEventRecord(ev_a, st), "oo_hessian_batch: hipEventRecord");
+            OOVQE_CHECK_HIP(hipStreamWaitEvent(fork.sK, ev_a, 0), "oo_hessian_batch: hipStreamWaitEvent");
+            OOVQE_CHECK_HIP(hipStreamWaitEvent(fork.sJ, ev_a, 0), "oo_hessian_batch: hipStreamWaitEvent");
+            forked = true;
+        }
+    }
     // 1. circuit + tangents -> RDM sets -> CAS path: E, dE/dtheta, dE/dkappa, d^2E/dkappa dtheta, c1, c2, F
     if ((rc = oovqe_oo_eval_batched_impl(theta, n_theta, gates, n_gates, n_qubits, init_index, g_ao, h_ao, C, nuc,
                                          N, n_occ, ncas, kap_row, kap_col, n_kappa, 1, batch, ev_work, out,
@@ -413,14 +471,21 @@ extern "C" int oovqe_oo_hessian_batch(const double* theta, int n_theta, const oo
     //    circuit Hessian: that one reuses the scratch in which T2 / Vk of step 0 live)
     const double* gamma = ev_work;
     const double* Gamma = gamma + nb * nvec * na2;
+    if (forked) OOVQE_CHECK_HIP(hipEventRecord(fork.rdm_ready, st), "oo_hessian_batch: hipEventRecord");
     if ((rc = orbital_hessian_batched(g_ao, h_ao, C, gamma, (long)nvec * na2, Gamma, (long)nvec * na4, fock, N,
                                       n_occ, ncas, kap_row, kap_col, n_kappa, batch, hs_work,
                                       hessian + (size_t)n_theta * n + n_theta, n, n * n, nullptr, eri_flags, stream,
-                                      share ? 2 : 0)))
+                                      share ? 2 : 0, forked ? &fork : nullptr)))
         return rc;
-    // 3. theta-theta block (top left)
+    // 3. theta-theta block (top left); beside the orbital block it works in a block of its own
+    double* ch_work = hs_work;
+    if (forked) {
+        const int64_t ch = oovqe_circuit_hessian_work_size(n_theta, n_qubits, ncas, n_pairs);
+        const int64_t oh = oovqe_orbital_hessian_work_size(N, n_occ, ncas);
+        ch_work = hs_work + nb * (size_t)(ch > oh ? ch : oh);
+    }
     if ((rc = oovqe_circuit_hessian_batched_impl(theta, n_theta, gates, n_gates, n_qubits, ncas, init_index, c1,
-                                                 c2, out_stride, out_stride, pairs, n_pairs, batch, hs_work,
+                                                 c2, out_stride, out_stride, pairs, n_pairs, batch, ch_work,
                                                  hessian, n, n * n, stream)))
         return rc;
     // 4. kappa-theta blocks
@@ -431,5 +496,6 @@ extern "C" int oovqe_oo_hessian_batch(const double* theta, int n_theta, const oo
                                                                                   n_kappa, hessian, n, n * n);
         OOVQE_CHECK_LAUNCH("oo_hessian_batch/cross");
     }
+    if (forked) OOVQE_CHECK_HIP(hipStreamWaitEvent(st, fork.done, 0), "oo_hessian_batch: hipStreamWaitEvent");
     return 0;
 }

@@ -1333,8 +1333,10 @@ void newton_band_solve_kernel(int n, double lam_threshold, double mu, double rho
         if (tid == 0) {
             lowest[prob] = qnan;
             if (shift_out && !lowest_only) shift_out[prob] = qnan;
-            if (info && !lowest_only) info[prob] = -1.0;      // a hand-off of stage 1 timed out
-            if (info && lowest_only) info[prob] = 2.0;        // the direction stands, its eigenvalue is missing
+            // a hand-off of stage 1 timed out.  The eigenvalue-only route (lowest_only; it may run on a side stream
+            // BESIDE the route of the other problems) never writes info[]: the kernels of both routes decide what
+            // to skip from it, so it has to stay what the fast path left.  Its report is the NaN in lowest[].
+            if (info && !lowest_only) info[prob] = -1.0;
         }
         return;
     }
@@ -1411,7 +1413,7 @@ void newton_band_solve_kernel(int n, double lam_threshold, double mu, double rho
         if (tid == 0) {
             lowest[prob] = qnan;
             if (shift_out && !lowest_only) shift_out[prob] = qnan;
-            if (info) info[prob] = lowest_only ? 2.0 : -1.0;
+            if (info && !lowest_only) info[prob] = -1.0;
         }
         return;
     }
@@ -1426,7 +1428,7 @@ void newton_band_solve_kernel(int n, double lam_threshold, double mu, double rho
         if (tid == 0) {
             lowest[prob] = qnan;
             if (shift_out && !lowest_only) shift_out[prob] = qnan;
-            if (info) info[prob] = -3.0;
+            if (info && !lowest_only) info[prob] = -3.0;
         }
         return;
     }

@@ -529,14 +529,19 @@ void newton_chol_kernel(const double* __restrict__ H, const double* __restrict__
     }
 }
 
-// info[b] = 1 when both roles of problem b succeeded (dp[b] final, shift[b] = 0), else 0
-__global__ void newton_chol_info_kernel(const int* __restrict__ status, double* __restrict__ info, int batch, int roles)
+// info[b] = 1 when both roles of problem b succeeded (dp[b] final, shift[b] = 0), else 0 -- and then dp[b] = 0: a
+// caller that speculates (oovqe_oo_newton_step_batch: the band route of "the others" on a side stream) evaluates
+// its first trial on whatever dp holds, and a zero direction is a trial at the current point, never a NaN orbital
+// rotation.  One workgroup per problem.
+__global__ void newton_chol_info_kernel(const int* __restrict__ status, double* __restrict__ info,
+                                        double* __restrict__ dp, int n, int roles)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= batch) return;
+    const int b = blockIdx.x;
     bool ok = true;
     for (int r = 0; r < roles; ++r) ok = ok && status[b * roles + r] == 1;
-    info[b] = ok ? 1.0 : 0.0;
+    if (threadIdx.x == 0) info[b] = ok ? 1.0 : 0.0;
+    if (!ok)
+        for (int i = threadIdx.x; i < n; i += blockDim.x) dp[(size_t)b * n + i] = 0.0;
 }
 
 }  // namespace
@@ -572,7 +577,7 @@ int oovqe_newton_chol_launch(const double* hessian, const double* gradient, int 
         hipLaunchKernelGGL((newton_chol_kernel<6, 2>), dim3(batch * roles), dim3(CT), lds, st, hessian, gradient, n,
                            lambda_min, work, dp, shift, status, roles);
     OOVQE_CHECK_LAUNCH("newton_direction_pd");
-    hipLaunchKernelGGL(newton_chol_info_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, status, info, batch, roles);
+    hipLaunchKernelGGL(newton_chol_info_kernel, dim3(batch), dim3(256), 0, st, status, info, dp, n, roles);
     OOVQE_CHECK_LAUNCH("newton_direction_pd/info");
     return 0;
 }

@@ -321,7 +321,14 @@ class BatchedNewtonStep(NewtonStep):
         fl = first_flags
         if fl is None:
             points(True)
-            fl = update(trial_energies(), 1, 0, True)
+            try:
+                fl = update(trial_energies(), 1, 0, True)
+            except _lib.OovqeError:
+                # a direction the library refused (info < 0: dp = NaN) makes the trial's orbital rotation itself fail
+                # loudly beyond N = 48 (expm checks its input): that is the refusal, not a new error
+                if s.info is None or min(s.info.tolist()) >= 0:
+                    raise
+                fl = [1.0, -1.0, 0.0, 0.0]
         if fl[1] < 0:
             # the library refused a problem loudly: repeat without inter-workgroup waits / eigh fallback (or
             # raise), then search from scratch

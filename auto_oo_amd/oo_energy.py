@@ -391,6 +391,8 @@ class OO_energy:
         self.__dict__.pop("_eri_pack_cache", None)
         self.__dict__.pop("_plans2", None)
         self.__dict__.pop("_full_pair_tables", None)
+        self.__dict__.pop("_stack1", None)          # (OO_pqc: the one-geometry stack holds a copy of the integrals)
+        self.__dict__.pop("_hess1_plans", None)
 
     def _cas_eval(self, mo_coeff, gamma_sets, Gamma_sets, want_matrices=False):
         """Fused energy / Fock / orbital gradient for a stack of RDM sets (set 0 = RDMs, sets k>=1

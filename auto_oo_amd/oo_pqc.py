@@ -319,9 +319,12 @@ class OO_pqc(OO_energy):
                 or n > ops._lib.load().oovqe_newton_direction_max_n()):
             return None
         g, h = self.int2e_ao, self.int1e_ao
-        key = (id(g), g._version, id(h), h._version, id(self.oao_coeff))
+        # the stack holds its own copy of the integrals: it belongs to ONE state of these tensors.  The key keeps the
+        # tensors themselves (compared with `is`: an id() can be reused by a new tensor once the old one is freed)
+        key = (g, g._version, h, h._version, self.oao_coeff)
         hit = self.__dict__.get("_stack1")
-        if hit is None or hit[0] != key:
+        if hit is None or not (hit[0][0] is g and hit[0][1] == g._version and hit[0][2] is h
+                               and hit[0][3] == h._version and hit[0][4] is self.oao_coeff):
             oo = self
 
             class _Mol:                      # what OO_pqc_batch reads of a Moldata

@@ -300,10 +300,38 @@ def eri_flags(g_ao):
     batch = g_ao.shape[0] if g_ao.dim() == 5 else 1
     if tuple(g_ao.shape[-4:]) != (N, N, N, N) or batch > 65535 or N > 65535:
         return 0
+    if N <= 48:
+        # the one-pass ingest kernel without its copy: every slab read once, the r <-> s test through LDS
+        both = ERI_PQ_SYMMETRIC | ERI_RS_SYMMETRIC
+        for f in eri_ingest(g_ao, pack=False)[0]:
+            both &= f
+        return both
     flags = ctypes.c_uint(0)
     check(lib.oovqe_eri_symmetry_flags(dptr(g_ao), N, batch, ctypes.byref(flags), stream_ptr()),
           "oovqe_eri_symmetry_flags")
     return int(flags.value)
+
+
+def eri_ingest(g_ao, pack=True, out=None):
+    """Ingest of resident integrals ([N,N,N,N] or a stack [G,N,N,N,N], contiguous fp64) in one library call
+    (oovqe_eri_ingest; N <= 48: ONE pass over the tensor): -> (per-geometry flags [G] as a list of ints, packed
+    copy [G, size] / [size] or None).  The copy of a geometry is meaningful when its flags carry both bits.
+    ``out``: write the copy there.  Synchronises the stream."""
+    lib = _lib.load()
+    dev = _dev(g_ao)
+    if g_ao.dtype != F64 or not g_ao.is_contiguous() or g_ao.dim() not in (4, 5):
+        raise _lib.OovqeError("eri_ingest: g_ao must be a contiguous fp64 [N,N,N,N] tensor or a stack of them")
+    N = g_ao.shape[-1]
+    G = g_ao.shape[0] if g_ao.dim() == 5 else 1
+    packed = None
+    if pack:
+        size = int(lib.oovqe_eri_packed_size(N))
+        if size > 0:
+            packed = out if out is not None else torch.empty((G, size) if g_ao.dim() == 5 else (size,), dtype=F64,
+                                                             device=dev)
+    flags = (ctypes.c_uint * G)()
+    check(lib.oovqe_eri_ingest(dptr(g_ao), N, G, dptr(packed), flags, stream_ptr()), "oovqe_eri_ingest")
+    return [int(f) for f in flags], packed
 
 
 def eri_pack(g_ao):
@@ -527,14 +555,34 @@ def _side_stream(dev):
     return entry[0][entry[1]]
 
 
+class PendingTensor:
+    """A result still being computed on one of the library's side streams (``OO_pqc_batch.evaluate_deferred``:
+    independent evaluation calls in flight on two streams, the latency-bound tail of one under the N^4 sweep of the
+    next).  ``result()`` makes the CURRENT stream wait for it and returns the tensor; until then nothing may read
+    the tensor."""
+
+    def __init__(self, tensor, event, view=None):
+        self._tensor, self._event, self._view = tensor, event, view
+
+    def result(self):
+        if self._event is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self._event)
+            self._tensor.record_stream(cur)
+            self._event = None
+        return self._tensor if self._view is None else self._view(self._tensor)
+
+
 class PendingLowest:
     """Lowest Hessian eigenvalues still being computed on the library's side stream (the band route runs
     beside the line search: the eigenvalue of a positive definite Hessian is a reported number that no step of
     the optimisation reads, newton_raphson.py:105-128).  ``result()`` makes the current stream wait for them
     and returns the tensor."""
 
-    def __init__(self, tensor, event):
-        self._tensor, self._event = tensor, event
+    def __init__(self, tensor, event, retry=None):
+        # retry: callable that recomputes the eigenvalues on the CALLING stream with one workgroup per problem
+        # (no hand-off between workgroups left that could time out); used when the side route reports NaN
+        self._tensor, self._event, self._retry = tensor, event, retry
 
     def result(self):
         if self._event is not None:
@@ -542,11 +590,23 @@ class PendingLowest:
             self._event = None
         return self._tensor
 
-    def tolist(self):
-        """Host values; raises if the band route could not deliver an eigenvalue (NaN)."""
+    def checked(self):
+        """``result()`` with the values verified on the host: an eigenvalue the side route could not deliver (NaN: a
+        hand-off between its workgroups timed out beside a kernel that held the chip) is computed again on the
+        calling stream without any inter-workgroup wait.  The eigenvalue is a diagnostic no step reads
+        (hess_eig_l of oo_pqc.py:155-207), so a missing one never discards an optimisation."""
         vals = self.result().reshape(-1).tolist()
+        if any(v != v for v in vals) and self._retry is not None:
+            retry, self._retry = self._retry, None
+            retry()
+        return self._tensor
+
+    def tolist(self):
+        """Host values; raises only if the eigenvalue is still missing after the one-workgroup repeat (a NaN / Inf
+        in the Hessian itself)."""
+        vals = self.checked().reshape(-1).tolist()
         if any(v != v for v in vals):
-            raise _lib.OovqeError("lowest Hessian eigenvalue missing (NaN): a hand-off of the band route timed out")
+            raise _lib.OovqeError("lowest Hessian eigenvalue missing (NaN): the Hessian holds a NaN or an Inf")
         return vals
 
     def item(self):
@@ -624,7 +684,16 @@ def newton_direction(hessian, gradient, lambda_min=1e-6, mu=1e-6, rho=1.1, aug=T
     if single:
         dpc, low, nu = dpc[0], low[0], nu[0]
     if defer_lowest:
-        low = PendingLowest(low, event)
+        retry = None
+        if event is not None:
+            def retry(H=H, g=g, info=info, low_all=low if not single else low.reshape(1), dpc_all=dpc.reshape(G, n),
+                      nu_all=nu.reshape(G)):
+                # the eigenvalues of the problems the fast path served, once more: calling stream, ONE workgroup each
+                w1 = _newton_work("rest", n, G, dev, lib.oovqe_newton_direction_rest_work_size(n, G))
+                check(lib.oovqe_newton_direction_rest(dptr(H), dptr(g), n, G, *args, dptr(info), 2, 1, dptr(w1),
+                                                      dptr(dpc_all), dptr(low_all), dptr(nu_all), stream_ptr()),
+                      "oovqe_newton_direction_rest")
+        low = PendingLowest(low, event, retry)
     elif event is not None:
         torch.cuda.current_stream().wait_event(event)
     if want_info:

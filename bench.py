@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--general-eri", action="store_true",
                     help="treat g_ao as a general tensor (eri_flags = 0: every slab is read) in the "
                          "headline run, for comparison with the default symmetric-integral path")
+    ap.add_argument("--in-order", action="store_true",
+                    help="headline steps as in-order calls on the current stream (rounds 1-4) instead of deferred "
+                         "calls over the library's two side streams (OO_pqc_batch.evaluate_deferred)")
     ap.add_argument("--no-transform", action="store_true")
     ap.add_argument("--no-kupccd", action="store_true", help="skip the configs[4] kUpCCD CAS(8e,8o) extra")
     ap.add_argument("--no-berry", action="store_true",
@@ -179,6 +182,7 @@ def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl", mode="weak",
     definite and no step is shifted."""
     import contextlib
     import auto_oo_amd as aoo
+    from auto_oo_amd import ops as ops_mod
     from auto_oo_amd.synthetic import synthetic_problem, synthetic_loop
     from auto_oo_amd.parallel import gather_results
     pqc = aoo.Parameterized_circuit(NCAS, NELECAS, None, ansatz="ucc")
@@ -295,6 +299,25 @@ def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl", mode="weak",
         restore()
     el_b = sorted(times)[len(times) // 2]
     agree = float((res_b - res).abs().max().item())
+    # ingest of the shard's geometries (untimed above: SURVEY.md section 8(d) fixes g_ao): in the reference's loop every
+    # point is a NEW molecule (Tutorial_Berry_phase.ipynb raw 408-418), so its integrals are verified and packed
+    # once per step -- one pass over the stack (oovqe_eri_ingest); per object of the sequential path: the symmetry
+    # test alone (single geometries keep no packed copy at this size).  Host -> device copies are not in it.
+    t_ing = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        batch.reverify_integrals()
+        torch.cuda.synchronize()
+        t_ing.append(time.perf_counter() - t1)
+    ing_b = min(t_ing)
+    restore()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for oo in objs:
+        ops_mod.eri_flags(oo.int2e_ao)
+    torch.cuda.synchronize()
+    ing_seq = time.perf_counter() - t1
     # where the step's time goes (untimed extra pass): gradient + Hessian call, direction launch
     def timed(fn, n_rep=5):
         fn()
@@ -320,11 +343,21 @@ def berry_loop_extra(my_geoms, n_geom, dist, world, backend="nccl", mode="weak",
             "cholesky_fast_path_fraction": fast_fraction, "lowest_hessian_eigenvalue_range": low_range,
             "geometries": n_geom, "seconds": el, "geometries_per_s": n_geom / el,
             "per_geometry_ms": el / max(len(objs), 1) * 1e3, "hessian_dim": objs[0].n_kappa + pqc.theta_shape,
+            "including_ingest": {"ingest_seconds": ing_seq, "seconds": el + ing_seq,
+                                 "geometries_per_s": n_geom / (el + ing_seq),
+                                 "note": "+ the bitwise symmetry test of every geometry's integrals (one pass each, "
+                                         "a host readback each: what OO_pqc does on first use of a new molecule); "
+                                         "this rank's share, host->device copies excluded"},
             "scaling": (f"{mode} ({n_geom} geometries in the job, {len(objs)} on this GPU, geometry g on "
                         f"rank g mod n_gpus)"),
             "lockstep": {"seconds": el_b, "geometries_per_s": n_geom / el_b,
                          "per_geometry_ms": el_b / max(len(objs), 1) * 1e3,
                          "step_ms_all_reps": [t * 1e3 for t in times],
+                         "including_ingest": {"ingest_ms": ing_b * 1e3, "seconds": el_b + ing_b,
+                                              "geometries_per_s": n_geom / (el_b + ing_b),
+                                              "note": "+ OO_pqc_batch.reverify_integrals(): symmetry tests + packed copy "
+                                                      "of the shard's geometries in ONE pass over the stack, flags read "
+                                                      "back; host->device copies excluded"},
                          "max_abs_energy_difference_vs_sequential": agree,
                          "energy_gradient_hessian_call_us": egh_us,
                          "direction_launch_us": dir_us,
@@ -711,13 +744,25 @@ def main():
     n_out = 1 + batch.n_theta + batch.n_kappa
     results = torch.zeros((G, n_out), dtype=torch.float64, device="cuda")
 
-    def run(n_calls):
+    deferred = not args.in_order
+
+    def run(n_calls, defer=None):
         """n_calls steps: each one batched call over ALL G geometries of this rank's shard.  Each
         call returns its own [G, 1 + n_theta + n_kappa] result tensor; the rows of the last call
-        are what the final exchange gathers."""
-        last = None
+        are what the final exchange gathers.  The steps are independent evaluations: by default each call is
+        DEFERRED (OO_pqc_batch.energy_and_gradient(defer=True): enqueued on the library's two side streams in
+        turn, each with its own workspace) and all of them are joined to the current stream before the exchange --
+        the latency-bound tail of one call (q -> x / p -> n, Fock panels, assembly) then runs under the N^4 sweep of
+        the next call instead of in front of it.  Per call the same launches, the same bits."""
+        defer = deferred if defer is None else defer
+        last, pend = None, []
         for _ in range(n_calls):
-            last = batch.energy_and_gradient(thetas)
+            if defer:
+                pend.append(batch.energy_and_gradient(thetas, defer=True))
+            else:
+                last = batch.energy_and_gradient(thetas)
+        for p_ in pend:
+            last = p_.result()             # (every call joined: all n_calls result tensors are complete)
         if last is not None:
             results.copy_(last)
         return n_calls
@@ -753,32 +798,72 @@ def main():
 
     kern_total_ms, kern_count, _ = ops.profile_end()
 
-    # extra (untimed for `value`): the same independent calls issued alternately on TWO streams with 224 of the
-    # 256 geometries each.  The stage-1 sweep keeps one workgroup per geometry busy and fills their CUs'
-    # register files, so on 256 geometries nothing can run beside it; with 224 the other 32 CUs take the
-    # latency-bound tail kernels of the previous call.  More evaluations per second, but each stage-1 launch then
-    # streams 12.5 % fewer bytes in the same time -- `value` and `roofline` stay on the one-stream design point.
-    two_stream = None
-    if world == 1 and G >= 224 and not args.general_eri:
-        streams2 = ops.side_streams()       # (no further streams: HIP's few hardware queues are shared round robin)
-
-        def run2(n, count):
+    # extras (untimed for `value`): the same steps as in-order calls on the current stream (the headline of rounds
+    # 1-4: every call's tail in front of the next call's sweep), and deferred calls of 224 of the 256 geometries (the
+    # sweep then leaves 32 CUs to the tails of the previous call: more evaluations per second, but each sweep launch
+    # streams 12.5 % fewer bytes in about the same time -- `value` and `roofline` stay on 256 geometries per call)
+    pipelining = None
+    if world == 1 and not args.general_eri:
+        def timed_calls(n, count, defer):
             torch.cuda.synchronize()
             t = time.perf_counter()
-            for s_ in streams2:
-                s_.wait_stream(torch.cuda.current_stream())
-            for i in range(n):
-                with torch.cuda.stream(streams2[i & 1]):
-                    batch.evaluate(thetas, count=count, slot=i & 1)
+            pend = [batch.evaluate_deferred(thetas, count=count) if defer else batch.evaluate(thetas, count=count)
+                    for _ in range(n)]
+            if defer:
+                for p_ in pend:
+                    p_.result()
             torch.cuda.synchronize()
             return (time.perf_counter() - t) / n
-        run2(6, 224)
-        t224 = min(run2(40, 224) for _ in range(2))
-        two_stream = {"geometries_per_call": 224, "us_per_call": t224 * 1e6, "evaluations_per_s": 224 / t224,
-                      "note": "independent calls alternating over two streams / workspace slots, 224 geometries "
-                              "each (one stage-1 workgroup per geometry on 224 CUs, the tail kernels of the "
-                              "previous call on the other 32); not the headline: per launch the dominant kernel "
-                              "streams 224 / 256 of the bytes in the same time"}
+        pipelining = {"headline_calls": "deferred" if deferred else "in order"}
+        for label, count, defer in (("in_order_256", G, False), ("deferred_256", G, True),
+                                    ("deferred_224", G - 32, True)):
+            if count < 1:
+                continue
+            timed_calls(6, count, defer)
+            t_c = min(timed_calls(40, count, defer) for _ in range(2))
+            pipelining[label] = {"geometries_per_call": count, "us_per_call": t_c * 1e6,
+                                 "evaluations_per_s": count / t_c}
+        pipelining["note"] = ("independent calls; deferred = OO_pqc_batch.evaluate_deferred (two side streams / workspace "
+                              "slots in turn, N^4 sweeps of the two streams ordered one after the other, all calls "
+                              "joined at the end); bit-identical to the in-order calls "
+                              "(tests/test_full_size_gpu.py::test_deferred_evaluations_equal_the_in_order_calls_bit_for_bit)")
+    # ingest (untimed for `value`; SURVEY.md section 8(d) fixes g_ao): what it costs to make a geometry's integrals
+    # usable once they are in HBM -- the bitwise symmetry tests and the packed resident copy, ONE pass over the stack
+    # (oovqe_eri_ingest) -- and the host -> device copy of one geometry's tensors from pinned memory, separately
+    ingest = None
+    if world == 1 and not args.general_eri:
+        torch.cuda.synchronize()
+        t_i = []
+        for _ in range(3):
+            t = time.perf_counter()
+            batch.reverify_integrals()
+            torch.cuda.synchronize()
+            t_i.append(time.perf_counter() - t)
+        t_ing = min(t_i)
+        tensor_bytes = 8.0 * NAO ** 4
+        packed_bytes = 8.0 * batch._eri_packed.shape[1] if batch._eri_packed is not None else 0.0
+        host = torch.empty((NAO,) * 4, dtype=torch.float64).pin_memory()
+        host.copy_(batch.int2e_ao[0])
+        dst = torch.empty_like(batch.int2e_ao[0])
+        dst.copy_(host, non_blocking=True)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(8):
+            dst.copy_(host, non_blocking=True)
+        torch.cuda.synchronize()
+        t_h2d = (time.perf_counter() - t) / 8
+        del host, dst
+        ingest = {"setup_us_per_geometry": t_ing / G * 1e6, "geometries": G, "ms_per_stack": t_ing * 1e3,
+                  "bytes_per_geometry": tensor_bytes + packed_bytes,
+                  "effective_GBs": (tensor_bytes + packed_bytes) * G / t_ing / 1e9,
+                  "frac_of_hbm_peak": (tensor_bytes + packed_bytes) * G / t_ing / 1e9 / HBM_PEAK_GBS,
+                  "h2d_us_per_geometry_pinned": t_h2d * 1e6, "h2d_GBs": tensor_bytes / t_h2d / 1e9,
+                  "evaluation_calls_equivalent": None,
+                  "note": "OO_pqc_batch.reverify_integrals() = oovqe_eri_ingest over the stack (every slab of g_ao read "
+                          "once: bitwise p<->q / r<->s tests, packed copy written; rounds 1-4: a check pass + a pack "
+                          "pass, 3.24 ms per 256 geometries) + mo_coeff refresh, one host readback of the flags included; "
+                          "the host->device copy of a geometry's 27 MB (pinned) is NOT in it and NOT in any figure of "
+                          "this line (SURVEY.md section 8(d): inputs resident in HBM)"}
     # per-launch breakdown of one evaluation call, from a separate untimed pass (bracketing every
     # launch costs dispatch gaps, so it is kept out of the timed region)
     ops.profile_begin(detail=True)
@@ -870,13 +955,17 @@ def main():
             "workload": (f"configs[1] shape: N={NAO} AOs, n_occ=6, CAS(4e,3o), UCCD n_theta=4, "
                          f"n_kappa={batch.n_kappa}; one step = one batched call evaluating energy + full "
                          f"gradient of all {G} geometries of the rank ({n_geom_total} synthetic "
-                         f"geometries in the job, geometry g on rank g mod n_gpus); value = evaluations/s"),
+                         f"geometries in the job, geometry g on rank g mod n_gpus); value = evaluations/s; "
+                         + ("the steps are independent calls, deferred over the library's two side streams and all "
+                            "joined before the exchange" if deferred else "in-order calls on one stream")),
             "evals_per_step": G,
             "geometries_per_rank": G,
             "batched_calls": n_calls,
+            "calls": "deferred (OO_pqc_batch.energy_and_gradient(defer=True))" if deferred else "in order",
             "host_submit_us_per_call": t_submit / max(n_calls, 1) * 1e6,
             "parallelism": f"geometry-sharded x{world}, one all_gather at the end",
-            "two_stream_pipelining": two_stream,
+            "pipelining": pipelining,
+            "ingest": ingest,
             # what torch.distributed itself reports (a SCALE line proves RCCL saw N ranks)
             "dist_backend": dist.get_backend() if dist is not None else None,
             "dist_world_size": dist.get_world_size() if dist is not None else 1,
@@ -905,6 +994,8 @@ def main():
             "launches_timed": kern_count,
         },
     }
+    if ingest is not None:
+        ingest["evaluation_calls_equivalent"] = ingest["ms_per_stack"] / out["ms_per_step"]
     if pq_sym and rs_sym and t3_path and NAO == 43 and M == 9:
         # The same launch against the fp64 matrix pipe (informational; DESIGN.md "What bounds stage 1": the
         # kernel is bound by MFMA issue at a power-limited clock, not by HBM).  34 v_mfma_f64_16x16x4 per

@@ -197,6 +197,13 @@ int oovqe_eri_symmetry_flags(const double* g_ao, int N, int batch, unsigned* eri
  * every entry point (paths that cannot use the copy read it). */
 int64_t oovqe_eri_packed_size(int N);
 int oovqe_eri_pack(const double* g_ao, int N, int batch, double* packed, oovqe_stream_t stream);
+/* INGEST of a stack of AO tensors (what `OO_energy.__init__` does once per molecule with `mol.int2e_ao`,
+ * oo_energy.py:143-171, and the Berry-phase notebook once per loop point): eri_flags[g] (HOST array [batch]) = the
+ * OOVQE_ERI_* bits of geometry g, and -- `packed` non-null -- the packed copy of every geometry (meaningful for those
+ * that carry both bits).  N <= 48: ONE pass over g_ao (every slab read once, the copy written: 1.27 x the tensor's
+ * bytes; the two calls above move 2.3 x); beyond: the check pass and the tile pack.  Synchronises `stream`. */
+int oovqe_eri_ingest(const double* g_ao, int N, int batch, double* packed, unsigned* eri_flags,
+                     oovqe_stream_t stream);
 /* oovqe_cas_eval (below) with the packed copy of g_ao: the same outputs; stage 1 streams g_packed where a
  * kernel for it exists (N > 48: the T2 paths), g_ao otherwise.  eri_flags must carry both bits. */
 int oovqe_cas_eval_packed(const double* g_ao, const double* h_ao, const double* C, const double* gamma,

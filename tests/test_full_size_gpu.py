@@ -113,6 +113,39 @@ def test_batched_evaluation_256_geometries_matches_smaller_batches():
         assert (eg[g, 1:] - grad).abs().max().item() < 1e-11
 
 
+def test_deferred_evaluations_equal_the_in_order_calls_bit_for_bit():
+    """OO_pqc_batch.evaluate_deferred: independent 256-geometry calls in flight on the library's two side streams
+    (the tail of one call under the N^4 sweep of the next), with different thetas per call, against the same calls
+    made in order on the current stream -- the same launches per call, so the same bits; with the N^4 sweeps of
+    the two streams ordered one after the other (default) and free-running."""
+    import auto_oo_amd as aoo
+    from auto_oo_amd import _lib
+    from auto_oo_amd.synthetic import synthetic_problem
+    N, ncas, nelecas, nelec, G = 43, 3, 4, 16, 256
+    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="ucc")
+    base = [synthetic_problem(N, 9600 + g) for g in range(4)]
+    mols = [aoo.Moldata(base[g % 4]["int1e_ao"], base[g % 4]["int2e_ao"], base[g % 4]["overlap"],
+                        base[g % 4]["nuc"] + 0.001 * g, nelec) for g in range(G)]
+    big = aoo.OO_pqc_batch(pqc, mols, ncas, nelecas, oao_mo_coeffs=[base[g % 4]["oao_mo_coeff"] for g in range(G)])
+    rng = np.random.default_rng(16)
+    sets = [torch.tensor(rng.uniform(0, 2 * np.pi, (G, pqc.theta_shape)), device=DEV) for _ in range(5)]
+    ref = [big.energy_and_gradient(th).clone() for th in sets]
+    assert not torch.equal(ref[0], ref[1])
+    with _lib.debug_options(stage1_free_run=1):        # (sweeps of different streams not ordered: the same bits)
+        free = [big.energy_and_gradient(th, defer=True) for th in sets]
+        inorder = [p.result().clone() for p in free]
+    pend = [big.energy_and_gradient(th, defer=True) for th in sets]
+    pend += [big.evaluate_deferred(sets[0], derivatives=False, count=100)]
+    got = [p.result() for p in pend]
+    for r, a, b in zip(ref, inorder, got):
+        assert torch.equal(r, a) and torch.equal(r, b)
+    assert torch.equal(got[5][:, 1], ref[0][:100, 0])
+    # a second round reuses both workspaces while results of the first are still referenced
+    again = [big.energy_and_gradient(th, defer=True) for th in reversed(sets)]
+    for r, p in zip(reversed(ref), again):
+        assert torch.equal(r, p.result())
+
+
 def test_expm_n200_orthogonality_and_inverse():
     """configs[2]: expm(-K) of a 200 x 200 skew-symmetric K is orthogonal, expm(K) is its inverse,
     and the exponential of a sum of commuting generators (K, 0.5 K) factorises."""

@@ -456,6 +456,37 @@ def test_eri_symmetry_flags():
     assert ops.eri_flags(stack) == ops.ERI_RS_SYMMETRIC
 
 
+@pytest.mark.parametrize("N", [5, 13, 16, 43, 48])
+def test_eri_ingest_one_pass_equals_check_and_pack(N):
+    """oovqe_eri_ingest (N <= 48: symmetry tests and packed copy from ONE pass over the stack) against torch's own
+    comparison of the tensor with its transposes and against oovqe_eri_pack: per-geometry flags for a stack whose
+    geometries break the symmetries in different ways (one bit flipped in a slab p < q, in a mirror slab q > p only,
+    in one element (r, s) of a diagonal slab), the packed copy bit for bit."""
+    rng = np.random.default_rng(100 + N)
+    g = torch.tensor(R.synthetic_problem(N, 4300 + N)["int2e_ao"]).to(DEV).contiguous()
+    stack = torch.stack([g] * 6).contiguous()
+    eps = 1.0 + 2.0 ** -52
+    stack[1, 0, N - 1, 1, 2] *= eps                 # slab (0, N-1), one element: p<->q and r<->s broken
+    stack[2, 0, N - 1, 1, 2] *= eps
+    stack[2, 0, N - 1, 2, 1] = stack[2, 0, N - 1, 1, 2]        # r<->s repaired: p<->q only
+    stack[3, N - 1, 0, 1, 2] *= eps                 # the MIRROR slab (q, p) alone: both broken (its own r<->s test)
+    stack[4, 2, 2, 0, N - 1] *= eps                 # a diagonal slab: r<->s only
+    stack[5] = torch.tensor(rng.standard_normal((N, N, N, N))).to(DEV)
+    want = []
+    for k in range(6):
+        t = stack[k]
+        want.append((1 if torch.equal(t, t.transpose(0, 1)) else 0) | (2 if torch.equal(t, t.transpose(2, 3)) else 0))
+    assert want == [3, 0, 2, 0, 1, 0]
+    flags, packed = ops.eri_ingest(stack)
+    assert flags == want
+    assert torch.equal(packed[0], ops.eri_pack(g))
+    assert torch.equal(packed, ops.eri_pack(stack))           # (the copy is made whatever the flags say)
+    flags1, packed1 = ops.eri_ingest(g)
+    assert flags1 == [3] and torch.equal(packed1, packed[0])
+    assert ops.eri_ingest(stack, pack=False) == (want, None)
+    assert ops.eri_flags(stack) == 0 and ops.eri_flags(stack[:1].contiguous()) == 3
+
+
 @pytest.mark.parametrize("flags", [1, 3])
 @pytest.mark.parametrize("path", ["auto", "t3x1", "t3x2", "two_step", "simple", "mirror", "t2"])
 @pytest.mark.parametrize("N,nelec,ncas,nelecas", [(13, 16, 3, 4), (43, 16, 3, 4), (17, 8, 4, 4),

@@ -668,6 +668,69 @@ def test_one_call_newton_step_beyond_the_cholesky_kernel():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("N,G", [(13, 3), (43, 8), (43, 1)])
+def test_hessian_call_chains_on_internal_streams_equal_the_one_stream_call(N, G):
+    """oovqe_oo_hessian_batch runs the chains of its graph that do not depend on each other beside each other (the
+    evaluation + circuit block on the caller's stream, the K-type chain + assembly and the J-type chain on the
+    library's two internal streams, forked and joined inside the call) -- against the same call with every launch on
+    the caller's stream (option ``one_stream``): the same launches, the same bits; repeated calls reuse the
+    workspace while the previous call's chains have been joined."""
+    from auto_oo_amd import _lib
+    pqc, batch, objs, probs = _batch_of(N, G, seed0=811, freeze_active=(N == 43))
+    rng = np.random.default_rng(N + G)
+    sets = [torch.tensor(rng.uniform(0, 2 * np.pi, (G, pqc.theta_shape)), device="cuda") for _ in range(3)]
+    with _lib.debug_options(one_stream=1):
+        ref = [tuple(t.clone() for t in batch.energy_gradient_hessian(th)) for th in sets]
+    got = [tuple(t.clone() for t in batch.energy_gradient_hessian(th)) for th in sets]
+    for r, g_ in zip(ref, got):
+        for a, b in zip(r, g_):
+            assert torch.equal(a, b)
+    assert not torch.equal(ref[0][2], ref[1][2])
+    H = got[0][2]
+    assert (H - H.transpose(1, 2)).abs().max() < 1e-9
+
+
+def test_one_call_newton_step_with_symmetric_integrals_and_more_than_16_orbitals():
+    """N <= 48 with n_occ + ncas > 16: the integrals carry both symmetry flags but no packed copy exists for that
+    shape (the packed-triangle kernels end at M = 16) -- the one-call step must hand the library a null packed
+    pointer, not fail on it; same bits as the step driven call by call."""
+    N, G = 24, 2
+    outs = []
+    for by_calls in (True, False):
+        pqc, batch, objs, probs = _batch_of(N, G, seed0=733, nelec=32)
+        assert batch.eri_flags == 3 and batch._eri_packed is None and batch._n_occ + batch.ncas == 17
+        batch.step_by_calls = by_calls
+        th = torch.full((G, pqc.theta_shape), 0.1, dtype=torch.float64, device="cuda")
+        e0 = batch.energy(th)
+        new_t, e_new, low = batch.damped_newton_step(th)
+        assert (e_new < e0).all()
+        outs.append((new_t.clone(), e_new.clone(), low.clone(), batch.oao_mo_coeff.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # the same through OO_pqc.full_optimization's one-geometry stack
+    oo = objs[0]
+    e_l, th_l, *_ = oo.full_optimization(torch.full((pqc.theta_shape,), 0.1, dtype=torch.float64), max_iterations=3,
+                                         verbose=None)
+    assert e_l[-1] < e_l[0]
+
+
+def test_missing_side_stream_eigenvalue_is_recomputed_not_raised():
+    """ops.PendingLowest: a NaN eigenvalue from the side route (a hand-off that timed out) is computed again on
+    the calling stream with one workgroup per problem instead of aborting the caller -- forced here by
+    overwriting the delivered values."""
+    rng = np.random.default_rng(3)
+    n, G = 58, 4
+    H = torch.tensor(_pd_stack(rng, n, G), device="cuda")
+    g = torch.tensor(rng.standard_normal((G, n)), device="cuda")
+    dp, low, nu = ops.newton_direction(H, g, defer_lowest=True)
+    want = low.result().clone()
+    low._tensor[1] = float("nan")
+    vals = low.tolist()
+    assert max(abs(a - b) for a, b in zip(vals, want.tolist())) < 1e-10
+    ev = np.linalg.eigvalsh(H.cpu().numpy())[:, 0]
+    assert np.abs(np.array(vals) - ev).max() < 1e-9
+
+
 def _pd_stack(rng, n, G, low=0.05):
     out = []
     for k in range(G):
