@@ -57,18 +57,70 @@ class SectorEngine:
         self._tables_ptr = None
         self._hess_tables = None
 
-    # ---- derivatives (round 4) --------------------------------------------------------------------
-    def param_gates(self, gates_host):
-        """gate index of every parameter, for circuits in which each parameter drives exactly one gate
-        (UCCD / UCCSD / kUpCCD: one Givens pass per excitation); None otherwise (GateFabric's orbital
-        rotations spread a parameter over several gates: their tangents need the product rule)."""
+    # ---- derivatives (round 4; parameters shared between gates: round 5) ---------------------------
+    def param_gate_lists(self, gates_host):
+        """The gates every parameter drives (UCCD / UCCSD / kUpCCD: one Givens pass per excitation; GateFabric's
+        OrbitalRotation: two Givens rotations on the same angle, pqc.py:79-83 of the reference)."""
         if self._param_gate is None:
             owner = [[] for _ in range(self.n_theta)]
             for gi, g in enumerate(gates_host):
                 if g.theta_idx >= 0:
                     owner[g.theta_idx].append(gi)
-            self._param_gate = [o[0] for o in owner] if all(len(o) == 1 for o in owner) else False
-        return self._param_gate or None
+            self._param_gate = owner
+        return self._param_gate
+
+    def _tangent_plan(self, gates_host, second):
+        """Which differentiated circuits (``oovqe_sector_state_deriv`` specs: up to two gates differentiated) sum to
+        the tangent states, by the product rule over the gates that share a parameter:
+            d psi / d theta_k            = sum_{g in gates(k)} psi[g]
+            d^2 psi / d theta_j d theta_k = sum_{g in gates(j)} sum_{h in gates(k)} psi[g, h]
+        (psi[g, g] = the gate's own second derivative; for j = k the mixed terms g != h appear in both orders: weight 2).
+        -> (specs [n_spec, 2] int32 device, owner [n_spec] int64 device: row of the output each spec adds to, weights
+        [n_spec] device or None when all 1, n_out, pairs).  Row 0 = psi, rows 1..n_theta = first tangents, then the
+        second tangents of the pairs j <= k in row-major order (``second=True``)."""
+        key = bool(second)
+        plans = self.__dict__.setdefault("_tangent_plans", {})
+        if key not in plans:
+            gl = self.param_gate_lists(gates_host)
+            nt = self.n_theta
+            specs, owner, weight = [(-1, -1)], [0], [1.0]
+            for k in range(nt):
+                for g in gl[k]:
+                    specs.append((g, -1)); owner.append(1 + k); weight.append(1.0)
+            pairs = []
+            if second:
+                pairs = [(j, k) for j in range(nt) for k in range(j, nt)]
+                for row, (j, k) in enumerate(pairs):
+                    if j == k:
+                        gs = gl[j]
+                        for a_, g in enumerate(gs):
+                            specs.append((g, g)); owner.append(1 + nt + row); weight.append(1.0)
+                            for h in gs[a_ + 1:]:
+                                specs.append((g, h)); owner.append(1 + nt + row); weight.append(2.0)
+                    else:
+                        for g in gl[j]:
+                            for h in gl[k]:
+                                specs.append((g, h)); owner.append(1 + nt + row); weight.append(1.0)
+            dev = self.device
+            w = None if all(x == 1.0 for x in weight) else torch.as_tensor(weight, dtype=F64, device=dev)
+            one_each = all(len(g_) == 1 for g_ in gl)                        # one gate per parameter: no sums at all
+            plans[key] = (torch.as_tensor(np.asarray(specs, dtype=np.int32).reshape(-1, 2)).to(dev),
+                          None if one_each else torch.as_tensor(owner, dtype=torch.int64, device=dev), w,
+                          1 + nt + len(pairs), pairs)
+        return plans[key]
+
+    def tangent_states(self, theta, gates_host, second=False):
+        """theta [batch, n_theta] -> [batch, 1 + n_theta (+ n_pairs), Dc]: psi, its first tangents and (``second``) its
+        second tangents for the pairs j <= k, whatever the number of gates per parameter."""
+        spec, owner, w, n_out, _ = self._tangent_plan(gates_host, second)
+        st = self.derivative_states(theta, spec)
+        if owner is None:
+            return st
+        if w is not None:
+            st = st * w[None, :, None]
+        out = torch.zeros((st.shape[0], n_out, self.Dc), dtype=F64, device=self.device)
+        out.index_add_(1, owner, st)
+        return out
 
     def derivative_states(self, theta, specs):
         """theta [batch, n_theta], specs: list of (gate_a, gate_b) (-1 = none) -> [batch, len(specs), Dc]:
@@ -100,12 +152,10 @@ class SectorEngine:
         set 0 = the RDMs of psi, set k = their derivative with respect to theta_k.  The RDMs are quadratic
         forms of the (real) state, so with the tangent tau_k = d psi / d theta_k the derivative is EXACTLY
         [RDM(psi + tau_k) - RDM(psi - tau_k)] / 2 -- the plain RDM kernel on 2 n_theta + 1 vectors, no
-        transition-RDM kernel."""
-        pg = self.param_gates(gates_host)
-        if pg is None:
-            raise NotImplementedError("sector derivatives need one gate per parameter (UCCD / UCCSD / kUpCCD)")
+        transition-RDM kernel.  (Parameters that drive several gates -- GateFabric's orbital rotations -- have their
+        tangents summed over those gates: ``tangent_states``.)"""
         nt = self.n_theta
-        st = self.derivative_states(theta, [(-1, -1)] + [(pg[k], -1) for k in range(nt)])[0]   # [1 + nt, Dc]
+        st = self.tangent_states(theta, gates_host)[0]                              # [1 + nt, Dc]
         psi, tau = st[0:1], st[1:]
         g1, g2 = self.rdms_chunked(torch.cat((psi, psi + tau, psi - tau)))
         gamma = torch.cat((g1[0:1], 0.5 * (g1[1:1 + nt] - g1[1 + nt:])))
@@ -132,18 +182,13 @@ class SectorEngine:
         operator (``oovqe_sector_lambda``) and two small products, where the polarisation of Q through the plain RDM
         kernel (``by_rdms=True``, the first form of round 4: [Q(a + b) - Q(a - b)] / 2 for every pair) took 4 n_pairs
         RDM evaluations: 6 384 sector vectors at CAS(8e,8o), k = 1."""
-        pg = self.param_gates(gates_host)
-        if pg is None:
-            raise NotImplementedError("sector derivatives need one gate per parameter (UCCD / UCCSD / kUpCCD)")
         nt = self.n_theta
         if self._hess_tables is None:      # (index tables of the pairs j <= k: once per engine, not per call)
-            pairs = [(j, k) for j in range(nt) for k in range(j, nt)]
-            specs = [(-1, -1)] + [(pg[k], -1) for k in range(nt)] + [(pg[j], pg[k]) for j, k in pairs]
-            self._hess_tables = (torch.as_tensor(np.asarray(specs, dtype=np.int32).reshape(-1, 2)).to(self.device),
-                                 torch.as_tensor([j for j, _ in pairs], device=self.device),
+            pairs = self._tangent_plan(gates_host, True)[4]
+            self._hess_tables = (torch.as_tensor([j for j, _ in pairs], device=self.device),
                                  torch.as_tensor([k for _, k in pairs], device=self.device), len(pairs))
-        spec, ja, ka, npair = self._hess_tables
-        st = self.derivative_states(theta, spec)[0]
+        ja, ka, npair = self._hess_tables
+        st = self.tangent_states(theta, gates_host, second=True)[0]
         psi, tau, tau2 = st[0], st[1:1 + nt], st[1 + nt:]
         if by_rdms:
             vecs = torch.cat((tau2 + psi, tau2 - psi, tau[ja] + tau[ka], tau[ja] - tau[ka]))

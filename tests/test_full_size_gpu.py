@@ -522,6 +522,73 @@ def test_sector_second_derivatives_vs_oracle_autograd_cas44():
             - torch.autograd.functional.jacobian(ooo.energy_from_parameters, theta)).abs().max().item() < 1e-8
 
 
+def _fabric_problem(N, ncas, nelecas, nelec, seed, n_layers=2):
+    import auto_oo_amd as aoo
+    from auto_oo_amd.synthetic import synthetic_problem
+    P = synthetic_problem(N, seed)
+    mol = aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec)
+    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="np_fabric", n_layers=n_layers)
+    oo = aoo.OO_pqc(pqc, mol, ncas, nelecas, oao_mo_coeff=P["oao_mo_coeff"])
+    return P, mol, pqc, oo
+
+
+def test_sector_second_derivatives_with_shared_parameters_np_fabric_cas66():
+    """GateFabric (np_fabric, the ansatz of every reference integration test: test/test_oo_pqc.py:92,167): its
+    OrbitalRotation is two Givens rotations on ONE angle (pqc.py:79-83, 136-160), so the tangent states are sums over
+    the gates of a parameter and the second tangents sums over gate PAIRS (round 5: SectorEngine.tangent_states).
+    CAS(6e,6o), 12 qubits, inside the (N_alpha, N_beta) sector against the dense 2^12 register: derivative RDMs,
+    full gradient, every block of OO_pqc.full_hessian (oo_pqc.py:103-148); and a damped Newton step lowers the
+    energy (full_optimization's body was out of reach for this ansatz beyond 10 qubits)."""
+    import auto_oo_amd as aoo
+    P, mol, pqc, oo = _fabric_problem(18, 6, 6, 10, 661)
+    assert pqc._use_sector and pqc.n_qubits == 12
+    assert max(len(g_) for g_ in pqc._sector.param_gate_lists(pqc._gates)) == 2
+    theta = torch.tensor(np.random.default_rng(67).uniform(0, 2 * np.pi, pqc.theta_shape), device=DEV)
+    g1s, g2s = pqc.rdms_with_derivatives(theta)
+    Hs = oo.full_hessian(theta)
+    gs = oo.full_gradient(theta)
+    pqc._use_sector = False
+    try:
+        g1d, g2d = pqc.rdms_with_derivatives(theta)
+        Hd = oo.full_hessian(theta)
+        gd = oo.full_gradient(theta)
+    finally:
+        pqc._use_sector = True
+    assert (g1s - g1d).abs().max().item() < 1e-12 and (g2s - g2d).abs().max().item() < 1e-12
+    scale = max(1.0, Hd.abs().max().item())
+    assert (Hs - Hd).abs().max().item() < 1e-10 * scale
+    assert (Hs - Hs.T).abs().max().item() < 1e-10 * scale
+    assert (gs - gd).abs().max().item() < 1e-10 * max(1.0, gd.abs().max().item())
+    th_s = torch.tensor(np.random.default_rng(5).normal(0, 0.3, pqc.theta_shape), device=DEV)
+    e0 = oo.energy_from_parameters(th_s).item()
+    kap0 = torch.zeros(oo.n_kappa, dtype=torch.float64, device=DEV)
+    new, low = aoo.NewtonStep(verbose=0).damped_newton_step(oo.energy_from_parameters, (th_s, kap0),
+                                                            oo.full_gradient(th_s), oo.full_hessian(th_s))
+    assert oo.energy_from_parameters(new[0], new[1]).item() < e0
+
+
+def test_sector_second_derivatives_with_shared_parameters_vs_oracle_autograd_cas44():
+    """The same against autograd through the oracle's gate-level GateFabric circuit at CAS(4e,4o) (the sector engine
+    forced on the 8-qubit register): theta-theta and kappa-theta blocks of OO_pqc.full_hessian and the circuit
+    gradient (test/test_oo_pqc.py:101-125), 1e-8."""
+    from oracle import cpu_ref as R
+    from torch.autograd.functional import hessian as thessian
+    P, mol, pqc, oo = _fabric_problem(8, 4, 4, 8, 441)
+    assert pqc._sector.fits()
+    pqc._use_sector = True
+    omol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], 8)
+    ooo = R.OracleOOPQC(R.OraclePQC(4, 4, "np_fabric", n_layers=2), omol, 4, 4, P["oao_mo_coeff"])
+    theta = torch.tensor(np.random.default_rng(45).uniform(0, 2 * np.pi, pqc.theta_shape))
+    H = oo.full_hessian(theta.to(DEV)).cpu()
+    nt = int(pqc.theta_shape)
+    htt = thessian(ooo.energy_from_parameters, theta)
+    hkt = torch.autograd.functional.jacobian(ooo.orbital_gradient, theta)
+    assert (H[:nt, :nt] - htt).abs().max().item() < 1e-8
+    assert (H[nt:, :nt] - hkt).abs().max().item() < 1e-8
+    assert (oo.full_gradient(theta.to(DEV)).cpu()[:nt]
+            - torch.autograd.functional.jacobian(ooo.energy_from_parameters, theta)).abs().max().item() < 1e-8
+
+
 def test_kupccd_cas88_damped_newton_step_lowers_the_energy():
     """configs[4] has a Newton step: full gradient + full Hessian of kUpCCD CAS(8e,8o), k = 1 (56 thetas, sector
     engine: 4 900 determinants, 1 596 second tangents) and one damped Newton step of OO_pqc.full_optimization's
