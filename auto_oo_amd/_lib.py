@@ -152,6 +152,16 @@ SIGNATURES = {
     "oovqe_sector_lambda": (ctypes.c_int, [c_double_p, ctypes.c_int, c_int32_p, c_int32_p, c_int32_p, c_int32_p,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p,
                                            ctypes.c_void_p, c_double_p, c_double_p, c_stream]),
+    "oovqe_sector_geometry_coefficients_ok": (ctypes.c_int, [ctypes.c_int] * 3),
+    "oovqe_sector_adjoint_pg": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                               ctypes.c_int, c_int32_p, c_int32_p, c_int32_p, c_int32_p,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p,
+                                               c_double_p, c_double_p, ctypes.c_int64, c_int32_p, ctypes.c_int,
+                                               ctypes.c_void_p, c_double_p, c_double_p, c_stream]),
+    "oovqe_sector_lambda_pg": (ctypes.c_int, [c_double_p, ctypes.c_int, c_int32_p, c_int32_p, c_int32_p, c_int32_p,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_double_p,
+                                              c_double_p, ctypes.c_int64, ctypes.c_void_p, c_double_p, c_double_p,
+                                              c_stream]),
     "oovqe_sector_tables_size": (ctypes.c_int64, [ctypes.c_int] * 3),
     "oovqe_sector_rdms_tb": (ctypes.c_int, [c_double_p, ctypes.c_int, c_int32_p, c_int32_p, c_int32_p,
                                             c_int32_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
@@ -189,6 +199,10 @@ SIGNATURES = {
                                            ctypes.c_uint, c_double_p, c_stream]),
     "oovqe_eri_packed_size": (ctypes.c_int64, [ctypes.c_int]),
     "oovqe_eri_pack": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_int, c_double_p, c_stream]),
+    "oovqe_cas_eval_batch": (ctypes.c_int, [c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_int,
+                                            c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_int32_p, c_int32_p,
+                                            ctypes.c_int, ctypes.c_int, c_double_p, c_double_p, c_double_p,
+                                            ctypes.c_uint, c_double_p, c_stream]),
     "oovqe_eri_ingest": (ctypes.c_int, [c_double_p, ctypes.c_int, ctypes.c_int, c_double_p,
                                         ctypes.POINTER(ctypes.c_uint), c_stream]),
     "oovqe_circuit_rdms_is_small": (ctypes.c_int, [ctypes.c_int] * 4),

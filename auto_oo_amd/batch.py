@@ -6,6 +6,13 @@ little to fill an MI355X, so ``OO_pqc_batch`` stacks the per-geometry tensors of
 problems (same basis size, same active space, same circuit) and evaluates all of them with ONE
 call of ``oovqe_oo_eval_batch`` -- 5 kernel launches in which the geometry index is a grid
 dimension.  Per geometry the arithmetic is exactly that of ``OO_pqc.energy_and_gradient``.
+
+Circuits whose state lives in the (N_alpha, N_beta)-sector engine (more than 10 qubits: kUpCCD CAS(8e,8o), GateFabric
+CAS(6e,6o), ...) take the same entry points (round 5): states, RDMs and derivative RDMs of ALL geometries from the
+sector kernels with the geometry as their batch index, the CAS path of all geometries in one ``oovqe_cas_eval_batch``
+call, the orbital Hessians in one ``oovqe_orbital_hessian_batch`` call, directions and line search in lockstep; only
+the stages that take ONE set of CAS coefficients per call (the reverse sweep's operator, the theta-theta block) run
+geometry by geometry.
 """
 import ctypes
 
@@ -170,6 +177,8 @@ class OO_pqc_batch:
         if not 1 <= G <= self.G:
             raise ValueError(f"count must be in 1..{self.G}")
         thetas = ops.as_device(thetas, self.device).reshape(-1, self.n_theta)[:G]
+        if getattr(self.pqc, "_use_sector", False):
+            return self._evaluate_sector(thetas, derivatives, G, slot, mo_coeff)
         work, osz = self._plan(derivatives, slot)
         out = torch.empty((G, osz), dtype=F64, device=self.device)
         pqc = self.pqc
@@ -183,6 +192,115 @@ class OO_pqc_batch:
             dptr(self._eri_packed) if self.eri_flags == 3 else None, stream_ptr()),
             "oovqe_oo_eval_batch")
         return out
+
+    # ---- circuits in the sector engine ---------------------------------------------------------------
+    def _cas_batch(self, gamma, Gamma, G, slot=0, mo_coeff=None, want_fock=False):
+        """The CAS path of the first G geometries from RDM sets gamma [G, nrdm, a, a], Gamma [G, nrdm, a,a,a,a]
+        (``oovqe_cas_eval_batch``) -> (packed outputs [G, osz] in the layout of ``evaluate``, n_t, fock or None)."""
+        nrdm = int(gamma.shape[1])
+        key = ("cas", nrdm, slot)
+        if key not in self._plans:
+            wsz = self.lib.oovqe_cas_eval_work_size(self.nao, self._n_occ, self.ncas, nrdm)
+            osz = self.lib.oovqe_oo_eval_out_size(nrdm - 1, self.n_kappa, self.ncas, int(nrdm > 1))
+            self._plans[key] = (torch.empty(self.G * wsz, dtype=F64, device=self.device), int(osz))
+        work, osz = self._plans[key]
+        out = torch.empty((G, osz), dtype=F64, device=self.device)
+        fock = torch.empty((G, self.nao, self.nao), dtype=F64, device=self.device) if want_fock else None
+        gamma = gamma if gamma.is_contiguous() else gamma.contiguous()
+        Gamma = Gamma if Gamma.is_contiguous() else Gamma.contiguous()
+        check(self.lib.oovqe_cas_eval_batch(
+            dptr(self.int2e_ao), dptr(self.int1e_ao), dptr(self.mo_coeff if mo_coeff is None else mo_coeff),
+            dptr(gamma), dptr(Gamma), nrdm, dptr(self.nuc), self.nao, self._n_occ, self.ncas,
+            dptr(self._kap_row, torch.int32), dptr(self._kap_col, torch.int32), self.n_kappa, G, dptr(work), dptr(out),
+            dptr(fock), int(self.eri_flags), dptr(self._eri_packed) if self.eri_flags == 3 else None, stream_ptr()),
+            "oovqe_cas_eval_batch")
+        return out, (nrdm - 1 if nrdm > 1 else 1), fock
+
+    def _evaluate_sector(self, thetas, derivatives, G, slot, mo_coeff):
+        """``evaluate`` for a circuit in the sector engine: the states and RDMs of all geometries in one launch each
+        (the geometry is the sector kernels' batch index), the CAS path of all geometries in one call, dE/dtheta by
+        the reverse sweep with each geometry's (c1, c2) as cotangents (oo_pqc.py:86-95).  The packed layout is that
+        of the dense path; the rows d gvec / d theta_k (the kappa-theta block, which the reverse sweep does not
+        produce) are NaN here -- ``energy_gradient_hessian`` delivers them."""
+        pqc, eng = self.pqc, self.pqc._sector
+        nt, nk, a = self.n_theta, self.n_kappa, self.ncas
+        psi = eng.state(thetas)
+        g1, g2 = eng.rdms(psi)
+        cas, _, _ = self._cas_batch(g1[:, None], g2[:, None], G, slot, mo_coeff)
+        if not derivatives:
+            return cas
+        osz = int(self.lib.oovqe_oo_eval_out_size(nt, nk, a, 1))
+        out = torch.full((G, osz), float("nan"), dtype=F64, device=self.device)
+        out[:, 0:2] = cas[:, 0:2]                                    # c0, E
+        out[:, 2 + nt:2 + nt + nk] = cas[:, 3:3 + nk]                # gvec row 0 = dE/dkappa
+        c12 = cas[:, 3 + nk:]
+        out[:, 2 + nt + (1 + nt) * nk:] = c12                        # c1 | c2
+        if eng.geometry_coefficients_ok():
+            # every geometry's reverse sweep in one launch sequence, its (c1 | c2) read where the CAS path left them
+            out[:, 2:2 + nt] = eng.adjoint_geometries(thetas, psi, c12, cas.stride(0))
+        else:
+            c1 = c12[:, :a * a].reshape(G, a, a)
+            c2 = c12[:, a * a:].reshape(G, a, a, a, a)
+            for g in range(G):      # (the operator of the reverse sweep takes ONE set of coefficients per call)
+                out[g, 2:2 + nt] = eng.adjoint(thetas[g:g + 1], psi[g:g + 1], c1[g], c2[g])[0]
+        return out
+
+    def _energy_gradient_hessian_sector(self, thetas):
+        pqc, eng = self.pqc, self.pqc._sector
+        G, nt, nk, a = self.G, self.n_theta, self.n_kappa, self.ncas
+        n = nt + nk
+        st = eng.tangent_states(thetas, pqc._gates, second=True)                 # [G, 1 + nt + n_pairs, Dc]
+        psi, tau = st[:, 0:1], st[:, 1:1 + nt]
+        # derivative RDMs by polarisation of the plain RDM kernel (exact: the RDMs are quadratic forms of the real
+        # state), all geometries in one list of sector vectors
+        vecs = torch.cat((psi, psi + tau, psi - tau), dim=1).reshape(G * (2 * nt + 1), eng.Dc)
+        r1, r2 = eng.rdms_chunked(vecs)
+        r1 = r1.reshape(G, 2 * nt + 1, a, a)
+        r2 = r2.reshape(G, 2 * nt + 1, a, a, a, a)
+        gamma = torch.cat((r1[:, 0:1], 0.5 * (r1[:, 1:1 + nt] - r1[:, 1 + nt:])), dim=1)
+        Gamma = torch.cat((r2[:, 0:1], 0.5 * (r2[:, 1:1 + nt] - r2[:, 1 + nt:])), dim=1)
+        out, _, fock = self._cas_batch(gamma, Gamma, G, want_fock=True)
+        E, dE = out[:, 1], out[:, 2:2 + nt]
+        gv = out[:, 2 + nt:2 + nt + (1 + nt) * nk].reshape(G, 1 + nt, nk)
+        c12 = out[:, 2 + nt + (1 + nt) * nk:]
+        H = torch.empty((G, n, n), dtype=F64, device=self.device)
+        # kappa-kappa blocks of all geometries in one call
+        key = ("orbital_hessian", 0)
+        if key not in self._plans:
+            wsz = self.lib.oovqe_orbital_hessian_work_size(self.nao, self._n_occ, self.ncas)
+            self._plans[key] = (torch.empty(G * wsz, dtype=F64, device=self.device), 0)
+        Hkk = torch.empty((G, nk, nk), dtype=F64, device=self.device)
+        check(self.lib.oovqe_orbital_hessian_batch(
+            dptr(self.int2e_ao), dptr(self.int1e_ao), dptr(self.mo_coeff), dptr(gamma[:, 0].contiguous()),
+            dptr(Gamma[:, 0].contiguous()), dptr(fock), self.nao, self._n_occ, self.ncas,
+            dptr(self._kap_row, torch.int32), dptr(self._kap_col, torch.int32), nk, G, dptr(self._plans[key][0]),
+            dptr(Hkk), int(self.eri_flags), stream_ptr()), "oovqe_orbital_hessian_batch")
+        H[:, nt:, nt:] = Hkk
+        H[:, nt:, :nt] = gv[:, 1:].transpose(1, 2)
+        H[:, :nt, nt:] = gv[:, 1:]
+        if eng.geometry_coefficients_ok():
+            # theta-theta blocks: H_jk = tau_jk . lam(psi) + tau_j . lam(tau_k), lam = the operator of EACH geometry
+            # applied to its psi and first tangents -- one launch sequence for all geometries
+            ja, ka, _ = eng.hessian_pair_tables(pqc._gates)
+            lam = eng.lam_geometries(st[:, :1 + nt].reshape(G * (1 + nt), eng.Dc), 1 + nt, c12,
+                                     out.stride(0)).reshape(G, 1 + nt, eng.Dc)
+            first = (st[:, 1 + nt:] * lam[:, 0:1]).sum(dim=2)                           # [G, n_pairs]
+            # tau_j . lam(tau_k): scalar products over the sector dimension, geometry by geometry (elementwise multiply
+            # + sum, as SectorEngine.circuit_hessian_from_states: no vendor GEMM on this path)
+            second = torch.stack([(st[g, 1:1 + nt, None, :] * lam[g, None, 1:, :]).sum(dim=2) for g in range(G)])
+            val = first + second[:, ja, ka]
+            Htt = torch.zeros((G, nt, nt), dtype=F64, device=self.device)
+            Htt[:, ja, ka] = val
+            Htt[:, ka, ja] = val
+            H[:, :nt, :nt] = Htt
+        else:
+            c1 = c12[:, :a * a].reshape(G, a, a)
+            c2 = c12[:, a * a:].reshape(G, a, a, a, a)
+            for g in range(G):      # (one set of CAS coefficients per application of the operator)
+                H[g, :nt, :nt] = eng.circuit_hessian_from_states(st[g], pqc._gates, c1[g].contiguous(),
+                                                                 c2[g].contiguous())
+        grad = torch.cat((dE, gv[:, 0]), dim=1)
+        return E, grad, H
 
     def evaluate_deferred(self, thetas, derivatives=True, count=None, mo_coeff=None, view=None):
         """``evaluate`` enqueued on one of the library's two side streams (taken in turn, each with a workspace of its
@@ -260,6 +378,8 @@ class OO_pqc_batch:
         n = nt + nk
         thetas = ops.as_device(thetas, self.device).reshape(G, nt)
         pqc = self.pqc
+        if getattr(pqc, "_use_sector", False):
+            return self._energy_gradient_hessian_sector(thetas)
         pairs_dev, _, _ = ops._hessian_pair_tables(nt, self.device)
         n_pairs = pairs_dev.shape[0]
         key = ("hessian", 0)
@@ -321,7 +441,8 @@ class OO_pqc_batch:
             return self.evaluate(pa, derivatives=False, mo_coeff=t_mo)[:, 1]
 
         n = nt + self.n_kappa
-        if self.step_by_calls or n > self.lib.oovqe_newton_direction_max_n() or self.G > 32767:
+        if (self.step_by_calls or n > self.lib.oovqe_newton_direction_max_n() or self.G > 32767
+                or getattr(self.pqc, "_use_sector", False)):
             E, grad, H = self.energy_gradient_hessian(thetas)
             flat = self._flat0
             if flat is None:

@@ -3994,6 +3994,8 @@ static bool column_fits(int N, int M, int ncas)
 // Where the circuit launch of an evaluation may leave W = C^T h_ao [G][N][N] for the panel kernel: the T3 block of
 // the packed-triangle path's workspace, which its one-launch q -> x / p -> n kernel does not use.  False when the
 // call will not take that path (the decision tree of cas_eval_batched below).
+extern "C" int64_t oovqe_oo_eval_out_size(int n_theta, int n_kappa, int ncas, int derivatives);
+
 static bool cas_w_block(int N, int M, int batch, unsigned eri_flags, double* work, double** W)
 {
     if (N > 48 || oovqe_opt(OOVQE_OPT_CAS_UNFUSED) != 0 || oovqe_opt(OOVQE_OPT_SYM_MIRROR) != 0 ||
@@ -4297,6 +4299,33 @@ extern "C" int oovqe_cas_eval_packed(const double* g_ao, const double* h_ao, con
     return cas_eval_batched(g_ao, h_ao, C, gamma, Gamma, nrdm, nuc, nullptr, N, n_occ, ncas, kap_row,
                             kap_col, n_kappa, work, c0, c1, c2, E, gvec, dE, fock, gmat, Gm, hmo, 1, 0,
                             stream, nullptr, eri_flags, g_packed);
+}
+
+// The CAS path for a STACK of geometries from given RDM sets (the circuit lives elsewhere: the sector engine of large
+// registers): geometry g reads gamma [g][nrdm][a^2], Gamma [g][nrdm][a^4] and writes the packed outputs of
+// oovqe_oo_eval_batch for n_theta = nrdm - 1 at out + g * oovqe_oo_eval_out_size(nrdm - 1, n_kappa, ncas, nrdm > 1).
+extern "C" int oovqe_cas_eval_batch(const double* g_ao, const double* h_ao, const double* C, const double* gamma,
+                                    const double* Gamma, int nrdm, const double* nuc, int N, int n_occ, int ncas,
+                                    const int32_t* kap_row, const int32_t* kap_col, int n_kappa, int batch,
+                                    double* work, double* out, double* fock, unsigned eri_flags,
+                                    const double* g_packed, oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(nuc && out, "cas_eval_batch: null pointer");
+    OOVQE_REQUIRE(nrdm >= 1 && batch >= 1, "cas_eval_batch: nrdm = %d, batch = %d", nrdm, batch);
+    OOVQE_REQUIRE(!g_packed || eri_flags == (OOVQE_ERI_PQ_SYMMETRIC | OOVQE_ERI_RS_SYMMETRIC),
+                  "cas_eval_batch: a packed copy needs both symmetry flags");
+    const size_t na2 = (size_t)ncas * ncas;
+    const size_t out_stride = (size_t)oovqe_oo_eval_out_size(nrdm - 1, n_kappa, ncas, nrdm > 1);
+    const int n_t = nrdm > 1 ? nrdm - 1 : 1;
+    double* c0 = out;
+    double* E = out + 1;
+    double* dE = out + 2;
+    double* gvec = dE + n_t;
+    double* c1 = gvec + (size_t)nrdm * n_kappa;
+    double* c2 = c1 + na2;
+    return cas_eval_batched(g_ao, h_ao, C, gamma, Gamma, nrdm, 0.0, nuc, N, n_occ, ncas, kap_row, kap_col, n_kappa,
+                            work, c0, c1, c2, E, gvec, dE, fock, nullptr, nullptr, nullptr, batch, out_stride, stream,
+                            nullptr, eri_flags, g_packed);
 }
 
 extern "C" int64_t oovqe_cas_eval_work_size(int N, int n_occ, int ncas, int nrdm)

@@ -1035,8 +1035,13 @@ __global__ void sector_rdm_finish_kernel(const double* __restrict__ R, int ncas,
 // (round 2 carried the transposed half as a second set of a^2 vectors W': twice the bytes written and read).
 __global__ void sector_coeff_kernel(const double* __restrict__ c1, const double* __restrict__ c2,
                                     int ncas, const uint32_t* __restrict__ unrank_a,
-                                    const uint32_t* __restrict__ unrank_b, double* __restrict__ Ms)
+                                    const uint32_t* __restrict__ unrank_b, double* __restrict__ Ms,
+                                    long c1_bs, long c2_bs, long ms_bs)
 {
+    // blockIdx.y: the coefficient set (one per geometry of a stack: c1 + y c1_bs, c2 + y c2_bs -> Ms + y ms_bs)
+    c1 += (size_t)blockIdx.y * c1_bs;
+    c2 += (size_t)blockIdx.y * c2_bs;
+    Ms += (size_t)blockIdx.y * ms_bs;
     // Ms [a^2][a^2]: row k = (r,s) of V, column j = (p,q) of W.  The one-body term u = sum_k s_k V_k rides
     // along: on the sector sum_p E_pp = N (the electron number), so adding s_k / N to the columns (p,p) of
     // row k adds sum_p E_pp (s_k / N) V_k = s_k V_k to lambda = sum_j E_j W_j -- no extra row of W to write
@@ -1174,8 +1179,14 @@ __host__ __device__ inline size_t sec_lambda_lds_bytes(int na, int nb, int ncas)
 __global__ __launch_bounds__(256)
 void sector_gmat_kernel(const double* __restrict__ Ms, Sector s, double* __restrict__ Ga,
                         double* __restrict__ Gb, double* __restrict__ sigma, uint16_t* __restrict__ tabs,
-                        const uint16_t* __restrict__ tabs_g)
+                        const uint16_t* __restrict__ tabs_g, long ms_bs, long g_bs)
 {
+    // blockIdx.y: the coefficient set (Ms + y ms_bs -> Ga + y g_bs, Gb + y g_bs); sigma and the tables do not depend
+    // on the coefficients: set 0 makes them
+    Ms += (size_t)blockIdx.y * ms_bs;
+    Ga += (size_t)blockIdx.y * g_bs;
+    Gb += (size_t)blockIdx.y * g_bs;
+    const bool first_set = blockIdx.y == 0;
     // tabs [a^2][na] | [a^2][nb]: the excitation tables, for the kernels of the launches that follow
     // (tabs_g: the per-circuit copy, when the caller holds one: copied instead of built)
     extern __shared__ double lds[];
@@ -1183,7 +1194,7 @@ void sector_gmat_kernel(const double* __restrict__ Ms, Sector s, double* __restr
     int blk = blockIdx.x;
     if (blk >= s.na + s.nb) {
         const int c = (blk - s.na - s.nb) * 256 + tid;
-        if (c < s.na * s.nb) {
+        if (first_set && c < s.na * s.nb) {
             const int ia = c / s.nb, ib = c - ia * s.nb;
             const uint32_t sa = s.unrank_a[ia], sb = s.unrank_b[ib];
             uint32_t par = 0;
@@ -1205,7 +1216,7 @@ void sector_gmat_kernel(const double* __restrict__ Ms, Sector s, double* __restr
     }
     for (int i = tid; i < na2 * nstr; i += 256) part[i] = 0.0;
     __syncthreads();
-    if (row == 0) {
+    if (row == 0 && first_set) {
         uint16_t* out = tabs + (alpha ? 0 : (size_t)s.na * na2);
         for (int i = tid; i < na2 * nstr; i += 256) out[i] = tab[i];
         if (!alpha) {
@@ -1247,8 +1258,11 @@ void sector_gmat_kernel(const double* __restrict__ Ms, Sector s, double* __restr
 __global__ __launch_bounds__(512)
 void sector_lambda_dense_kernel(const double* __restrict__ psi_c, const double* __restrict__ Ga,
                                 const double* __restrict__ Gb, const double* __restrict__ sigma, int na, int nb,
-                                double* __restrict__ lam)
+                                double* __restrict__ lam, long g_bs, int group)
 {
+    // state b takes the matrices of coefficient set b / group (g_bs = 0: one set for all)
+    Ga += (size_t)(blockIdx.x / group) * g_bs;
+    Gb += (size_t)(blockIdx.x / group) * g_bs;
     extern __shared__ double lds[];
     const int Dc = na * nb, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1298,9 +1312,11 @@ template <int NT>
 __global__ __launch_bounds__(512)
 void sector_lambda_fused_kernel(const double* __restrict__ psi_c, const double* __restrict__ Ms,
                                 const double* __restrict__ sigma, const uint16_t* __restrict__ tabs, Sector s,
-                                double* __restrict__ lam, int probe)
+                                double* __restrict__ lam, int probe, long ms_bs, int group)
 {
     // probe (timing only, wrong results): 1 no chunk build after the first, 2 no MFMA, 3 no gather
+    // state b takes the coefficients of set b / group (ms_bs = 0: one set for all)
+    Ms += (size_t)(blockIdx.x / group) * ms_bs;
     extern __shared__ double lds[];
     const int na = s.na, nb = s.nb, Dc = na * nb, a = s.ncas, na2 = a * a;
     const int LA = (na + 8) & ~7;                        // columns of one beta string inside a chunk (>= 1 zero column)
@@ -2427,7 +2443,7 @@ static int sector_adjoint_impl(const double* theta, int n_theta, const oovqe_gat
                                const int32_t* rank_b, int na, int nb, int batch, const double* psi_c,
                                const double* c1, const double* c2, const uint32_t* pairs, int max_pairs,
                                const uint16_t* tabs_g, double* work, double* dtheta, double* lam_out,
-                               oovqe_stream_t stream);
+                               oovqe_stream_t stream, long c1_bs = 0, long c2_bs = 0, int group = 1);
 
 // The same with the reverse sweep from the pair lists of oovqe_sector_pairs (pairs == NULL: the gate sweep).
 extern "C" int oovqe_sector_adjoint_pl(const double* theta, int n_theta, const oovqe_gate_t* gates,
@@ -2456,12 +2472,48 @@ extern "C" int oovqe_sector_lambda(const double* vecs, int ncas, const uint32_t*
                                c2, nullptr, 0, tabs, work, nullptr, lam, stream);
 }
 
+// The same two with the CAS coefficients of a STACK OF GEOMETRIES (kUpCCD CAS(8e,8o) over the points of a Berry-phase
+// loop): state b takes c1 + (b / group) c_stride, c2 + (b / group) c_stride -- e.g. columns of the packed outputs of
+// oovqe_cas_eval_batch.  group = 1: the reverse sweep of every geometry's state in one call; group = 1 + n_theta:
+// the operator applied to psi and its first tangents of every geometry (the theta-theta blocks).
+extern "C" int oovqe_sector_geometry_coefficients_ok(int ncas, int na, int nb)
+{
+    const int na2 = ncas * ncas;
+    const int LAp = (na + 8) & ~7;
+    return (na2 == 16 || na2 == 64) && na < SEC_TAB_MAXSTR && nb < SEC_TAB_MAXSTR && LAp <= SEC_LCH &&
+           sec_fused_lds_bytes(na, nb, ncas) <= 140 * 1024 && sec_lambda_lds_bytes(na, nb, ncas) <= 160 * 1024 &&
+           oovqe_opt(OOVQE_OPT_SECTOR_UNFUSED) == 0 && na * nb <= 32767;
+}
+
+extern "C" int oovqe_sector_adjoint_pg(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates,
+                                       int ncas, const uint32_t* unrank_a, const uint32_t* unrank_b,
+                                       const int32_t* rank_a, const int32_t* rank_b, int na, int nb, int batch,
+                                       const double* psi_c, const double* c1, const double* c2, int64_t c_stride,
+                                       const uint32_t* pairs, int max_pairs, const uint16_t* tabs, double* work,
+                                       double* dtheta, oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(theta && gates && dtheta && c_stride > 0, "sector_adjoint_pg: null pointer / stride");
+    return sector_adjoint_impl(theta, n_theta, gates, n_gates, ncas, unrank_a, unrank_b, rank_a, rank_b, na, nb, batch,
+                               psi_c, c1, c2, pairs, max_pairs, tabs, work, dtheta, nullptr, stream, (long)c_stride,
+                               (long)c_stride, 1);
+}
+
+extern "C" int oovqe_sector_lambda_pg(const double* vecs, int ncas, const uint32_t* unrank_a, const uint32_t* unrank_b,
+                                      const int32_t* rank_a, const int32_t* rank_b, int na, int nb, int batch,
+                                      int group, const double* c1, const double* c2, int64_t c_stride,
+                                      const uint16_t* tabs, double* work, double* lam, oovqe_stream_t stream)
+{
+    OOVQE_REQUIRE(lam && c_stride > 0 && group >= 1, "sector_lambda_pg: null pointer / stride / group");
+    return sector_adjoint_impl(nullptr, 0, nullptr, 0, ncas, unrank_a, unrank_b, rank_a, rank_b, na, nb, batch, vecs, c1,
+                               c2, nullptr, 0, tabs, work, nullptr, lam, stream, (long)c_stride, (long)c_stride, group);
+}
+
 static int sector_adjoint_impl(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates, int ncas,
                                const uint32_t* unrank_a, const uint32_t* unrank_b, const int32_t* rank_a,
                                const int32_t* rank_b, int na, int nb, int batch, const double* psi_c,
                                const double* c1, const double* c2, const uint32_t* pairs, int max_pairs,
                                const uint16_t* tabs_g, double* work, double* dtheta, double* lam_out,
-                               oovqe_stream_t stream)
+                               oovqe_stream_t stream, long c1_bs, long c2_bs, int group)
 {
     // lam_out: stop after the lambda stage and leave it there (theta, gates, dtheta unused)
     OOVQE_REQUIRE(psi_c && c1 && c2 && work && unrank_a && unrank_b && rank_a && rank_b, "sector_adjoint: null pointer");
@@ -2481,9 +2533,17 @@ static int sector_adjoint_impl(const double* theta, int n_theta, const oovqe_gat
     double* lam = lam_out ? lam_out : W12 + nb_ * (2 * (size_t)na2 + 1) * Dc;
     double* R = W12 + nb_ * (2 * (size_t)na2 + 1) * Dc + nb_ * Dc;
     double* M12 = R + 8 * nb_ * (size_t)(MT * 16) * (NT * 16);
-    hipLaunchKernelGGL(sector_coeff_kernel, dim3((na2 * na2 + 255) / 256), dim3(256), 0, st, c1, c2, ncas,
-                       unrank_a, unrank_b, M12);
-    OOVQE_CHECK_LAUNCH("sector_adjoint/coeff");
+    // per_set: state b takes the CAS coefficients c1 + (b / group) c1_bs, c2 + (b / group) c2_bs (a stack of geometries:
+    // group = 1 for the reverse sweep, 1 + n_theta for the operator applied to psi and its tangents); one set for all
+    // otherwise.  Served by the string-driven form only (its coefficient matrices per set are small: a^4 + na^2 + nb^2).
+    const bool per_set = c1_bs != 0 || c2_bs != 0;
+    OOVQE_REQUIRE(group >= 1 && (!per_set || batch % group == 0), "sector_adjoint: batch %d, group %d", batch, group);
+    const int nset = per_set ? batch / group : 1;
+    if (!per_set) {
+        hipLaunchKernelGGL(sector_coeff_kernel, dim3((na2 * na2 + 255) / 256), dim3(256), 0, st, c1, c2, ncas,
+                           unrank_a, unrank_b, M12, 0L, 0L, 0L);
+        OOVQE_CHECK_LAUNCH("sector_adjoint/coeff");
+    }
     int rc;
     uint16_t* tabs = reinterpret_cast<uint16_t*>(M12 + (size_t)na2 * na2);   // [a^2][na] | [a^2][nb], 16-bit
     const size_t fused_lds = sec_fused_lds_bytes(na, nb, ncas);
@@ -2504,20 +2564,34 @@ static int sector_adjoint_impl(const double* theta, int n_theta, const oovqe_gat
                                    nb_ * (2 * (size_t)na2 + 1) * Dc &&
                                // (its two small extra launches cost ~55 us: CAS(8e,8o) 230 us whatever the batch up
                                // to 32 states, where W in memory takes 175 ... 230 us; 64: 264 vs 315; 256: 485 vs 603)
-                               (oovqe_opt(OOVQE_OPT_SECTOR_LAMBDA_W) >= 2 ||
+                               (per_set || oovqe_opt(OOVQE_OPT_SECTOR_LAMBDA_W) >= 2 ||
                                 (oovqe_opt(OOVQE_OPT_SECTOR_LAMBDA_W) == 0 && batch >= 32));
+    const long g_bs = per_set ? (long)na * na + (long)nb * nb : 0, ms_bs = per_set ? (long)na2 * na2 : 0;
+    OOVQE_REQUIRE(!per_set || (string_driven && (size_t)nset * (size_t)(g_bs + ms_bs) + Dc +
+                                                        ((size_t)(na + nb) * na2 + 3) / 4 + ((size_t)nb * na2 + 1) / 2 + 2 <=
+                                                    nb_ * (2 * (size_t)na2 + 1) * Dc),
+                  "sector_adjoint: per-geometry coefficients need the string-driven form (ncas = 4 or 8)");
     if (string_driven) {
         double* Ga = W12;                                   // (the W region of the workspace is free here)
         double* Gb = Ga + (size_t)na * na;
-        double* sigma = Gb + (size_t)nb * nb;
+        // per set: [G_a | G_b] of every set, then the coefficient matrices of every set; sigma and the tables behind
+        double* Ms_sets = W12 + (size_t)nset * g_bs;
+        double* sigma = per_set ? Ms_sets + (size_t)nset * ms_bs : Gb + (size_t)nb * nb;
         uint16_t* tabs2 = reinterpret_cast<uint16_t*>(sigma + Dc);      // [a^2][na] | [a^2][nb]
+        const double* Msrc = M12;
+        if (per_set) {
+            hipLaunchKernelGGL(sector_coeff_kernel, dim3((na2 * na2 + 255) / 256, nset), dim3(256), 0, st, c1, c2, ncas,
+                               unrank_a, unrank_b, Ms_sets, c1_bs, c2_bs, ms_bs);
+            OOVQE_CHECK_LAUNCH("sector_adjoint/coeff");
+            Msrc = Ms_sets;
+        }
         if ((rc = oovqe_ensure_dynamic_lds((const void*)sector_gmat_kernel, gmat_lds))) return rc;
-        hipLaunchKernelGGL(sector_gmat_kernel, dim3(na + nb + (Dc + 255) / 256), dim3(256), gmat_lds, st, M12, s, Ga,
-                           Gb, sigma, tabs2, tabs_g);
+        hipLaunchKernelGGL(sector_gmat_kernel, dim3(na + nb + (Dc + 255) / 256, nset), dim3(256), gmat_lds, st, Msrc, s,
+                           Ga, Gb, sigma, tabs2, tabs_g, ms_bs, g_bs);
         OOVQE_CHECK_LAUNCH("sector_adjoint/gmat");
         if ((rc = oovqe_ensure_dynamic_lds((const void*)sector_lambda_dense_kernel, dense_lds))) return rc;
         hipLaunchKernelGGL(sector_lambda_dense_kernel, dim3(batch), dim3(512), dense_lds, st, psi_c, Ga, Gb, sigma,
-                           na, nb, lam);
+                           na, nb, lam, g_bs, group);
         OOVQE_CHECK_LAUNCH("sector_adjoint/lambda_dense");
         const int nchunk = (nb + SEC_LCH / LAp - 1) / (SEC_LCH / LAp);
         int nsplit = sector_cu_count() / batch;             // one workgroup per CU (LDS), the chip filled once
@@ -2525,7 +2599,7 @@ static int sector_adjoint_impl(const double* theta, int n_theta, const oovqe_gat
         if (nsplit < 1) nsplit = 1;
         if (nsplit > nchunk) nsplit = nchunk;
         const size_t pipe_lds = sec_lambda_pipe_lds_bytes(na, nb, ncas);
-        if (na2 == 64 && na <= 70 && pipe_lds <= 160 * 1024 && oovqe_opt(OOVQE_OPT_SECTOR_LAMBDA_W) == 4) {
+        if (!per_set && na2 == 64 && na <= 70 && pipe_lds <= 160 * 1024 && oovqe_opt(OOVQE_OPT_SECTOR_LAMBDA_W) == 4) {
             // the phases overlapped: multiplier and helper waves, one beta string per chunk -- measured and NOT the
             // default (344 us against 311 at 256 states: see the kernel's header)
             int nsp = sector_cu_count() / batch;
@@ -2538,11 +2612,11 @@ static int sector_adjoint_impl(const double* theta, int n_theta, const oovqe_gat
         } else if (na2 == 64) {
             if ((rc = oovqe_ensure_dynamic_lds((const void*)sector_lambda_fused_kernel<4>, lam_lds))) return rc;
             hipLaunchKernelGGL(sector_lambda_fused_kernel<4>, dim3(batch, nsplit), dim3(512), lam_lds, st, psi_c,
-                               M12, sigma, tabs2, s, lam, oovqe_opt(OOVQE_OPT_SECTOR_PROBE));
+                               Msrc, sigma, tabs2, s, lam, oovqe_opt(OOVQE_OPT_SECTOR_PROBE), ms_bs, group);
         } else {
             if ((rc = oovqe_ensure_dynamic_lds((const void*)sector_lambda_fused_kernel<1>, lam_lds))) return rc;
             hipLaunchKernelGGL(sector_lambda_fused_kernel<1>, dim3(batch, nsplit), dim3(512), lam_lds, st, psi_c,
-                               M12, sigma, tabs2, s, lam, oovqe_opt(OOVQE_OPT_SECTOR_PROBE));
+                               Msrc, sigma, tabs2, s, lam, oovqe_opt(OOVQE_OPT_SECTOR_PROBE), ms_bs, group);
         }
         OOVQE_CHECK_LAUNCH("sector_adjoint/lambda_fused");
     } else {

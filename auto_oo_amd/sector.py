@@ -187,8 +187,22 @@ class SectorEngine:
             pairs = self._tangent_plan(gates_host, True)[4]
             self._hess_tables = (torch.as_tensor([j for j, _ in pairs], device=self.device),
                                  torch.as_tensor([k for _, k in pairs], device=self.device), len(pairs))
-        ja, ka, npair = self._hess_tables
         st = self.tangent_states(theta, gates_host, second=True)[0]
+        return self.circuit_hessian_from_states(st, gates_host, c1, c2, by_rdms)
+
+    def hessian_pair_tables(self, gates_host):
+        """(j indices, k indices, count) of the pairs j <= k in the order of the second tangents (device)."""
+        if self._hess_tables is None:
+            pairs = self._tangent_plan(gates_host, True)[4]
+            self._hess_tables = (torch.as_tensor([j for j, _ in pairs], device=self.device),
+                                 torch.as_tensor([k for _, k in pairs], device=self.device), len(pairs))
+        return self._hess_tables
+
+    def circuit_hessian_from_states(self, st, gates_host, c1, c2, by_rdms=False):
+        """The theta-theta block from psi, its first and its second tangents (``tangent_states(.., second=True)[g]``,
+        [1 + n_theta + n_pairs, Dc]) and the CAS coefficients of ONE geometry."""
+        nt = self.n_theta
+        ja, ka, npair = self.hessian_pair_tables(gates_host)
         psi, tau, tau2 = st[0], st[1:1 + nt], st[1 + nt:]
         if by_rdms:
             vecs = torch.cat((tau2 + psi, tau2 - psi, tau[ja] + tau[ka], tau[ja] - tau[ka]))
@@ -208,6 +222,41 @@ class SectorEngine:
         H[ja, ka] = val
         H[ka, ja] = val
         return H
+
+    # ---- a stack of geometries, each with its own CAS coefficients (round 5) ---------------------------
+    def geometry_coefficients_ok(self):
+        """True when the library applies the operator / runs the reverse sweep for a stack of states with PER-GEOMETRY
+        coefficients in one launch sequence (ncas = 4, 8); the callers loop over the geometries otherwise."""
+        return bool(self.lib.oovqe_sector_geometry_coefficients_ok(self.ncas, self.na, self.nb))
+
+    def adjoint_geometries(self, theta, psi_c, c1, c_stride):
+        """d/dtheta (c1[g] . gamma + c2[g] . Gamma) of state g for a stack of geometries: theta [G, n_theta], psi_c
+        [G, Dc]; c1 = a view whose element g starts c_stride doubles after element g - 1 and is followed by c2[g]
+        (the c1 | c2 columns of ``oovqe_cas_eval_batch``'s packed outputs) -> [G, n_theta]."""
+        G = theta.shape[0]
+        a = self.ncas
+        dth = torch.empty((G, self.n_theta), dtype=F64, device=self.device)
+        pairs, max_pairs = self.pair_lists()
+        p1 = c1.data_ptr()
+        check(self.lib.oovqe_sector_adjoint_pg(dptr(theta), self.n_theta, dptr(self.gates_dev, torch.uint8),
+                                               self.n_gates, a, *self._tabs(), G, dptr(psi_c), ctypes.c_void_p(p1),
+                                               ctypes.c_void_p(p1 + 8 * a * a), int(c_stride), dptr(pairs, torch.int32),
+                                               max_pairs, self._tables_ptr, dptr(self.work(G)), dptr(dth),
+                                               stream_ptr()), "oovqe_sector_adjoint_pg")
+        return dth
+
+    def lam_geometries(self, vecs, group, c1, c_stride):
+        """(Hop_g + Hop_g^T) v for vecs [G * group, Dc], geometry g = row // group, coefficients as in
+        ``adjoint_geometries`` -> [G * group, Dc]."""
+        n = vecs.shape[0]
+        a = self.ncas
+        out = torch.empty((n, self.Dc), dtype=F64, device=self.device)
+        self.pair_lists()
+        p1 = c1.data_ptr()
+        check(self.lib.oovqe_sector_lambda_pg(dptr(vecs), a, *self._tabs(), n, int(group), ctypes.c_void_p(p1),
+                                              ctypes.c_void_p(p1 + 8 * a * a), int(c_stride), self._tables_ptr,
+                                              dptr(self.work(n)), dptr(out), stream_ptr()), "oovqe_sector_lambda_pg")
+        return out
 
     def pair_lists(self):
         """(pairs, max_pairs): the gates of the circuit as lists of the determinant pairs they rotate

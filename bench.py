@@ -564,7 +564,44 @@ def kupccd_extra():
             rec["newton_step_energy_drop"] = e_before - oo.energy_from_parameters(new[0], new[1]).item()
             rec["hessian_dim"] = n_theta + oo.n_kappa
         layers.append(rec)
-    return {"layers": layers}
+    # round 5: configs[4]'s circuit on configs[3]'s loop -- the sector engine under the geometry batch: kUpCCD CAS(8e,8o),
+    # k = 1, over a stack of synthetic N = 43 geometries (OO_pqc_batch: states, RDMs, reverse sweeps and the operator
+    # of all geometries in one launch sequence each, per-geometry CAS coefficients inside the sector kernels)
+    Gb = 16
+    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz="kupccd", k=1)
+    probs = [synthetic_problem(NAO, 20265 + 1000 * g) for g in range(Gb)]
+    mols = [aoo.Moldata(P_["int1e_ao"], P_["int2e_ao"], P_["overlap"], P_["nuc"], NELEC) for P_ in probs]
+    batch = aoo.OO_pqc_batch(pqc, mols, ncas, nelecas, oao_mo_coeffs=[P_["oao_mo_coeff"] for P_ in probs])
+    n_theta = int(pqc.theta_shape)
+    ths = torch.tensor(rng.normal(0, 0.3, (Gb, n_theta)), device="cuda")
+    single = aoo.OO_pqc(pqc, mols[0], ncas, nelecas, oao_mo_coeff=probs[0]["oao_mo_coeff"])
+    t_eval = timed(lambda: batch.energy_and_gradient(ths), warm=2, reps=5)
+    t_one = timed(lambda: single.energy_and_gradient(ths[0]), warm=2, reps=5)
+    t_hess = timed(lambda: batch.energy_gradient_hessian(ths), warm=1, reps=3)
+    c_saved = batch.oao_mo_coeff.clone()
+    e0 = batch.energy(ths)
+
+    def step():
+        batch.oao_mo_coeff.copy_(c_saved)
+        batch.refresh_mo_coeff()
+        return batch.damped_newton_step(ths)
+    t_step = timed(step, warm=1, reps=3)
+    _, e1, _ = step()
+    batch.oao_mo_coeff.copy_(c_saved)              # (the step adopted new orbitals: back to the start for the comparison)
+    batch.refresh_mo_coeff()
+    eg_b = batch.energy_and_gradient(ths)
+    e_s, g_s = single.energy_and_gradient(ths[0])
+    geometry_batch = {"geometries": Gb, "n_theta": n_theta, "n_kappa": batch.n_kappa, "N": NAO,
+                      "energy_gradient_us": t_eval * 1e6, "evaluations_per_s": Gb / t_eval,
+                      "single_geometry_energy_gradient_us": t_one * 1e6,
+                      "energy_gradient_hessian_us": t_hess * 1e6, "lockstep_newton_step_us": t_step * 1e6,
+                      "max_abs_difference_vs_single_geometry": float(max(abs(eg_b[0, 0] - e_s), (eg_b[0, 1:] - g_s).abs().max())),
+                      "every_energy_lowered_by_the_step": bool((e1 < e0).all().item()),
+                      "note": "OO_pqc_batch on a sector circuit: one state / RDM / reverse-sweep launch sequence and one "
+                              "oovqe_cas_eval_batch call for all geometries; the Hessian adds the derivative RDMs of all "
+                              "geometries by polarisation, one oovqe_orbital_hessian_batch call and the operator on psi and "
+                              "its tangents of all geometries (oovqe_sector_lambda_pg)"}
+    return {"layers": layers, "geometry_batch": geometry_batch}
 
 
 def transform_microbench(N):

@@ -433,6 +433,22 @@ int64_t oovqe_sector_work_size(int ncas, int na, int nb, int batch);
 int oovqe_sector_lambda(const double* vecs, int ncas, const uint32_t* unrank_a, const uint32_t* unrank_b,
                         const int32_t* rank_a, const int32_t* rank_b, int na, int nb, int batch, const double* c1,
                         const double* c2, const uint16_t* tabs, double* work, double* lam, oovqe_stream_t stream);
+/* The same two for a STACK OF GEOMETRIES, each with its own CAS coefficients (the sector engine under the
+ * geometry batch: ansatze/kUpCCD.py:36-154 under oo_pqc.py:64-148, one launch sequence for all geometries): state b
+ * takes c1 + (b / group) * c_stride and c2 + (b / group) * c_stride (doubles; e.g. columns of the packed outputs of
+ * oovqe_cas_eval_batch).  oovqe_sector_adjoint_pg: group = 1.  oovqe_sector_lambda_pg with group = 1 + n_theta: the
+ * operator on psi and its first tangents of every geometry (theta-theta blocks).  Served for ncas = 4 and 8
+ * (oovqe_sector_geometry_coefficients_ok); callers loop over the geometries otherwise. */
+int oovqe_sector_geometry_coefficients_ok(int ncas, int na, int nb);
+int oovqe_sector_adjoint_pg(const double* theta, int n_theta, const oovqe_gate_t* gates, int n_gates, int ncas,
+                            const uint32_t* unrank_a, const uint32_t* unrank_b, const int32_t* rank_a,
+                            const int32_t* rank_b, int na, int nb, int batch, const double* psi_c, const double* c1,
+                            const double* c2, int64_t c_stride, const uint32_t* pairs, int max_pairs,
+                            const uint16_t* tabs, double* work, double* dtheta, oovqe_stream_t stream);
+int oovqe_sector_lambda_pg(const double* vecs, int ncas, const uint32_t* unrank_a, const uint32_t* unrank_b,
+                           const int32_t* rank_a, const int32_t* rank_b, int na, int nb, int batch, int group,
+                           const double* c1, const double* c2, int64_t c_stride, const uint16_t* tabs, double* work,
+                           double* lam, oovqe_stream_t stream);
 int64_t oovqe_sector_pairs_size(int n_gates, int na, int nb);
 /* oovqe_sector_pairs also leaves the sector's two excitation tables ([a^2][na] | [a^2][nb], 16-bit: source string,
  * valid bit, parities) behind the lists -- its buffer must hold oovqe_sector_pairs_size + oovqe_sector_tables_size
@@ -476,6 +492,16 @@ int oovqe_oo_eval(const double* theta, int n_theta, const oovqe_gate_t* gates, i
                   unsigned eri_flags, oovqe_stream_t stream);
 int64_t oovqe_oo_eval_work_size(int n_theta, int n_gates, int n_qubits, int N, int n_occ, int ncas,
                                 int derivatives);
+/* The CAS path of a STACK of geometries from GIVEN RDM sets (circuits whose state lives in the sector engine:
+ * kUpCCD CAS(8e,8o) over the geometries of a Berry-phase loop): gamma [G][nrdm][a^2], Gamma [G][nrdm][a^4] (set 0 =
+ * the RDMs, sets k >= 1 = derivative RDMs), nuc [G] (device); out [G][oovqe_oo_eval_out_size(nrdm - 1, n_kappa, ncas,
+ * nrdm > 1)] in the packed layout of oovqe_oo_eval_batch; work G * oovqe_cas_eval_work_size(N, n_occ, ncas, nrdm);
+ * fock [G][N][N] or NULL.  Replaces, per geometry, what oovqe_cas_eval replaces (oo_energy.py:178-309). */
+int oovqe_cas_eval_batch(const double* g_ao, const double* h_ao, const double* C, const double* gamma,
+                         const double* Gamma, int nrdm, const double* nuc, int N, int n_occ, int ncas,
+                         const int32_t* kap_row, const int32_t* kap_col, int n_kappa, int batch, double* work,
+                         double* out, double* fock, unsigned eri_flags, const double* g_packed,
+                         oovqe_stream_t stream);
 int64_t oovqe_oo_eval_out_size(int n_theta, int n_kappa, int ncas, int derivatives);
 /* The same for a BATCH of geometries in one call (the Berry-phase-loop batch of the north star;
  * examples/Tutorial_Berry_phase.ipynb): every per-geometry array is stacked along a leading batch

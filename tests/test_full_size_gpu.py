@@ -589,6 +589,100 @@ def test_sector_second_derivatives_with_shared_parameters_vs_oracle_autograd_cas
             - torch.autograd.functional.jacobian(ooo.energy_from_parameters, theta)).abs().max().item() < 1e-8
 
 
+def _sector_batch(N, ncas, nelecas, nelec, G, seed, ansatz="kupccd", **kw):
+    import auto_oo_amd as aoo
+    from auto_oo_amd.synthetic import synthetic_problem
+    pqc = aoo.Parameterized_circuit(ncas, nelecas, None, ansatz=ansatz, **kw)
+    probs = [synthetic_problem(N, seed + 1000 * g) for g in range(G)]
+    mols = [aoo.Moldata(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec) for P in probs]
+    objs = [aoo.OO_pqc(pqc, m, ncas, nelecas, oao_mo_coeff=P["oao_mo_coeff"]) for m, P in zip(mols, probs)]
+    batch = aoo.OO_pqc_batch(pqc, mols, ncas, nelecas, oao_mo_coeffs=[P["oao_mo_coeff"] for P in probs])
+    return pqc, probs, objs, batch
+
+
+@pytest.mark.parametrize("ansatz,kw", [("kupccd", {"k": 1}), ("np_fabric", {"n_layers": 2})])
+def test_sector_circuits_in_the_geometry_batch_cas44(ansatz, kw):
+    """The sector engine composed with the geometry batch (round 5; ansatze/kUpCCD.py:36-154 under oo_pqc.py:64-148):
+    OO_pqc_batch on a circuit whose state lives in the (N_alpha, N_beta) sector (forced here on the 8-qubit register
+    of CAS(4e,4o)) -- energy + full gradient, full Hessian and a lockstep damped Newton step of 3 geometries against
+    the per-geometry OO_pqc objects (1e-11 / 1e-10), against the dense-register batched kernels (the same stack
+    with the sector engine switched off) and against the oracle (energy, gradient, theta-theta block: 1e-8)."""
+    import auto_oo_amd as aoo
+    from oracle import cpu_ref as R
+    from torch.autograd.functional import hessian as thessian
+    N, ncas, nelecas, nelec, G = 10, 4, 4, 8, 3
+    pqc, probs, objs, batch = _sector_batch(N, ncas, nelecas, nelec, G, 7100, ansatz, **kw)
+    assert pqc._sector.fits()
+    pqc._use_sector = True
+    nt = int(pqc.theta_shape)
+    rng = np.random.default_rng(71)
+    thetas = torch.tensor(rng.uniform(0, 2 * np.pi, (G, nt)), device=DEV)
+    eg = batch.energy_and_gradient(thetas)
+    E, grad, H = batch.energy_gradient_hessian(thetas)
+    for g, oo in enumerate(objs):
+        e1, g1 = oo.energy_and_gradient(thetas[g])
+        assert abs(eg[g, 0].item() - e1.item()) < 1e-11 and (eg[g, 1:] - g1).abs().max().item() < 1e-11
+        assert abs(E[g].item() - e1.item()) < 1e-11 and (grad[g] - g1).abs().max().item() < 1e-10
+        H1 = oo.full_hessian(thetas[g])
+        assert (H[g] - H1).abs().max().item() < 1e-10 * max(1.0, H1.abs().max().item())
+    # per-geometry CAS coefficients inside the sector kernels (one launch sequence for all geometries: the default at
+    # ncas = 4, 8) against the loop over geometries that other active spaces take
+    assert pqc._sector.geometry_coefficients_ok()
+    pqc._sector.geometry_coefficients_ok = lambda: False
+    try:
+        eg_l = batch.energy_and_gradient(thetas)
+        E_l, grad_l, H_l = batch.energy_gradient_hessian(thetas)
+    finally:
+        del pqc._sector.geometry_coefficients_ok
+    assert (eg - eg_l).abs().max().item() < 1e-11 and (H - H_l).abs().max().item() < 1e-10
+    # the oracle on geometry 0
+    P = probs[0]
+    omol = R.OracleMol(P["int1e_ao"], P["int2e_ao"], P["overlap"], P["nuc"], nelec)
+    ooo = R.OracleOOPQC(R.OraclePQC(ncas, nelecas, ansatz, **kw), omol, ncas, nelecas, P["oao_mo_coeff"])
+    th0 = thetas[0].cpu()
+    assert abs(ooo.energy_from_parameters(th0).item() - E[0].item()) < 1e-9
+    assert (ooo.full_gradient(th0) - grad[0].cpu()).abs().max().item() < 1e-8
+    assert (thessian(ooo.energy_from_parameters, th0) - H[0, :nt, :nt].cpu()).abs().max().item() < 1e-8
+    # the dense-register batched kernels on the same stack
+    pqc._use_sector = False
+    try:
+        Ed, gd, Hd = batch.energy_gradient_hessian(thetas)
+    finally:
+        pqc._use_sector = True
+    assert (E - Ed).abs().max().item() < 1e-11 and (grad - gd).abs().max().item() < 1e-10
+    assert (H - Hd).abs().max().item() < 1e-10 * max(1.0, Hd.abs().max().item())
+    # one lockstep damped Newton step == the per-geometry steps (oo_pqc.py:172-196)
+    th_s = torch.tensor(rng.normal(0, 0.3, (G, nt)), device=DEV)
+    e_before = batch.energy(th_s)
+    new_t, e_new, low = batch.damped_newton_step(th_s)
+    assert (e_new < e_before).all()
+    opt = aoo.NewtonStep(verbose=0)
+    for g, oo in enumerate(objs):
+        kap0 = torch.zeros(oo.n_kappa, dtype=torch.float64, device=DEV)
+        new, lo = opt.damped_newton_step(oo.energy_from_parameters, (th_s[g], kap0), oo.full_gradient(th_s[g]),
+                                         oo.full_hessian(th_s[g]))
+        assert (new[0] - new_t[g]).abs().max().item() < 1e-8
+        assert abs(oo.energy_from_parameters(new[0], new[1]).item() - e_new[g].item()) < 1e-9
+        assert abs(float(lo) - low[g].item()) < 1e-8
+
+
+def test_kupccd_cas88_geometry_batch_equals_single_geometries():
+    """configs[4]'s circuit on configs[3]'s loop: kUpCCD CAS(8e,8o) (4 900-determinant sector, 56 thetas) over a stack
+    of geometries -- batched energy + gradient and full Hessian equal the single-geometry OO_pqc values."""
+    pqc, probs, objs, batch = _sector_batch(20, 8, 8, 16, 2, 8800, "kupccd", k=1)
+    assert pqc._use_sector and pqc._sector.Dc == 4900
+    nt = int(pqc.theta_shape)
+    thetas = torch.tensor(np.random.default_rng(88).uniform(0, 2 * np.pi, (2, nt)), device=DEV)
+    eg = batch.energy_and_gradient(thetas)
+    E, grad, H = batch.energy_gradient_hessian(thetas)
+    for g, oo in enumerate(objs):
+        e1, g1 = oo.energy_and_gradient(thetas[g])
+        assert abs(eg[g, 0].item() - e1.item()) < 1e-10 and (eg[g, 1:] - g1).abs().max().item() < 1e-10
+        H1 = oo.full_hessian(thetas[g])
+        assert (H[g] - H1).abs().max().item() < 1e-9 * max(1.0, H1.abs().max().item())
+        assert (grad[g] - g1).abs().max().item() < 1e-9
+
+
 def test_kupccd_cas88_damped_newton_step_lowers_the_energy():
     """configs[4] has a Newton step: full gradient + full Hessian of kUpCCD CAS(8e,8o), k = 1 (56 thetas, sector
     engine: 4 900 determinants, 1 596 second tangents) and one damped Newton step of OO_pqc.full_optimization's
