@@ -96,9 +96,9 @@ extern "C" int oovqe_debug_get_option(const char* name)
 namespace {
 struct Internals {
     hipEvent_t ev[64] = {};
-    hipStream_t st[2] = {nullptr, nullptr};
+    hipStream_t st[1] = {nullptr};
     unsigned next = 0;
-    bool tried = false;
+    bool tried = false, streams_tried = false;
 };
 Internals g_int[16];
 std::mutex g_int_mu;
@@ -112,8 +112,6 @@ Internals* internals()
         I.tried = true;
         for (int i = 0; i < 64; ++i)
             if (hipEventCreateWithFlags(&I.ev[i], hipEventDisableTiming) != hipSuccess) I.ev[i] = nullptr;
-        for (int i = 0; i < 2; ++i)
-            if (hipStreamCreateWithFlags(&I.st[i], hipStreamNonBlocking) != hipSuccess) I.st[i] = nullptr;
     }
     return &I;
 }
@@ -130,10 +128,17 @@ hipEvent_t oovqe_internal_event()
 
 hipStream_t oovqe_internal_stream(int k)
 {
-    if (oovqe_opt(OOVQE_OPT_ONE_STREAM) != 0 || k < 0 || k > 1) return nullptr;
+    if (oovqe_opt(OOVQE_OPT_ONE_STREAM) != 0 || k != 0) return nullptr;
     std::lock_guard<std::mutex> lock(g_int_mu);
     Internals* I = internals();
-    return I ? I->st[k] : nullptr;
+    if (!I) return nullptr;
+    // made on first use: HIP multiplexes its streams over a few hardware queues (four by default), and a stream that
+    // exists takes its share of them whether it is used or not
+    if (!I->streams_tried) {
+        I->streams_tried = true;
+        if (hipStreamCreateWithFlags(&I->st[0], hipStreamNonBlocking) != hipSuccess) I->st[0] = nullptr;
+    }
+    return I->st[k];
 }
 
 static hipStream_t g_s1_stream[16];

@@ -4020,8 +4020,11 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
                             double* gmat, double* Gm, double* hmo, int batch, size_t out_stride,
                             oovqe_stream_t stream, const oovqe_circuit_job_t* cj = nullptr,
                             unsigned eri_flags = 0, const double* g_packed = nullptr,
-                            const double* T2_ready = nullptr, bool w_ready = false)
+                            const double* T2_ready = nullptr, bool w_ready = false, hipEvent_t rdm_event = nullptr)
 {
+    // rdm_event: recorded on the stream where gamma / Gamma are complete when the circuit rides along (cj): behind the
+    // q -> x / p -> n launch -- another stream of the caller (the orbital Hessian's assembly) waits for the RDMs, not
+    // for the end of this call
     // w_ready: the caller's circuit launch has left W = C^T h_ao [G][N][N] in this workspace's T3 block
     // (cas_w_block: packed-triangle path, one-launch q -> x / p -> n kernel)
     // T2_ready [G][N][N][M][M]: the caller has stage 1's result in memory (the Hessian call); the
@@ -4091,6 +4094,10 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
         }
         if (!two_step) {
             if ((rc = sym_gm_batched(Jp, C, Gmw, N, M, batch, st, cj, rs_sym))) return rc;
+            if (rdm_event && cj) {
+                OOVQE_CHECK_HIP(hipEventRecord(rdm_event, st), "cas_eval: hipEventRecord");
+                rdm_event = nullptr;
+            }
             if (w_ready) {                                       // (the block this path leaves unused)
                 double* wchk = nullptr;
                 OOVQE_REQUIRE(cas_w_block(N, M, batch, eri_flags, work, &wchk) && wchk == T3,
@@ -4271,6 +4278,7 @@ static int cas_eval_batched(const double* g_ao, const double* h_ao, const double
                        out_stride);
     oovqe_profile_mark_stop(st);
     OOVQE_CHECK_LAUNCH("cas_eval/final");
+    if (rdm_event) OOVQE_CHECK_HIP(hipEventRecord(rdm_event, st), "cas_eval: hipEventRecord");   // (no earlier point on this path)
     return 0;
 }
 
@@ -4365,7 +4373,7 @@ static int oo_eval_batched(const double* theta, int n_theta, const oovqe_gate_t*
                            int ncas, const int32_t* kap_row, const int32_t* kap_col, int n_kappa,
                            int derivatives, int batch, double* work, double* out,
                            unsigned eri_flags, oovqe_stream_t stream, const double* g_packed = nullptr,
-                           double* fock = nullptr, const double* T2_ready = nullptr)
+                           double* fock = nullptr, const double* T2_ready = nullptr, hipEvent_t rdm_event = nullptr)
 {
     OOVQE_REQUIRE(theta && gates && g_ao && h_ao && C && work && out, "oo_eval: null pointer");
     OOVQE_REQUIRE(n_qubits == 2 * ncas, "oo_eval: n_qubits != 2*ncas");
@@ -4436,6 +4444,10 @@ static int oo_eval_batched(const double* theta, int n_theta, const oovqe_gate_t*
                                       w_ready ? Wpre : nullptr, stream);
         if (rc) return rc;
         oovqe_profile_mark_stop((hipStream_t)stream);
+        if (rdm_event) {                                  // the RDMs are complete behind the circuit's own launch
+            OOVQE_CHECK_HIP(hipEventRecord(rdm_event, (hipStream_t)stream), "oo_eval: hipEventRecord");
+            rdm_event = nullptr;
+        }
     }
     // packed output per geometry: [c0 | E | dE (max(nvec-1,1)) | gvec (nvec x n_kappa) | c1 | c2]
     const size_t out_stride = (size_t)oovqe_oo_eval_out_size(n_theta, n_kappa, ncas, derivatives);
@@ -4449,7 +4461,7 @@ static int oo_eval_batched(const double* theta, int n_theta, const oovqe_gate_t*
     return cas_eval_batched(g_ao, h_ao, C, gamma, Gamma, nvec, nuc, nuc_arr, N, n_occ, ncas, kap_row,
                             kap_col, n_kappa, cas_work, c0, c1, c2, E, gvec, dE, fock, nullptr,
                             nullptr, nullptr, batch, out_stride, stream, ride ? &cj : nullptr, eri_flags,
-                            g_packed, T2_ready, w_ready);
+                            g_packed, T2_ready, w_ready, rdm_event);
 }
 
 // hessian.hip (oovqe_oo_hessian_batch): the batched evaluation with the generalized Fock matrices
@@ -4461,11 +4473,11 @@ int oovqe_oo_eval_batched_impl(const double* theta, int n_theta, const oovqe_gat
                                const int32_t* kap_row, const int32_t* kap_col, int n_kappa, int derivatives,
                                int batch, double* work, double* out, unsigned eri_flags,
                                oovqe_stream_t stream, const double* g_packed, double* fock,
-                               const double* T2_ready)
+                               const double* T2_ready, hipEvent_t rdm_event)
 {
     return oo_eval_batched(theta, n_theta, gates, n_gates, n_qubits, init_index, g_ao, h_ao, C, 0.0, nuc_arr,
                            N, n_occ, ncas, kap_row, kap_col, n_kappa, derivatives, batch, work, out,
-                           eri_flags, stream, g_packed, fock, T2_ready);
+                           eri_flags, stream, g_packed, fock, T2_ready, rdm_event);
 }
 
 // hessian.hip: stage 1 (T2[p,q,y,z]) for a stack of geometries, reading only the slabs p <= q when the

@@ -62,9 +62,12 @@ int oovqe_opt(int id);
 int oovqe_ensure_dynamic_lds(const void* kernel, size_t bytes);
 void oovqe_note_stage1(const char* fmt, ...);
 // the next event of a small per-device ring (timing disabled; nullptr on failure), and the library's internal
-// streams of the current device (k = 0, 1; made once, non-blocking; nullptr on failure or with option
+// stream of the current device (k = 0; made on first use, non-blocking; nullptr on failure or with option
 // one_stream): independent chains of ONE library call run beside each other, forked from and joined to the
-// caller's stream inside the call -- the caller sees in-order stream semantics.
+// caller's stream inside the call -- the caller sees in-order stream semantics.  ONE stream: HIP multiplexes a
+// process' streams over four hardware queues; the caller's stream and the two side streams of the Python layer
+// (ops.side_streams) take three of them, and streams that share a queue run one after the other (measured: with
+// two internal streams the deferred evaluations of OO_pqc_batch lost all their overlap).
 hipEvent_t oovqe_internal_event();
 hipStream_t oovqe_internal_stream(int k);
 // Around every launch of the packed N^4 sweep: sweeps enqueued on DIFFERENT streams (calls in flight on two streams:

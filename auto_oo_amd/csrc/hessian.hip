@@ -222,13 +222,15 @@ int oovqe_mode_contract_batched(const double* T, const double* Cm, double* out, 
 // leading batch axis with the given strides (doubles), every intermediate stacked in `work`
 // (batch * oovqe_orbital_hessian_work_size() doubles); the geometry index is a grid dimension of
 // every launch.  H_matrix element (t1,t2) of geometry b -> H_matrix[b * h_bs + t1 * ldh + t2].
-// The chains of stage 2 that do not depend on each other, beside each other (oovqe_oo_hessian_batch): the K-type
-// integrals and the assembly on sK, the one-electron and J-type integrals on sJ.  Both streams must already wait for
-// stage 1 (T2 / Vk); rdm_ready: recorded by the caller where gamma / Gamma / fock are final; done: recorded on sK
-// behind the last launch (the caller's stream waits for it when it needs the block).
+// The chains of stage 2 that do not depend on each other, beside each other (oovqe_oo_hessian_batch): the K-type AND
+// J-type integrals, the Y products and the assembly on sK (ONE internal stream of the library: HIP multiplexes a
+// process' streams over four hardware queues, and the caller's stream + the two side streams of the eigenvalue route
+// leave one), the one-electron integrals on the caller's stream behind the evaluation.  sK must already wait for
+// stage 1 (T2 / Vk); its only waits are for the RDMs (recorded inside the evaluation, behind the launch the circuit
+// rides on) and, before the last kernel, for fock + h_mo; done: recorded on sK behind the last launch.
 struct HessFork {
-    hipStream_t sK, sJ;
-    hipEvent_t rdm_ready, done;
+    hipStream_t sK;
+    hipEvent_t rdm_ready, rest_ready, done;      // RDMs complete | fock and h_mo complete (caller's stream) | block written (sK)
 };
 
 static int orbital_hessian_batched(const double* g_ao, const double* h_ao, const double* C,
@@ -240,10 +242,14 @@ static int orbital_hessian_batched(const double* g_ao, const double* h_ao, const
                                    HessFork* fork = nullptr)
 {
     // stage 0: everything; 1: stage 1 of the integrals only (T2 and, when available, Vk: needs neither
-    // the RDMs nor the Fock matrices); 2: the rest, on the T2 / Vk a stage-1 call left in `work`
-    OOVQE_REQUIRE(g_ao && h_ao && C && work && (stage == 1 || (gamma && Gamma && fock)),
+    // the RDMs nor the Fock matrices); 2: the rest, on the T2 / Vk a stage-1 call left in `work`; 3 (with a fork):
+    // the K-type chain alone, on the fork's stream (needs stage 1 only: the caller enqueues it FIRST -- the host hands
+    // out launches at a few microseconds apiece, and what sits at the back of the host's order starts late whatever
+    // the streams allow); a stage-2 call with a fork then skips that chain
+    OOVQE_REQUIRE(g_ao && h_ao && C && work && (stage == 1 || stage == 3 || (gamma && Gamma && fock)),
                   "orbital_hessian: null pointer");
-    OOVQE_REQUIRE(stage == 1 || H_matrix || H_full, "orbital_hessian: no output requested");
+    OOVQE_REQUIRE(stage == 1 || stage == 3 || H_matrix || H_full, "orbital_hessian: no output requested");
+    OOVQE_REQUIRE(stage != 3 || fork, "orbital_hessian: stage 3 needs a fork");
     OOVQE_REQUIRE(!H_matrix || (kap_row && kap_col && n_kappa > 0), "orbital_hessian: index tables");
     OOVQE_REQUIRE(N >= 1 && n_occ >= 0 && ncas >= 1 && n_occ + ncas <= N, "orbital_hessian: sizes");
     OOVQE_REQUIRE(batch >= 1 && batch <= 65535 && (batch == 1 || !H_full), "orbital_hessian: batch=%d", batch);
@@ -267,16 +273,14 @@ static int orbital_hessian_batched(const double* g_ao, const double* h_ao, const
     double* YjT = YkT + nb * n2 * m2;       // [G][N][N][M*M]
     int rc;
     const long t4 = n2 * n2, y = n2 * m2;
-    // sj / sk: the streams of the J-type (+ one-electron) chain and of the K-type chain + assembly
-    hipStream_t sj = st, sk = st;
-    hipEvent_t ev_ab = nullptr, ev_yj = nullptr;
-    if (fork && stage == 2) {
-        sj = fork->sJ;
+    // sk: the stream of the K-type and J-type chains, the Y products and the assembly (the caller's unless forked)
+    hipStream_t sk = st;
+    const bool forked = fork && stage >= 2;
+    if (forked) {
         sk = fork->sK;
-        ev_ab = oovqe_internal_event();
-        ev_yj = oovqe_internal_event();
-        OOVQE_REQUIRE(sj && sk && ev_ab && ev_yj && fork->rdm_ready && fork->done, "orbital_hessian: fork without streams / events");
+        OOVQE_REQUIRE(sk && fork->rdm_ready && fork->rest_ready && fork->done, "orbital_hessian: fork without stream / events");
     }
+    const bool k_chain = !(fork && stage == 2), rest = stage != 3;
     hipStream_t ms = st;           // the stream the MC macro launches on
 #define MC(T_, tb, C_, cb, O_, ob, ...) \
     if ((rc = oovqe_mode_contract_batched(T_, C_, O_, __VA_ARGS__, batch, tb, cb, ob, ms))) return rc
@@ -285,18 +289,20 @@ static int orbital_hessian_batched(const double* g_ao, const double* h_ao, const
     // (the quarter transform of the K-type path), so the AO tensor is read once instead of twice
     const bool vk_tri = (eri_flags & OOVQE_ERI_PQ_SYMMETRIC) != 0 && N <= 48 && M <= 16 &&
                         (size_t)m2 * N * sizeof(double) <= 150 * 1024 && oovqe_opt(OOVQE_OPT_HESS_VK_PASS) == 0;
-    if (stage != 2 &&
+    if (stage < 2 &&
         (rc = oovqe_half_transform_batched_impl(g_ao, C, N, M, T2, batch, eri_flags, stream, vk_tri ? Vk : nullptr)))
         return rc;
     if (stage == 1) return 0;
-    ms = sj;
-    MC(T2, y, C, n2, Uj, y, 1, N, N, n * m2, N, 0);          // Uj[q',q,yz]  = sum_p C[p,q'] T2[p,q,yz]
-    MC(Uj, y, C, n2, Jint, y, n, N, N, m2, N, 0);            // Jint[q',s',yz] = sum_q C[q,s'] Uj[q',q,yz]
-    // ---- one-electron integrals ------------------------------------------------------------------
+    if (rest) {
+    // ---- one-electron integrals (the caller's stream) ---------------------------------------------
+    ms = st;
     MC(h_ao, n2, C, n2, X1, n2, 1, N, N, n, N, 0);           // X1 = C^T h
     MC(X1, n2, C, n2, hmo, n2, n, N, N, 1, N, 1);            // hmo = X1 C
+    if (forked) OOVQE_CHECK_HIP(hipEventRecord(fork->rest_ready, st), "orbital_hessian: hipEventRecord");
+    }
     ms = sk;
     // ---- K-type integrals: g_mo[q,m,n,s] ---------------------------------------------------------
+    if (k_chain) {
     if (vk_tri) {
         const size_t lds_bytes = (size_t)m2 * N * sizeof(double);
 #define OOVQE_LAUNCH_T2K(MT_)                                                                             \
@@ -319,20 +325,19 @@ static int orbital_hessian_batched(const double* g_ao, const double* h_ao, const
     }
     MC(T2K, y, C, n2, W, y, n * m2, N, N, 1, N, 1);          // W[p,m,n,s']  = sum_s T2K[p,m,n,s] C[s,s']
     MC(W, y, C, n2, Kint, y, 1, N, N, m2 * n, N, 0);         // Kint[q',m,n,s'] = sum_p C[p,q'] W[p,m,n,s']
+    }
+    if (!rest) return 0;
     // ---- Y ------------------------------------------------------------------------------------------
-    if (ev_ab) OOVQE_CHECK_HIP(hipStreamWaitEvent(sk, fork->rdm_ready, 0), "orbital_hessian: hipStreamWaitEvent");
+    if (forked) OOVQE_CHECK_HIP(hipStreamWaitEvent(sk, fork->rdm_ready, 0), "orbital_hessian: hipStreamWaitEvent");
     hess_ab_kernel<<<dim3(64, batch), 256, 0, sk>>>(gamma, Gamma, n_occ, ncas, At, Bt, gamma_bs, Gamma_bs);
-    if (ev_ab) OOVQE_CHECK_HIP(hipEventRecord(ev_ab, sk), "orbital_hessian: hipEventRecord");
     // YkT[q,(pr),s] = sum_(mn) At[(mn),(pr)] Kint[q,(mn),s]
     MC(Kint, y, At, m2 * m2, YkT, y, n, (int)m2, (int)m2, n, (int)m2, 0);
+    // ---- J-type integrals: g_mo[q,s,m,n] ---------------------------------------------------------
+    MC(T2, y, C, n2, Uj, y, 1, N, N, n * m2, N, 0);          // Uj[q',q,yz]  = sum_p C[p,q'] T2[p,q,yz]
+    MC(Uj, y, C, n2, Jint, y, n, N, N, m2, N, 0);            // Jint[q',s',yz] = sum_q C[q,s'] Uj[q',q,yz]
     // YjT[(qs),(pr)] = sum_(mn) Jint[(qs),(mn)] Bt[(mn),(pr)]
-    ms = sj;
-    if (ev_ab) OOVQE_CHECK_HIP(hipStreamWaitEvent(sj, ev_ab, 0), "orbital_hessian: hipStreamWaitEvent");
     MC(Jint, y, Bt, m2 * m2, YjT, y, n2, (int)m2, (int)m2, 1, (int)m2, 1);
-    if (ev_ab) {
-        OOVQE_CHECK_HIP(hipEventRecord(ev_yj, sj), "orbital_hessian: hipEventRecord");
-        OOVQE_CHECK_HIP(hipStreamWaitEvent(sk, ev_yj, 0), "orbital_hessian: hipStreamWaitEvent");
-    }
+    if (forked) OOVQE_CHECK_HIP(hipStreamWaitEvent(sk, fork->rest_ready, 0), "orbital_hessian: hipStreamWaitEvent");
 #undef MC
     HessArgs a{YkT, YjT, hmo, fock, gamma, N, n_occ, ncas, y, n2, n2, gamma_bs};
     if (H_matrix) {
@@ -346,7 +351,7 @@ static int orbital_hessian_batched(const double* g_ao, const double* h_ao, const
         hess_full_kernel<<<nbk, 256, 0, sk>>>(a, H_full);
     }
     OOVQE_CHECK_LAUNCH("orbital_hessian");
-    if (ev_ab) OOVQE_CHECK_HIP(hipEventRecord(fork->done, sk), "orbital_hessian: hipEventRecord");
+    if (forked) OOVQE_CHECK_HIP(hipEventRecord(fork->done, sk), "orbital_hessian: hipEventRecord");
     return 0;
 }
 
@@ -383,7 +388,7 @@ int oovqe_oo_eval_batched_impl(const double* theta, int n_theta, const oovqe_gat
                                const int32_t* kap_row, const int32_t* kap_col, int n_kappa, int derivatives,
                                int batch, double* work, double* out, unsigned eri_flags,
                                oovqe_stream_t stream, const double* g_packed, double* fock,
-                               const double* T2_ready = nullptr);
+                               const double* T2_ready = nullptr, hipEvent_t rdm_event = nullptr);
 int oovqe_circuit_hessian_batched_impl(const double* theta, int n_theta, const oovqe_gate_t* gates,
                                        int n_gates, int n_qubits, int ncas, uint32_t init_index,
                                        const double* c1, const double* c2, long c1_bs, long c2_bs,
@@ -436,31 +441,35 @@ extern "C" int oovqe_oo_hessian_batch(const double* theta, int n_theta, const oo
                                                eri_flags, stream, 1)))
         return rc;
     // The call is a graph, not a chain: behind stage 1 the evaluation (j_from_t2 -> q -> x / p -> n -> panels ->
-    // assembly, then the circuit Hessian and the cross block: this stream), the K-type integrals + the assembly of
-    // the orbital block (internal stream 0) and the one-electron + J-type integrals (internal stream 1) do not depend
-    // on each other.  Run one after the other they are 22 launches of 5-37 us at 8 geometries, 230 us; the longest
-    // path through the graph is stage 1 -> K-type chain -> Y -> matrix, ~110 us.  Forked from and joined to the
-    // caller's stream in here.
+    // assembly), the one-electron + J-type integrals, the circuit Hessian and the cross block (this stream) and the
+    // K-type integrals + the assembly of the orbital block (the library's internal stream) do not depend on each
+    // other.  Run one after the other they are 22 launches of 5-37 us at 8 geometries, 230 us.  Forked from and joined
+    // to the caller's stream in here.
     hipStream_t st = (hipStream_t)stream;
     HessFork fork{nullptr, nullptr, nullptr, nullptr};
     bool forked = false;
     if (share && hess_circuit_own_block(n_qubits)) {
         fork.sK = oovqe_internal_stream(0);
-        fork.sJ = oovqe_internal_stream(1);
         hipEvent_t ev_a = oovqe_internal_event();
         fork.rdm_ready = oovqe_internal_event();
+        fork.rest_ready = oovqe_internal_event();
         fork.done = oovqe_internal_event();
-        if (fork.sK && fork.sJ && ev_a && fork.rdm_ready && fork.done) {
+        if (fork.sK && ev_a && fork.rdm_ready && fork.rest_ready && fork.done) {
             OOVQE_CHECK_HIP(hipEventRecord(ev_a, st), "oo_hessian_batch: hipEventRecord");
             OOVQE_CHECK_HIP(hipStreamWaitEvent(fork.sK, ev_a, 0), "oo_hessian_batch: hipStreamWaitEvent");
-            OOVQE_CHECK_HIP(hipStreamWaitEvent(fork.sJ, ev_a, 0), "oo_hessian_batch: hipStreamWaitEvent");
             forked = true;
+            // the K-type chain needs stage 1 only: enqueued first
+            if ((rc = orbital_hessian_batched(g_ao, h_ao, C, nullptr, 0, nullptr, 0, nullptr, N, n_occ, ncas, kap_row,
+                                              kap_col, n_kappa, batch, hs_work, nullptr, 0, 0, nullptr, eri_flags,
+                                              stream, 3, &fork)))
+                return rc;
         }
     }
     // 1. circuit + tangents -> RDM sets -> CAS path: E, dE/dtheta, dE/dkappa, d^2E/dkappa dtheta, c1, c2, F
     if ((rc = oovqe_oo_eval_batched_impl(theta, n_theta, gates, n_gates, n_qubits, init_index, g_ao, h_ao, C, nuc,
                                          N, n_occ, ncas, kap_row, kap_col, n_kappa, 1, batch, ev_work, out,
-                                         eri_flags, stream, g_packed, fock, share ? hs_work : nullptr)))
+                                         eri_flags, stream, g_packed, fock, share ? hs_work : nullptr,
+                                         forked ? fork.rdm_ready : nullptr)))
         return rc;
     const long out_stride = (long)oovqe_oo_eval_out_size(n_theta, n_kappa, ncas, 1);
     const long n = (long)n_theta + n_kappa;
@@ -471,7 +480,6 @@ extern "C" int oovqe_oo_hessian_batch(const double* theta, int n_theta, const oo
     //    circuit Hessian: that one reuses the scratch in which T2 / Vk of step 0 live)
     const double* gamma = ev_work;
     const double* Gamma = gamma + nb * nvec * na2;
-    if (forked) OOVQE_CHECK_HIP(hipEventRecord(fork.rdm_ready, st), "oo_hessian_batch: hipEventRecord");
     if ((rc = orbital_hessian_batched(g_ao, h_ao, C, gamma, (long)nvec * na2, Gamma, (long)nvec * na4, fock, N,
                                       n_occ, ncas, kap_row, kap_col, n_kappa, batch, hs_work,
                                       hessian + (size_t)n_theta * n + n_theta, n, n * n, nullptr, eri_flags, stream,

@@ -671,8 +671,8 @@ def test_one_call_newton_step_beyond_the_cholesky_kernel():
 @pytest.mark.parametrize("N,G", [(13, 3), (43, 8), (43, 1)])
 def test_hessian_call_chains_on_internal_streams_equal_the_one_stream_call(N, G):
     """oovqe_oo_hessian_batch runs the chains of its graph that do not depend on each other beside each other (the
-    evaluation + circuit block on the caller's stream, the K-type chain + assembly and the J-type chain on the
-    library's two internal streams, forked and joined inside the call) -- against the same call with every launch on
+    evaluation, the J-type chain and the circuit block on the caller's stream, the K-type chain + assembly on the
+    library's internal stream, forked and joined inside the call) -- against the same call with every launch on
     the caller's stream (option ``one_stream``): the same launches, the same bits; repeated calls reuse the
     workspace while the previous call's chains have been joined."""
     from auto_oo_amd import _lib
