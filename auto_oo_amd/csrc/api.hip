@@ -141,22 +141,45 @@ hipStream_t oovqe_internal_stream(int k)
     return I->st[k];
 }
 
+// Sweeps enqueued on different streams are ordered one after the other -- but an event record behind every sweep costs
+// the launch that follows ~7 us (a barrier packet), which a one-stream caller (every small-batch evaluation: the
+// trials of a line search) must not pay.  So the record is made only while sweeps actually alternate between
+// streams: the first sweep that arrives on another stream orders itself behind EVERYTHING enqueued on the previous
+// stream so far (an event recorded there at that moment), and from then on every sweep leaves its event; after 64
+// sweeps in a row on one stream the records stop again.
 static hipStream_t g_s1_stream[16];
 static hipEvent_t g_s1_event[16];
+static bool g_s1_seen[16];
+static int g_s1_multi[16];          // > 0: sweeps have been alternating between streams (counts down on one stream)
 
 int oovqe_stage1_enter(hipStream_t st)
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
     if (oovqe_opt(OOVQE_OPT_STAGE1_FREE_RUN) != 0) return 0;
-    hipEvent_t ev;
-    hipStream_t last;
+    hipEvent_t ev = nullptr;
+    hipStream_t last = nullptr;
+    bool seen, was_multi;
     {
         std::lock_guard<std::mutex> lock(g_int_mu);
-        ev = g_s1_event[dev];
+        seen = g_s1_seen[dev];
         last = g_s1_stream[dev];
+        was_multi = g_s1_multi[dev] > 0;
+        ev = was_multi ? g_s1_event[dev] : nullptr;
+        if (seen && last != st) g_s1_multi[dev] = 64;
+        else if (g_s1_multi[dev] > 0) --g_s1_multi[dev];
     }
-    if (ev && last != st) OOVQE_CHECK_HIP(hipStreamWaitEvent(st, ev, 0), "stage 1: hipStreamWaitEvent");
+    if (!seen || last == st) return 0;
+    if (!ev) {
+        // the previous sweep left no event: one recorded on its stream now stands behind it (and behind what followed)
+        ev = oovqe_internal_event();
+        if (!ev) return 0;
+        if (hipEventRecord(ev, last) != hipSuccess) {       // (a stream the caller has destroyed since: nothing to wait for)
+            (void)hipGetLastError();
+            return 0;
+        }
+    }
+    OOVQE_CHECK_HIP(hipStreamWaitEvent(st, ev, 0), "stage 1: hipStreamWaitEvent");
     return 0;
 }
 
@@ -165,12 +188,20 @@ int oovqe_stage1_leave(hipStream_t st)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
     if (oovqe_opt(OOVQE_OPT_STAGE1_FREE_RUN) != 0) return 0;
+    bool multi;
+    {
+        std::lock_guard<std::mutex> lock(g_int_mu);
+        g_s1_seen[dev] = true;
+        g_s1_stream[dev] = st;
+        g_s1_event[dev] = nullptr;
+        multi = g_s1_multi[dev] > 0;
+    }
+    if (!multi) return 0;
     hipEvent_t ev = oovqe_internal_event();
     if (!ev) return 0;
     OOVQE_CHECK_HIP(hipEventRecord(ev, st), "stage 1: hipEventRecord");
     std::lock_guard<std::mutex> lock(g_int_mu);
     g_s1_event[dev] = ev;
-    g_s1_stream[dev] = st;
     return 0;
 }
 

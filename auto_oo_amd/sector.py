@@ -69,6 +69,11 @@ class SectorEngine:
             self._param_gate = owner
         return self._param_gate
 
+    def param_gates(self, gates_host):
+        """gate index of every parameter when each drives exactly one gate (UCCD / UCCSD / kUpCCD); None otherwise."""
+        gl = self.param_gate_lists(gates_host)
+        return [g[0] for g in gl] if all(len(g) == 1 for g in gl) else None
+
     def _tangent_plan(self, gates_host, second):
         """Which differentiated circuits (``oovqe_sector_state_deriv`` specs: up to two gates differentiated) sum to
         the tangent states, by the product rule over the gates that share a parameter:
