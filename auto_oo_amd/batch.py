@@ -15,6 +15,7 @@ the stages that take ONE set of CAS coefficients per call (the reverse sweep's o
 geometry by geometry.
 """
 import ctypes
+import time
 
 import numpy as np
 import torch
@@ -485,6 +486,12 @@ class OO_pqc_batch:
         b = _lib.NewtonStepT()
         keep = {"pairs": pairs_dev, "trial_out": torch.empty((G, osz0), dtype=F64, device=self.device),
                 "flat": torch.empty((G, n), dtype=F64, device=self.device)}
+        # the first trial's verdict goes straight into pinned host memory (the library's last kernel of the step writes
+        # its four flags through the device-visible pointer; the host polls them instead of a 32-byte memcpy + stream
+        # synchronisation: ~12 us of every step); later trials (rare) keep a device tensor and a readback
+        keep["flags_host"] = torch.full((4,), float("nan"), dtype=F64).pin_memory()
+        keep["flags_np"] = keep["flags_host"].numpy()
+        keep["flags_dev"] = torch.empty(4, dtype=F64, device=self.device)
         has_pd = bool(lib.oovqe_newton_direction_has_pd(n, 1))
         if has_pd:
             keep["work_pd"] = torch.empty(int(lib.oovqe_newton_direction_pd_work_size(n, G)), dtype=F64,
@@ -531,6 +538,9 @@ class OO_pqc_batch:
         base = slab.data_ptr()
         for k, (o, _) in offs.items():
             setattr(b, k, base + 8 * o)
+        flags_np = keep["flags_np"]
+        flags_np[:] = np.nan
+        b.flags = keep["flags_host"].data_ptr()
 
         def view(k, *shape):
             o, sz = offs[k]
@@ -581,9 +591,20 @@ class OO_pqc_batch:
         s = LockstepSearch(flat=keep["flat"], g=view("grad", G, n), H=view("hessian", G, n, n), dp=view("dp", G, n),
                            low=ops.PendingLowest(view("lowest", G), event, retry_lowest), nu=view("shift", G),
                            info=view("info", G), energy=view("energy", G), t=view("t", G), active=state[0],
-                           best=state[1], slope=state[2], flags=view("flags", 4), pa=view("points_a", G, nt),
+                           best=state[1], slope=state[2], flags=keep["flags_dev"], pa=view("points_a", G, nt),
                            pb=view("points_b", G, nk))
-        fl = [1.0, -1.0, 0.0, 0.0] if refused else s.flags.tolist()    # the one readback of the common case
+        if refused:
+            fl = [1.0, -1.0, 0.0, 0.0]
+        else:
+            # the verdict of the first trial: polled in pinned memory (falls back to a stream synchronisation should
+            # the flags not arrive within seconds -- a failed launch surfaces there)
+            t_poll = time.perf_counter()
+            while np.isnan(flags_np).any():
+                if time.perf_counter() - t_poll > 5.0:
+                    torch.cuda.current_stream().synchronize()
+                    if np.isnan(flags_np).any():
+                        raise _lib.OovqeError("oovqe_oo_newton_step_batch: the step's verdict never arrived")
+            fl = flags_np.tolist()
         self._all_pd_last_step = fl[1] >= 1.0
         if refused:
             s.t.fill_(1.0)

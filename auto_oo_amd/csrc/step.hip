@@ -94,6 +94,7 @@ extern "C" int oovqe_oo_newton_step_batch(const oovqe_newton_step_t* s, oovqe_st
     // 2. directions
     const bool pd = oovqe_newton_direction_has_pd(n, s->aug) != 0 && s->work_pd != nullptr;
     double* info = s->info;
+    bool fork_side = false, fork_spec = false;
     if (pd) {
         if ((rc = oovqe_newton_direction_pd(s->hessian, s->grad, n, G, s->lambda_min, s->work_pd, s->dp, s->shift, info,
                                             stream)))
@@ -105,16 +106,11 @@ extern "C" int oovqe_oo_newton_step_batch(const oovqe_newton_step_t* s, oovqe_st
                                               s->work_rest, s->dp, s->lowest, s->shift, stream)))
             return rc;
         if (side_ok) {
-            hipEvent_t ev = fork_event();
-            OOVQE_REQUIRE(ev, "oo_newton_step_batch: no event for the side stream");
-            OOVQE_CHECK_HIP(hipEventRecord(ev, st), "oo_newton_step_batch: hipEventRecord");
-            OOVQE_CHECK_HIP(hipStreamWaitEvent(sd, ev, 0), "oo_newton_step_batch: hipStreamWaitEvent");
-            // speculate: everything the fast path left (which = 0) beside the trial; else only the eigenvalues of
-            // the problems it served (which = 2)
-            if ((rc = oovqe_newton_direction_rest(s->hessian, s->grad, n, G, s->lambda_min, s->mu, s->rho, s->aug, info,
-                                                  spec ? 0 : 2, s->side_wg, s->work_rest_side, s->dp, s->lowest,
-                                                  s->shift, side_stream)))
-                return rc;
+            // (the side stream's route is forked BEHIND the trial below: an event record between the direction and
+            // the trial's first launch costs that launch ~7 us, and nothing the step's outputs depend on waits for
+            // the eigenvalues)
+            fork_side = true;
+            fork_spec = spec;
         } else if ((rc = oovqe_newton_direction_rest(s->hessian, s->grad, n, G, s->lambda_min, s->mu, s->rho, s->aug, info,
                                                      2, 0, s->work_rest, s->dp, s->lowest, s->shift, stream))) {
             return rc;      // (no side stream: the eigenvalues on the calling stream, behind the others)
@@ -140,6 +136,20 @@ extern "C" int oovqe_oo_newton_step_batch(const oovqe_newton_step_t* s, oovqe_st
                                   s->trial_mo, s->nuc, N, s->n_occ, s->ncas, s->kap_row, s->kap_col, nk, 0, G,
                                   s->work_eval, s->trial_out, s->eri_flags, s->g_packed, stream)))
         return rc;
-    return oovqe_linesearch_update(s->trial_out + 1, osz0, s->energy, slope, info, s->beta, 1, 0, G, s->t, active, best,
-                                   s->flags, stream);
+    if ((rc = oovqe_linesearch_update(s->trial_out + 1, osz0, s->energy, slope, info, s->beta, 1, 0, G, s->t, active,
+                                      best, s->flags, stream)))
+        return rc;
+    if (fork_side) {
+        hipEvent_t ev = fork_event();
+        OOVQE_REQUIRE(ev, "oo_newton_step_batch: no event for the side stream");
+        OOVQE_CHECK_HIP(hipEventRecord(ev, st), "oo_newton_step_batch: hipEventRecord");
+        OOVQE_CHECK_HIP(hipStreamWaitEvent(sd, ev, 0), "oo_newton_step_batch: hipStreamWaitEvent");
+        // speculate: everything the fast path left (which = 0); else only the eigenvalues of the problems it
+        // served (which = 2)
+        if ((rc = oovqe_newton_direction_rest(s->hessian, s->grad, n, G, s->lambda_min, s->mu, s->rho, s->aug, info,
+                                              fork_spec ? 0 : 2, s->side_wg, s->work_rest_side, s->dp, s->lowest,
+                                              s->shift, side_stream)))
+            return rc;
+    }
+    return 0;
 }

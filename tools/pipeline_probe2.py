@@ -8,7 +8,8 @@ sys.path.insert(0, ".")
 import bench  # noqa: E402
 from auto_oo_amd import ops  # noqa: E402
 
-pqc, batch, single, thetas = bench.build_geometries(list(range(256)))
+GEOMS = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+pqc, batch, single, thetas = bench.build_geometries(list(range(GEOMS)))
 
 
 def run(n, deferred, prof):
@@ -30,8 +31,8 @@ def run(n, deferred, prof):
 
 for deferred in (False, True):
     for prof in (False, True):
-        for n in (20, 40, 200):
+        for n in (20, 40):
             run(8, deferred, prof)
             best = min(run(n, deferred, prof) for _ in range(4))
-            print(f"deferred={int(deferred)} events={int(prof)} calls={n:3d}: {best[0]:7.1f} us/call  {256 / best[0] * 1e6:9.0f} evals/s"
+            print(f"deferred={int(deferred)} events={int(prof)} calls={n:3d}: {best[0]:7.1f} us/call  {GEOMS / best[0] * 1e6:9.0f} evals/s"
                   f"  sweep {best[1]:6.1f} us", flush=True)
