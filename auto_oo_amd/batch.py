@@ -576,7 +576,12 @@ class OO_pqc_batch:
             refused = True
         event = torch.cuda.Event()
         event.record(side)
-        slab.record_stream(side)
+        # the side stream's route reads and writes this slab: it stays referenced here until that route's event has
+        # completed (a host-side query per step) -- record_stream() on a megabyte block costs the allocator ~35 us at the
+        # NEXT torch.empty (event bookkeeping on the critical path of the next step)
+        held = self.__dict__.setdefault("_slabs_in_flight", [])
+        held[:] = [(sl, ev) for sl, ev in held if not ev.query()]
+        held.append((slab, event))
         # (the views are made while the device works through the step, the readback comes last)
         state = view("state", 3, G)
         lam_args = (float(opt.lambda_min), float(opt.mu), float(opt.rho), int(bool(opt.aug)))
