@@ -572,6 +572,13 @@ class PendingTensor:
             self._event = None
         return self._tensor if self._view is None else self._view(self._tensor)
 
+    def wait(self):
+        """Make the current stream wait for the computation WITHOUT taking the tensor (joining the last call of a side
+        stream joins every call enqueued on that stream before it: a loop over many deferred calls needs one wait
+        per stream, not one per call)."""
+        if self._event is not None:
+            torch.cuda.current_stream().wait_event(self._event)
+
 
 class PendingLowest:
     """Lowest Hessian eigenvalues still being computed on the library's side stream (the band route runs

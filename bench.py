@@ -64,9 +64,12 @@ def parse():
     ap.add_argument("--general-eri", action="store_true",
                     help="treat g_ao as a general tensor (eri_flags = 0: every slab is read) in the "
                          "headline run, for comparison with the default symmetric-integral path")
-    ap.add_argument("--in-order", action="store_true",
-                    help="headline steps as in-order calls on the current stream (rounds 1-4) instead of deferred "
-                         "calls over the library's two side streams (OO_pqc_batch.evaluate_deferred)")
+    ap.add_argument("--deferred", action="store_true",
+                    help="headline steps as deferred calls over the library's two side streams "
+                         "(OO_pqc_batch.evaluate_deferred) instead of in-order calls on the current stream: the tail of "
+                         "one call under the N^4 sweep of the next.  Measured (round 5): +3 ... 6 % in short bursts, "
+                         "nothing in the sustained regime the headline is taken in (0.5 s of priming: the chip is "
+                         "power-limited there and the sweep slows by what the tails use) -- so not the default")
     ap.add_argument("--no-transform", action="store_true")
     ap.add_argument("--no-kupccd", action="store_true", help="skip the configs[4] kUpCCD CAS(8e,8o) extra")
     ap.add_argument("--no-berry", action="store_true",
@@ -521,8 +524,20 @@ def kupccd_extra():
             nt = (a2 + 15) // 16
             gram_issued = 2.0 * (nt * (nt + 1) // 2) * 256 * eng.Dc * batch
             w_bytes = 2.0 * a2 * eng.Dc * 8 * batch                  # W = Ms^T V written once, read once
+            dense_bytes = batch * pqc._n_gates * 2.0 * (1 << pqc.n_qubits) * 16.0   # SURVEY.md section 8(d)'s gate-apply figure
             rec["batches"].append({
                 "batch": batch, "state_us": t_state * 1e6,
+                "gate_apply": {"us_per_gate_per_state": t_state * 1e6 / pqc._n_gates / batch,
+                               "gates": pqc._n_gates, "us_per_circuit_per_state": t_state * 1e6 / batch,
+                               "dense_complex128_bytes_of_the_reference_simulator": dense_bytes,
+                               "dense_equivalent_GBs": dense_bytes / t_state / 1e9,
+                               "hbm_bytes_actually_moved": batch * (n_theta + eng.Dc) * 8.0,
+                               "note": "SURVEY.md section 8(d) prices a gate at 2 x D x 16 B (a dense complex128 register read and "
+                                       "written per FermionicDoubleExcitation: 2 MiB per gate and state at 16 qubits); here the "
+                                       "state is the REAL 4 900-determinant (N_alpha, N_beta) sector vector, LDS-resident for the "
+                                       "whole circuit (one workgroup per state, every gate a list of determinant pairs): HBM sees "
+                                       "theta in and psi out, so the dense-equivalent GB/s is a statement about the work avoided, "
+                                       "not about memory traffic; the kernel is latency-bound (one workgroup per state)"},
                 "state_rdm_grad_us": t_full * 1e6,
                 "state_rdm_grad_evals_per_s": batch / t_full,
                 "rdm_stage": {"us": t_rdm * 1e6, "bound": "mfma", "flops": gram_issued,
@@ -781,12 +796,14 @@ def main():
     n_out = 1 + batch.n_theta + batch.n_kappa
     results = torch.zeros((G, n_out), dtype=torch.float64, device="cuda")
 
-    deferred = not args.in_order
+    # (multi-rank jobs always keep the in-order calls: their RCCL streams and GPU_MAX_HW_QUEUES = 8 change how HIP maps
+    # streams to hardware queues, and the deferred form has only been measured on one-rank boxes)
+    deferred = args.deferred and world == 1
 
     def run(n_calls, defer=None):
         """n_calls steps: each one batched call over ALL G geometries of this rank's shard.  Each
         call returns its own [G, 1 + n_theta + n_kappa] result tensor; the rows of the last call
-        are what the final exchange gathers.  The steps are independent evaluations: by default each call is
+        are what the final exchange gathers.  The steps are independent evaluations; with --deferred each call is
         DEFERRED (OO_pqc_batch.energy_and_gradient(defer=True): enqueued on the library's two side streams in
         turn, each with its own workspace) and all of them are joined to the current stream before the exchange --
         the latency-bound tail of one call (q -> x / p -> n, Fock panels, assembly) then runs under the N^4 sweep of
@@ -798,8 +815,12 @@ def main():
                 pend.append(batch.energy_and_gradient(thetas, defer=True))
             else:
                 last = batch.energy_and_gradient(thetas)
-        for p_ in pend:
-            last = p_.result()             # (every call joined: all n_calls result tensors are complete)
+        # every call joined: the side streams are in-order, so the last call of each of the two streams stands for all
+        # calls before it -- all n_calls result tensors are complete behind these two waits
+        for p_ in pend[-2:]:
+            p_.wait()
+        if pend:
+            last = pend[-1].result()
         if last is not None:
             results.copy_(last)
         return n_calls
@@ -807,6 +828,10 @@ def main():
     # set-up (not part of W or K): every code path of the timed region runs once, so that lazily
     # loaded code objects (ours and torch's index_put/copy kernels used by the final exchange: ~30 ms
     # the first time a fresh box reads them from disk) are resident, and the GPU clocks have ramped.
+    # (the library's pool of HIP events is made on the first profile_begin: 16 384 hipEventCreate calls, ~20 ms of host
+    # time during which the GPU idles and its clocks fall -- made here, not in front of the timed region)
+    ops.profile_begin()
+    ops.profile_end()
     t_prime = time.perf_counter()
     while time.perf_counter() - t_prime < args.prime_seconds:
         run(8)
@@ -822,6 +847,7 @@ def main():
     n_calls = run(args.steps)
     t_submit = time.perf_counter() - t0                              # host time to enqueue everything
     gathered = gather_results(results, my_geoms, n_geom_total, dist)   # the one exchange step
+    t_gather = time.perf_counter() - t0
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -835,10 +861,10 @@ def main():
 
     kern_total_ms, kern_count, _ = ops.profile_end()
 
-    # extras (untimed for `value`): the same steps as in-order calls on the current stream (the headline of rounds
-    # 1-4: every call's tail in front of the next call's sweep), and deferred calls of 224 of the 256 geometries (the
-    # sweep then leaves 32 CUs to the tails of the previous call: more evaluations per second, but each sweep launch
-    # streams 12.5 % fewer bytes in about the same time -- `value` and `roofline` stay on 256 geometries per call)
+    # extras (untimed for `value`; SHORT BURSTS of 40 calls after other work, not the sustained regime of the headline:
+    # the chip runs this workload against its power limit and a burst finds higher clocks): the same steps as in-order
+    # calls on the current stream and as deferred calls over the two side streams, and deferred calls of 224 of the
+    # 256 geometries (the sweep then leaves 32 CUs to the tails of the previous call)
     pipelining = None
     if world == 1 and not args.general_eri:
         def timed_calls(n, count, defer):
@@ -860,10 +886,14 @@ def main():
             t_c = min(timed_calls(40, count, defer) for _ in range(2))
             pipelining[label] = {"geometries_per_call": count, "us_per_call": t_c * 1e6,
                                  "evaluations_per_s": count / t_c}
-        pipelining["note"] = ("independent calls; deferred = OO_pqc_batch.evaluate_deferred (two side streams / workspace "
-                              "slots in turn, N^4 sweeps of the two streams ordered one after the other, all calls "
+        pipelining["note"] = ("independent calls in bursts of 40; deferred = OO_pqc_batch.evaluate_deferred (two side streams / "
+                              "workspace slots in turn, N^4 sweeps of the two streams ordered one after the other, all calls "
                               "joined at the end); bit-identical to the in-order calls "
-                              "(tests/test_full_size_gpu.py::test_deferred_evaluations_equal_the_in_order_calls_bit_for_bit)")
+                              "(tests/test_full_size_gpu.py::test_deferred_evaluations_equal_the_in_order_calls_bit_for_bit).  "
+                              "In the SUSTAINED regime of the headline (0.5 s of priming in front of the timed steps) both forms "
+                              "give the same evaluations/s to within the run-to-run spread (bench.py --deferred): the sweep "
+                              "slows by what the overlapped tails take (its HIP-event duration 370 -> 410 us) -- the chip is "
+                              "power-limited on this workload (DESIGN.md section 5), so hiding latency does not buy throughput")
     # ingest (untimed for `value`; SURVEY.md section 8(d) fixes g_ao): what it costs to make a geometry's integrals
     # usable once they are in HBM -- the bitwise symmetry tests and the packed resident copy, ONE pass over the stack
     # (oovqe_eri_ingest) -- and the host -> device copy of one geometry's tensors from pinned memory, separately
@@ -1000,6 +1030,8 @@ def main():
             "batched_calls": n_calls,
             "calls": "deferred (OO_pqc_batch.energy_and_gradient(defer=True))" if deferred else "in order",
             "host_submit_us_per_call": t_submit / max(n_calls, 1) * 1e6,
+            "timed_region_us": {"enqueue_and_join": t_submit * 1e6, "exchange_enqueued_at": t_gather * 1e6,
+                                "elapsed": elapsed * 1e6},
             "parallelism": f"geometry-sharded x{world}, one all_gather at the end",
             "pipelining": pipelining,
             "ingest": ingest,
