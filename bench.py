@@ -799,6 +799,7 @@ def main():
     # (multi-rank jobs always keep the in-order calls: their RCCL streams and GPU_MAX_HW_QUEUES = 8 change how HIP maps
     # streams to hardware queues, and the deferred form has only been measured on one-rank boxes)
     deferred = args.deferred and world == 1
+    step_marks = None          # (debugging aid: OOVQE_BENCH_STEP_TIMES=1 records an event behind every step of the timed region)
 
     def run(n_calls, defer=None):
         """n_calls steps: each one batched call over ALL G geometries of this rank's shard.  Each
@@ -815,6 +816,10 @@ def main():
                 pend.append(batch.energy_and_gradient(thetas, defer=True))
             else:
                 last = batch.energy_and_gradient(thetas)
+            if step_marks is not None:
+                ev_ = torch.cuda.Event(enable_timing=True)
+                ev_.record()
+                step_marks.append(ev_)
         # every call joined: the side streams are in-order, so the last call of each of the two streams stands for all
         # calls before it -- all n_calls result tensors are complete behind these two waits
         for p_ in pend[-2:]:
@@ -832,17 +837,26 @@ def main():
     # time during which the GPU idles and its clocks fall -- made here, not in front of the timed region)
     ops.profile_begin()
     ops.profile_end()
+    # The exchange runs once BEFORE the priming: its first call reads torch's index_put kernel from disk (tens of
+    # milliseconds with an idle GPU).  Rounds 1-4 made that call between the priming and the warm-up steps, the clocks
+    # fell during it and needed ~25 steps (12 ms) to come back: with the driver's --warmup 5 the 20 timed steps ran
+    # through that ramp (540 -> 475 us per step: OOVQE_BENCH_STEP_TIMES=1 prints the intervals; --warmup 30 hid it).
+    run(2)
+    gather_results(results, my_geoms, n_geom_total, dist)
+    torch.cuda.synchronize()
     t_prime = time.perf_counter()
     while time.perf_counter() - t_prime < args.prime_seconds:
         run(8)
         torch.cuda.synchronize()
-    gather_results(results, my_geoms, n_geom_total, dist)
     run(args.warmup)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     ops.profile_begin()   # HIP events around every half-transform launch, on its stream
+    if os.environ.get("OOVQE_BENCH_STEP_TIMES"):
+        step_marks = [torch.cuda.Event(enable_timing=True)]
+        step_marks[0].record()
     t0 = time.perf_counter()
     n_calls = run(args.steps)
     t_submit = time.perf_counter() - t0                              # host time to enqueue everything
@@ -860,6 +874,10 @@ def main():
         elapsed = float(tmax.item())
 
     kern_total_ms, kern_count, _ = ops.profile_end()
+    if step_marks is not None:
+        print("step intervals (us):", [round(a_.elapsed_time(b_) * 1e3, 1) for a_, b_ in zip(step_marks, step_marks[1:])],
+              file=sys.stderr, flush=True)
+        step_marks = None
 
     # extras (untimed for `value`; SHORT BURSTS of 40 calls after other work, not the sustained regime of the headline:
     # the chip runs this workload against its power limit and a burst finds higher clocks): the same steps as in-order
