@@ -311,6 +311,11 @@ class OO_pqc_batch:
         during which HBM idles) runs under the N^4 sweep of the next call instead of in front of it.  The inputs
         must be complete on the current stream when this is called (the side stream is forked from it here);
         per call the launches and the arithmetic are those of ``evaluate``: the same bits."""
+        if getattr(self.pqc, "_use_sector", False):
+            # the sector engine keeps ONE workspace per batch size (not per stream): its calls stay in order on the
+            # current stream; the result is complete in stream order, the handle has nothing to wait for
+            out = self.evaluate(thetas, derivatives=derivatives, count=count, mo_coeff=mo_coeff)
+            return ops.PendingTensor(out, None, view)
         side_streams = ops.side_streams(self.device)
         k = self._defer_next = (getattr(self, "_defer_next", 1) + 1) & 1
         side = side_streams[k]
