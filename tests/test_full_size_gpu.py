@@ -683,6 +683,29 @@ def test_kupccd_cas88_geometry_batch_equals_single_geometries():
         assert (grad[g] - g1).abs().max().item() < 1e-9
 
 
+def test_np_fabric_cas66_geometry_batch_takes_the_loop_over_geometries():
+    """GateFabric CAS(6e,6o) (12 qubits: sector engine; a^2 = 36 is outside the per-geometry-coefficient kernels, so the
+    reverse sweep and the theta-theta block loop over the geometries; parameters shared between gates): batched
+    energy + gradient and full Hessian equal the single-geometry OO_pqc values, and a lockstep step lowers every
+    energy."""
+    pqc, probs, objs, batch = _sector_batch(14, 6, 6, 12, 2, 6600, "np_fabric", n_layers=2)
+    assert pqc._use_sector and not pqc._sector.geometry_coefficients_ok()
+    nt = int(pqc.theta_shape)
+    rng = np.random.default_rng(66)
+    thetas = torch.tensor(rng.normal(0, 0.4, (2, nt)), device=DEV)
+    eg = batch.energy_and_gradient(thetas)
+    E, grad, H = batch.energy_gradient_hessian(thetas)
+    for g, oo in enumerate(objs):
+        e1, g1 = oo.energy_and_gradient(thetas[g])
+        assert abs(eg[g, 0].item() - e1.item()) < 1e-11 and (eg[g, 1:] - g1).abs().max().item() < 1e-11
+        H1 = oo.full_hessian(thetas[g])
+        assert (H[g] - H1).abs().max().item() < 1e-10 * max(1.0, H1.abs().max().item())
+        assert (grad[g] - g1).abs().max().item() < 1e-10
+    e0 = batch.energy(thetas)
+    _, e_new, _ = batch.damped_newton_step(thetas)
+    assert (e_new < e0).all()
+
+
 def test_kupccd_cas88_damped_newton_step_lowers_the_energy():
     """configs[4] has a Newton step: full gradient + full Hessian of kUpCCD CAS(8e,8o), k = 1 (56 thetas, sector
     engine: 4 900 determinants, 1 596 second tangents) and one damped Newton step of OO_pqc.full_optimization's
